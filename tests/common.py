@@ -1,0 +1,63 @@
+"""Shared helpers for the parity tests: golden fixtures -> batches, tolerances."""
+import os
+from functools import lru_cache
+
+import numpy as np
+import torch
+
+from gnn_branching_amd import nets, synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLDEN_CASES = ["cifar_base_kw_B3", "cifar_wide_kw_B2", "cifar_deep_kw_B2"]
+FAMILIES = ["shipped", "random"]
+STAGES = ["r0_fwd", "r0_bwd", "r1_fwd", "r1_bwd"]
+
+# north_star: scores within 1e-4 (fp32, absolute) of the reference CPU forward
+SCORE_ATOL = 1e-4
+
+
+@lru_cache(None)
+def shipped_state():
+    d = dict(np.load(os.path.join(nets.ASSETS, "cifar_trained_gnn.npz")))
+    order = [str(k) for k in d.pop("__order__")]
+    return {k: d[k] for k in order}
+
+
+@lru_cache(None)
+def random_state(seed=20240917):
+    from oracle.gnn_oracle import random_gnn_state
+    return random_gnn_state(seed)
+
+
+def state_of(fam):
+    return shipped_state() if fam == "shipped" else random_state()
+
+
+@lru_cache(None)
+def load_golden(case):
+    g = dict(np.load(os.path.join(GOLDEN, case + ".npz")))
+    net = str(g["net"])
+    B = int(g["B"])
+    props = [tuple(int(v) for v in pr) for pr in g["props"]]
+    base = nets.build_net(net)
+    cache = {}
+    prop_layers = []
+    for pr in props:
+        if pr not in cache:
+            cache[pr] = nets.fold_property(base, *pr)[-1]
+        prop_layers.append(cache[pr])
+    nl = sum(1 for k in g if k.startswith("lb"))
+    lbs = [torch.from_numpy(g[f"lb{i}"]) for i in range(nl)]
+    ubs = [torch.from_numpy(g[f"ub{i}"]) for i in range(nl)]
+    duals = [torch.from_numpy(g[f"dual{i}"]) for i in range(nl - 2)]
+    npm = sum(1 for k in g if k.startswith("primal") and k != "primal_input")
+    primals = [torch.from_numpy(g[f"primal{i}"]) for i in range(npm)]
+    bab = [torch.from_numpy(g[f"bab{i}"].astype(np.int64)) for i in range(nl - 2)]
+    batch = synth.SubproblemBatch(lbs, ubs, duals, primals, torch.from_numpy(g["primal_input"]),
+                                  {"fixed_layers": base[:-1], "prop_layers": prop_layers},
+                                  torch.from_numpy(g["masks"].astype(np.float32)), bab)
+    return g, batch
+
+
+def relu_sizes(batch):
+    return [int(np.prod(t.shape[1:])) for t in batch.lower_bounds_all[1:-1]]
