@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""Benchmark of the GNN branching-score hot path on MI355X.
+
+Metric (BASELINE.json): ReLU branching scores/s = subproblems x ambiguous ReLUs per second on
+cifar_base_kw.  One "step" = one batched forward (T=2 rounds of message passing + score head +
+per-subproblem argmax) over a batch of synthetic subproblems already resident in HBM; with N > 1
+ranks each rank scores its own shard of the live subproblems and ONE RCCL all-gather collects the
+padded scores for the branch selector (weak scaling: per-GPU batch fixed).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--net cifar_base_kw] [--batch 256]
+
+Prints ONE JSON line (rank 0).  The CPU oracle is imported only for the `cpu_baseline` leg.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_HBM_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6.3 TB/s achievable)
+PEAK_F32_MFMA_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32, same guide
+
+
+def node_update_flops(sizes, B, T):
+    """Algorithmic flops of all k_node_update launches of one forward: per ReLU node and half-pass
+    128x64 + 3 x 64x64 MACs (fc3|bc3, fc3_2|bc3_1, second half of fc4|bc4, fc4_2|bc4_1)."""
+    R = sum(sizes[1:-1])
+    return 2.0 * (128 * 64 + 3 * 64 * 64) * R * B * 2 * T
+
+
+def message_passing_bytes(sizes, B, T):
+    """4*p*(N_src + N_dst) bytes per half-pass update src->dst, summed over the
+    live half-passes (the last round's input-layer update is dead)."""
+    p = 64
+    L = len(sizes) - 2
+    fwd = sum(sizes[k - 1] + sizes[k] for k in range(1, L + 2))
+    bwd = sum(sizes[k + 1] + sizes[k] for k in range(1, L + 1))
+    inp = sizes[1] + sizes[0]
+    return 4.0 * p * B * (T * (fwd + bwd) + (T - 1) * inp)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--net", default="cifar_base_kw")
+    ap.add_argument("--batch", type=int, default=256, help="subproblems per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=16)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    from gnn_branching_amd import _lib, synth
+    from gnn_branching_amd.graphnet.graph_conv import GraphNet
+    _lib.build_library()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the scorer)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    ckpt = os.path.join(ROOT, "models/cifar_trained_gnn/best_snapshot_None_0_val_acc_0.826_loss_val_0.1036_epoch_57.pt")
+    sd = torch.load(ckpt, map_location="cpu", weights_only=True)
+    model = GraphNet(2, 64)
+    model.load_state_dict(sd)
+    model.eval()
+    eng = model.engine()
+
+    B = args.batch
+    batch = synth.make_batch(args.net, B, seed=1234 + rank)
+    n_amb = int(batch.masks.sum().item())
+
+    def dev_list(ts):
+        return [t.to(dev).float().contiguous() for t in ts]
+    d_args = (dev_list(batch.lower_bounds_all), dev_list(batch.upper_bounds_all), dev_list(batch.dual_vars),
+              dev_list(batch.primals), batch.primal_inputs.to(dev), batch.layers, batch.masks.to(dev))
+    gathered = None
+
+    def step():
+        nonlocal gathered
+        res = eng.forward(*d_args)
+        if world > 1:
+            if gathered is None:
+                gathered = torch.empty(world * B, eng.R, dtype=torch.float32, device=dev)
+            dist.all_gather_into_tensor(gathered, res.scores)      # the one exchange step: scores -> branch selector
+        return res
+
+    for _ in range(args.warmup):
+        res = step()
+    res.check()
+    sizes = eng.sizes
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([n_amb], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot)
+        total_amb = float(tot.item())
+    else:
+        total_amb = float(n_amb)
+    res.check()
+
+    # ---- per-kernel durations with HIP events on the launch stream (same K steps, instrumented) ----
+    eng.profile_enable(True)
+    eng.profile_read(reset=True)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.forward(*d_args)
+    torch.cuda.synchronize()
+    instrumented = time.perf_counter() - t1
+    prof = eng.profile_read(reset=True)
+    eng.profile_enable(False)
+
+    if rank == 0:
+        T = model.T
+        kern = {k: {"ms_total": round(v[0], 4), "launches": int(v[1]), "avg_us": round(1e3 * v[0] / max(v[1], 1), 2)}
+                for k, v in prof.items() if v[1]}
+        dom = max(kern, key=lambda k: kern[k]["ms_total"])
+        nu = prof["k_node_update"]
+        flops = node_update_flops(sizes, B, T) * args.steps
+        ach_tf = flops / (nu[0] * 1e-3) / 1e12 if nu[0] > 0 else 0.0
+        roofline = {"kernel": "k_node_update", "bound": "mfma", "achieved": round(ach_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "avg_launch_us": kern["k_node_update"]["avg_us"], "dominant_by_time": dom}
+        mp_ms = sum(prof[k][0] for k in ("k_conv_fwd", "k_convT_bwd", "k_dense_agg", "k_prop_fwd", "k_prop_bwd_nb"))
+        mp_bytes = message_passing_bytes(sizes, B, T) * args.steps
+        mp_gbs = mp_bytes / (mp_ms * 1e-3) / 1e9 if mp_ms > 0 else 0.0
+        roofline_mp = {"kernels": "k_conv_fwd+k_convT_bwd+k_dense_agg+k_prop_*", "bound": "hbm", "achieved": round(mp_gbs, 1),
+                       "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(mp_gbs / PEAK_HBM_GBS, 4), "traffic": None,
+                       "bytes_per_subproblem": message_passing_bytes(sizes, 1, T)}
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(sd, args.net, args.cpu_batch)
+        out = {
+            "metric": "ReLU branching scores/sec (subproblems x ambiguous-ReLUs/s)",
+            "value": round(total_amb * args.steps / elapsed, 1),
+            "unit": "scores/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.net}, batch={B} synthetic subproblems per GPU, T=2, p=64, shipped cifar_trained_gnn weights",
+                       "subproblems_per_s": round(world * B * args.steps / elapsed, 1),
+                       "ambiguous_per_subproblem": round(total_amb / (world * B), 1),
+                       "parallelism": f"dp{world}" + (" + 1 all-gather(scores)/step" if world > 1 else "")},
+            "roofline": roofline,
+            "roofline_message_passing": roofline_mp,
+            "cpu_baseline": cpu,
+            "kernels": kern,
+            "instrumented_ms_per_step": round(1e3 * instrumented / args.steps, 4),
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sd, net, cpu_batch):
+    """The CPU oracle (a torch-CPU port with the reference's op sequence) on a bounded sample of the
+    same workload, all host threads torch uses by default, default denormal handling."""
+    from gnn_branching_amd import synth
+    from oracle import gnn_oracle
+    state = {k: v.numpy() for k, v in sd.items()}
+    batch = synth.make_batch(net, cpu_batch, seed=1234)
+    n_amb = int(batch.masks.sum().item())
+    with torch.no_grad():
+        gnn_oracle.oracle_forward(state, *batch.forward_args())      # warm-up
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            gnn_oracle.oracle_forward(state, *batch.forward_args())
+            reps += 1
+            if time.perf_counter() - t0 > 10.0 or reps >= 20:
+                break
+        dt = time.perf_counter() - t0
+    return {"value": round(n_amb * reps / dt, 1), "unit": "scores/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{reps} forwards of {cpu_batch} {net} subproblems (seed 1234), oracle/gnn_oracle.py, {dt:.1f}s",
+            "subproblems_per_s": round(cpu_batch * reps / dt, 2)}
+
+
+if __name__ == "__main__":
+    main()

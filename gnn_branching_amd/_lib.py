@@ -1,0 +1,100 @@
+"""ctypes binding of libgnnb.so (C-ABI in include/gnnb.h) and its in-tree build.
+
+No HIP call is made at import or load time: the BaB harness forks one child per
+property and creates the GPU context inside the child (reference
+experiments/bab_mip.py:244-249), so device work starts at the first forward.
+There is NO CPU fallback: if the library is missing or no MI355X is visible the
+product path raises.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(CSRC, "libgnnb.so")
+SOURCES = ["gnnb.hip", "gnnb_pack.h"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"]
+
+GNNB_CONV, GNNB_LINEAR, GNNB_RELU, GNNB_FLATTEN = 0, 1, 2, 3
+
+
+class LayerDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("c_in", C.c_int32), ("c_out", C.c_int32), ("kh", C.c_int32),
+                ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("n_in", C.c_int32),
+                ("n_out", C.c_int32), ("weight", C.c_void_p), ("bias", C.c_void_p)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("lb", C.POINTER(C.c_void_p)), ("ub", C.POINTER(C.c_void_p)),
+                ("dual", C.POINTER(C.c_void_p)), ("primal", C.POINTER(C.c_void_p)),
+                ("x_lp", C.c_void_p), ("prop_w", C.c_void_p), ("prop_b", C.c_void_p), ("mask", C.c_void_p),
+                ("n_graph", C.c_int32), ("n_relu", C.c_int32), ("n_primal", C.c_int32)]
+
+
+# every symbol include/gnnb.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("gnnb_create", C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t, C.c_int, C.c_int]),
+    ("gnnb_bind_network", C.c_int, [C.c_void_p, C.POINTER(LayerDesc), C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("gnnb_graph_info", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("gnnb_workspace_bytes", C.c_size_t, [C.c_void_p, C.c_int]),
+    ("gnnb_forward", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("gnnb_destroy", C.c_int, [C.c_void_p]),
+    ("gnnb_last_error", C.c_char_p, []),
+    ("gnnb_abi_version", C.c_int, []),
+    ("gnnb_mu_location", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    ("gnnb_set_halfpass_limit", C.c_int, [C.c_void_p, C.c_int]),
+    ("gnnb_profile_enable", C.c_int, [C.c_void_p, C.c_int]),
+    ("gnnb_profile_classes", C.c_int, []),
+    ("gnnb_profile_class_name", C.c_char_p, [C.c_int]),
+    ("gnnb_profile_read", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int, C.c_int]),
+]
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in SOURCES) or \
+        os.path.getmtime(os.path.join(CSRC, "..", "..", "include", "gnnb.h")) > t
+
+
+def build_library(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 ... -> csrc/libgnnb.so (cross-compiles without a GPU)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = ["hipcc"] + HIPCC_FLAGS + ["-o", LIB_PATH, os.path.join(CSRC, "gnnb.hip")]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libgnnb.so failed:\n" + r.stdout + r.stderr)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """dlopen the library and declare the prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback for the branching scorer)")
+        lib = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().gnnb_last_error().decode(errors="replace")
+        print(f"[gnn_branching_amd] {what} failed ({rc}): {msg}", file=sys.stderr)
+        raise RuntimeError(f"{what} failed ({rc}): {msg}")

@@ -1,0 +1,1148 @@
+// gnnb.hip -- MI355X (gfx950 / CDNA4) GNN branching-score forward pass: HIP kernels + C-ABI.
+//
+// What runs here is the reference's graphnet/graph_conv.py (EmbedLayerUpdate.forward :77-388,
+// ComputeFinalScore.forward :442-470) and the argmax of graphnet/graph_score.py :41-47, for a
+// batch of B subproblems, re-designed for CDNA4:
+//
+//   * embeddings mu[k] live in HBM as (B, N_k, 64) fp32, one 256-B row per node;
+//   * every node MLP is a chain of exact-fp32 MFMAs (v_mfma_f32_32x32x2_f32) run TRANSPOSED:
+//     weights are the A operand (staged once per workgroup in LDS, pre-permuted on the host, see
+//     gnnb_pack.h), the 32 nodes of a tile sit on the lanes, and the accumulators of one layer
+//     are the B operands of the next -- no LDS round trip between layers;
+//   * node-feature-only sub-chains (fc1*, bc1*/bc2*, inp_b*) do not depend on the embeddings, so
+//     they are evaluated ONCE per forward (not once per round) and folded through the first half
+//     of the following 128->64 layer into a cached 64-vector per node ("P");
+//   * edge aggregation (the message passing): conv / conv-transpose gathers run on the VALU with
+//     lane = embedding channel (coalesced 256-B row loads, wave-uniform weights in SGPRs), dense
+//     Linear edges run on the MFMA;
+//   * provably dead work of the reference is not executed: the `ratio` chain (:214-216,228,243,356)
+//     and the last round's input-layer update (:360-385), whose result nothing reads.
+//
+// gfx950 only.  No HIP call at load time.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "../../include/gnnb.h"
+#include "gnnb_pack.h"
+
+using namespace gnnb;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+struct Frag {
+  f32x16 t[2];  // 64 features x 32 nodes; register R = 16*it + r <-> feature 8*(R>>2) + 4*h + (R&3)
+};
+
+#define FRAG_AT(x, R) ((x).t[(R) >> 4][(R)&15])
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// acc += W(64 x 2*KSTEPS, operand order in LDS) * in, where getB(s) yields the B operand of k-step s
+template <int KSTEPS, class GetB>
+__device__ __forceinline__ void gemm_w64(const float* wl, int lane, Frag& acc, GetB getB) {
+  // A operands are prefetched one 4-k-step block ahead; the sched_barrier keeps hipcc from hoisting
+  // every LDS read of the fully unrolled chain to the top (which spills the 256-VGPR budget).
+  const f32x4* w4 = reinterpret_cast<const f32x4*>(wl) + lane;
+  f32x4 a0 = w4[0], a1 = w4[64];
+#pragma unroll
+  for (int s4 = 0; s4 < KSTEPS / 4; ++s4) {
+    f32x4 n0 = a0, n1 = a1;
+    if (s4 + 1 < KSTEPS / 4) {
+      n0 = w4[((s4 + 1) * 2 + 0) * 64];
+      n1 = w4[((s4 + 1) * 2 + 1) * 64];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float b = getB(s4 * 4 + c);
+      acc.t[0] = mfma32(a0[c], b, acc.t[0]);
+      acc.t[1] = mfma32(a1[c], b, acc.t[1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    a0 = n0;
+    a1 = n1;
+  }
+}
+
+// first layers on scalar node features: x[s] = input feature 2*s + h of this lane's node
+template <int KSTEPS>
+__device__ __forceinline__ void gemm_small(const float* wl, int lane, Frag& acc, const float (&x)[KSTEPS]) {
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s) {
+    const float a0 = wl[(s * 2 + 0) * 64 + lane];
+    const float a1 = wl[(s * 2 + 1) * 64 + lane];
+    acc.t[0] = mfma32(a0, x[s], acc.t[0]);
+    acc.t[1] = mfma32(a1, x[s], acc.t[1]);
+  }
+}
+
+__device__ __forceinline__ void frag_bias(Frag& a, const float* bl, int h) {
+  const f32x4* b4 = reinterpret_cast<const f32x4*>(bl + h * 32);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const f32x4 v = b4[q];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) FRAG_AT(a, 4 * q + c) = v[c];
+  }
+}
+
+__device__ __forceinline__ void frag_relu(Frag& a) {
+#pragma unroll
+  for (int R = 0; R < 32; ++R) FRAG_AT(a, R) = fmaxf(FRAG_AT(a, R), 0.0f);
+}
+
+__device__ __forceinline__ void frag_scale(Frag& a, float s) {
+#pragma unroll
+  for (int R = 0; R < 32; ++R) FRAG_AT(a, R) *= s;
+}
+
+// row-major (G, 64) <-> fragment: lane (j, h) owns features [8q+4h, 8q+4h+4) of row `row`, q = 0..7
+__device__ __forceinline__ void frag_load_rows(Frag& x, const float* base, long row, int h) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(base + row * 64 + 4 * h);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const f32x4 v = p[2 * q];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) FRAG_AT(x, 4 * q + c) = v[c];
+  }
+}
+__device__ __forceinline__ void frag_store_rows(const Frag& x, float* base, long row, int h) {
+  f32x4* p = reinterpret_cast<f32x4*>(base + row * 64 + 4 * h);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    f32x4 v;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = FRAG_AT(x, 4 * q + c);
+    p[2 * q] = v;
+  }
+}
+// tile-major scratch layout for the cached P vectors: float4 index (tile*8 + q)*64 + lane (1 KiB per wave-instruction)
+__device__ __forceinline__ void frag_load_tiled(Frag& x, const float* base, long tile, int lane) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(base) + tile * 512 + lane;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const f32x4 v = p[q * 64];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) FRAG_AT(x, 4 * q + c) = v[c];
+  }
+}
+__device__ __forceinline__ void frag_store_tiled(const Frag& x, float* base, long tile, int lane) {
+  f32x4* p = reinterpret_cast<f32x4*>(base) + tile * 512 + lane;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    f32x4 v;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = FRAG_AT(x, 4 * q + c);
+    p[q * 64] = v;
+  }
+}
+
+__device__ __forceinline__ bool frag_has_nan(const Frag& x) {
+  bool bad = false;
+#pragma unroll
+  for (int R = 0; R < 32; ++R) bad |= (FRAG_AT(x, R) != FRAG_AT(x, R));
+  return bad;
+}
+
+// compute_ratio (graph_conv.py:499-514), op for op
+struct Ratio { float r0, r1, beta, amb, live; };
+__device__ __forceinline__ Ratio compute_ratio(float lb, float ub) {
+  Ratio r;
+  const float lower_temp = lb - fmaxf(lb, 0.0f);
+  const float upper_temp = fmaxf(ub, 0.0f);
+  r.r0 = upper_temp / (upper_temp - lower_temp);
+  r.beta = -1.0f * lower_temp * r.r0;
+  r.amb = r.beta > 0.0f ? 1.0f : 0.0f;
+  r.r1 = (1.0f - 2.0f * (r.r0 * r.amb)) * r.amb + r.r0;
+  r.live = (r.r0 != 0.0f) ? 1.0f : 0.0f;   // (ratio_0 != 0), :178 / :347 (NaN != 0 is true)
+  return r;
+}
+
+__device__ __forceinline__ void stage_pack(float* lds, const float* pack, int nfloats) {
+  const f32x4* g = reinterpret_cast<const f32x4*>(pack);
+  f32x4* l = reinterpret_cast<f32x4*>(lds);
+  for (int i = threadIdx.x; i < nfloats / 4; i += blockDim.x) l[i] = g[i];
+  __syncthreads();
+}
+
+#define WG_MLP 512       // 8 waves: 2 per SIMD share one LDS copy of the weights
+#define WAVES_MLP 8
+
+// ------------------------------------------------------------------------------------------
+// MFMA node-MLP kernels.  One wave = one tile of 32 consecutive nodes of a (B*N_k) flat layer.
+// ------------------------------------------------------------------------------------------
+struct EmbedArgs { const float* pack; const float* lb; const float* x; const float* ub; float* mu; long G; long ntiles; };
+
+// mu0 = inp_f_1(relu(inp_f([l0, x_LP, u0])))   graph_conv.py:90-95
+__global__ __launch_bounds__(WG_MLP, 2) void k_embed(EmbedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_pack(lds, a.pack, PackEmbed::FLOATS);
+  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
+  for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < a.ntiles; tile += (long)gridDim.x * WAVES_MLP) {
+    const long g = tile * 32 + j;
+    const bool valid = g < a.G;
+    const long gc = valid ? g : a.G - 1;
+    // features [l, x, u]: half 0 holds even features (l, u), half 1 odd (x, pad)
+    float x[2];
+    x[0] = h ? a.x[gc] : a.lb[gc];
+    x[1] = h ? 0.0f : a.ub[gc];
+    Frag H;
+    frag_bias(H, lds + PackEmbed::B1, h);
+    gemm_small<2>(lds + PackEmbed::W1, lane, H, x);
+    frag_relu(H);
+    Frag M;
+    frag_bias(M, lds + PackEmbed::B2, h);
+    gemm_w64<32>(lds + PackEmbed::W2, lane, M, [&](int s) { return FRAG_AT(H, s); });
+    if (valid) frag_store_rows(M, a.mu, g, h);
+  }
+}
+
+struct PreArgs {
+  const float* pack;
+  const float *lb, *ub, *dual, *z_pre, *z_post, *bias;   // per-node scalars (flat B*N), bias per channel
+  float* P;                                               // tile-major cache
+  long G, ntiles;
+  int N, hw;                                              // nodes per sample; nodes per bias entry (H*W or 1)
+};
+
+// P_f = fc4[:, :64] . (fc1_1(relu(fc1(feat7))) * amb) + fc4.bias      graph_conv.py:153-161,176-177
+__global__ __launch_bounds__(WG_MLP, 2) void k_pre_fwd(PreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_pack(lds, a.pack, PackPreFwd::FLOATS);
+  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
+  for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < a.ntiles; tile += (long)gridDim.x * WAVES_MLP) {
+    const long g = tile * 32 + j;
+    const long gc = g < a.G ? g : a.G - 1;
+    const float lb = a.lb[gc], ub = a.ub[gc];
+    const Ratio r = compute_ratio(lb, ub);
+    const float dd = a.dual[gc * 3 + 1] - a.dual[gc * 3 + 2];
+    const float c = a.bias[(int)(gc % a.N) / a.hw];
+    // feat7 = [beta, l, u, d1-d2, z_pre, z_post, c]: even features on half 0, odd on half 1
+    float x[4];
+    x[0] = h ? lb : r.beta;
+    x[1] = h ? dd : ub;
+    x[2] = h ? a.z_post[gc] : a.z_pre[gc];
+    x[3] = h ? 0.0f : c;
+    Frag H;
+    frag_bias(H, lds + PackPreFwd::B1, h);
+    gemm_small<4>(lds + PackPreFwd::W1, lane, H, x);
+    frag_relu(H);
+    Frag S;
+    frag_bias(S, lds + PackPreFwd::B2, h);
+    gemm_w64<32>(lds + PackPreFwd::W2, lane, S, [&](int s) { return FRAG_AT(H, s); });
+    frag_scale(S, r.amb);                                                  // layer_relax * ambi_mask :161
+    Frag Pf;
+    frag_bias(Pf, lds + PackPreFwd::B3, h);
+    gemm_w64<32>(lds + PackPreFwd::W3, lane, Pf, [&](int s) { return FRAG_AT(S, s); });
+    frag_store_tiled(Pf, a.P, tile, lane);
+  }
+}
+
+// P_b = bc4[:, :64] . (bc2_1(relu(bc2([s, -d2 s, d1 s]))) * amb) + bc4.bias,
+// s = bc1_2(relu(bc1_1(relu(bc1(feat7')))))                              graph_conv.py:273-293,344-345
+__global__ __launch_bounds__(WG_MLP, 2) void k_pre_bwd(PreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_pack(lds, a.pack, PackPreBwd::FLOATS);
+  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
+  for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < a.ntiles; tile += (long)gridDim.x * WAVES_MLP) {
+    const long g = tile * 32 + j;
+    const long gc = g < a.G ? g : a.G - 1;
+    const float lb = a.lb[gc], ub = a.ub[gc];
+    const Ratio r = compute_ratio(lb, ub);
+    const float d1 = a.dual[gc * 3 + 1], d2 = a.dual[gc * 3 + 2];
+    const float c = a.bias[(int)(gc % a.N) / a.hw];
+    // feat7' = [l, u, beta, -d2+d1, z_post, z_pre, c]
+    float x[4];
+    x[0] = h ? ub : lb;
+    x[1] = h ? (-d2 + d1) : r.beta;
+    x[2] = h ? a.z_pre[gc] : a.z_post[gc];
+    x[3] = h ? 0.0f : c;
+    Frag H1;
+    frag_bias(H1, lds + PackPreBwd::B1, h);
+    gemm_small<4>(lds + PackPreBwd::W1, lane, H1, x);
+    frag_relu(H1);
+    Frag H2;
+    frag_bias(H2, lds + PackPreBwd::B2, h);
+    gemm_w64<32>(lds + PackPreBwd::W2, lane, H2, [&](int s) { return FRAG_AT(H1, s); });
+    frag_relu(H2);
+    Frag S;
+    frag_bias(S, lds + PackPreBwd::B3, h);
+    gemm_w64<32>(lds + PackPreBwd::W3, lane, S, [&](int s) { return FRAG_AT(H2, s); });
+    // bc2 on [s, s*(-d2), s*d1]  (:287-291)
+    const float nd2 = -d2;
+    Frag H4;
+    frag_bias(H4, lds + PackPreBwd::B4, h);
+    gemm_w64<96>(lds + PackPreBwd::W4, lane, H4, [&](int s) {
+      const float v = FRAG_AT(S, s & 31);
+      return s < 32 ? v : (s < 64 ? v * nd2 : v * d1);
+    });
+    frag_relu(H4);
+    Frag X;
+    frag_bias(X, lds + PackPreBwd::B5, h);
+    gemm_w64<32>(lds + PackPreBwd::W5, lane, X, [&](int s) { return FRAG_AT(H4, s); });
+    frag_scale(X, r.amb);                                                   // :293
+    Frag Pb;
+    frag_bias(Pb, lds + PackPreBwd::B6, h);
+    gemm_w64<32>(lds + PackPreBwd::W6, lane, Pb, [&](int s) { return FRAG_AT(X, s); });
+    frag_store_tiled(Pb, a.P, tile, lane);
+  }
+}
+
+// Q = inp_b2[:, :64] . inp_b_1(relu(inp_b([l0, u0]))) + inp_b2.bias       graph_conv.py:380-384
+__global__ __launch_bounds__(WG_MLP, 2) void k_pre_inp(PreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_pack(lds, a.pack, PackPreInp::FLOATS);
+  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
+  for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < a.ntiles; tile += (long)gridDim.x * WAVES_MLP) {
+    const long g = tile * 32 + j;
+    const long gc = g < a.G ? g : a.G - 1;
+    float x[1];
+    x[0] = h ? a.ub[gc] : a.lb[gc];
+    Frag H;
+    frag_bias(H, lds + PackPreInp::B1, h);
+    gemm_small<1>(lds + PackPreInp::W1, lane, H, x);
+    frag_relu(H);
+    Frag S;
+    frag_bias(S, lds + PackPreInp::B2, h);
+    gemm_w64<32>(lds + PackPreInp::W2, lane, S, [&](int s) { return FRAG_AT(H, s); });
+    Frag Q;
+    frag_bias(Q, lds + PackPreInp::B3, h);
+    gemm_w64<32>(lds + PackPreInp::W3, lane, Q, [&](int s) { return FRAG_AT(S, s); });
+    frag_store_tiled(Q, a.P, tile, lane);
+  }
+}
+
+struct UpdArgs {
+  const float* pack;
+  const float *lb, *ub;     // pre-activation bounds of this layer, flat (B*N)
+  const float* nb;          // aggregated neighbour embeddings, row-major (B*N, 64)
+  const float* P;           // cached feature term, tile-major
+  float* mu;                // out: row-major (B*N, 64)
+  int* status;
+  long G, ntiles;
+};
+
+// mu_k = Wd.relu(P + Wc.e) + bd, e = Wb.relu(Wa.[r0*nb, r1*nb] + ba) + bb, times [r0 != 0]
+// forward:  fc3, fc3_2, fc4, fc4_2   graph_conv.py:169-181
+// backward: bc3, bc3_1, bc4, bc4_1   graph_conv.py:331-349
+__global__ __launch_bounds__(WG_MLP, 2) void k_node_update(UpdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_pack(lds, a.pack, PackUpd::FLOATS);
+  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
+  for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < a.ntiles; tile += (long)gridDim.x * WAVES_MLP) {
+    const long g = tile * 32 + j;
+    const bool valid = g < a.G;
+    const long gc = valid ? g : a.G - 1;
+    const Ratio r = compute_ratio(a.lb[gc], a.ub[gc]);
+    Frag X;
+    frag_load_rows(X, a.nb, gc, h);
+    Frag H;
+    frag_bias(H, lds + PackUpd::BA, h);
+    const float r0 = r.r0, r1 = r.r1;
+    gemm_w64<64>(lds + PackUpd::WA, lane, H, [&](int s) { return FRAG_AT(X, s & 31) * (s < 32 ? r0 : r1); });
+    frag_relu(H);
+    Frag E;
+    frag_bias(E, lds + PackUpd::BB, h);
+    gemm_w64<32>(lds + PackUpd::WB, lane, E, [&](int s) { return FRAG_AT(H, s); });
+    Frag H2;
+    frag_load_tiled(H2, a.P, tile, lane);
+    gemm_w64<32>(lds + PackUpd::WC, lane, H2, [&](int s) { return FRAG_AT(E, s); });
+    frag_relu(H2);
+    Frag M;
+    frag_bias(M, lds + PackUpd::BD, h);
+    gemm_w64<32>(lds + PackUpd::WD, lane, M, [&](int s) { return FRAG_AT(H2, s); });
+    frag_scale(M, r.live);
+    if (valid) {
+      if (frag_has_nan(M)) atomicOr(a.status, 1);
+      frag_store_rows(M, a.mu, g, h);
+    }
+  }
+}
+
+struct UpdInpArgs { const float* pack; const float* nb; const float* Q; float* mu; long G, ntiles; };
+
+// mu_0 = inp_b2_2(relu(Q + inp_b2[:, 64:] . nb))                          graph_conv.py:383-385
+__global__ __launch_bounds__(WG_MLP, 2) void k_input_update(UpdInpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_pack(lds, a.pack, PackUpdInp::FLOATS);
+  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
+  for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < a.ntiles; tile += (long)gridDim.x * WAVES_MLP) {
+    const long g = tile * 32 + j;
+    const bool valid = g < a.G;
+    const long gc = valid ? g : a.G - 1;
+    Frag X;
+    frag_load_rows(X, a.nb, gc, h);
+    Frag H;
+    frag_load_tiled(H, a.Q, tile, lane);
+    gemm_w64<32>(lds + PackUpdInp::WC, lane, H, [&](int s) { return FRAG_AT(X, s); });
+    frag_relu(H);
+    Frag M;
+    frag_bias(M, lds + PackUpdInp::BD, h);
+    gemm_w64<32>(lds + PackUpdInp::WD, lane, M, [&](int s) { return FRAG_AT(H, s); });
+    if (valid) frag_store_rows(M, a.mu, g, h);
+  }
+}
+
+struct ScoreArgs {
+  const float* pack; const float* mu; const float* mask; float* scores;
+  long G, ntiles; int N, R, off;   // nodes per sample in this layer, total ReLUs per sample, offset of this layer
+};
+
+// score = fscore(relu(fnode(mu))) where the BaB mask is -1, -inf elsewhere    graph_conv.py:445-450
+__global__ __launch_bounds__(WG_MLP, 2) void k_score(ScoreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_pack(lds, a.pack, PackScore::FLOATS);
+  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
+  const float bs = lds[PackScore::BS];
+  for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < a.ntiles; tile += (long)gridDim.x * WAVES_MLP) {
+    const long g = tile * 32 + j;
+    const bool valid = g < a.G;
+    const long gc = valid ? g : a.G - 1;
+    const long b = gc / a.N;
+    const long oidx = b * a.R + a.off + (gc - b * a.N);
+    const bool amb = valid && a.mask[oidx] != 0.0f;
+    float score = -INFINITY;
+    if (__any(amb)) {     // wave-uniform: tiles without an undecided ReLU only write -inf
+      Frag X;
+      frag_load_rows(X, a.mu, gc, h);
+      Frag H;
+      frag_bias(H, lds + PackScore::B1, h);
+      gemm_w64<32>(lds + PackScore::W1, lane, H, [&](int s) { return FRAG_AT(X, s); });
+      frag_relu(H);
+      const f32x4* w4 = reinterpret_cast<const f32x4*>(lds + PackScore::WS + h * 32);
+      float part = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const f32x4 w = w4[q];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) part = fmaf(FRAG_AT(H, 4 * q + c), w[c], part);
+      }
+      part += __shfl_xor(part, 32);
+      if (amb) score = part + bs;
+    }
+    if (valid && h == 0) a.scores[oidx] = score;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// message passing (edge aggregation)
+// ------------------------------------------------------------------------------------------
+struct ConvArgs {
+  const float* src; float* dst; const float* w;
+  int B, C_in, H_in, W_in, C_out, H_out, W_out, kh, kw, stride, pad, normalise;
+};
+
+// forward: nb[b,(co,oy,ox),:] = sum_{ci,ky,kx} W[co,ci,ky,kx] * mu_src[b,(ci,iy,ix),:]   graph_conv.py:110-121
+// one wave per (b, oy, ox): lane = embedding channel, all C_out accumulators in registers,
+// the 256-B source row is loaded once per tap and reused for C_out FMAs with scalar weights.
+template <int CO>
+__global__ __launch_bounds__(256) void k_conv_fwd(ConvArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (wv >= a.B * a.H_out * a.W_out) return;
+  const int ox = wv % a.W_out, oy = (wv / a.W_out) % a.H_out, b = wv / (a.W_out * a.H_out);
+  float acc[CO];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) acc[co] = 0.0f;
+  const float* src = a.src + (long)b * a.C_in * a.H_in * a.W_in * 64 + lane;
+  for (int ci = 0; ci < a.C_in; ++ci)
+    for (int ky = 0; ky < a.kh; ++ky) {
+      const int iy = oy * a.stride - a.pad + ky;
+      if ((unsigned)iy >= (unsigned)a.H_in) continue;
+      for (int kx = 0; kx < a.kw; ++kx) {
+        const int ix = ox * a.stride - a.pad + kx;
+        if ((unsigned)ix >= (unsigned)a.W_in) continue;
+        const float v = src[(long)((ci * a.H_in + iy) * a.W_in + ix) * 64];
+        const float* w = a.w + ((ci * a.kh + ky) * a.kw + kx) * CO;
+#pragma unroll
+        for (int co = 0; co < CO; ++co) acc[co] = fmaf(w[co], v, acc[co]);
+      }
+    }
+  float* dst = a.dst + ((long)b * CO * a.H_out * a.W_out + (long)oy * a.W_out + ox) * 64 + lane;
+#pragma unroll
+  for (int co = 0; co < CO; ++co) dst[(long)co * a.H_out * a.W_out * 64] = acc[co];
+}
+
+// backward: nb[b,(ci,y,x),:] = sum_{co,ky,kx} W[co,ci,ky,kx] * mu_up[b,(co,oy,ox),:] with y = oy*s - p + ky,
+// divided by the number of taps touching (y,x) when `normalise`         graph_conv.py:299-318 (and :361-372 without)
+template <int CI>
+__global__ __launch_bounds__(256) void k_convT_bwd(ConvArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (wv >= a.B * a.H_in * a.W_in) return;
+  const int x = wv % a.W_in, y = (wv / a.W_in) % a.H_in, b = wv / (a.W_in * a.H_in);
+  float acc[CI];
+#pragma unroll
+  for (int ci = 0; ci < CI; ++ci) acc[ci] = 0.0f;
+  const float* src = a.src + (long)b * a.C_out * a.H_out * a.W_out * 64 + lane;
+  int ny = 0, nx = 0;
+  for (int ky = 0; ky < a.kh; ++ky) {
+    const int t = y + a.pad - ky;
+    if (t >= 0 && t % a.stride == 0 && t / a.stride < a.H_out) ++ny;
+  }
+  for (int kx = 0; kx < a.kw; ++kx) {
+    const int t = x + a.pad - kx;
+    if (t >= 0 && t % a.stride == 0 && t / a.stride < a.W_out) ++nx;
+  }
+  for (int co = 0; co < a.C_out; ++co)
+    for (int ky = 0; ky < a.kh; ++ky) {
+      const int ty = y + a.pad - ky;
+      if (ty < 0 || ty % a.stride != 0 || ty / a.stride >= a.H_out) continue;
+      const int oy = ty / a.stride;
+      for (int kx = 0; kx < a.kw; ++kx) {
+        const int tx = x + a.pad - kx;
+        if (tx < 0 || tx % a.stride != 0 || tx / a.stride >= a.W_out) continue;
+        const int ox = tx / a.stride;
+        const float v = src[(long)((co * a.H_out + oy) * a.W_out + ox) * 64];
+        const float* w = a.w + ((co * a.kh + ky) * a.kw + kx) * CI;
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) acc[ci] = fmaf(w[ci], v, acc[ci]);
+      }
+    }
+  const float freq = a.normalise ? (float)(ny * nx) : 1.0f;
+  float* dst = a.dst + ((long)b * CI * a.H_in * a.W_in + (long)y * a.W_in + x) * 64 + lane;
+#pragma unroll
+  for (int ci = 0; ci < CI; ++ci) dst[(long)ci * a.H_in * a.W_in * 64] = a.normalise ? acc[ci] / freq : acc[ci];
+}
+
+struct DenseArgs {
+  const float* At;   // (K, ldA): At[k][i] = A[i][k]
+  const float* X;    // (B, K, 64)
+  float* out;        // (B, M, 64)
+  int B, K, M, ldA, MT;
+};
+
+// dense edge: out[b, i, :] = sum_k A[i][k] X[b, k, :]   (graph_conv.py:131 forward, :321 backward)
+// one wave per (b, 32-row tile of i, 32-channel half): D[i][ch] on the MFMA, A from L2, X rows coalesced.
+__global__ __launch_bounds__(256) void k_dense_agg(DenseArgs a) {
+  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+  const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wv >= a.B * a.MT * 2) return;
+  const int ft = wv & 1, mt = (wv >> 1) % a.MT, b = (wv >> 1) / a.MT;
+  const int i = mt * 32 + j;
+  const bool iok = i < a.M;
+  const float* At = a.At + (iok ? i : 0);
+  const float* X = a.X + (long)b * a.K * 64 + ft * 32 + j;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  const int ksteps = (a.K + 1) / 2;
+#pragma unroll 8
+  for (int s = 0; s < ksteps; ++s) {
+    const int k = 2 * s + h;
+    const bool kok = k < a.K;
+    const int kc = kok ? k : 0;
+    float av = At[(long)kc * a.ldA];
+    float bv = X[(long)kc * 64];
+    av = (kok && iok) ? av : 0.0f;
+    bv = kok ? bv : 0.0f;
+    acc = mfma32(av, bv, acc);
+  }
+  float* out = a.out + (long)b * a.M * 64 + ft * 32 + j;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (row < a.M) out[(long)row * 64] = acc[r];
+  }
+}
+
+struct PropArgs {
+  const float* pack; const float* mu_last; const float* prop_w; const float* prop_b;
+  const float *lb, *ub, *z_out; float* mu_prop; int B, N_last;
+};
+
+// property node (graph_conv.py:194-210): nb = W_prop[b] . mu_L[b];
+// mu_K = out3(relu(out2([relu(out1([l, u, z_out, c])), nb]))).  One wave per sample, lane = channel.
+__global__ __launch_bounds__(256) void k_prop_fwd(PropArgs a) {
+  __shared__ float xs[4][128];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + w;
+  const bool ok = b < a.B;
+  const int bc = ok ? b : a.B - 1;
+  float nb = 0.0f;
+  const float* mu = a.mu_last + (long)bc * a.N_last * 64 + lane;
+  const float* pw = a.prop_w + (long)bc * a.N_last;
+  for (int n = 0; n < a.N_last; ++n) nb = fmaf(pw[n], mu[(long)n * 64], nb);
+  const float f[4] = {a.lb[bc], a.ub[bc], a.z_out[bc], a.prop_b[bc]};
+  const float* pk = a.pack;
+  float h1 = pk[PackProp::B1 + lane];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) h1 = fmaf(pk[PackProp::W1T + k * 64 + lane], f[k], h1);
+  xs[w][lane] = fmaxf(h1, 0.0f);
+  xs[w][64 + lane] = nb;
+  __syncthreads();
+  float h2 = pk[PackProp::B2 + lane];
+  for (int k = 0; k < 128; ++k) h2 = fmaf(pk[PackProp::W2T + k * 64 + lane], xs[w][k], h2);
+  __syncthreads();
+  xs[w][lane] = fmaxf(h2, 0.0f);
+  __syncthreads();
+  float o = pk[PackProp::B3 + lane];
+  for (int k = 0; k < 64; ++k) o = fmaf(pk[PackProp::W3T + k * 64 + lane], xs[w][k], o);
+  if (ok) a.mu_prop[(long)b * 64 + lane] = o;
+}
+
+// backward edge from the property node (graph_conv.py:324-326): nb[b, n, :] = W_prop[b][n] * mu_K[b, :]
+__global__ __launch_bounds__(256) void k_prop_bwd_nb(const float* prop_w, const float* mu_prop, float* nb, long rows, int N_last) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const long b = row / N_last;
+  nb[row * 64 + lane] = prop_w[row] * mu_prop[b * 64 + lane];
+}
+
+struct ArgmaxArgs { const float* scores; int* dec; int B, R, n_relu; int cum[16]; };
+
+// torch.max(scores, 0) -> first maximal index; flat index -> [layer, idx]      graph_score.py:41-47
+__global__ __launch_bounds__(256) void k_argmax(ArgmaxArgs a) {
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  const int b = blockIdx.x;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  const float* s = a.scores + (long)b * a.R;
+  for (int i = threadIdx.x; i < a.R; i += 256) {
+    const float v = s[i];
+    if (v > best) { best = v; bi = i; }     // strided ascending: keeps the first index per thread
+  }
+  sv[threadIdx.x] = best;
+  si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) {
+      const float v = sv[threadIdx.x + st];
+      const int i = si[threadIdx.x + st];
+      if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && i < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = i; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    int lay = -1, idx = -1;
+    if (si[0] != 0x7fffffff) {
+      const int flat = si[0];
+      lay = 0;
+      while (lay < a.n_relu - 1 && a.cum[lay] <= flat) ++lay;
+      idx = lay == 0 ? flat : flat - a.cum[lay - 1];
+    }
+    a.dec[b * 2] = lay;
+    a.dec[b * 2 + 1] = idx;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  fprintf(stderr, "[gnnb] error: %s\n", buf);   // the BaB harness swallows exceptions (bab_mip.py:73-76): log first
+  return code;
+}
+#define HIPCHK(x)                                                                         \
+  do {                                                                                    \
+    hipError_t e_ = (x);                                                                  \
+    if (e_ != hipSuccess) return fail(GNNB_E_HIP, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+enum ProfClass {
+  PC_EMBED, PC_PRE_FWD, PC_PRE_BWD, PC_PRE_INP, PC_CONV_FWD, PC_CONVT_BWD, PC_DENSE_AGG, PC_PROP_FWD,
+  PC_PROP_BWD_NB, PC_NODE_UPDATE, PC_INPUT_UPDATE, PC_SCORE, PC_ARGMAX, PC_COUNT
+};
+static const char* kProfNames[PC_COUNT] = {
+    "k_embed", "k_pre_fwd", "k_pre_bwd", "k_pre_inp", "k_conv_fwd", "k_convT_bwd", "k_dense_agg", "k_prop_fwd",
+    "k_prop_bwd_nb", "k_node_update", "k_input_update", "k_score", "k_argmax"};
+
+struct DevEdge {
+  float *w_fwd = nullptr, *w_bwd = nullptr, *bias = nullptr;   // conv: tap-major copies; linear: W^T padded / W
+  int ld_fwd = 0, mt_fwd = 0, mt_bwd = 0;
+};
+
+struct gnnb_handle {
+  int T = 2, p = 64, device = 0, n_cu = 256;
+  Packs packs;
+  float* d_pack[9] = {nullptr};
+  bool bound = false;
+  std::vector<Edge> edges;       // edges[k], k = 1..L (edges[0] unused)
+  std::vector<DevEdge> dev;
+  std::vector<int> N;            // graph layer sizes, N[0..L+1]
+  std::vector<int> relu_q;       // fixed-layer index of the ReLU of graph layer k
+  std::vector<int> hw;           // nodes per bias entry of layer k
+  int n_fixed = 0, R = 0;
+  int halfpass_limit = 0;
+  bool prof = false;
+  struct Ev { int cls; hipEvent_t a, b; };
+  std::vector<Ev> pending;
+  std::vector<hipEvent_t> pool;
+  double prof_ms[PC_COUNT] = {0};
+  int64_t prof_n[PC_COUNT] = {0};
+  hipStream_t prof_stream = nullptr;
+};
+
+enum { PK_EMBED, PK_PRE_FWD, PK_UPD_FWD, PK_PRE_BWD, PK_UPD_BWD, PK_PRE_INP, PK_UPD_INP, PK_SCORE, PK_PROP };
+
+static int upload(float** d, const float* h, size_t n) {
+  HIPCHK(hipMalloc((void**)d, n * sizeof(float)));
+  HIPCHK(hipMemcpy(*d, h, n * sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int gnnb_abi_version(void) { return GNNB_ABI_VERSION; }
+extern "C" const char* gnnb_last_error(void) { return g_err.c_str(); }
+
+extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, int T, int p) {
+  if (!out || !w_blob) return fail(GNNB_E_INVALID, "gnnb_create: null argument");
+  if (p != P) return fail(GNNB_E_INVALID, "gnnb_create: embedding size %d unsupported (kernels are built for p=64)", p);
+  if (T < 1 || T > 16) return fail(GNNB_E_INVALID, "gnnb_create: T=%d out of range", T);
+  if (n_floats != blob_floats()) return fail(GNNB_E_INVALID, "gnnb_create: weight blob has %zu floats, expected %zu", n_floats, blob_floats());
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) return fail(GNNB_E_HIP, "gnnb_create: no HIP device (%s)", hipGetErrorString(e));
+  gnnb_t* h = new gnnb_handle();
+  h->T = T;
+  h->p = p;
+  HIPCHK(hipGetDevice(&h->device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, h->device));
+  h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  build_packs(w_blob, h->packs);
+  const std::vector<float>* pv[9] = {&h->packs.embed, &h->packs.pre_fwd, &h->packs.upd_fwd, &h->packs.pre_bwd, &h->packs.upd_bwd,
+                                     &h->packs.pre_inp, &h->packs.upd_inp, &h->packs.score, &h->packs.prop};
+  for (int i = 0; i < 9; ++i)
+    if (int rc = upload(&h->d_pack[i], pv[i]->data(), pv[i]->size())) return rc;
+  // > 64 KiB of dynamic LDS needs the attribute
+  HIPCHK(hipFuncSetAttribute((const void*)k_embed, hipFuncAttributeMaxDynamicSharedMemorySize, PackEmbed::FLOATS * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_pre_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, PackPreFwd::FLOATS * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_pre_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, PackPreBwd::FLOATS * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_pre_inp, hipFuncAttributeMaxDynamicSharedMemorySize, PackPreInp::FLOATS * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_node_update, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpd::FLOATS * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_input_update, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpdInp::FLOATS * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_score, hipFuncAttributeMaxDynamicSharedMemorySize, PackScore::FLOATS * 4));
+  *out = h;
+  return GNNB_OK;
+}
+
+static void free_network(gnnb_t* h) {
+  for (auto& d : h->dev) {
+    if (d.w_fwd) (void)hipFree(d.w_fwd);
+    if (d.w_bwd) (void)hipFree(d.w_bwd);
+    if (d.bias) (void)hipFree(d.bias);
+  }
+  h->dev.clear();
+  h->edges.clear();
+  h->N.clear();
+  h->relu_q.clear();
+  h->hw.clear();
+  h->bound = false;
+}
+
+extern "C" int gnnb_destroy(gnnb_t* h) {
+  if (!h) return GNNB_OK;
+  free_network(h);
+  for (int i = 0; i < 9; ++i)
+    if (h->d_pack[i]) (void)hipFree(h->d_pack[i]);
+  for (auto& ev : h->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+  for (auto& ev : h->pool) (void)hipEventDestroy(ev);
+  delete h;
+  return GNNB_OK;
+}
+
+static bool conv_channels_ok(int c) { return c == 3 || c == 8 || c == 16 || c == 32; }
+
+extern "C" int gnnb_bind_network(gnnb_t* h, const gnnb_layer_desc* L, int n, int c0, int h0, int w0) {
+  if (!h || !L || n < 2) return fail(GNNB_E_INVALID, "gnnb_bind_network: bad arguments");
+  free_network(h);
+  int C = c0, H = h0, W = w0;
+  bool flat = false;
+  int nflat = c0 * h0 * w0;
+  h->N.push_back(nflat);
+  h->edges.emplace_back();
+  h->relu_q.push_back(-1);
+  h->hw.push_back(1);
+  Edge pend;
+  bool have = false;
+  int pend_hw = 1;
+  for (int q = 0; q < n; ++q) {
+    const gnnb_layer_desc& d = L[q];
+    if (d.kind == GNNB_CONV) {
+      if (flat) return fail(GNNB_E_INVALID, "layer %d: conv after flatten", q);
+      if (have) return fail(GNNB_E_INVALID, "layer %d: two linear maps without a ReLU between them", q);
+      if (d.c_in != C) return fail(GNNB_E_INVALID, "layer %d: conv expects %d input channels, graph has %d", q, d.c_in, C);
+      if (!d.weight || !d.bias) return fail(GNNB_E_INVALID, "layer %d: null weight/bias", q);
+      Edge e;
+      e.kind = 0;
+      e.c_in = C; e.h_in = H; e.w_in = W; e.c_out = d.c_out; e.kh = d.kh; e.kw = d.kw; e.stride = d.stride; e.pad = d.pad;
+      if (d.stride < 1 || d.kh < 1 || d.kw < 1) return fail(GNNB_E_INVALID, "layer %d: bad conv geometry", q);
+      if ((H + 2 * d.pad - d.kh) % d.stride || (W + 2 * d.pad - d.kw) % d.stride)
+        return fail(GNNB_E_INVALID, "layer %d: conv geometry leaves a remainder (conv_transpose2d of the reference would need output_padding)", q);
+      e.h_out = (H + 2 * d.pad - d.kh) / d.stride + 1;
+      e.w_out = (W + 2 * d.pad - d.kw) / d.stride + 1;
+      if (!conv_channels_ok(e.c_in) || !conv_channels_ok(e.c_out))
+        return fail(GNNB_E_INVALID, "layer %d: conv channel counts %d->%d not in {3,8,16,32}", q, e.c_in, e.c_out);
+      e.n_in = C * H * W;
+      e.n_out = e.c_out * e.h_out * e.w_out;
+      e.w.assign(d.weight, d.weight + (size_t)e.c_out * e.c_in * e.kh * e.kw);
+      e.b.assign(d.bias, d.bias + e.c_out);
+      C = e.c_out; H = e.h_out; W = e.w_out;
+      nflat = e.n_out;
+      pend_hw = H * W;
+      pend = e;
+      have = true;
+    } else if (d.kind == GNNB_LINEAR) {
+      if (have) return fail(GNNB_E_INVALID, "layer %d: two linear maps without a ReLU between them", q);
+      if (d.n_in != nflat) return fail(GNNB_E_INVALID, "layer %d: linear expects %d inputs, graph has %d", q, d.n_in, nflat);
+      if (!d.weight || !d.bias) return fail(GNNB_E_INVALID, "layer %d: null weight/bias", q);
+      Edge e;
+      e.kind = 1;
+      e.n_in = d.n_in; e.n_out = d.n_out;
+      e.c_in = e.h_in = e.w_in = e.c_out = e.h_out = e.w_out = e.kh = e.kw = e.stride = e.pad = 0;
+      e.w.assign(d.weight, d.weight + (size_t)d.n_out * d.n_in);
+      e.b.assign(d.bias, d.bias + d.n_out);
+      nflat = d.n_out;
+      flat = true;
+      pend_hw = 1;
+      pend = e;
+      have = true;
+    } else if (d.kind == GNNB_RELU) {
+      if (!have) return fail(GNNB_E_INVALID, "layer %d: ReLU without a preceding conv/linear", q);
+      h->N.push_back(nflat);
+      h->edges.push_back(pend);
+      h->relu_q.push_back(q);
+      h->hw.push_back(pend_hw);
+      have = false;
+    } else if (d.kind == GNNB_FLATTEN) {
+      flat = true;
+    } else {
+      return fail(GNNB_E_INVALID, "layer %d: unknown kind %d", q, d.kind);
+    }
+  }
+  if (have) return fail(GNNB_E_INVALID, "fixed layers must end after a ReLU (the property layer is passed per batch)");
+  const int Lr = (int)h->N.size() - 1;
+  if (Lr < 1 || Lr > 15) return fail(GNNB_E_INVALID, "unsupported number of ReLU layers %d", Lr);
+  h->N.push_back(1);   // property node
+  h->n_fixed = n;
+  h->R = 0;
+  for (int k = 1; k <= Lr; ++k) h->R += h->N[k];
+  h->dev.resize(Lr + 1);
+  for (int k = 1; k <= Lr; ++k) {
+    const Edge& e = h->edges[k];
+    DevEdge& d = h->dev[k];
+    if (int rc = upload(&d.bias, e.b.data(), e.b.size())) return rc;
+    if (e.kind == 0) {
+      std::vector<float> t(e.w.size());
+      pack_conv_fwd(t.data(), e);
+      if (int rc = upload(&d.w_fwd, t.data(), t.size())) return rc;
+      pack_conv_bwd(t.data(), e);
+      if (int rc = upload(&d.w_bwd, t.data(), t.size())) return rc;
+    } else {
+      d.mt_fwd = (e.n_out + 31) / 32;
+      d.ld_fwd = d.mt_fwd * 32;
+      d.mt_bwd = (e.n_in + 31) / 32;
+      std::vector<float> t((size_t)e.n_in * d.ld_fwd, 0.f);
+      for (int o = 0; o < e.n_out; ++o)
+        for (int i = 0; i < e.n_in; ++i) t[(size_t)i * d.ld_fwd + o] = e.w[(size_t)o * e.n_in + i];
+      if (int rc = upload(&d.w_fwd, t.data(), t.size())) return rc;
+      if (int rc = upload(&d.w_bwd, e.w.data(), e.w.size())) return rc;
+    }
+  }
+  h->bound = true;
+  return GNNB_OK;
+}
+
+extern "C" int gnnb_graph_info(const gnnb_t* h, int* n_graph, int* sizes, int* n_relu_total) {
+  if (!h || !h->bound) return fail(GNNB_E_STATE, "gnnb_graph_info: no network bound");
+  if (n_graph) *n_graph = (int)h->N.size();
+  if (sizes)
+    for (size_t k = 0; k < h->N.size(); ++k) sizes[k] = h->N[k];
+  if (n_relu_total) *n_relu_total = h->R;
+  return GNNB_OK;
+}
+
+// ---- workspace layout (float offsets, every region 256-B aligned) ----
+struct WsLayout {
+  std::vector<size_t> mu, Pf, Pb;
+  size_t nb = 0, Q = 0, total = 0;
+};
+static size_t align64(size_t nfloats) { return (nfloats + 63) & ~(size_t)63; }
+static size_t tiled_floats(size_t rows) { return ((rows + 31) / 32) * 2048; }
+static WsLayout ws_layout(const gnnb_t* h, int B) {
+  WsLayout w;
+  const int K = (int)h->N.size() - 1;
+  size_t off = 0;
+  w.mu.resize(K + 1);
+  for (int k = 0; k <= K; ++k) { w.mu[k] = off; off += align64((size_t)B * h->N[k] * 64); }
+  size_t maxn = 0;
+  for (int k = 0; k < K; ++k) maxn = std::max(maxn, (size_t)h->N[k]);
+  w.nb = off; off += align64((size_t)B * maxn * 64);
+  w.Pf.resize(K); w.Pb.resize(K);
+  for (int k = 1; k < K; ++k) { w.Pf[k] = off; off += tiled_floats((size_t)B * h->N[k]); }
+  for (int k = 1; k < K; ++k) { w.Pb[k] = off; off += tiled_floats((size_t)B * h->N[k]); }
+  w.Q = off; off += tiled_floats((size_t)B * h->N[0]);
+  w.total = off;
+  return w;
+}
+
+extern "C" size_t gnnb_workspace_bytes(const gnnb_t* h, int B) {
+  if (!h || !h->bound || B < 1) return 0;
+  return ws_layout(h, B).total * sizeof(float);
+}
+
+extern "C" int gnnb_mu_location(const gnnb_t* h, int B, int k, size_t* offset_bytes, size_t* n_floats) {
+  if (!h || !h->bound) return fail(GNNB_E_STATE, "gnnb_mu_location: no network bound");
+  if (k < 0 || k >= (int)h->N.size() || B < 1) return fail(GNNB_E_INVALID, "gnnb_mu_location: bad layer/batch");
+  WsLayout w = ws_layout(h, B);
+  if (offset_bytes) *offset_bytes = w.mu[k] * sizeof(float);
+  if (n_floats) *n_floats = (size_t)B * h->N[k] * 64;
+  return GNNB_OK;
+}
+
+extern "C" int gnnb_set_halfpass_limit(gnnb_t* h, int n) {
+  if (!h) return fail(GNNB_E_INVALID, "null handle");
+  h->halfpass_limit = n;
+  return GNNB_OK;
+}
+
+// ---- profiling ----
+extern "C" int gnnb_profile_enable(gnnb_t* h, int on) {
+  if (!h) return fail(GNNB_E_INVALID, "null handle");
+  h->prof = on != 0;
+  return GNNB_OK;
+}
+extern "C" int gnnb_profile_classes(void) { return PC_COUNT; }
+extern "C" const char* gnnb_profile_class_name(int cls) { return (cls >= 0 && cls < PC_COUNT) ? kProfNames[cls] : ""; }
+extern "C" int gnnb_profile_read(gnnb_t* h, double* total_ms, int64_t* launches, int n, int reset) {
+  if (!h) return fail(GNNB_E_INVALID, "null handle");
+  if (!h->pending.empty()) {
+    HIPCHK(hipStreamSynchronize(h->prof_stream));
+    for (auto& ev : h->pending) {
+      float ms = 0.f;
+      HIPCHK(hipEventElapsedTime(&ms, ev.a, ev.b));
+      h->prof_ms[ev.cls] += ms;
+      h->prof_n[ev.cls] += 1;
+      h->pool.push_back(ev.a);
+      h->pool.push_back(ev.b);
+    }
+    h->pending.clear();
+  }
+  for (int i = 0; i < n && i < PC_COUNT; ++i) {
+    if (total_ms) total_ms[i] = h->prof_ms[i];
+    if (launches) launches[i] = h->prof_n[i];
+  }
+  if (reset)
+    for (int i = 0; i < PC_COUNT; ++i) { h->prof_ms[i] = 0; h->prof_n[i] = 0; }
+  return GNNB_OK;
+}
+
+struct Launcher {
+  gnnb_t* h;
+  hipStream_t st;
+  int rc = 0;
+  hipEvent_t get_event() {
+    if (!h->pool.empty()) { hipEvent_t e = h->pool.back(); h->pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) rc = fail(GNNB_E_HIP, "hipEventCreate failed");
+    return e;
+  }
+  template <class F>
+  void run(int cls, F&& f) {
+    if (rc) return;
+    if (h->prof) {
+      gnnb_handle::Ev ev{cls, get_event(), get_event()};
+      if (rc) return;
+      (void)hipEventRecord(ev.a, st);
+      f();
+      (void)hipEventRecord(ev.b, st);
+      h->pending.push_back(ev);
+      h->prof_stream = st;
+    } else {
+      f();
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) rc = fail(GNNB_E_HIP, "launch of %s failed: %s", kProfNames[cls], hipGetErrorString(e));
+  }
+};
+
+static int mlp_grid(const gnnb_t* h, long ntiles) {
+  long g = (ntiles + WAVES_MLP - 1) / WAVES_MLP;
+  if (g > h->n_cu) g = h->n_cu;
+  return (int)(g < 1 ? 1 : g);
+}
+
+template <int C>
+static void launch_conv_fwd(const ConvArgs& a, hipStream_t st) {
+  const long waves = (long)a.B * a.H_out * a.W_out;
+  hipLaunchKernelGGL(k_conv_fwd<C>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
+}
+template <int C>
+static void launch_convT(const ConvArgs& a, hipStream_t st) {
+  const long waves = (long)a.B * a.H_in * a.W_in;
+  hipLaunchKernelGGL(k_convT_bwd<C>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
+}
+
+extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* scores, int32_t* decisions, int32_t* status,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+  if (!h || !in || !scores || !decisions || !status || !workspace) return fail(GNNB_E_INVALID, "gnnb_forward: null argument");
+  if (!h->bound) return fail(GNNB_E_STATE, "gnnb_forward: call gnnb_bind_network first");
+  if (B < 1) return fail(GNNB_E_INVALID, "gnnb_forward: B=%d", B);
+  const int K = (int)h->N.size() - 1, L = K - 1;
+  if (in->n_graph != K + 1 || in->n_relu != L || in->n_primal != h->n_fixed + 1)
+    return fail(GNNB_E_INVALID, "gnnb_forward: batch has %d graph layers / %d dual / %d primal tensors, network needs %d / %d / %d",
+                in->n_graph, in->n_relu, in->n_primal, K + 1, L, h->n_fixed + 1);
+  for (int k = 0; k <= K; ++k)
+    if (!in->lb[k] || !in->ub[k]) return fail(GNNB_E_INVALID, "gnnb_forward: null bounds pointer for graph layer %d", k);
+  for (int k = 0; k < L; ++k)
+    if (!in->dual[k]) return fail(GNNB_E_INVALID, "gnnb_forward: null dual pointer %d", k);
+  for (int m = 0; m < in->n_primal; ++m)
+    if (!in->primal[m]) return fail(GNNB_E_INVALID, "gnnb_forward: null primal pointer %d", m);
+  if (!in->x_lp || !in->prop_w || !in->prop_b || !in->mask) return fail(GNNB_E_INVALID, "gnnb_forward: null input pointer");
+  if ((long)B * h->N[0] * 64 >= (1L << 40)) return fail(GNNB_E_INVALID, "gnnb_forward: batch too large");
+  const WsLayout w = ws_layout(h, B);
+  if (workspace_bytes < w.total * sizeof(float))
+    return fail(GNNB_E_NOMEM, "gnnb_forward: workspace %zu bytes < required %zu", workspace_bytes, w.total * sizeof(float));
+  float* ws = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  Launcher lz{h, st};
+  auto mu = [&](int k) { return ws + w.mu[k]; };
+  float* nb = ws + w.nb;
+
+  HIPCHK(hipMemsetAsync(status, 0, sizeof(int32_t), st));
+
+  // ---- once per forward: input embedding and the embedding-independent feature chains ----
+  {
+    const long G = (long)B * h->N[0], nt = (G + 31) / 32;
+    EmbedArgs a{h->d_pack[PK_EMBED], in->lb[0], in->x_lp, in->ub[0], mu(0), G, nt};
+    lz.run(PC_EMBED, [&] { hipLaunchKernelGGL(k_embed, dim3(mlp_grid(h, nt)), dim3(WG_MLP), PackEmbed::FLOATS * 4, st, a); });
+  }
+  const int total_halfpasses = 2 * h->T;
+  const int limit = h->halfpass_limit > 0 ? std::min(h->halfpass_limit, total_halfpasses) : total_halfpasses;
+  const bool debug_full = h->halfpass_limit > 0;   // with a limit set every input-layer update is executed too
+  for (int k = 1; k <= L; ++k) {
+    const long G = (long)B * h->N[k], nt = (G + 31) / 32;
+    const int q = h->relu_q[k];
+    PreArgs a{nullptr, in->lb[k], in->ub[k], in->dual[k - 1], in->primal[q - 1], in->primal[q], h->dev[k].bias,
+              nullptr, G, nt, h->N[k], h->hw[k]};
+    a.pack = h->d_pack[PK_PRE_FWD];
+    a.P = ws + w.Pf[k];
+    lz.run(PC_PRE_FWD, [&] { hipLaunchKernelGGL(k_pre_fwd, dim3(mlp_grid(h, nt)), dim3(WG_MLP), PackPreFwd::FLOATS * 4, st, a); });
+    if (limit >= 2) {
+      a.pack = h->d_pack[PK_PRE_BWD];
+      a.P = ws + w.Pb[k];
+      lz.run(PC_PRE_BWD, [&] { hipLaunchKernelGGL(k_pre_bwd, dim3(mlp_grid(h, nt)), dim3(WG_MLP), PackPreBwd::FLOATS * 4, st, a); });
+    }
+  }
+  const bool need_inp = (limit >= 2) && (h->T > 1 || debug_full);
+  if (need_inp) {
+    const long G = (long)B * h->N[0], nt = (G + 31) / 32;
+    PreArgs a{h->d_pack[PK_PRE_INP], in->lb[0], in->ub[0], nullptr, nullptr, nullptr, nullptr, ws + w.Q, G, nt, h->N[0], 1};
+    lz.run(PC_PRE_INP, [&] { hipLaunchKernelGGL(k_pre_inp, dim3(mlp_grid(h, nt)), dim3(WG_MLP), PackPreInp::FLOATS * 4, st, a); });
+  }
+
+  auto conv_args = [&](const Edge& e, const float* src, float* dst, const float* wt, int normalise) {
+    return ConvArgs{src, dst, wt, B, e.c_in, e.h_in, e.w_in, e.c_out, e.h_out, e.w_out, e.kh, e.kw, e.stride, e.pad, normalise};
+  };
+  // nb <- A_k mu[k-1]
+  auto agg_fwd = [&](int k) {
+    const Edge& e = h->edges[k];
+    if (e.kind == 0) {
+      ConvArgs a = conv_args(e, mu(k - 1), nb, h->dev[k].w_fwd, 0);
+      lz.run(PC_CONV_FWD, [&] {
+        switch (e.c_out) {
+          case 3: launch_conv_fwd<3>(a, st); break;
+          case 8: launch_conv_fwd<8>(a, st); break;
+          case 16: launch_conv_fwd<16>(a, st); break;
+          default: launch_conv_fwd<32>(a, st); break;
+        }
+      });
+    } else {
+      DenseArgs a{h->dev[k].w_fwd, mu(k - 1), nb, B, e.n_in, e.n_out, h->dev[k].ld_fwd, h->dev[k].mt_fwd};
+      const long waves = (long)B * a.MT * 2;
+      lz.run(PC_DENSE_AGG, [&] { hipLaunchKernelGGL(k_dense_agg, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a); });
+    }
+  };
+  // nb <- A_{k+1}^T mu[k+1]  (k+1 <= L), conv case divided by the tap count when `normalise`
+  auto agg_bwd = [&](int k, int normalise) {
+    const Edge& e = h->edges[k + 1];
+    if (e.kind == 0) {
+      ConvArgs a = conv_args(e, mu(k + 1), nb, h->dev[k + 1].w_bwd, normalise);
+      lz.run(PC_CONVT_BWD, [&] {
+        switch (e.c_in) {
+          case 3: launch_convT<3>(a, st); break;
+          case 8: launch_convT<8>(a, st); break;
+          case 16: launch_convT<16>(a, st); break;
+          default: launch_convT<32>(a, st); break;
+        }
+      });
+    } else {
+      DenseArgs a{h->dev[k + 1].w_bwd, mu(k + 1), nb, B, e.n_out, e.n_in, e.n_in, h->dev[k + 1].mt_bwd};
+      const long waves = (long)B * a.MT * 2;
+      lz.run(PC_DENSE_AGG, [&] { hipLaunchKernelGGL(k_dense_agg, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a); });
+    }
+  };
+  auto node_update = [&](int k, bool fwd) {
+    const long G = (long)B * h->N[k], nt = (G + 31) / 32;
+    UpdArgs a{h->d_pack[fwd ? PK_UPD_FWD : PK_UPD_BWD], in->lb[k], in->ub[k], nb, ws + (fwd ? w.Pf[k] : w.Pb[k]), mu(k), status, G, nt};
+    lz.run(PC_NODE_UPDATE, [&] { hipLaunchKernelGGL(k_node_update, dim3(mlp_grid(h, nt)), dim3(WG_MLP), PackUpd::FLOATS * 4, st, a); });
+  };
+
+  int done = 0;
+  for (int t = 0; t < h->T && done < limit; ++t) {
+    // forward sweep (graph_conv.py:107-192) + property node (:194-210)
+    for (int k = 1; k <= L; ++k) {
+      agg_fwd(k);
+      node_update(k, true);
+    }
+    {
+      PropArgs a{h->d_pack[PK_PROP], mu(L), in->prop_w, in->prop_b, in->lb[K], in->ub[K], in->primal[in->n_primal - 1], mu(K), B, h->N[L]};
+      lz.run(PC_PROP_FWD, [&] { hipLaunchKernelGGL(k_prop_fwd, dim3((B + 3) / 4), dim3(256), 0, st, a); });
+    }
+    if (++done >= limit) break;
+    // backward sweep (:222-350), Gauss-Seidel order: layer k reads the already-updated mu[k+1]
+    for (int k = L; k >= 1; --k) {
+      if (k == L) {
+        const long rows = (long)B * h->N[L];
+        const float* pw = in->prop_w;
+        const float* mk = mu(K);
+        const int nl = h->N[L];
+        lz.run(PC_PROP_BWD_NB, [&] { hipLaunchKernelGGL(k_prop_bwd_nb, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, pw, mk, nb, rows, nl); });
+      } else {
+        agg_bwd(k, 1);
+      }
+      node_update(k, false);
+    }
+    // input layer (:360-385): its last-round result is never read, so it only runs when another round follows
+    if (t < h->T - 1 || debug_full) {
+      agg_bwd(0, 0);
+      const long G = (long)B * h->N[0], nt = (G + 31) / 32;
+      UpdInpArgs a{h->d_pack[PK_UPD_INP], nb, ws + w.Q, mu(0), G, nt};
+      lz.run(PC_INPUT_UPDATE, [&] { hipLaunchKernelGGL(k_input_update, dim3(mlp_grid(h, nt)), dim3(WG_MLP), PackUpdInp::FLOATS * 4, st, a); });
+    }
+    ++done;
+  }
+
+  // scores (graph_conv.py:442-450) and decision (graph_score.py:41-47)
+  int off = 0;
+  ArgmaxArgs am{scores, decisions, B, h->R, L, {0}};
+  for (int k = 1; k <= L; ++k) {
+    const long G = (long)B * h->N[k], nt = (G + 31) / 32;
+    ScoreArgs a{h->d_pack[PK_SCORE], mu(k), in->mask, scores, G, nt, h->N[k], h->R, off};
+    lz.run(PC_SCORE, [&] { hipLaunchKernelGGL(k_score, dim3(mlp_grid(h, nt)), dim3(WG_MLP), PackScore::FLOATS * 4, st, a); });
+    off += h->N[k];
+    am.cum[k - 1] = off;
+  }
+  lz.run(PC_ARGMAX, [&] { hipLaunchKernelGGL(k_argmax, dim3(B), dim3(256), 0, st, am); });
+  return lz.rc;
+}

@@ -1,0 +1,238 @@
+"""Host plumbing between the reference-shaped Python surface and the C-ABI (include/gnnb.h).
+
+``ScorerEngine`` owns one gnnb handle: the packed GNN weights, the bound verified
+network and a workspace per batch size.  Tensors are only carriers of device
+memory here (``data_ptr()``); all arithmetic of the hot path runs in libgnnb.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from .plnn.modules import Flatten
+
+
+def _is_flatten(layer):
+    # the caller may hand over the reference's own plnn.modules.Flatten instances
+    return isinstance(layer, Flatten) or type(layer).__name__ == "Flatten"
+
+
+def state_blob(state_dict):
+    """The checkpoint's 52 tensors concatenated in state-dict order (host fp32 array)."""
+    parts = [np.asarray(v.detach().cpu().float().numpy() if torch.is_tensor(v) else v, dtype=np.float32).reshape(-1)
+             for v in state_dict.values()]
+    return np.ascontiguousarray(np.concatenate(parts))
+
+
+class ForwardResult:
+    """Device outputs of one batched forward."""
+    __slots__ = ("scores", "decisions", "status", "masks")
+
+    def __init__(self, scores, decisions, status, masks):
+        self.scores, self.decisions, self.status, self.masks = scores, decisions, status, masks
+
+    def check(self):
+        """Synchronises.  Raises like the reference would stop (it enters pdb on NaN embeddings,
+        graph_conv.py:184-186, :339-341)."""
+        if int(self.status.item()) & 1:
+            msg = "mu contains nan"
+            print(f"[gnn_branching_amd] {msg}", flush=True)
+            raise FloatingPointError(msg)
+        return self
+
+    def ragged(self):
+        """list of B 1-D tensors: the scores of the ambiguous ReLUs of each sample (graph_conv.py:470)."""
+        return [self.scores[b][self.masks[b] != 0] for b in range(self.scores.shape[0])]
+
+
+class ScorerEngine:
+    def __init__(self, state_dict, T=2, p=64, device=None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("gnn_branching_amd needs an AMD GPU (MI355X / gfx950); there is no CPU path")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.T, self.p = T, p
+        blob = state_blob(state_dict)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.gnnb_create(C.byref(h), blob.ctypes.data_as(C.c_void_p), blob.size, T, p), "gnnb_create")
+        self.h = h
+        self._net_key = None
+        self._net_keepalive = None
+        self.sizes = None
+        self.R = 0
+        self._ws = {}
+        self._prop_cache = {}
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            try:
+                self.lib.gnnb_destroy(h)
+            except Exception:
+                pass
+
+    # ---- verified network -------------------------------------------------------------------
+    def bind(self, fixed_layers, input_shape):
+        key = (tuple(id(l) for l in fixed_layers),
+               tuple((l.weight.data_ptr(), l.weight._version) for l in fixed_layers if hasattr(l, "weight")),
+               tuple(input_shape))
+        if key == self._net_key:
+            return
+        descs = (_lib.LayerDesc * len(fixed_layers))()
+        keep = []
+        for d, l in zip(descs, fixed_layers):
+            if type(l) is nn.Conv2d:
+                if l.dilation != (1, 1) or l.groups != 1 or l.stride[0] != l.stride[1] or l.padding[0] != l.padding[1]:
+                    raise NotImplementedError(f"unsupported conv geometry: {l}")
+                w = np.ascontiguousarray(l.weight.detach().cpu().float().numpy())
+                b = np.ascontiguousarray(l.bias.detach().cpu().float().numpy())
+                keep += [w, b]
+                d.kind, d.c_in, d.c_out = _lib.GNNB_CONV, l.in_channels, l.out_channels
+                d.kh, d.kw, d.stride, d.pad = l.kernel_size[0], l.kernel_size[1], l.stride[0], l.padding[0]
+                d.weight, d.bias = w.ctypes.data, b.ctypes.data
+            elif type(l) is nn.Linear:
+                w = np.ascontiguousarray(l.weight.detach().cpu().float().numpy())
+                b = np.ascontiguousarray(l.bias.detach().cpu().float().numpy())
+                keep += [w, b]
+                d.kind, d.n_in, d.n_out = _lib.GNNB_LINEAR, l.in_features, l.out_features
+                d.weight, d.bias = w.ctypes.data, b.ctypes.data
+            elif type(l) is nn.ReLU:
+                d.kind = _lib.GNNB_RELU
+            elif _is_flatten(l):
+                d.kind = _lib.GNNB_FLATTEN
+            else:
+                raise NotImplementedError(type(l))        # reference: graph_conv.py:191-192
+        c0, h0, w0 = (tuple(input_shape) + (1, 1))[:3]
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.gnnb_bind_network(self.h, descs, len(fixed_layers), c0, h0, w0), "gnnb_bind_network")
+        ng, R = C.c_int(), C.c_int()
+        _lib.check(self.lib.gnnb_graph_info(self.h, C.byref(ng), None, C.byref(R)), "gnnb_graph_info")
+        sizes = (C.c_int * ng.value)()
+        _lib.check(self.lib.gnnb_graph_info(self.h, C.byref(ng), sizes, C.byref(R)), "gnnb_graph_info")
+        self.sizes, self.R = list(sizes), R.value
+        self._net_key = key
+        self._net_keepalive = list(fixed_layers)
+        self._ws.clear()
+
+    # ---- one forward ------------------------------------------------------------------------
+    def _dev(self, t):
+        if not torch.is_tensor(t):
+            t = torch.tensor(t, dtype=torch.float32)       # python lists of LP primals (graph_score.py:30)
+        return t.to(device=self.device, dtype=torch.float32, non_blocking=True).contiguous()
+
+    def _prop(self, prop_layers):
+        """(B, N_L) weights and (B,) biases of the per-sample property layers (graph_conv.py:196-199)."""
+        key = tuple(id(l) for l in prop_layers)
+        vkey = tuple((l.weight.data_ptr(), l.weight._version) for l in {id(l): l for l in prop_layers}.values())
+        hit = self._prop_cache.get(key)
+        if hit is not None and hit[0] == vkey:
+            return hit[1], hit[2]
+        uniq, index = {}, []
+        for l in prop_layers:
+            if id(l) not in uniq:
+                if l.weight.shape[0] != 1:
+                    raise NotImplementedError("the property layer must be Linear(., 1)")   # graph_conv.py:80
+                uniq[id(l)] = (len(uniq), l)
+            index.append(uniq[id(l)][0])
+        w = torch.stack([l.weight.detach()[0].float() for _, l in uniq.values()]).to(self.device)
+        b = torch.stack([l.bias.detach()[0].float() for _, l in uniq.values()]).to(self.device)
+        idx = torch.tensor(index, device=self.device)
+        pw, pb = w[idx].contiguous(), b[idx].contiguous()
+        if len(self._prop_cache) > 8:
+            self._prop_cache.clear()
+        self._prop_cache[key] = (vkey, pw, pb, list(prop_layers))
+        return pw, pb
+
+    def workspace(self, B):
+        ws = self._ws.get(B)
+        if ws is None:
+            n = self.lib.gnnb_workspace_bytes(self.h, B)
+            if n == 0:
+                raise RuntimeError("gnnb_workspace_bytes returned 0 (no network bound?)")
+            ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+            if len(self._ws) > 4:
+                self._ws.clear()
+            self._ws[B] = ws
+        return ws
+
+    def forward(self, lower_bounds_all, upper_bounds_all, dual_vars, primals, primal_inputs, layers, masks):
+        fixed = layers["fixed_layers"]
+        self.bind(fixed, tuple(lower_bounds_all[0].shape[1:]))
+        B = int(lower_bounds_all[0].shape[0])
+        if len(layers["prop_layers"]) != B:
+            raise ValueError(f"{len(layers['prop_layers'])} property layers for a batch of {B}")
+        lbs = [self._dev(t) for t in lower_bounds_all]
+        ubs = [self._dev(t) for t in upper_bounds_all]
+        duals = [self._dev(t) for t in dual_vars]
+        prim = [self._dev(t) for t in primals]
+        x_lp = self._dev(primal_inputs)
+        mask = self._dev(masks)
+        ng = len(self.sizes)
+        if len(lbs) != ng or len(ubs) != ng:
+            raise ValueError(f"{len(lbs)} bound tensors, layer graph has {ng} layers")
+        for k, (l, u) in enumerate(zip(lbs, ubs)):
+            if l.numel() != B * self.sizes[k] or u.numel() != B * self.sizes[k]:
+                raise ValueError(f"bounds of graph layer {k}: {tuple(l.shape)} does not hold {B}x{self.sizes[k]} values")
+        for k, d in enumerate(duals):
+            if d.numel() != B * self.sizes[k + 1] * 3:
+                raise ValueError(f"dual_vars[{k}] has {tuple(d.shape)}, expected ({B * self.sizes[k + 1]}, 3)")
+        if mask.numel() != B * self.R:
+            raise ValueError(f"masks has {tuple(mask.shape)}, expected ({B}, {self.R})")
+        if x_lp.numel() != B * self.sizes[0]:
+            raise ValueError("primal_inputs has the wrong size")
+        self._check_primals(fixed, prim, B)
+        pw, pb = self._prop(layers["prop_layers"])
+
+        def table(ts):
+            return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        t_lb, t_ub, t_du, t_pr = table(lbs), table(ubs), table(duals), table(prim)
+        batch = _lib.Batch(t_lb, t_ub, t_du, t_pr, x_lp.data_ptr(), pw.data_ptr(), pb.data_ptr(), mask.data_ptr(),
+                           len(lbs), len(duals), len(prim))
+        scores = torch.empty(B, self.R, dtype=torch.float32, device=self.device)
+        dec = torch.empty(B, 2, dtype=torch.int32, device=self.device)
+        status = torch.empty(1, dtype=torch.int32, device=self.device)
+        ws = self.workspace(B)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            rc = self.lib.gnnb_forward(self.h, C.byref(batch), B, scores.data_ptr(), dec.data_ptr(), status.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), C.c_void_p(stream))
+        _lib.check(rc, "gnnb_forward")
+        # inputs were consumed asynchronously on the current stream; torch's caching allocator is
+        # stream-ordered, so letting the temporaries go here is safe
+        return ForwardResult(scores, dec, status, mask.view(B, self.R))
+
+    def _check_primals(self, fixed, prim, B):
+        if len(prim) != len(fixed) + 1:
+            raise ValueError(f"{len(prim)} primal tensors for {len(fixed) + 1} network layers")
+        k = 0
+        for q, l in enumerate(fixed):
+            if type(l) is nn.ReLU:
+                k += 1
+                n = B * self.sizes[k]
+                if prim[q - 1].numel() != n or prim[q].numel() != n:
+                    raise ValueError(f"primals[{q - 1}], primals[{q}] must hold {n} values each")
+        if prim[-1].numel() != B:
+            raise ValueError("primals[-1] must hold one value per subproblem")
+
+    # ---- inspection (tests / bench) ---------------------------------------------------------
+    def mu(self, B, k):
+        """View of embedding mu[k] (B, N_k, p) inside the workspace of the last forward at batch B."""
+        off, n = C.c_size_t(), C.c_size_t()
+        _lib.check(self.lib.gnnb_mu_location(self.h, B, k, C.byref(off), C.byref(n)), "gnnb_mu_location")
+        ws = self.workspace(B)
+        return ws[off.value:off.value + 4 * n.value].view(torch.float32).view(B, self.sizes[k], self.p)
+
+    def set_halfpass_limit(self, n):
+        _lib.check(self.lib.gnnb_set_halfpass_limit(self.h, n), "gnnb_set_halfpass_limit")
+
+    def profile_enable(self, on):
+        _lib.check(self.lib.gnnb_profile_enable(self.h, int(on)), "gnnb_profile_enable")
+
+    def profile_read(self, reset=True):
+        n = self.lib.gnnb_profile_classes()
+        ms, cnt = (C.c_double * n)(), (C.c_int64 * n)()
+        _lib.check(self.lib.gnnb_profile_read(self.h, ms, cnt, n, int(reset)), "gnnb_profile_read")
+        return {self.lib.gnnb_profile_class_name(i).decode(): (ms[i], cnt[i]) for i in range(n)}

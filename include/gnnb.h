@@ -1,0 +1,119 @@
+/*
+ * gnnb.h -- C-ABI of libgnnb.so: the MI355X (gfx950) GNN branching-score forward pass.
+ *
+ * The reference (oval-group/GNN_branching) is pure Python/PyTorch and has NO native
+ * interface for this path; the entry points below are what a binding for the hot path
+ * would call.  Each one cites the reference code it replaces.  Plain pointers and sizes
+ * only -- no torch types.  The Python host side (gnn_branching_amd/graphnet) binds them
+ * with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions: every function returns 0 on success or a negative GNNB_E_* code and never
+ * throws; gnnb_last_error() returns a thread-local message for the last failure.
+ * gnnb_forward is stream-ordered and asynchronous, allocates nothing and never
+ * synchronises; one handle per host thread.  No HIP call happens at library load time
+ * (the reference creates its GPU context inside a forked child: experiments/bab_mip.py:244-249).
+ */
+#ifndef GNNB_H
+#define GNNB_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNNB_ABI_VERSION 1
+
+enum {
+  GNNB_OK = 0,
+  GNNB_E_INVALID = -1,   /* bad argument / unsupported shape */
+  GNNB_E_HIP = -2,       /* a HIP runtime call failed */
+  GNNB_E_STATE = -3,     /* call order (e.g. forward before bind_network) */
+  GNNB_E_NOMEM = -4      /* workspace too small */
+};
+
+/* layer kinds of the verified network's layer list (reference graph_conv.py:110,130,139,188
+ * dispatches on type(layer) is nn.Conv2d / nn.Linear / nn.ReLU / Flatten) */
+enum { GNNB_CONV = 0, GNNB_LINEAR = 1, GNNB_RELU = 2, GNNB_FLATTEN = 3 };
+
+typedef struct gnnb_handle gnnb_t;
+
+/* One entry of layers['fixed_layers'] (reference plnn/relu_conv_gnnkwthreshold.py:111-112).
+ * weight/bias are HOST pointers in torch's row-major layout (conv: [c_out][c_in][kh][kw],
+ * linear: [n_out][n_in]); they are copied, the caller keeps ownership. */
+typedef struct {
+  int32_t kind;
+  int32_t c_in, c_out, kh, kw, stride, pad;   /* GNNB_CONV  (square stride/pad, dilation 1, groups 1) */
+  int32_t n_in, n_out;                         /* GNNB_LINEAR */
+  const float* weight;
+  const float* bias;
+} gnnb_layer_desc;
+
+/* One batch of B subproblems = the tensor arguments of GraphNet.forward
+ * (reference graph_conv.py:479) as DEVICE pointers to contiguous fp32 arrays.
+ * The pointer tables themselves (lb, ub, dual, primal) are HOST arrays. */
+typedef struct {
+  const float* const* lb;      /* n_graph ptrs: lower_bounds_all[k], (B, N_k)                */
+  const float* const* ub;      /* n_graph ptrs: upper_bounds_all[k]                          */
+  const float* const* dual;    /* n_relu  ptrs: dual_vars[j], (B*N_{j+1}, 3)                 */
+  const float* const* primal;  /* n_primal ptrs: primals[m], (B*n_m), one per net.layers[m]  */
+  const float* x_lp;           /* primal_inputs (B, N_0)                                     */
+  const float* prop_w;         /* layers['prop_layers'][b].weight, (B, N_L)                  */
+  const float* prop_b;         /* layers['prop_layers'][b].bias,   (B)                       */
+  const float* mask;           /* masks (B, R): 1.0 where the BaB mask is -1                 */
+  int32_t n_graph, n_relu, n_primal;
+} gnnb_batch;
+
+/* GraphNet(T, p) + load_state_dict (reference graph_score.py:9-13, graph_conv.py:22-74,
+ * :421-432): w_blob = the 52 tensors of the checkpoint concatenated in state-dict order
+ * (weight (out,in) row-major, then bias), 117 825 floats for T=2, p=64.  HOST pointer. */
+int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, int T, int p);
+
+/* The verified network's fixed layers, i.e. the static part of the `layers` argument
+ * (reference relu_conv_gnnkwthreshold.py:110-113; graph structure walked at
+ * graph_conv.py:107-192 and :222-385).  (c0,h0,w0) = input tensor shape. */
+int gnnb_bind_network(gnnb_t* h, const gnnb_layer_desc* layers, int n_layers, int c0, int h0, int w0);
+
+/* Sizes of the bound layer graph: n_graph = L+2 graph layers, sizes[k] = N_k, *n_relu_total = R. */
+int gnnb_graph_info(const gnnb_t* h, int* n_graph, int* sizes /* >= n_graph ints or NULL */, int* n_relu_total);
+
+/* Bytes of device scratch gnnb_forward needs for a batch of B (embeddings `mu`, init_mu
+ * graph_conv.py:487-496, plus aggregation and cached feature terms). */
+size_t gnnb_workspace_bytes(const gnnb_t* h, int B);
+
+/* GraphNet.forward + the argmax of GraphChoice.decision (reference graph_conv.py:479-483,
+ * graph_score.py:32-47).  scores_padded: device (B, R) fp32, score of every ambiguous ReLU in
+ * flat ReLU order, -inf elsewhere (the reference returns the ragged list of graph_conv.py:470).
+ * decisions: device (B, 2) int32 [dec_lay, dec_idx], first maximal score; [-1,-1] if a sample
+ * has no ambiguous ReLU.  status: device int32[1], bit 0 set if an embedding was NaN
+ * (reference enters pdb, graph_conv.py:184-186, :339-341).  stream: hipStream_t (NULL = default). */
+int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* scores_padded, int32_t* decisions,
+                 int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
+
+int gnnb_destroy(gnnb_t* h);
+
+const char* gnnb_last_error(void);
+int gnnb_abi_version(void);
+
+/* ---- inspection hooks used by the parity tests and bench.py (not needed by a caller) ---- */
+
+/* Location of embedding mu[k] inside the workspace: row-major (B, N_k, p) fp32. */
+int gnnb_mu_location(const gnnb_t* h, int B, int k, size_t* offset_bytes, size_t* n_floats);
+
+/* Stop after `n` half-passes (1 = round-0 forward sweep, 2 = + round-0 backward sweep, ...;
+ * <= 0 = run everything).  With a limit set the scores are computed from the embeddings so far. */
+int gnnb_set_halfpass_limit(gnnb_t* h, int n);
+
+/* Per-kernel-class timing with HIP events recorded on the launch stream.  When enabled every
+ * launch in gnnb_forward is bracketed by a pair of events; gnnb_profile_read synchronises the
+ * stream, accumulates and returns per class: total ms and launch count since the last reset. */
+int gnnb_profile_enable(gnnb_t* h, int on);
+int gnnb_profile_classes(void);                          /* number of classes */
+const char* gnnb_profile_class_name(int cls);            /* kernel (class) name */
+int gnnb_profile_read(gnnb_t* h, double* total_ms, int64_t* launches, int n, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNNB_H */

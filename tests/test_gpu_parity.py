@@ -1,0 +1,144 @@
+"""-m gpu: the HIP path (through the C-ABI) against the golden vectors of the reference and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from tests.common import FAMILIES, GOLDEN_CASES, SCORE_ATOL, STAGES, load_golden, relu_sizes, state_of
+
+pytestmark = pytest.mark.gpu
+
+
+def make_model(fam):
+    from gnn_branching_amd.graphnet.graph_conv import GraphNet
+    m = GraphNet(2, 64)
+    m.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in state_of(fam).items()})
+    return m.eval()
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+@pytest.mark.parametrize("fam", FAMILIES)
+def test_scores_and_decisions_match_reference(case, fam):
+    g, batch = load_golden(case)
+    model = make_model(fam)
+    with torch.no_grad():
+        res = model.forward_device(*batch.forward_args()).check()
+    got = res.scores.cpu().numpy()
+    want = g[f"{fam}_scores"]
+    assert np.array_equal(np.isinf(got), np.isinf(want))
+    fin = np.isfinite(want)
+    err = np.abs(got[fin] - want[fin]).max()
+    print(f"{case} {fam}: max|score - reference| = {err:.3e}")
+    assert err <= SCORE_ATOL
+    assert res.decisions.cpu().tolist() == g[f"{fam}_decisions"].tolist()
+    # ragged list, as the reference returns it
+    with torch.no_grad():
+        rag = model(*batch.forward_args())
+    for b, s in enumerate(rag):
+        np.testing.assert_allclose(s.cpu().numpy(), want[b][fin[b]], atol=SCORE_ATOL)
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+@pytest.mark.parametrize("fam", FAMILIES)
+def test_embeddings_after_every_halfpass(case, fam):
+    """mu after r0_fwd, r0_bwd, r1_fwd, r1_bwd against rows sampled from the reference's embeddings."""
+    g, batch = load_golden(case)
+    model = make_model(fam)
+    eng = model.engine()
+    stride = int(g["sample_stride"])
+    B = batch.batch_size
+    try:
+        for n, st in enumerate(STAGES, 1):
+            eng.set_halfpass_limit(n)
+            with torch.no_grad():
+                model.forward_device(*batch.forward_args()).check()
+            for k in range(len(batch.lower_bounds_all)):
+                rows = g[f"{fam}_{st}_mu{k}_rows"]
+                got = eng.mu(B, k)[:, ::stride, :].cpu().numpy()
+                scale = max(1.0, float(np.abs(rows).max()))
+                err = np.abs(got - rows).max()
+                assert err <= 2e-5 * scale, (st, k, err)
+                want_abs = g[f"{fam}_{st}_mu{k}_sum"][1]
+                got_abs = eng.mu(B, k).double().abs().sum().item()
+                assert abs(got_abs - want_abs) <= 1e-4 * max(want_abs, 1.0), (st, k, got_abs, want_abs)
+    finally:
+        eng.set_halfpass_limit(0)
+
+
+def test_graphchoice_decision_surface():
+    """The reference's B=1 call surface: python-list primals, {-1,0,1} masks, CPU tensors in."""
+    import os
+    from gnn_branching_amd.graphnet.graph_score import GraphChoice
+    g, batch = load_golden("cifar_base_kw_B3")
+    ckpt = os.path.join(os.path.dirname(__file__), "..", "models", "cifar_trained_gnn",
+                        "best_snapshot_None_0_val_acc_0.826_loss_val_0.1036_epoch_57.pt")
+    for b in range(batch.batch_size):
+        one = batch.slice(b, b + 1)
+        init_mask = [m[0] for m in one.bab_masks]
+        gc = GraphChoice(init_mask, ckpt)
+        lb_before = [t.clone() for t in one.lower_bounds_all]
+        dec = gc.decision(one.lower_bounds_all, one.upper_bounds_all, one.dual_vars, one.primal_inputs,
+                          [p.tolist() for p in one.primals], one.layers, init_mask)
+        assert dec == g["shipped_decisions"][b].tolist()
+        assert all(isinstance(v, int) for v in dec)
+        for t0, t1 in zip(lb_before, one.lower_bounds_all):      # caller's tensors untouched
+            assert torch.equal(t0, t1)
+
+
+def test_batched_equals_single_and_permutation():
+    """Subproblems are independent: batched == per-sample, and permuting the batch permutes the result."""
+    from gnn_branching_amd import synth
+    model = make_model("random")
+    batch = synth.make_batch("cifar_base_kw", 5, seed=11, props=[(3, 5), (1, 2), (3, 5), (0, 9), (4, 4 - 1)])
+    with torch.no_grad():
+        full = model.forward_device(*batch.forward_args()).check()
+        s_full = full.scores.cpu()
+        for b in range(5):
+            one = model.forward_device(*batch.slice(b, b + 1).forward_args()).check()
+            assert torch.equal(one.scores.cpu()[0], s_full[b])        # same kernels, same order: bit-exact
+            assert one.decisions.cpu()[0].tolist() == full.decisions.cpu()[b].tolist()
+
+
+def test_masks_all_and_none():
+    """Edge cases: nothing undecided -> all -inf and decision [-1,-1]; everything marked undecided."""
+    from gnn_branching_amd import synth
+    from oracle import gnn_oracle
+    model = make_model("random")
+    batch = synth.make_batch("cifar_base_kw", 2, seed=3)
+    args = list(batch.forward_args())
+    args[6] = torch.zeros_like(batch.masks)
+    with torch.no_grad():
+        res = model.forward_device(*args).check()
+    assert torch.isinf(res.scores).all() and res.decisions.cpu().tolist() == [[-1, -1], [-1, -1]]
+    assert [int(s.numel()) for s in res.ragged()] == [0, 0]
+    args[6] = torch.ones_like(batch.masks)
+    with torch.no_grad():
+        res = model.forward_device(*args).check()
+        want = gnn_oracle.oracle_forward(state_of("random"), *args)
+    got = res.scores.cpu()
+    for b in range(2):
+        np.testing.assert_allclose(got[b].numpy(), want[b].numpy(), atol=SCORE_ATOL)
+
+
+def test_nan_is_reported():
+    """lb = ub = 0 makes compute_ratio 0/0 (graph_conv.py:502); the reference drops into pdb, we raise."""
+    from gnn_branching_amd import synth
+    model = make_model("random")
+    batch = synth.make_batch("cifar_base_kw", 1, seed=5)
+    batch.lower_bounds_all[1].view(-1)[7] = 0.0
+    batch.upper_bounds_all[1].view(-1)[7] = 0.0
+    with torch.no_grad(), pytest.raises(FloatingPointError):
+        model(*batch.forward_args())
+
+
+def test_bad_inputs_raise():
+    from gnn_branching_amd import synth
+    model = make_model("random")
+    batch = synth.make_batch("cifar_base_kw", 2, seed=5)
+    args = list(batch.forward_args())
+    args[2] = args[2][:-1]                      # one dual tensor short
+    with pytest.raises((ValueError, RuntimeError)):
+        model.forward_device(*args)
+    args = list(batch.forward_args())
+    args[6] = args[6][:, :-1]                   # ragged mask
+    with pytest.raises(ValueError):
+        model.forward_device(*args)

@@ -1,0 +1,177 @@
+"""Host logic on the CPU: the operand-order weight packs of gnnb_pack.h, checked by emulating the
+gfx950 MFMA lane maps (v_mfma_f32_32x32x2_f32) in numpy against plain matmuls."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.common import random_state
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gnn_branching_amd", "csrc")
+LANES = np.arange(64)
+J, H = LANES & 31, LANES >> 5
+
+
+@pytest.fixture(scope="module")
+def packlib(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("pack") / "libgnnb_packtest.so")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-o", so,
+                           os.path.join(CSRC, "gnnb_pack_test.cpp")])
+    lib = C.CDLL(so)
+    lib.gnnb_pt_blob_floats.restype = C.c_size_t
+    lib.gnnb_pt_pack.restype = C.c_size_t
+    lib.gnnb_pt_pack.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    return lib
+
+
+@pytest.fixture(scope="module")
+def packs(packlib):
+    sd = random_state()
+    blob = np.concatenate([np.asarray(v, np.float32).reshape(-1) for v in sd.values()])
+    assert blob.size == packlib.gnnb_pt_blob_floats() == 117825
+    out = {}
+    for which, name in enumerate(["embed", "pre_fwd", "upd_fwd", "pre_bwd", "upd_bwd", "pre_inp", "upd_inp", "score", "prop"]):
+        n = packlib.gnnb_pt_pack(blob.ctypes.data, which, None, 0)
+        buf = np.zeros(n, np.float32)
+        assert packlib.gnnb_pt_pack(blob.ctypes.data, which, buf.ctypes.data, n) == n
+        out[name] = buf
+    return sd, out
+
+
+# ---- numpy model of the wave-level data layout used by the kernels ----
+def feat(R, h):
+    return 8 * (R >> 2) + 4 * h + (R & 3)
+
+
+def frag_from_rows(X):
+    """(32 nodes, 64 features) -> frag[lane, R]"""
+    f = np.zeros((64, 32), np.float64)
+    for R in range(32):
+        f[:, R] = X[J, feat(R, H)]
+    return f
+
+
+def rows_from_frag(f):
+    X = np.zeros((32, 64))
+    for R in range(32):
+        X[J, feat(R, H)] = f[:, R]
+    return X
+
+
+def mfma(a, b, acc):
+    """acc[lane, r] (16 regs) += A(32x2) B(2x32) with the gfx950 operand maps."""
+    A = np.zeros((32, 2)); Bm = np.zeros((2, 32))
+    A[J, H] = a
+    Bm[H, J] = b
+    D = A @ Bm
+    for r in range(16):
+        acc[:, r] += D[(r & 3) + 8 * (r >> 2) + 4 * H, J]
+
+
+def frag_bias(bl):
+    f = np.zeros((64, 32))
+    for R in range(32):
+        f[:, R] = bl[H * 32 + R]
+    return f
+
+
+def gemm_w64(wl, ksteps, acc, getB):
+    for s in range(ksteps):
+        for it in range(2):
+            a = wl[(((s >> 2) * 2 + it) * 64 + LANES) * 4 + (s & 3)]
+            mfma(a, getB(s), acc[:, 16 * it:16 * it + 16])
+
+
+def gemm_small(wl, ksteps, acc, x):
+    for s in range(ksteps):
+        for it in range(2):
+            mfma(wl[(s * 2 + it) * 64 + LANES], x[s], acc[:, 16 * it:16 * it + 16])
+
+
+def lin(sd, name, x):
+    return x @ np.asarray(sd[name + ".weight"], np.float64).T + np.asarray(sd[name + ".bias"], np.float64)
+
+
+E = "EmbedUpdates.update."
+
+
+def test_node_update_chain(packs):
+    """k_node_update's chain on one tile == fc4_2(relu(fc4([relax, fc3_2(relu(fc3([r0 nb, r1 nb])))])))."""
+    sd, pk = packs
+    rng = np.random.RandomState(1)
+    nb = rng.standard_normal((32, 64)); relax = rng.standard_normal((32, 64))
+    r0 = rng.uniform(0, 1, 32); r1 = 1 - r0
+    w4, b4 = np.asarray(sd[E + "fc4.weight"], np.float64), np.asarray(sd[E + "fc4.bias"], np.float64)
+    P = relax @ w4[:, :64].T + b4                      # what k_pre_fwd caches
+    p = pk["upd_fwd"]
+    WA, BA, WB, BB, WC, WD, BD = 0, 8192, 8256, 12352, 12416, 16512, 20608
+    X = frag_from_rows(nb)
+    Hf = frag_bias(p[BA:BA + 64])
+    gemm_w64(p[WA:], 64, Hf, lambda s: X[:, s & 31] * (r0[J] if s < 32 else r1[J]))
+    Hf = np.maximum(Hf, 0)
+    Ef = frag_bias(p[BB:BB + 64])
+    gemm_w64(p[WB:], 32, Ef, lambda s: Hf[:, s])
+    H2 = frag_from_rows(P)
+    gemm_w64(p[WC:], 32, H2, lambda s: Ef[:, s])
+    H2 = np.maximum(H2, 0)
+    M = frag_bias(p[BD:BD + 64])
+    gemm_w64(p[WD:], 32, M, lambda s: H2[:, s])
+    got = rows_from_frag(M)
+    e = lin(sd, E + "fc3_2", np.maximum(lin(sd, E + "fc3", np.concatenate([nb * r0[:, None], nb * r1[:, None]], 1)), 0))
+    want = lin(sd, E + "fc4_2", np.maximum(lin(sd, E + "fc4", np.concatenate([relax, e], 1)), 0))
+    np.testing.assert_allclose(got, want, atol=1e-5)
+
+
+def test_pre_bwd_chain(packs):
+    """k_pre_bwd: bc1 (7 scalar features, zero-padded k-steps) .. bc2 on [s, -d2 s, d1 s] .. bc4[:, :64]."""
+    sd, pk = packs
+    rng = np.random.RandomState(2)
+    f7 = rng.standard_normal((32, 7)); d1 = rng.uniform(0, 1, 32); d2 = rng.uniform(0, 1, 32)
+    p = pk["pre_bwd"]
+    W1, B1, W2, B2, W3, B3, W4, B4, W5, B5, W6, B6 = 0, 512, 576, 4672, 4736, 8832, 8896, 21184, 21248, 25344, 25408, 29504
+    f8 = np.concatenate([f7, np.zeros((32, 1))], 1)
+    x = [f8[J, 2 * s + H] for s in range(4)]
+    H1 = frag_bias(p[B1:B1 + 64]); gemm_small(p[W1:], 4, H1, x); H1 = np.maximum(H1, 0)
+    H2 = frag_bias(p[B2:B2 + 64]); gemm_w64(p[W2:], 32, H2, lambda s: H1[:, s]); H2 = np.maximum(H2, 0)
+    S = frag_bias(p[B3:B3 + 64]); gemm_w64(p[W3:], 32, S, lambda s: H2[:, s])
+    H4 = frag_bias(p[B4:B4 + 64])
+    gemm_w64(p[W4:], 96, H4, lambda s: S[:, s & 31] * (1.0 if s < 32 else (-d2[J] if s < 64 else d1[J])))
+    H4 = np.maximum(H4, 0)
+    X = frag_bias(p[B5:B5 + 64]); gemm_w64(p[W5:], 32, X, lambda s: H4[:, s])
+    Pb = frag_bias(p[B6:B6 + 64]); gemm_w64(p[W6:], 32, Pb, lambda s: X[:, s])
+    got = rows_from_frag(Pb)
+    s_ = lin(sd, E + "bc1_2", np.maximum(lin(sd, E + "bc1_1", np.maximum(lin(sd, E + "bc1", f7), 0)), 0))
+    relax = lin(sd, E + "bc2_1", np.maximum(lin(sd, E + "bc2", np.concatenate([s_, s_ * -d2[:, None], s_ * d1[:, None]], 1)), 0))
+    w4, b4 = np.asarray(sd[E + "bc4.weight"], np.float64), np.asarray(sd[E + "bc4.bias"], np.float64)
+    np.testing.assert_allclose(got, relax @ w4[:, :64].T + b4, atol=1e-5)
+
+
+def test_embed_and_score_packs(packs):
+    sd, pk = packs
+    rng = np.random.RandomState(3)
+    f3 = rng.standard_normal((32, 3))
+    p = pk["embed"]
+    f4 = np.concatenate([f3, np.zeros((32, 1))], 1)
+    Hf = frag_bias(p[256:320]); gemm_small(p[0:], 2, Hf, [f4[J, 2 * s + H] for s in range(2)]); Hf = np.maximum(Hf, 0)
+    M = frag_bias(p[4416:4480]); gemm_w64(p[320:], 32, M, lambda s: Hf[:, s])
+    np.testing.assert_allclose(rows_from_frag(M), lin(sd, E + "inp_f_1", np.maximum(lin(sd, E + "inp_f", f3), 0)), atol=1e-5)
+    # score head: per-lane partial dot over the lane's 32 features + the other half
+    mu = rng.standard_normal((32, 64))
+    p = pk["score"]
+    X = frag_from_rows(mu)
+    Hs = frag_bias(p[4096:4160]); gemm_w64(p[0:], 32, Hs, lambda s: X[:, s]); Hs = np.maximum(Hs, 0)
+    ws = p[4160:4224]
+    part = np.array([sum(Hs[l, R] * ws[H[l] * 32 + R] for R in range(32)) for l in range(64)])
+    score = part[:32] + part[32:] + p[4224]
+    want = lin(sd, "ComputeFinalScore.fscore", np.maximum(lin(sd, "ComputeFinalScore.fnode", mu), 0))[:, 0]
+    np.testing.assert_allclose(score, want, atol=1e-5)
+
+
+def test_prop_pack_is_transposed(packs):
+    sd, pk = packs
+    p = pk["prop"]
+    w2 = np.asarray(sd[E + "out2.weight"])
+    np.testing.assert_array_equal(p[320:320 + 128 * 64].reshape(128, 64), w2.T)
+    np.testing.assert_array_equal(p[0:256].reshape(4, 64), np.asarray(sd[E + "out1.weight"]).T)
