@@ -84,6 +84,10 @@ def load():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback for the branching scorer)")
+        # torch bundles its own HIP runtime (torch/lib/libamdhip64.so): it must be the one already in
+        # the process when libgnnb.so is dlopened, or two runtimes fight over the device ("no
+        # ROCm-capable device is detected").  Importing torch does not initialise the GPU.
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(lib, name)

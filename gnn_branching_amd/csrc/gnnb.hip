@@ -97,9 +97,12 @@ __device__ __forceinline__ void frag_bias(Frag& a, const float* bl, int h) {
   }
 }
 
+// torch's relu propagates NaN (fmaxf would swallow it and hide a 0/0 of compute_ratio)
+__device__ __forceinline__ float relu_nan(float x) { return x < 0.0f ? 0.0f : x; }
+
 __device__ __forceinline__ void frag_relu(Frag& a) {
 #pragma unroll
-  for (int R = 0; R < 32; ++R) FRAG_AT(a, R) = fmaxf(FRAG_AT(a, R), 0.0f);
+  for (int R = 0; R < 32; ++R) FRAG_AT(a, R) = relu_nan(FRAG_AT(a, R));
 }
 
 __device__ __forceinline__ void frag_scale(Frag& a, float s) {
@@ -159,8 +162,8 @@ __device__ __forceinline__ bool frag_has_nan(const Frag& x) {
 struct Ratio { float r0, r1, beta, amb, live; };
 __device__ __forceinline__ Ratio compute_ratio(float lb, float ub) {
   Ratio r;
-  const float lower_temp = lb - fmaxf(lb, 0.0f);
-  const float upper_temp = fmaxf(ub, 0.0f);
+  const float lower_temp = lb - relu_nan(lb);
+  const float upper_temp = relu_nan(ub);
   r.r0 = upper_temp / (upper_temp - lower_temp);
   r.beta = -1.0f * lower_temp * r.r0;
   r.amb = r.beta > 0.0f ? 1.0f : 0.0f;
@@ -579,13 +582,13 @@ __global__ __launch_bounds__(256) void k_prop_fwd(PropArgs a) {
   float h1 = pk[PackProp::B1 + lane];
 #pragma unroll
   for (int k = 0; k < 4; ++k) h1 = fmaf(pk[PackProp::W1T + k * 64 + lane], f[k], h1);
-  xs[w][lane] = fmaxf(h1, 0.0f);
+  xs[w][lane] = relu_nan(h1);
   xs[w][64 + lane] = nb;
   __syncthreads();
   float h2 = pk[PackProp::B2 + lane];
   for (int k = 0; k < 128; ++k) h2 = fmaf(pk[PackProp::W2T + k * 64 + lane], xs[w][k], h2);
   __syncthreads();
-  xs[w][lane] = fmaxf(h2, 0.0f);
+  xs[w][lane] = relu_nan(h2);
   __syncthreads();
   float o = pk[PackProp::B3 + lane];
   for (int k = 0; k < 64; ++k) o = fmaf(pk[PackProp::W3T + k * 64 + lane], xs[w][k], o);
