@@ -43,6 +43,7 @@ SYMBOLS = [
     ("gnnb_destroy", C.c_int, [C.c_void_p]),
     ("gnnb_last_error", C.c_char_p, []),
     ("gnnb_abi_version", C.c_int, []),
+    ("gnnb_describe", C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     ("gnnb_mu_location", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     ("gnnb_set_halfpass_limit", C.c_int, [C.c_void_p, C.c_int]),
     ("gnnb_profile_enable", C.c_int, [C.c_void_p, C.c_int]),

@@ -25,6 +25,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -179,6 +180,52 @@ __device__ __forceinline__ void stage_pack(float* lds, const float* pack, int nf
   __syncthreads();
 }
 
+// ---- tile -> node mapping (gnnb_pack.h TileMap) ----
+struct DTileMap { int mode, N, C, H, W, CT, PY, PX, ay, ax, NBY, NBX, NCG, TPS; };
+struct TileCtx { long sample; int n, cg, by, bx, y, x; bool valid; };
+
+// lane j of tile `tile`: which node of which sample.  mode 0: 32 consecutive rows of the flat (B*N) layer;
+// mode 1: CT channels x (PY x PX) pixel block of one sample (the blocks an MFMA gather works on).
+__device__ __forceinline__ TileCtx tile_decode(const DTileMap& tm, long tile, int j, long total_rows) {
+  TileCtx c;
+  if (tm.mode == 0) {
+    const long g = tile * 32 + j;
+    c.valid = g < total_rows;
+    const long gc = c.valid ? g : total_rows - 1;
+    c.sample = gc / tm.N;
+    c.n = (int)(gc - c.sample * tm.N);
+    c.cg = c.by = c.bx = c.y = c.x = 0;
+  } else {
+    c.sample = tile / tm.TPS;
+    const int t = (int)(tile - c.sample * tm.TPS);
+    const int nb = tm.NBY * tm.NBX;
+    c.cg = t / nb;
+    const int rem = t - c.cg * nb;
+    c.by = rem / tm.NBX;
+    c.bx = rem - c.by * tm.NBX;
+    const int pp = tm.PY * tm.PX;
+    const int cl = j / pp;
+    const int r2 = j - cl * pp;
+    const int py = r2 / tm.PX, px = r2 - py * tm.PX;
+    c.y = c.by * tm.PY + tm.ay + py;
+    c.x = c.bx * tm.PX + tm.ax + px;
+    c.valid = cl < tm.CT && (unsigned)c.y < (unsigned)tm.H && (unsigned)c.x < (unsigned)tm.W;
+    c.n = c.valid ? ((c.cg * tm.CT + cl) * tm.H + c.y) * tm.W + c.x : 0;
+  }
+  return c;
+}
+
+// persistent tile loop: workgroup -> contiguous chunk of tiles, chunks dealt so that the workgroups of one
+// XCD (blockIdx % 8 labels the XCD group) own neighbouring chunks: the samples they gather from stay in that L2.
+__device__ __forceinline__ void tile_range(long ntiles, int waves, long& begin, long& end) {
+  int wg = blockIdx.x;
+  const int nwg = gridDim.x;
+  if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
+  const long per = ((ntiles + (long)nwg * waves - 1) / ((long)nwg * waves)) * waves;
+  begin = (long)wg * per;
+  end = begin + per < ntiles ? begin + per : ntiles;
+}
+
 #define WG_MLP 512       // 8 waves: 2 per SIMD share one LDS copy of the weights
 #define WAVES_MLP 8
 
@@ -217,6 +264,7 @@ struct PreArgs {
   float* P;                                               // tile-major cache
   long G, ntiles;
   int N, hw;                                              // nodes per sample; nodes per bias entry (H*W or 1)
+  DTileMap tm;                                            // which node sits on which (tile, lane)
 };
 
 // P_f = fc4[:, :64] . (fc1_1(relu(fc1(feat7))) * amb) + fc4.bias      graph_conv.py:153-161,176-177
@@ -225,12 +273,12 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_pre_fwd(PreArgs a) {
   stage_pack(lds, a.pack, PackPreFwd::FLOATS);
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
   for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < a.ntiles; tile += (long)gridDim.x * WAVES_MLP) {
-    const long g = tile * 32 + j;
-    const long gc = g < a.G ? g : a.G - 1;
+    const TileCtx tc = tile_decode(a.tm, tile, j, a.G);
+    const long gc = tc.sample * a.N + tc.n;
     const float lb = a.lb[gc], ub = a.ub[gc];
     const Ratio r = compute_ratio(lb, ub);
     const float dd = a.dual[gc * 3 + 1] - a.dual[gc * 3 + 2];
-    const float c = a.bias[(int)(gc % a.N) / a.hw];
+    const float c = a.bias[tc.n / a.hw];
     // feat7 = [beta, l, u, d1-d2, z_pre, z_post, c]: even features on half 0, odd on half 1
     float x[4];
     x[0] = h ? lb : r.beta;
@@ -259,12 +307,12 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_pre_bwd(PreArgs a) {
   stage_pack(lds, a.pack, PackPreBwd::FLOATS);
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
   for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < a.ntiles; tile += (long)gridDim.x * WAVES_MLP) {
-    const long g = tile * 32 + j;
-    const long gc = g < a.G ? g : a.G - 1;
+    const TileCtx tc = tile_decode(a.tm, tile, j, a.G);
+    const long gc = tc.sample * a.N + tc.n;
     const float lb = a.lb[gc], ub = a.ub[gc];
     const Ratio r = compute_ratio(lb, ub);
     const float d1 = a.dual[gc * 3 + 1], d2 = a.dual[gc * 3 + 2];
-    const float c = a.bias[(int)(gc % a.N) / a.hw];
+    const float c = a.bias[tc.n / a.hw];
     // feat7' = [l, u, beta, -d2+d1, z_post, z_pre, c]
     float x[4];
     x[0] = h ? ub : lb;
@@ -308,8 +356,8 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_pre_inp(PreArgs a) {
   stage_pack(lds, a.pack, PackPreInp::FLOATS);
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
   for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < a.ntiles; tile += (long)gridDim.x * WAVES_MLP) {
-    const long g = tile * 32 + j;
-    const long gc = g < a.G ? g : a.G - 1;
+    const TileCtx tc = tile_decode(a.tm, tile, j, a.G);
+    const long gc = tc.sample * a.N + tc.n;
     float x[1];
     x[0] = h ? a.ub[gc] : a.lb[gc];
     Frag H;
@@ -394,6 +442,162 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_input_update(UpdInpArgs a) {
     frag_bias(M, lds + PackUpdInp::BD, h);
     gemm_w64<32>(lds + PackUpdInp::WD, lane, M, [&](int s) { return FRAG_AT(H, s); });
     if (valid) frag_store_rows(M, a.mu, g, h);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// fused message passing + node update for conv edges: the neighbour aggregate never leaves registers.
+//   nb^T (64 ch x 32 dst) = mu_src^T (64 ch x K window nodes) . Cmat (K x 32 dst)      on the MFMA,
+// A operand = source embedding rows straight from HBM/L2 (one coalesced 256-B row per lane half and k-step:
+// lane i holds channels 2i, 2i+1), B operand = the tap matrix of the tile shape, resident in LDS.
+// Forward edges: graph_conv.py:110-127; transposed edges + tap-count division: :299-318; input layer :361-372.
+// ------------------------------------------------------------------------------------------
+struct DGather {
+  const float* cmat;     // [NCG][K2][64]
+  const int2* koff;      // [2*K2]: {row offset relative to the window origin, wy | wx << 16}
+  int K2, ncg_k2, Hs, Ws, Ns, ystep, ybase, xstep, xbase, WY, WX, normalise, kh, kw, stride, pad;
+};
+
+#define GATHER_CH 8   // k-steps per prefetch chunk
+
+__device__ __forceinline__ void gather_tile(Frag& X, const float* cm, const int2* ko, int K2, const float* src,
+                                            int wy0, int wx0, int Hs, int Ws, int lane) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = 0.0f;
+  const long origin = (long)wy0 * Ws + wx0;
+  float2 cur[GATHER_CH], nxt[GATHER_CH];
+  auto load = [&](float2 (&dst)[GATHER_CH], int s0) {
+#pragma unroll
+    for (int u = 0; u < GATHER_CH; ++u) {
+      const int2 e = ko[2 * (s0 + u) + h];
+      const int wy = wy0 + (e.y & 0xffff), wx = wx0 + (e.y >> 16);
+      const bool ok = (unsigned)wy < (unsigned)Hs && (unsigned)wx < (unsigned)Ws;
+      const long row = ok ? origin + e.x : 0;
+      const float2 v = *reinterpret_cast<const float2*>(src + row * 64);
+      dst[u].x = ok ? v.x : 0.0f;
+      dst[u].y = ok ? v.y : 0.0f;
+    }
+  };
+  load(cur, 0);
+  for (int s0 = 0; s0 < K2; s0 += GATHER_CH) {
+    if (s0 + GATHER_CH < K2) load(nxt, s0 + GATHER_CH);
+#pragma unroll
+    for (int u = 0; u < GATHER_CH; ++u) {
+      const float b = cm[(s0 + u) * 64 + lane];
+      X.t[0] = mfma32(cur[u].x, b, X.t[0]);
+      X.t[1] = mfma32(cur[u].y, b, X.t[1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < GATHER_CH; ++u) cur[u] = nxt[u];
+  }
+}
+
+// number of kernel taps that touch dst position t along one axis (the reference's `freq`, graph_conv.py:306-311)
+__device__ __forceinline__ int tap_count(int t, int w0, int WN, int Hs, int k, int stride, int pad) {
+  int n = 0;
+  for (int w = 0; w < WN; ++w) {
+    const int o = w0 + w;
+    const int kk = t + pad - o * stride;
+    n += ((unsigned)o < (unsigned)Hs && kk >= 0 && kk < k) ? 1 : 0;
+  }
+  return n;
+}
+
+__device__ __forceinline__ void stage_gather(float* lds_cm, int2* lds_ko, const DGather& g) {
+  const f32x4* src = reinterpret_cast<const f32x4*>(g.cmat);
+  f32x4* dst = reinterpret_cast<f32x4*>(lds_cm);
+  for (int i = threadIdx.x; i < g.ncg_k2 * 16; i += blockDim.x) dst[i] = src[i];
+  for (int i = threadIdx.x; i < 2 * g.K2; i += blockDim.x) lds_ko[i] = g.koff[i];
+}
+
+struct GUArgs {
+  const float* pack;
+  const float *lb, *ub;     // bounds of the dst layer, flat (B*N)
+  const float* mu_src;      // (B, Ns, 64)
+  const float* P;           // cached feature term, tile-major (tiles of `tm`)
+  float* mu;                // out (B, N, 64)
+  int* status;
+  long ntiles;
+  DTileMap tm;
+  DGather g;
+};
+
+__global__ __launch_bounds__(WG_MLP, 2) void k_gather_update(GUArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* lds_cm = lds + PackUpd::FLOATS;
+  int2* lds_ko = reinterpret_cast<int2*>(lds_cm + a.g.ncg_k2 * 64);
+  stage_gather(lds_cm, lds_ko, a.g);
+  stage_pack(lds, a.pack, PackUpd::FLOATS);
+  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
+  long t0, t1;
+  tile_range(a.ntiles, WAVES_MLP, t0, t1);
+  for (long tile = t0 + wave; tile < t1; tile += WAVES_MLP) {
+    const TileCtx tc = tile_decode(a.tm, tile, j, 0);
+    const long gc = tc.sample * a.tm.N + tc.n;
+    const Ratio r = compute_ratio(a.lb[gc], a.ub[gc]);
+    const int wy0 = tc.by * a.g.ystep + a.g.ybase, wx0 = tc.bx * a.g.xstep + a.g.xbase;
+    Frag X;
+    gather_tile(X, lds_cm + tc.cg * a.g.K2 * 64, lds_ko, a.g.K2, a.mu_src + tc.sample * a.g.Ns * 64 + 2 * j, wy0, wx0,
+                a.g.Hs, a.g.Ws, lane);
+    if (a.g.normalise) {
+      const int ny = tap_count(tc.y, wy0, a.g.WY, a.g.Hs, a.g.kh, a.g.stride, a.g.pad);
+      const int nx = tap_count(tc.x, wx0, a.g.WX, a.g.Ws, a.g.kw, a.g.stride, a.g.pad);
+      const float freq = tc.valid ? (float)(ny * nx) : 1.0f;
+#pragma unroll
+      for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = FRAG_AT(X, R) / freq;
+    }
+    Frag H;
+    frag_bias(H, lds + PackUpd::BA, h);
+    const float r0 = r.r0, r1 = r.r1;
+    gemm_w64<64>(lds + PackUpd::WA, lane, H, [&](int s) { return FRAG_AT(X, s & 31) * (s < 32 ? r0 : r1); });
+    frag_relu(H);
+    Frag E;
+    frag_bias(E, lds + PackUpd::BB, h);
+    gemm_w64<32>(lds + PackUpd::WB, lane, E, [&](int s) { return FRAG_AT(H, s); });
+    Frag H2;
+    frag_load_tiled(H2, a.P, tile, lane);
+    gemm_w64<32>(lds + PackUpd::WC, lane, H2, [&](int s) { return FRAG_AT(E, s); });
+    frag_relu(H2);
+    Frag M;
+    frag_bias(M, lds + PackUpd::BD, h);
+    gemm_w64<32>(lds + PackUpd::WD, lane, M, [&](int s) { return FRAG_AT(H2, s); });
+    frag_scale(M, r.live);
+    if (tc.valid) {
+      if (frag_has_nan(M)) atomicOr(a.status, 1);
+      frag_store_rows(M, a.mu, gc, h);
+    }
+  }
+}
+
+struct GIArgs { const float* pack; const float* mu_src; const float* Q; float* mu; long ntiles; DTileMap tm; DGather g; };
+
+// input layer: mu_0 = inp_b2_2(relu(Q + inp_b2[:, 64:] . (A_1^T mu_1)))     graph_conv.py:361-385
+__global__ __launch_bounds__(WG_MLP, 2) void k_gather_input_update(GIArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* lds_cm = lds + PackUpdInp::FLOATS;
+  int2* lds_ko = reinterpret_cast<int2*>(lds_cm + a.g.ncg_k2 * 64);
+  stage_gather(lds_cm, lds_ko, a.g);
+  stage_pack(lds, a.pack, PackUpdInp::FLOATS);
+  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
+  long t0, t1;
+  tile_range(a.ntiles, WAVES_MLP, t0, t1);
+  for (long tile = t0 + wave; tile < t1; tile += WAVES_MLP) {
+    const TileCtx tc = tile_decode(a.tm, tile, j, 0);
+    const long gc = tc.sample * a.tm.N + tc.n;
+    const int wy0 = tc.by * a.g.ystep + a.g.ybase, wx0 = tc.bx * a.g.xstep + a.g.xbase;
+    Frag X;
+    gather_tile(X, lds_cm + tc.cg * a.g.K2 * 64, lds_ko, a.g.K2, a.mu_src + tc.sample * a.g.Ns * 64 + 2 * j, wy0, wx0,
+                a.g.Hs, a.g.Ws, lane);
+    Frag H;
+    frag_load_tiled(H, a.Q, tile, lane);
+    gemm_w64<32>(lds + PackUpdInp::WC, lane, H, [&](int s) { return FRAG_AT(X, s); });
+    frag_relu(H);
+    Frag M;
+    frag_bias(M, lds + PackUpdInp::BD, h);
+    gemm_w64<32>(lds + PackUpdInp::WD, lane, M, [&](int s) { return FRAG_AT(H, s); });
+    if (tc.valid) frag_store_rows(M, a.mu, gc, h);
   }
 }
 
@@ -664,21 +868,31 @@ static int fail(int code, const char* fmt, ...) {
 
 enum ProfClass {
   PC_EMBED, PC_PRE_FWD, PC_PRE_BWD, PC_PRE_INP, PC_CONV_FWD, PC_CONVT_BWD, PC_DENSE_AGG, PC_PROP_FWD,
-  PC_PROP_BWD_NB, PC_NODE_UPDATE, PC_INPUT_UPDATE, PC_SCORE, PC_ARGMAX, PC_COUNT
+  PC_PROP_BWD_NB, PC_NODE_UPDATE, PC_INPUT_UPDATE, PC_SCORE, PC_ARGMAX, PC_GATHER_UPDATE, PC_GATHER_INPUT, PC_COUNT
 };
 static const char* kProfNames[PC_COUNT] = {
     "k_embed", "k_pre_fwd", "k_pre_bwd", "k_pre_inp", "k_conv_fwd", "k_convT_bwd", "k_dense_agg", "k_prop_fwd",
-    "k_prop_bwd_nb", "k_node_update", "k_input_update", "k_score", "k_argmax"};
+    "k_prop_bwd_nb", "k_node_update", "k_input_update", "k_score", "k_argmax", "k_gather_update", "k_gather_input_update"};
 
 struct DevEdge {
   float *w_fwd = nullptr, *w_bwd = nullptr, *bias = nullptr;   // conv: tap-major copies; linear: W^T padded / W
   int ld_fwd = 0, mt_fwd = 0, mt_bwd = 0;
 };
 
+struct DevGather {          // one conv edge in one direction, as MFMA gather tables on the device
+  bool ok = false;
+  GatherGeom g;
+  float* cmat = nullptr;
+  int* koff = nullptr;
+};
+
+#define N_PACKS 12
 struct gnnb_handle {
   int T = 2, p = 64, device = 0, n_cu = 256;
+  bool use_gather = true;       // fused MFMA gather for conv edges (false: VALU gather kernels + k_node_update)
   Packs packs;
-  float* d_pack[9] = {nullptr};
+  float* d_pack[N_PACKS] = {nullptr};
+  std::vector<DevGather> gf, gb;   // gf[k]: edge k forward (dst = layer k); gb[k]: edge k transposed (dst = layer k-1)
   bool bound = false;
   std::vector<Edge> edges;       // edges[k], k = 1..L (edges[0] unused)
   std::vector<DevEdge> dev;
@@ -696,7 +910,8 @@ struct gnnb_handle {
   hipStream_t prof_stream = nullptr;
 };
 
-enum { PK_EMBED, PK_PRE_FWD, PK_UPD_FWD, PK_PRE_BWD, PK_UPD_BWD, PK_PRE_INP, PK_UPD_INP, PK_SCORE, PK_PROP };
+enum { PK_EMBED, PK_PRE_FWD, PK_UPD_FWD, PK_PRE_BWD, PK_UPD_BWD, PK_PRE_INP, PK_UPD_INP, PK_SCORE, PK_PROP,
+       PK_UPD_FWD_G, PK_UPD_BWD_G, PK_UPD_INP_G };
 
 static int upload(float** d, const float* h, size_t n) {
   HIPCHK(hipMalloc((void**)d, n * sizeof(float)));
@@ -723,9 +938,10 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   HIPCHK(hipGetDeviceProperties(&prop, h->device));
   h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   build_packs(w_blob, h->packs);
-  const std::vector<float>* pv[9] = {&h->packs.embed, &h->packs.pre_fwd, &h->packs.upd_fwd, &h->packs.pre_bwd, &h->packs.upd_bwd,
-                                     &h->packs.pre_inp, &h->packs.upd_inp, &h->packs.score, &h->packs.prop};
-  for (int i = 0; i < 9; ++i)
+  const std::vector<float>* pv[N_PACKS] = {&h->packs.embed, &h->packs.pre_fwd, &h->packs.upd_fwd, &h->packs.pre_bwd, &h->packs.upd_bwd,
+                                           &h->packs.pre_inp, &h->packs.upd_inp, &h->packs.score, &h->packs.prop,
+                                           &h->packs.upd_fwd_g, &h->packs.upd_bwd_g, &h->packs.upd_inp_g};
+  for (int i = 0; i < N_PACKS; ++i)
     if (int rc = upload(&h->d_pack[i], pv[i]->data(), pv[i]->size())) return rc;
   // > 64 KiB of dynamic LDS needs the attribute
   HIPCHK(hipFuncSetAttribute((const void*)k_embed, hipFuncAttributeMaxDynamicSharedMemorySize, PackEmbed::FLOATS * 4));
@@ -735,6 +951,9 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   HIPCHK(hipFuncSetAttribute((const void*)k_node_update, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpd::FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_input_update, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpdInp::FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_score, hipFuncAttributeMaxDynamicSharedMemorySize, PackScore::FLOATS * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather_update, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  if (const char* e = getenv("GNNB_NO_GATHER")) h->use_gather = !(e[0] == '1');
   *out = h;
   return GNNB_OK;
 }
@@ -745,6 +964,13 @@ static void free_network(gnnb_t* h) {
     if (d.w_bwd) (void)hipFree(d.w_bwd);
     if (d.bias) (void)hipFree(d.bias);
   }
+  for (auto* v : {&h->gf, &h->gb})
+    for (auto& d : *v) {
+      if (d.cmat) (void)hipFree(d.cmat);
+      if (d.koff) (void)hipFree(d.koff);
+    }
+  h->gf.clear();
+  h->gb.clear();
   h->dev.clear();
   h->edges.clear();
   h->N.clear();
@@ -756,7 +982,7 @@ static void free_network(gnnb_t* h) {
 extern "C" int gnnb_destroy(gnnb_t* h) {
   if (!h) return GNNB_OK;
   free_network(h);
-  for (int i = 0; i < 9; ++i)
+  for (int i = 0; i < N_PACKS; ++i)
     if (h->d_pack[i]) (void)hipFree(h->d_pack[i]);
   for (auto& ev : h->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
   for (auto& ev : h->pool) (void)hipEventDestroy(ev);
@@ -862,8 +1088,46 @@ extern "C" int gnnb_bind_network(gnnb_t* h, const gnnb_layer_desc* L, int n, int
       if (int rc = upload(&d.w_bwd, e.w.data(), e.w.size())) return rc;
     }
   }
+  // MFMA gather tables for every conv edge, both directions (the input layer's transposed edge is not normalised)
+  h->gf.assign(Lr + 1, DevGather());
+  h->gb.assign(Lr + 1, DevGather());
+  if (h->use_gather)
+    for (int k = 1; k <= Lr; ++k) {
+      if (h->edges[k].kind != 0) continue;
+      for (int dir = 0; dir < 2; ++dir) {
+        GatherHost gh;
+        if (!build_gather(h->edges[k], dir, dir == 1 && k > 1, gh)) continue;
+        DevGather& d = dir == 0 ? h->gf[k] : h->gb[k];
+        d.g = gh.g;
+        if (int rc = upload(&d.cmat, gh.cmat.data(), gh.cmat.size())) return rc;
+        HIPCHK(hipMalloc((void**)&d.koff, gh.koff.size() * sizeof(int)));
+        HIPCHK(hipMemcpy(d.koff, gh.koff.data(), gh.koff.size() * sizeof(int), hipMemcpyHostToDevice));
+        d.ok = true;
+      }
+    }
   h->bound = true;
   return GNNB_OK;
+}
+
+// tile maps of the node-MLP kernels: the forward update of layer k walks the tiles of its incoming conv gather,
+// the backward update those of the transposed gather from layer k+1; everything else is flat.
+static TileMap flat_map(int N) { TileMap t; t.mode = 0; t.N = N; return t; }
+static TileMap fwd_map(const gnnb_t* h, int k) { return h->gf[k].ok ? h->gf[k].g.tm : flat_map(h->N[k]); }
+static TileMap bwd_map(const gnnb_t* h, int k) {
+  const int L = (int)h->N.size() - 2;
+  return (k + 1 <= L && h->gb[k + 1].ok) ? h->gb[k + 1].g.tm : flat_map(h->N[k]);
+}
+static long map_tiles(const TileMap& t, int B) { return t.mode ? (long)B * t.TPS : ((long)B * t.N + 31) / 32; }
+static DTileMap to_dtm(const TileMap& t) {
+  return DTileMap{t.mode, t.N, t.C, t.H, t.W, t.CT, t.PY, t.PX, t.ay, t.ax, t.NBY, t.NBX, t.NCG, t.TPS};
+}
+static DGather to_dg(const DevGather& d) {
+  const GatherGeom& g = d.g;
+  return DGather{d.cmat, reinterpret_cast<const int2*>(d.koff), g.K2, g.tm.NCG * g.K2, g.Hs, g.Ws, g.Ns, g.ystep, g.ybase,
+                 g.xstep, g.xbase, g.WY, g.WX, g.normalise, g.kh, g.kw, g.stride, g.pad};
+}
+static size_t gather_lds_bytes(const DevGather& d, size_t pack_floats) {
+  return (pack_floats + (size_t)d.g.tm.NCG * d.g.K2 * 64) * 4 + (size_t)2 * d.g.K2 * 8;
 }
 
 extern "C" int gnnb_graph_info(const gnnb_t* h, int* n_graph, int* sizes, int* n_relu_total) {
@@ -875,13 +1139,60 @@ extern "C" int gnnb_graph_info(const gnnb_t* h, int* n_graph, int* sizes, int* n
   return GNNB_OK;
 }
 
+// JSON description of the launch plan of one forward (per B=1): which kernel updates which layer, tile shapes and
+// MFMA counts.  bench.py derives the algorithmic flops per kernel class from it; DESIGN.md quotes it.
+extern "C" int gnnb_describe(const gnnb_t* h, char* buf, size_t cap) {
+  if (!h || !h->bound || !buf || cap < 64) return fail(GNNB_E_INVALID, "gnnb_describe: bad arguments");
+  const int L = (int)h->N.size() - 2;
+  std::string o = "{\"T\": " + std::to_string(h->T) + ", \"sizes\": [";
+  for (size_t k = 0; k < h->N.size(); ++k) o += (k ? ", " : "") + std::to_string(h->N[k]);
+  o += "], \"updates\": [";
+  auto nnz = [&](int e) -> long {     // edges of the layer graph between layer e-1 and e (no-padding upper bound)
+    if (e > L) return h->N[L];
+    const Edge& ed = h->edges[e];
+    return ed.kind == 0 ? (long)ed.c_out * ed.h_out * ed.w_out * ed.c_in * ed.kh * ed.kw : (long)ed.n_in * ed.n_out;
+  };
+  auto item = [&](const char* what, int k, const DevGather* d, const char* fallback, int n_src) {
+    char t[640];
+    const long ez = nnz(what[0] == 'f' ? k : k + 1);
+    if (d && d->ok) {
+      const GatherGeom& g = d->g;
+      snprintf(t, sizeof t,
+               "{\"update\": \"%s\", \"layer\": %d, \"kernel\": \"%s\", \"nodes\": %d, \"tiles_per_sample\": %d, "
+               "\"tile\": [%d, %d, %d], \"align\": [%d, %d], \"window\": [%d, %d], \"gather_ksteps\": %d, \"n_src\": %d, \"edge_nnz\": %ld}",
+               what, k, k == 0 ? "k_gather_input_update" : "k_gather_update", h->N[k], g.tm.TPS, g.tm.CT, g.tm.PY, g.tm.PX,
+               g.tm.ay, g.tm.ax, g.WY, g.WX, g.K2, n_src, ez);
+    } else {
+      snprintf(t, sizeof t, "{\"update\": \"%s\", \"layer\": %d, \"kernel\": \"%s\", \"nodes\": %d, \"n_src\": %d, \"edge_nnz\": %ld}",
+               what, k, fallback, h->N[k], n_src, ez);
+    }
+    o += t;
+  };
+  bool first = true;
+  for (int k = 1; k <= L; ++k) {
+    if (!first) o += ", ";
+    first = false;
+    item("fwd", k, &h->gf[k], h->edges[k].kind == 0 ? "k_conv_fwd+k_node_update" : "k_dense_agg+k_node_update", h->N[k - 1]);
+  }
+  for (int k = L; k >= 1; --k) {
+    o += ", ";
+    if (k == L) item("bwd", k, nullptr, "k_prop_bwd_nb+k_node_update", 1);
+    else item("bwd", k, &h->gb[k + 1], h->edges[k + 1].kind == 0 ? "k_convT_bwd+k_node_update" : "k_dense_agg+k_node_update", h->N[k + 1]);
+  }
+  o += ", ";
+  item("input", 0, &h->gb[1], h->edges[1].kind == 0 ? "k_convT_bwd+k_input_update" : "k_dense_agg+k_input_update", h->N[1]);
+  o += "]}";
+  if (o.size() + 1 > cap) return fail(GNNB_E_NOMEM, "gnnb_describe: buffer too small (%zu needed)", o.size() + 1);
+  memcpy(buf, o.c_str(), o.size() + 1);
+  return GNNB_OK;
+}
+
 // ---- workspace layout (float offsets, every region 256-B aligned) ----
 struct WsLayout {
   std::vector<size_t> mu, Pf, Pb;
   size_t nb = 0, Q = 0, total = 0;
 };
 static size_t align64(size_t nfloats) { return (nfloats + 63) & ~(size_t)63; }
-static size_t tiled_floats(size_t rows) { return ((rows + 31) / 32) * 2048; }
 static WsLayout ws_layout(const gnnb_t* h, int B) {
   WsLayout w;
   const int K = (int)h->N.size() - 1;
@@ -892,9 +1203,9 @@ static WsLayout ws_layout(const gnnb_t* h, int B) {
   for (int k = 0; k < K; ++k) maxn = std::max(maxn, (size_t)h->N[k]);
   w.nb = off; off += align64((size_t)B * maxn * 64);
   w.Pf.resize(K); w.Pb.resize(K);
-  for (int k = 1; k < K; ++k) { w.Pf[k] = off; off += tiled_floats((size_t)B * h->N[k]); }
-  for (int k = 1; k < K; ++k) { w.Pb[k] = off; off += tiled_floats((size_t)B * h->N[k]); }
-  w.Q = off; off += tiled_floats((size_t)B * h->N[0]);
+  for (int k = 1; k < K; ++k) { w.Pf[k] = off; off += (size_t)map_tiles(fwd_map(h, k), B) * 2048; }
+  for (int k = 1; k < K; ++k) { w.Pb[k] = off; off += (size_t)map_tiles(bwd_map(h, k), B) * 2048; }
+  w.Q = off; off += (size_t)map_tiles(bwd_map(h, 0), B) * 2048;
   w.total = off;
   return w;
 }
@@ -1034,23 +1345,33 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   const int limit = h->halfpass_limit > 0 ? std::min(h->halfpass_limit, total_halfpasses) : total_halfpasses;
   const bool debug_full = h->halfpass_limit > 0;   // with a limit set every input-layer update is executed too
   for (int k = 1; k <= L; ++k) {
-    const long G = (long)B * h->N[k], nt = (G + 31) / 32;
+    const long G = (long)B * h->N[k];
     const int q = h->relu_q[k];
     PreArgs a{nullptr, in->lb[k], in->ub[k], in->dual[k - 1], in->primal[q - 1], in->primal[q], h->dev[k].bias,
-              nullptr, G, nt, h->N[k], h->hw[k]};
-    a.pack = h->d_pack[PK_PRE_FWD];
-    a.P = ws + w.Pf[k];
-    lz.run(PC_PRE_FWD, [&] { hipLaunchKernelGGL(k_pre_fwd, dim3(mlp_grid(h, nt)), dim3(WG_MLP), PackPreFwd::FLOATS * 4, st, a); });
+              nullptr, G, 0, h->N[k], h->hw[k], DTileMap{}};
+    {
+      const TileMap tm = fwd_map(h, k);
+      a.pack = h->d_pack[PK_PRE_FWD];
+      a.P = ws + w.Pf[k];
+      a.tm = to_dtm(tm);
+      a.ntiles = map_tiles(tm, B);
+      lz.run(PC_PRE_FWD, [&] { hipLaunchKernelGGL(k_pre_fwd, dim3(mlp_grid(h, a.ntiles)), dim3(WG_MLP), PackPreFwd::FLOATS * 4, st, a); });
+    }
     if (limit >= 2) {
+      const TileMap tm = bwd_map(h, k);
       a.pack = h->d_pack[PK_PRE_BWD];
       a.P = ws + w.Pb[k];
-      lz.run(PC_PRE_BWD, [&] { hipLaunchKernelGGL(k_pre_bwd, dim3(mlp_grid(h, nt)), dim3(WG_MLP), PackPreBwd::FLOATS * 4, st, a); });
+      a.tm = to_dtm(tm);
+      a.ntiles = map_tiles(tm, B);
+      lz.run(PC_PRE_BWD, [&] { hipLaunchKernelGGL(k_pre_bwd, dim3(mlp_grid(h, a.ntiles)), dim3(WG_MLP), PackPreBwd::FLOATS * 4, st, a); });
     }
   }
   const bool need_inp = (limit >= 2) && (h->T > 1 || debug_full);
   if (need_inp) {
-    const long G = (long)B * h->N[0], nt = (G + 31) / 32;
-    PreArgs a{h->d_pack[PK_PRE_INP], in->lb[0], in->ub[0], nullptr, nullptr, nullptr, nullptr, ws + w.Q, G, nt, h->N[0], 1};
+    const long G = (long)B * h->N[0];
+    const TileMap tm = bwd_map(h, 0);
+    const long nt = map_tiles(tm, B);
+    PreArgs a{h->d_pack[PK_PRE_INP], in->lb[0], in->ub[0], nullptr, nullptr, nullptr, nullptr, ws + w.Q, G, nt, h->N[0], 1, to_dtm(tm)};
     lz.run(PC_PRE_INP, [&] { hipLaunchKernelGGL(k_pre_inp, dim3(mlp_grid(h, nt)), dim3(WG_MLP), PackPreInp::FLOATS * 4, st, a); });
   }
 
@@ -1095,44 +1416,65 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       lz.run(PC_DENSE_AGG, [&] { hipLaunchKernelGGL(k_dense_agg, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a); });
     }
   };
-  auto node_update = [&](int k, bool fwd) {
+  auto node_update = [&](int k, bool fwd) {      // flat tiles, nb already aggregated in HBM
     const long G = (long)B * h->N[k], nt = (G + 31) / 32;
     UpdArgs a{h->d_pack[fwd ? PK_UPD_FWD : PK_UPD_BWD], in->lb[k], in->ub[k], nb, ws + (fwd ? w.Pf[k] : w.Pb[k]), mu(k), status, G, nt};
     lz.run(PC_NODE_UPDATE, [&] { hipLaunchKernelGGL(k_node_update, dim3(mlp_grid(h, nt)), dim3(WG_MLP), PackUpd::FLOATS * 4, st, a); });
+  };
+  auto gather_update = [&](int k, bool fwd) {    // conv edge: aggregate + update in one kernel
+    const DevGather& d = fwd ? h->gf[k] : h->gb[k + 1];
+    const long nt = map_tiles(d.g.tm, B);
+    GUArgs a{h->d_pack[fwd ? PK_UPD_FWD_G : PK_UPD_BWD_G], in->lb[k], in->ub[k], fwd ? mu(k - 1) : mu(k + 1),
+             ws + (fwd ? w.Pf[k] : w.Pb[k]), mu(k), status, nt, to_dtm(d.g.tm), to_dg(d)};
+    const size_t lds = gather_lds_bytes(d, PackUpd::FLOATS);
+    lz.run(PC_GATHER_UPDATE, [&] { hipLaunchKernelGGL(k_gather_update, dim3(mlp_grid(h, nt)), dim3(WG_MLP), lds, st, a); });
+  };
+  auto update_fwd = [&](int k) {
+    if (h->gf[k].ok) { gather_update(k, true); return; }
+    agg_fwd(k);
+    node_update(k, true);
+  };
+  auto update_bwd = [&](int k) {
+    if (k < L && h->gb[k + 1].ok) { gather_update(k, false); return; }
+    if (k == L) {
+      const long rows = (long)B * h->N[L];
+      const float* pw = in->prop_w;
+      const float* mk = mu(K);
+      const int nl = h->N[L];
+      lz.run(PC_PROP_BWD_NB, [&] { hipLaunchKernelGGL(k_prop_bwd_nb, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, pw, mk, nb, rows, nl); });
+    } else {
+      agg_bwd(k, 1);
+    }
+    node_update(k, false);
+  };
+  auto update_input = [&]() {
+    if (h->gb[1].ok) {
+      const DevGather& d = h->gb[1];
+      const long nt = map_tiles(d.g.tm, B);
+      GIArgs a{h->d_pack[PK_UPD_INP_G], mu(1), ws + w.Q, mu(0), nt, to_dtm(d.g.tm), to_dg(d)};
+      const size_t lds = gather_lds_bytes(d, PackUpdInp::FLOATS);
+      lz.run(PC_GATHER_INPUT, [&] { hipLaunchKernelGGL(k_gather_input_update, dim3(mlp_grid(h, nt)), dim3(WG_MLP), lds, st, a); });
+      return;
+    }
+    agg_bwd(0, 0);
+    const long G = (long)B * h->N[0], nt = (G + 31) / 32;
+    UpdInpArgs a{h->d_pack[PK_UPD_INP], nb, ws + w.Q, mu(0), G, nt};
+    lz.run(PC_INPUT_UPDATE, [&] { hipLaunchKernelGGL(k_input_update, dim3(mlp_grid(h, nt)), dim3(WG_MLP), PackUpdInp::FLOATS * 4, st, a); });
   };
 
   int done = 0;
   for (int t = 0; t < h->T && done < limit; ++t) {
     // forward sweep (graph_conv.py:107-192) + property node (:194-210)
-    for (int k = 1; k <= L; ++k) {
-      agg_fwd(k);
-      node_update(k, true);
-    }
+    for (int k = 1; k <= L; ++k) update_fwd(k);
     {
       PropArgs a{h->d_pack[PK_PROP], mu(L), in->prop_w, in->prop_b, in->lb[K], in->ub[K], in->primal[in->n_primal - 1], mu(K), B, h->N[L]};
       lz.run(PC_PROP_FWD, [&] { hipLaunchKernelGGL(k_prop_fwd, dim3((B + 3) / 4), dim3(256), 0, st, a); });
     }
     if (++done >= limit) break;
     // backward sweep (:222-350), Gauss-Seidel order: layer k reads the already-updated mu[k+1]
-    for (int k = L; k >= 1; --k) {
-      if (k == L) {
-        const long rows = (long)B * h->N[L];
-        const float* pw = in->prop_w;
-        const float* mk = mu(K);
-        const int nl = h->N[L];
-        lz.run(PC_PROP_BWD_NB, [&] { hipLaunchKernelGGL(k_prop_bwd_nb, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, pw, mk, nb, rows, nl); });
-      } else {
-        agg_bwd(k, 1);
-      }
-      node_update(k, false);
-    }
+    for (int k = L; k >= 1; --k) update_bwd(k);
     // input layer (:360-385): its last-round result is never read, so it only runs when another round follows
-    if (t < h->T - 1 || debug_full) {
-      agg_bwd(0, 0);
-      const long G = (long)B * h->N[0], nt = (G + 31) / 32;
-      UpdInpArgs a{h->d_pack[PK_UPD_INP], nb, ws + w.Q, mu(0), G, nt};
-      lz.run(PC_INPUT_UPDATE, [&] { hipLaunchKernelGGL(k_input_update, dim3(mlp_grid(h, nt)), dim3(WG_MLP), PackUpdInp::FLOATS * 4, st, a); });
-    }
+    if (t < h->T - 1 || debug_full) update_input();
     ++done;
   }
 

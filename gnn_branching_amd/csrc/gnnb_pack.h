@@ -87,6 +87,21 @@ inline void pack_vec64(float* dst, const float* v) {
     for (int R = 0; R < 32; ++R) dst[h * 32 + R] = v[frag_feature(R, h)];
 }
 
+inline int gather_feature(int R, int h) {           // channel held by register R = 16*it + r after a gather
+  const int it = R >> 4, r = R & 15;
+  return 2 * ((r & 3) + 8 * (r >> 2) + 4 * h) + it;
+}
+// like pack_w64, for an input fragment in the gather channel map
+inline void pack_w64_gather(float* dst, const float* W, int ldw, int col0, int nfrag) {
+  for (int s = 0; s < 32 * nfrag; ++s)
+    for (int it = 0; it < 2; ++it)
+      for (int lane = 0; lane < 64; ++lane) {
+        int out = 32 * it + (lane & 31);
+        int in = col0 + 64 * (s >> 5) + gather_feature(s & 31, lane >> 5);
+        dst[(((size_t)(s >> 2) * 2 + it) * 64 + lane) * 4 + (s & 3)] = W[(size_t)out * ldw + in];
+      }
+}
+
 // W (out x in, row-major) -> W^T (in x out): lane = out index reads consecutive floats.
 inline void pack_transposed(float* dst, const float* W, int out, int in) {
   for (int o = 0; o < out; ++o)
@@ -117,6 +132,7 @@ struct PackProp { enum { W1T = 0, B1 = W1T + 4 * 64, W2T = B1 + 64, B2 = W2T + 1
 
 struct Packs {
   std::vector<float> embed, pre_fwd, upd_fwd, pre_bwd, upd_bwd, pre_inp, upd_inp, score, prop;
+  std::vector<float> upd_fwd_g, upd_bwd_g, upd_inp_g;   // first layer permuted for a gathered (MFMA) input fragment
 };
 
 inline void build_packs(const float* blob, Packs& pk) {
@@ -176,6 +192,14 @@ inline void build_packs(const float* blob, Packs& pk) {
   pack_w64(&pk.upd_inp[PackUpdInp::WD], W(L_INP_B2_2), 64, 0, 1);
   pack_vec64(&pk.upd_inp[PackUpdInp::BD], Bv(L_INP_B2_2));
 
+  // variants whose first layer reads the fragment produced by the MFMA gather (gather_feature map)
+  pk.upd_fwd_g = pk.upd_fwd;
+  pack_w64_gather(&pk.upd_fwd_g[PackUpd::WA], W(L_FC3), 128, 0, 2);
+  pk.upd_bwd_g = pk.upd_bwd;
+  pack_w64_gather(&pk.upd_bwd_g[PackUpd::WA], W(L_BC3), 128, 0, 2);
+  pk.upd_inp_g = pk.upd_inp;
+  pack_w64_gather(&pk.upd_inp_g[PackUpdInp::WC], W(L_INP_B2), 128, 64, 1);
+
   pk.score.assign(PackScore::FLOATS, 0.f);
   pack_w64(&pk.score[PackScore::W1], W(L_FNODE), 64, 0, 1);
   pack_vec64(&pk.score[PackScore::B1], Bv(L_FNODE));
@@ -216,6 +240,132 @@ inline void pack_conv_bwd(float* dst, const Edge& e) {
         for (int kx = 0; kx < e.kw; ++kx)
           dst[(((size_t)co * e.kh + ky) * e.kw + kx) * e.c_in + ci] =
               e.w[(((size_t)co * e.c_in + ci) * e.kh + ky) * e.kw + kx];
+}
+
+
+// ------------------------------------------------------------------------------------------
+// MFMA gather descriptors: conv / conv-transpose message passing as dense local blocks.
+//
+// A tile = 32 dst nodes of ONE sample = CT channels x (PY x PX) pixel block; all of them read the
+// same window of src nodes (C_s x WY x WX).  nb^T (64 ch x 32 dst) = mu_src^T (64 ch x K) . Cmat (K x 32):
+// the A operand is the source embedding row (lane i holds channels 2i, 2i+1 of src row 2s+h), the
+// B operand is the translation-invariant tap matrix Cmat[k][j] (weight of src window node k for dst
+// lane j, 0 where no tap connects them), held in LDS in operand order [cg][s][lane].
+// The result lands in fragment layout with the channel map  (it, r, h) -> 2*((r&3)+8*(r>>2)+4*h) + it,
+// which the first layer of the node MLP absorbs through pack_w64_gather().
+// ------------------------------------------------------------------------------------------
+struct TileMap {        // lane j of tile t <-> node of the dst layer
+  int mode = 0;         // 0: flat, tile = 32 consecutive rows of the (B*N) layer; 1: block
+  int N = 0;            // nodes per sample
+  int C = 0, H = 0, W = 0;
+  int CT = 0, PY = 0, PX = 0, ay = 0, ax = 0, NBY = 0, NBX = 0, NCG = 0, TPS = 0;
+};
+
+struct GatherGeom {     // everything the kernel needs besides the tables
+  TileMap tm;
+  int K2 = 0;           // k-steps (padded to a multiple of 8)
+  int Hs = 0, Ws = 0, Ns = 0;                 // src layer
+  int ystep = 0, ybase = 0, xstep = 0, xbase = 0;   // window origin: wy0 = by*ystep + ybase
+  int WY = 0, WX = 0;
+  int normalise = 0, kh = 0, kw = 0, stride = 0, pad = 0;
+};
+
+struct GatherHost {
+  GatherGeom g;
+  std::vector<float> cmat;       // [NCG][K2][64]
+  std::vector<int32_t> koff;     // [2*K2][2]: {row offset relative to the window origin, wy | wx << 16}
+  long mfma_per_sample = 0;
+};
+
+inline int floor_div(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+inline int ceil_div(int a, int b) { return -floor_div(-a, b); }
+
+// dir 0: forward (src = conv input, dst = conv output); dir 1: transposed (src = conv output, dst = conv input)
+inline bool build_gather_candidate(const Edge& e, int dir, int CT, int PY, int PX, int ay, int ax, GatherHost& out) {
+  const int s = e.stride, p = e.pad;
+  const int Cd = dir == 0 ? e.c_out : e.c_in, Hd = dir == 0 ? e.h_out : e.h_in, Wd = dir == 0 ? e.w_out : e.w_in;
+  const int Cs = dir == 0 ? e.c_in : e.c_out, Hs = dir == 0 ? e.h_in : e.h_out, Ws = dir == 0 ? e.w_in : e.w_out;
+  if (CT * PY * PX > 32 || Cd % CT) return false;
+  if (dir == 1 && (PY % s || PX % s)) return false;
+  GatherGeom& g = out.g;
+  g.tm.mode = 1; g.tm.N = Cd * Hd * Wd; g.tm.C = Cd; g.tm.H = Hd; g.tm.W = Wd;
+  g.tm.CT = CT; g.tm.PY = PY; g.tm.PX = PX; g.tm.ay = ay; g.tm.ax = ax;
+  g.tm.NBY = ceil_div(Hd - ay, PY); g.tm.NBX = ceil_div(Wd - ax, PX); g.tm.NCG = Cd / CT;
+  g.tm.TPS = g.tm.NCG * g.tm.NBY * g.tm.NBX;
+  g.Hs = Hs; g.Ws = Ws; g.Ns = Cs * Hs * Ws;
+  if (dir == 0) {
+    g.ystep = PY * s; g.ybase = ay * s - p; g.WY = (PY - 1) * s + e.kh;
+    g.xstep = PX * s; g.xbase = ax * s - p; g.WX = (PX - 1) * s + e.kw;
+  } else {
+    g.ystep = PY / s; g.ybase = ceil_div(ay + p - e.kh + 1, s); g.WY = floor_div(ay + PY - 1 + p, s) - g.ybase + 1;
+    g.xstep = PX / s; g.xbase = ceil_div(ax + p - e.kw + 1, s); g.WX = floor_div(ax + PX - 1 + p, s) - g.xbase + 1;
+  }
+  if (g.WY < 1 || g.WX < 1 || g.WY > 255 || g.WX > 255) return false;
+  const int K = Cs * g.WY * g.WX;
+  g.K2 = ((K + 15) / 16) * 8;
+  g.normalise = 0; g.kh = e.kh; g.kw = e.kw; g.stride = s; g.pad = p;
+  out.mfma_per_sample = (long)g.tm.TPS * g.K2 * 2;
+  return true;
+}
+
+inline void fill_gather_tables(const Edge& e, int dir, GatherHost& out) {
+  const GatherGeom& g = out.g;
+  const int s = e.stride, p = e.pad;
+  const int Cs = dir == 0 ? e.c_in : e.c_out;
+  const int K = Cs * g.WY * g.WX, Kpad = 2 * g.K2;
+  out.koff.assign((size_t)Kpad * 2, 0);
+  for (int k = 0; k < Kpad; ++k) {
+    if (k < K) {
+      const int cs = k / (g.WY * g.WX), wy = (k / g.WX) % g.WY, wx = k % g.WX;
+      out.koff[2 * k] = (cs * g.Hs + wy) * g.Ws + wx;
+      out.koff[2 * k + 1] = wy | (wx << 16);
+    } else {
+      out.koff[2 * k] = 0;
+      out.koff[2 * k + 1] = 0x7fff | (0x7fff << 16);      // always out of bounds -> contributes 0
+    }
+  }
+  out.cmat.assign((size_t)g.tm.NCG * g.K2 * 64, 0.f);
+  for (int cg = 0; cg < g.tm.NCG; ++cg)
+    for (int k = 0; k < K; ++k) {
+      const int cs = k / (g.WY * g.WX), wy = (k / g.WX) % g.WY, wx = k % g.WX;
+      for (int j = 0; j < g.tm.CT * g.tm.PY * g.tm.PX; ++j) {
+        const int cl = j / (g.tm.PY * g.tm.PX), py = (j / g.tm.PX) % g.tm.PY, px = j % g.tm.PX;
+        const int cd = cg * g.tm.CT + cl;
+        int ky, kx, co, ci;
+        if (dir == 0) {        // iy = oy*s - p + ky, window row wy = iy - (y0*s - p) = py*s + ky
+          ky = wy - py * s; kx = wx - px * s; co = cd; ci = cs;
+        } else {               // y = oy*s - p + ky with oy = wy0 + wy, y = y0 + py, y0 = by*PY + ay, wy0 = by*PY/s + ybase
+          ky = (g.tm.ay + py) + p - (g.ybase + wy) * s; kx = (g.tm.ax + px) + p - (g.xbase + wx) * s; co = cs; ci = cd;
+        }
+        if (ky < 0 || ky >= e.kh || kx < 0 || kx >= e.kw) continue;
+        const float w = e.w[(((size_t)co * e.c_in + ci) * e.kh + ky) * e.kw + kx];
+        const int sidx = k >> 1, h = k & 1;
+        out.cmat[((size_t)cg * g.K2 + sidx) * 64 + h * 32 + j] = w;
+      }
+    }
+}
+
+// pick the tile shape with the fewest MFMAs per sample
+inline bool build_gather(const Edge& e, int dir, bool normalise, GatherHost& best) {
+  const int Cd = dir == 0 ? e.c_out : e.c_in;
+  bool found = false;
+  long best_cost = 0;
+  for (int CT = 1; CT <= 32 && CT <= Cd; ++CT) {
+    if (Cd % CT) continue;
+    for (int PY = 1; PY <= 8; PY *= 2)
+      for (int PX = 1; PX <= 8; PX *= 2)
+        for (int ay = 0; ay > -PY; --ay)
+          for (int ax = 0; ax > -PX; --ax) {
+            GatherHost c;
+            if (!build_gather_candidate(e, dir, CT, PY, PX, ay, ax, c)) continue;
+            if ((size_t)c.g.tm.NCG * c.g.K2 * 64 * 4 > 40 * 1024) continue;   // tap matrix must fit beside the MLP weights in LDS
+            if (!found || c.mfma_per_sample < best_cost) { best = c; best_cost = c.mfma_per_sample; found = true; }
+          }
+  }
+  if (!found) return false;
+  best.g.normalise = normalise ? 1 : 0;
+  fill_gather_tables(e, dir, best);
+  return true;
 }
 
 }  // namespace gnnb

@@ -225,6 +225,13 @@ class ScorerEngine:
         ws = self.workspace(B)
         return ws[off.value:off.value + 4 * n.value].view(torch.float32).view(B, self.sizes[k], self.p)
 
+    def describe(self):
+        """The launch plan of one forward on the bound network (dict parsed from gnnb_describe's JSON)."""
+        import json
+        buf = C.create_string_buffer(1 << 16)
+        _lib.check(self.lib.gnnb_describe(self.h, buf, len(buf)), "gnnb_describe")
+        return json.loads(buf.value.decode())
+
     def set_halfpass_limit(self, n):
         _lib.check(self.lib.gnnb_set_halfpass_limit(self.h, n), "gnnb_set_halfpass_limit")
 

@@ -98,6 +98,10 @@ int gnnb_abi_version(void);
 
 /* ---- inspection hooks used by the parity tests and bench.py (not needed by a caller) ---- */
 
+/* JSON text describing the launch plan of one forward for the bound network: per half-pass update the
+ * kernel used, the tile shape of the MFMA gather (channels x pixel block, window, k-steps) and node counts. */
+int gnnb_describe(const gnnb_t* h, char* buf, size_t cap);
+
 /* Location of embedding mu[k] inside the workspace: row-major (B, N_k, p) fp32. */
 int gnnb_mu_location(const gnnb_t* h, int B, int k, size_t* offset_bytes, size_t* n_floats);
 

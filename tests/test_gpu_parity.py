@@ -142,3 +142,16 @@ def test_bad_inputs_raise():
     args[6] = args[6][:, :-1]                   # ragged mask
     with pytest.raises(ValueError):
         model.forward_device(*args)
+
+
+def test_unfused_valu_gather_path_matches(monkeypatch):
+    """GNNB_NO_GATHER=1 selects the unfused VALU conv gathers + flat node update: same scores."""
+    monkeypatch.setenv("GNNB_NO_GATHER", "1")
+    g, batch = load_golden("cifar_deep_kw_B2")
+    model = make_model("random")
+    with torch.no_grad():
+        res = model.forward_device(*batch.forward_args()).check()
+    want = g["random_scores"]
+    fin = np.isfinite(want)
+    assert np.abs(res.scores.cpu().numpy()[fin] - want[fin]).max() <= SCORE_ATOL
+    assert res.decisions.cpu().tolist() == g["random_decisions"].tolist()

@@ -32,7 +32,8 @@ def packs(packlib):
     blob = np.concatenate([np.asarray(v, np.float32).reshape(-1) for v in sd.values()])
     assert blob.size == packlib.gnnb_pt_blob_floats() == 117825
     out = {}
-    for which, name in enumerate(["embed", "pre_fwd", "upd_fwd", "pre_bwd", "upd_bwd", "pre_inp", "upd_inp", "score", "prop"]):
+    for which, name in enumerate(["embed", "pre_fwd", "upd_fwd", "pre_bwd", "upd_bwd", "pre_inp", "upd_inp", "score", "prop",
+                                  "upd_fwd_g", "upd_bwd_g", "upd_inp_g"]):
         n = packlib.gnnb_pt_pack(blob.ctypes.data, which, None, 0)
         buf = np.zeros(n, np.float32)
         assert packlib.gnnb_pt_pack(blob.ctypes.data, which, buf.ctypes.data, n) == n
@@ -175,3 +176,109 @@ def test_prop_pack_is_transposed(packs):
     w2 = np.asarray(sd[E + "out2.weight"])
     np.testing.assert_array_equal(p[320:320 + 128 * 64].reshape(128, 64), w2.T)
     np.testing.assert_array_equal(p[0:256].reshape(4, 64), np.asarray(sd[E + "out1.weight"]).T)
+
+
+# ---- MFMA gather tables (conv / conv-transpose message passing as dense local blocks) ----
+GEOM = ["N", "C", "H", "W", "CT", "PY", "PX", "ay", "ax", "NBY", "NBX", "NCG", "TPS", "K2", "Hs", "Ws", "Ns",
+        "ystep", "ybase", "xstep", "xbase", "WY", "WX", "normalise", "n_cmat", "n_koff"]
+
+
+def build_gather(packlib, w, h_in, w_in, stride, pad, direction, normalise):
+    c_out, c_in, kh, kw = w.shape
+    packlib.gnnb_pt_gather.restype = C.c_long
+    packlib.gnnb_pt_gather.argtypes = [C.c_void_p] + [C.c_int] * 10 + [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    w = np.ascontiguousarray(w, np.float32)
+    geom = np.zeros(26, np.int32)
+    cost = packlib.gnnb_pt_gather(w.ctypes.data, c_in, h_in, w_in, c_out, kh, kw, stride, pad, direction, normalise,
+                                  geom.ctypes.data, None, 0, None, 0)
+    assert cost > 0
+    g = dict(zip(GEOM, geom.tolist()))
+    cmat = np.zeros(g["n_cmat"], np.float32)
+    koff = np.zeros(g["n_koff"], np.int32)
+    packlib.gnnb_pt_gather(w.ctypes.data, c_in, h_in, w_in, c_out, kh, kw, stride, pad, direction, normalise,
+                           geom.ctypes.data, cmat.ctypes.data, cmat.size, koff.ctypes.data, koff.size)
+    return g, cmat.reshape(g["NCG"], g["K2"], 64), koff.reshape(-1, 2), cost
+
+
+def emulate_gather(g, cmat, koff, mu_src):
+    """nb (N_dst, p) for one sample from the tables, the way k_gather_update walks them."""
+    p = mu_src.shape[1]
+    nb = np.zeros((g["N"], p))
+    seen = np.zeros(g["N"], np.int32)
+    for t in range(g["TPS"]):
+        cg, rem = divmod(t, g["NBY"] * g["NBX"])
+        by, bx = divmod(rem, g["NBX"])
+        y0, x0 = by * g["PY"] + g["ay"], bx * g["PX"] + g["ax"]
+        wy0, wx0 = by * g["ystep"] + g["ybase"], bx * g["xstep"] + g["xbase"]
+        origin = wy0 * g["Ws"] + wx0
+        acc = np.zeros((32, p))
+        for k in range(2 * g["K2"]):
+            off, packed = koff[k]
+            wy, wx = wy0 + (packed & 0xffff), wx0 + (packed >> 16)
+            if not (0 <= wy < g["Hs"] and 0 <= wx < g["Ws"]):
+                continue
+            row = mu_src[origin + off]
+            acc += np.outer(cmat[cg, k >> 1, (k & 1) * 32:(k & 1) * 32 + 32], row)
+        for j in range(g["CT"] * g["PY"] * g["PX"]):
+            cl, rem = divmod(j, g["PY"] * g["PX"])
+            py, px = divmod(rem, g["PX"])
+            y, x = y0 + py, x0 + px
+            if 0 <= y < g["H"] and 0 <= x < g["W"]:
+                n = ((cg * g["CT"] + cl) * g["H"] + y) * g["W"] + x
+                nb[n] = acc[j]
+                seen[n] += 1
+    assert (seen == 1).all()          # every dst node belongs to exactly one (tile, lane)
+    return nb
+
+
+CONVS = [  # (c_in, c_out, k, stride, pad, h_in)  -- every conv of cifar_{base,wide,deep}_kw
+    (3, 8, 4, 2, 1, 32), (8, 16, 4, 2, 1, 16), (3, 16, 4, 2, 1, 32), (16, 32, 4, 2, 1, 16),
+    (8, 8, 3, 1, 1, 16), (8, 8, 4, 2, 1, 16),
+]
+
+
+@pytest.mark.parametrize("cfg", CONVS)
+@pytest.mark.parametrize("direction", [0, 1])
+def test_gather_tables_match_torch_conv(packlib, cfg, direction):
+    import torch
+    import torch.nn.functional as F
+    c_in, c_out, k, s, pad, h_in = cfg
+    rng = np.random.RandomState(c_in * 100 + c_out + direction)
+    w = rng.standard_normal((c_out, c_in, k, k)).astype(np.float32)
+    g, cmat, koff, cost = build_gather(packlib, w, h_in, h_in, s, pad, direction, normalise=direction)
+    h_out = (h_in + 2 * pad - k) // s + 1
+    p = 4
+    if direction == 0:
+        mu = rng.standard_normal((c_in * h_in * h_in, p))
+        x = torch.from_numpy(mu.T.reshape(p, c_in, h_in, h_in))
+        want = F.conv2d(x, torch.from_numpy(w).double(), None, s, pad).reshape(p, -1).T.numpy()
+    else:
+        mu = rng.standard_normal((c_out * h_out * h_out, p))
+        x = torch.from_numpy(mu.T.reshape(p, c_out, h_out, h_out))
+        y = F.conv_transpose2d(x, torch.from_numpy(w).double(), None, s, pad)
+        assert y.shape[-1] == h_in
+        want = y.reshape(p, -1).T.numpy()            # the tap-count division is applied by the kernel, not the tables
+    got = emulate_gather(g, cmat, koff, mu)
+    np.testing.assert_allclose(got, want, atol=1e-5)
+    dense = cost * 2 * 32 * 32 * 2 / 2          # MACs issued per sample (each MFMA: 32x32x2)
+    useful = w.size * (h_out * h_out)           # MACs of the sparse map per channel
+    print(f"conv {cfg} dir {direction}: tile {g['CT']}x{g['PY']}x{g['PX']} align ({g['ay']},{g['ax']}) window {g['WY']}x{g['WX']} "
+          f"K2={g['K2']} tiles/sample={g['TPS']} mfma/sample={cost} density={useful / (dense / 64 * 32):.2f}")
+
+
+def test_gather_fragment_feeds_first_layer(packs):
+    """The MFMA gather leaves channel 2*row+it in register (it, r); pack_w64_gather must absorb that map."""
+    sd, pk = packs
+    rng = np.random.RandomState(5)
+    nb = rng.standard_normal((32, 64))                       # (dst node j, channel)
+    r0 = rng.uniform(0, 1, 32); r1 = 1 - r0
+    # fragment as the gather produces it: D_it[row i][col j] = nb[j][2i + it]
+    X = np.zeros((64, 32))
+    for it in range(2):
+        for r in range(16):
+            X[:, 16 * it + r] = nb[J, 2 * ((r & 3) + 8 * (r >> 2) + 4 * H) + it]
+    p = pk["upd_fwd_g"]
+    Hf = frag_bias(p[8192:8256])
+    gemm_w64(p[0:], 64, Hf, lambda s: X[:, s & 31] * (r0[J] if s < 32 else r1[J]))
+    want = lin(sd, E + "fc3", np.concatenate([nb * r0[:, None], nb * r1[:, None]], 1))
+    np.testing.assert_allclose(rows_from_frag(Hf), want, atol=1e-5)
