@@ -32,29 +32,63 @@ MFMA_FLOP = 2 * 32 * 32 * 2          # one v_mfma_f32_32x32x2_f32
 MLP_MACS_PER_NODE = 128 * 64 + 3 * 64 * 64   # fc3|bc3, fc3_2|bc3_1, 2nd half of fc4|bc4, fc4_2|bc4_1 (SURVEY 8(d) minus the hoisted feature chains)
 
 
-def plan_flops(plan, B):
-    """Per kernel class, for ONE forward of batch B: algorithmic flops (the sparse edge sums 2*nnz*p plus the node
-    MLP MACs the reference evaluates for these updates) and issued MFMA flops (instructions x 4096)."""
+def node_stats(batch):
+    """Per ReLU layer: how many nodes are live (ub > 0), ambiguous (lb < 0 < ub) and scored (BaB mask -1) in the batch.
+    The engine compacts exactly these classes on the device (k_classify); dead nodes have zero embeddings by
+    definition (graph_conv.py:178/:347) and are not evaluated."""
+    out, off = {}, 0
+    for k in range(1, len(batch.lower_bounds_all) - 1):
+        lb, ub = batch.lower_bounds_all[k].flatten(1), batch.upper_bounds_all[k].flatten(1)
+        n = lb.shape[1]
+        out[k] = {"nodes": int(lb.numel()), "live": int((ub > 0).sum()), "amb": int(((lb < 0) & (ub > 0)).sum()),
+                  "scored": int(batch.masks[:, off:off + n].sum())}
+        off += n
+    return out
+
+
+def plan_flops(plan, B, stats, restrict_last=True):
+    """Per kernel class, for ONE forward of batch B: algorithmic flops (MACs the algorithm needs for the nodes that
+    are updated, sparse edge sums 2*nnz*p) and issued MFMA flops (instructions x 4096, incl. tile padding and the
+    zeros of the dense gather blocks)."""
     T = plan["T"]
     alg, issued = {}, {}
 
     def add(d, k, v):
         d[k] = d.get(k, 0.0) + v
+
+    def tiles(n):
+        return (n + 31) // 32
     for u in plan["updates"]:
-        reps = T if u["update"] != "input" else T - 1
-        nodes, nnz = u["nodes"] * B, u["edge_nnz"] * B
-        mlp = MLP_MACS_PER_NODE if u["update"] != "input" else 2 * 64 * 64
-        kern = u["kernel"]
-        if kern.startswith("k_gather"):
-            tiles = u["tiles_per_sample"] * B
-            add(alg, kern, reps * 2.0 * (mlp * nodes + nnz * 64))
-            add(issued, kern, reps * MFMA_FLOP * tiles * (2 * u["gather_ksteps"] + (320 if u["update"] != "input" else 128)))
-        else:
-            agg, upd = kern.split("+")
-            tiles = (nodes + 31) // 32
-            add(alg, upd, reps * 2.0 * mlp * nodes)
-            add(issued, upd, reps * MFMA_FLOP * tiles * (320 if u["update"] != "input" else 128))
-            add(alg, agg, reps * 2.0 * nnz * 64)
+        k = u["layer"]
+        nnz = u["edge_nnz"] * B
+        if u["update"] == "input":
+            reps, nodes = T - 1, u["nodes"] * B
+            if u["kernel"] == "k_gather_input_update":
+                add(alg, u["kernel"], reps * 2.0 * (2 * 64 * 64 * nodes + nnz * 64))
+                add(issued, u["kernel"], reps * MFMA_FLOP * u["tiles_per_sample"] * B * (2 * u["gather_ksteps"] + 128))
+            else:
+                agg, upd = u["kernel"].split("+")
+                add(alg, upd, reps * 2.0 * 2 * 64 * 64 * nodes)
+                add(issued, upd, reps * MFMA_FLOP * tiles(nodes) * 128)
+                add(alg, agg, reps * 2.0 * nnz * 64)
+            continue
+        agg, upd = u["kernel"].split("+")
+        for t in range(T):
+            restricted = restrict_last and u["update"] == "bwd" and k == 1 and t == T - 1
+            n_upd = stats[k]["scored"] if restricted else stats[k]["live"]
+            add(alg, upd, 2.0 * MLP_MACS_PER_NODE * n_upd)
+            add(issued, upd, MFMA_FLOP * tiles(n_upd) * 320)
+            frac = n_upd / max(stats[k]["nodes"], 1)
+            add(alg, agg, 2.0 * nnz * 64 * frac)
+            if agg == "k_gather":
+                add(issued, agg, MFMA_FLOP * u["tiles_per_sample"] * B * 2 * u["gather_ksteps"])
+    for k, st in stats.items():
+        add(alg, "k_pre_fwd", 2.0 * (7 * 64 + 2 * 64 * 64) * st["amb"])
+        add(issued, "k_pre_fwd", MFMA_FLOP * tiles(st["amb"]) * 136)
+        add(alg, "k_pre_bwd", 2.0 * (7 * 64 + 3 * 64 * 64 + 192 * 64 + 64 * 64) * st["amb"])
+        add(issued, "k_pre_bwd", MFMA_FLOP * tiles(st["amb"]) * 456)
+        add(alg, "k_score", 2.0 * (64 * 64 + 64) * st["scored"])
+        add(issued, "k_score", MFMA_FLOP * tiles(st["scored"]) * 64)
     return alg, issued
 
 
@@ -171,7 +205,8 @@ def main():
                 for k, v in prof.items() if v[1]}
         dom = max(kern, key=lambda k: kern[k]["ms_total"])
         plan = eng.describe()
-        alg, issued = plan_flops(plan, B)
+        stats = node_stats(batch)
+        alg, issued = plan_flops(plan, B, stats)
         dom_s = prof[dom][0] * 1e-3 / args.steps            # seconds of the dominant kernel class per forward
         ach_tf = alg.get(dom, 0.0) / dom_s / 1e12 if dom_s > 0 else 0.0
         iss_tf = issued.get(dom, 0.0) / dom_s / 1e12 if dom_s > 0 else 0.0
@@ -182,12 +217,12 @@ def main():
                     "issued_mfma_tflops": round(iss_tf, 2), "issued_mfma_frac": round(iss_tf / PEAK_F32_MFMA_TFLOPS, 4)}
         # message passing is fused into the update kernels (the aggregate never reaches HBM): its algorithmic bytes
         # 4*p*(N_src+N_dst) per half-pass over the time of every kernel that performs an update
-        mp_names = ("k_gather_update", "k_gather_input_update", "k_conv_fwd", "k_convT_bwd", "k_dense_agg", "k_prop_fwd",
+        mp_names = ("k_gather", "k_gather_input_update", "k_conv_fwd", "k_convT_bwd", "k_dense_agg", "k_prop_fwd",
                     "k_prop_bwd_nb", "k_node_update", "k_input_update")
         mp_ms = sum(prof[k][0] for k in mp_names if k in prof)
         mp_bytes = message_passing_bytes(sizes, B, T) * args.steps
         mp_gbs = mp_bytes / (mp_ms * 1e-3) / 1e9 if mp_ms > 0 else 0.0
-        roofline_mp = {"kernels": "all half-pass update kernels (message passing fused with the node MLP)", "bound": "hbm",
+        roofline_mp = {"kernels": "all half-pass kernels (edge aggregation + node update)", "bound": "hbm",
                        "achieved": round(mp_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(mp_gbs / PEAK_HBM_GBS, 4),
                        "traffic": None, "bytes_per_subproblem": message_passing_bytes(sizes, 1, T)}
         cpu = None
@@ -210,6 +245,7 @@ def main():
             "cpu_baseline": cpu,
             "kernels": kern,
             "plan": plan["updates"],
+            "node_classes": {str(k): v for k, v in stats.items()},
             "instrumented_ms_per_step": round(1e3 * instrumented / args.steps, 4),
         }
         print(json.dumps(out))

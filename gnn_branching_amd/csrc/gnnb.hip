@@ -258,27 +258,97 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_embed(EmbedArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// classification: what each ReLU node needs this forward (static over the T rounds)
+//   live  = [r0 != 0]  (graph_conv.py:178/:347): only these rows of mu can be non-zero -> node MLP runs on them only
+//   amb   = [beta > 0] (:504): only these have a non-zero relaxation term -> the hoisted feature chains run on them only
+//   score = BaB mask == -1 (:447): only these are scored
+// Each class is compacted into a list of flat node ids (wave-aggregated atomics; the order inside a list does not
+// affect any result: every lane of an MLP tile computes its own column).  Dead rows of mu are zeroed here, once,
+// and scores are preset to -inf.
+// ------------------------------------------------------------------------------------------
+struct ClassifyArgs {
+  const float *lb, *ub, *mask;
+  float* mu;       // (B*N, 64) rows of this layer
+  float* scores;   // (B, R)
+  int* cnt;        // [3]: live, amb, score
+  int *live, *amb, *score;
+  long G;
+  int N, R, off;
+};
+
+#define CLS_THREADS 1024
+// one global atomic per list and workgroup (a single counter word only sustains ~90 atomics/us)
+__global__ __launch_bounds__(CLS_THREADS) void k_classify(ClassifyArgs a) {
+  __shared__ int wcnt[3][CLS_THREADS / 64];
+  __shared__ int wbase[3][CLS_THREADS / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long g = (long)blockIdx.x * CLS_THREADS + threadIdx.x;
+  const bool valid = g < a.G;
+  const long gc = valid ? g : a.G - 1;
+  const Ratio r = compute_ratio(a.lb[gc], a.ub[gc]);
+  const long b = gc / a.N;
+  const long sidx = b * a.R + a.off + (gc - b * a.N);
+  bool flag[3];
+  flag[0] = valid && r.live != 0.0f;
+  flag[1] = valid && r.amb != 0.0f;
+  flag[2] = valid && a.mask[sidx] != 0.0f;
+  if (valid) a.scores[sidx] = -INFINITY;
+  unsigned long long bal[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    bal[c] = __ballot(flag[c]);
+    if (lane == 0) wcnt[c][wave] = __popcll(bal[c]);
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int c = threadIdx.x;
+    int total = 0;
+    for (int w = 0; w < CLS_THREADS / 64; ++w) { wbase[c][w] = total; total += wcnt[c][w]; }
+    const int base = total ? atomicAdd(a.cnt + c, total) : 0;
+    for (int w = 0; w < CLS_THREADS / 64; ++w) wbase[c][w] += base;
+  }
+  __syncthreads();
+  int* lists[3] = {a.live, a.amb, a.score};
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    if (flag[c]) lists[c][wbase[c][wave] + __popcll(bal[c] & ((1ull << lane) - 1ull))] = (int)gc;
+  unsigned long long dead = __ballot(valid && !flag[0]);
+  while (dead) {                       // the whole wave zeroes one dead row per iteration (coalesced 256 B)
+    const int l = __ffsll((long long)dead) - 1;
+    dead &= dead - 1;
+    const long row = g - lane + l;
+    a.mu[row * 64 + lane] = 0.0f;
+  }
+}
+
 struct PreArgs {
   const float* pack;
   const float *lb, *ub, *dual, *z_pre, *z_post, *bias;   // per-node scalars (flat B*N), bias per channel
-  float* P;                                               // tile-major cache
+  float* P;                                               // out: tile-major (k_pre_inp) or rows by node id (k_pre_fwd/bwd)
   long G, ntiles;
   int N, hw;                                              // nodes per sample; nodes per bias entry (H*W or 1)
-  DTileMap tm;                                            // which node sits on which (tile, lane)
+  DTileMap tm;                                            // k_pre_inp: which node sits on which (tile, lane)
+  const int* list;                                        // k_pre_fwd/bwd: ambiguous nodes of the layer
+  const int* cnt;
 };
 
-// P_f = fc4[:, :64] . (fc1_1(relu(fc1(feat7))) * amb) + fc4.bias      graph_conv.py:153-161,176-177
+// P_f[g] = fc4[:, :64] . fc1_1(relu(fc1(feat7))) + fc4.bias  for the ambiguous nodes g     graph_conv.py:153-161,176-177
 __global__ __launch_bounds__(WG_MLP, 2) void k_pre_fwd(PreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   stage_pack(lds, a.pack, PackPreFwd::FLOATS);
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
-  for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < a.ntiles; tile += (long)gridDim.x * WAVES_MLP) {
-    const TileCtx tc = tile_decode(a.tm, tile, j, a.G);
-    const long gc = tc.sample * a.N + tc.n;
+  const int count = *a.cnt;
+  const long ntiles = (count + 31) / 32;
+  for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < ntiles; tile += (long)gridDim.x * WAVES_MLP) {
+    const long idx = tile * 32 + j;
+    const bool valid = idx < count;
+    const long gc = a.list[valid ? idx : 0];
+    const int n = (int)(gc % a.N);
     const float lb = a.lb[gc], ub = a.ub[gc];
     const Ratio r = compute_ratio(lb, ub);
     const float dd = a.dual[gc * 3 + 1] - a.dual[gc * 3 + 2];
-    const float c = a.bias[tc.n / a.hw];
+    const float c = a.bias[n / a.hw];
     // feat7 = [beta, l, u, d1-d2, z_pre, z_post, c]: even features on half 0, odd on half 1
     float x[4];
     x[0] = h ? lb : r.beta;
@@ -292,27 +362,31 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_pre_fwd(PreArgs a) {
     Frag S;
     frag_bias(S, lds + PackPreFwd::B2, h);
     gemm_w64<32>(lds + PackPreFwd::W2, lane, S, [&](int s) { return FRAG_AT(H, s); });
-    frag_scale(S, r.amb);                                                  // layer_relax * ambi_mask :161
+    // (layer_relax * ambi_mask, :161: every node of this list has amb = 1)
     Frag Pf;
     frag_bias(Pf, lds + PackPreFwd::B3, h);
     gemm_w64<32>(lds + PackPreFwd::W3, lane, Pf, [&](int s) { return FRAG_AT(S, s); });
-    frag_store_tiled(Pf, a.P, tile, lane);
+    if (valid) frag_store_rows(Pf, a.P, gc, h);
   }
 }
 
-// P_b = bc4[:, :64] . (bc2_1(relu(bc2([s, -d2 s, d1 s]))) * amb) + bc4.bias,
-// s = bc1_2(relu(bc1_1(relu(bc1(feat7')))))                              graph_conv.py:273-293,344-345
+// P_b[g] = bc4[:, :64] . bc2_1(relu(bc2([s, -d2 s, d1 s]))) + bc4.bias,
+// s = bc1_2(relu(bc1_1(relu(bc1(feat7')))))     for the ambiguous nodes g                graph_conv.py:273-293,344-345
 __global__ __launch_bounds__(WG_MLP, 2) void k_pre_bwd(PreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   stage_pack(lds, a.pack, PackPreBwd::FLOATS);
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
-  for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < a.ntiles; tile += (long)gridDim.x * WAVES_MLP) {
-    const TileCtx tc = tile_decode(a.tm, tile, j, a.G);
-    const long gc = tc.sample * a.N + tc.n;
+  const int count = *a.cnt;
+  const long ntiles = (count + 31) / 32;
+  for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < ntiles; tile += (long)gridDim.x * WAVES_MLP) {
+    const long idx = tile * 32 + j;
+    const bool valid = idx < count;
+    const long gc = a.list[valid ? idx : 0];
+    const int n = (int)(gc % a.N);
     const float lb = a.lb[gc], ub = a.ub[gc];
     const Ratio r = compute_ratio(lb, ub);
     const float d1 = a.dual[gc * 3 + 1], d2 = a.dual[gc * 3 + 2];
-    const float c = a.bias[tc.n / a.hw];
+    const float c = a.bias[n / a.hw];
     // feat7' = [l, u, beta, -d2+d1, z_post, z_pre, c]
     float x[4];
     x[0] = h ? ub : lb;
@@ -342,11 +416,10 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_pre_bwd(PreArgs a) {
     Frag X;
     frag_bias(X, lds + PackPreBwd::B5, h);
     gemm_w64<32>(lds + PackPreBwd::W5, lane, X, [&](int s) { return FRAG_AT(H4, s); });
-    frag_scale(X, r.amb);                                                   // :293
     Frag Pb;
     frag_bias(Pb, lds + PackPreBwd::B6, h);
     gemm_w64<32>(lds + PackPreBwd::W6, lane, Pb, [&](int s) { return FRAG_AT(X, s); });
-    frag_store_tiled(Pb, a.P, tile, lane);
+    if (valid) frag_store_rows(Pb, a.P, gc, h);
   }
 }
 
@@ -377,24 +450,28 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_pre_inp(PreArgs a) {
 struct UpdArgs {
   const float* pack;
   const float *lb, *ub;     // pre-activation bounds of this layer, flat (B*N)
-  const float* nb;          // aggregated neighbour embeddings, row-major (B*N, 64)
-  const float* P;           // cached feature term, tile-major
-  float* mu;                // out: row-major (B*N, 64)
+  const float* nb;          // aggregated neighbour embeddings, rows by node id (B*N, 64)
+  const float* P;           // cached feature term of the ambiguous nodes, rows by node id
+  float* mu;                // out: rows by node id
   int* status;
-  long G, ntiles;
+  const int* list;          // nodes to update (the live ones; the scored ones for the last backward step of layer 1)
+  const int* cnt;
 };
 
-// mu_k = Wd.relu(P + Wc.e) + bd, e = Wb.relu(Wa.[r0*nb, r1*nb] + ba) + bb, times [r0 != 0]
-// forward:  fc3, fc3_2, fc4, fc4_2   graph_conv.py:169-181
-// backward: bc3, bc3_1, bc4, bc4_1   graph_conv.py:331-349
-__global__ __launch_bounds__(WG_MLP, 2) void k_node_update(UpdArgs a) {
+// mu_g = (Wd.relu(P_g + Wc.e) + bd) [r0 != 0],  e = Wb.relu(Wa.[r0*nb_g, r1*nb_g] + ba) + bb,  P_g = bias_c when amb = 0
+// forward:  fc3, fc3_2, fc4, fc4_2   graph_conv.py:169-181        backward: bc3, bc3_1, bc4, bc4_1   :331-349
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_node_update(UpdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   stage_pack(lds, a.pack, PackUpd::FLOATS);
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
-  for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < a.ntiles; tile += (long)gridDim.x * WAVES_MLP) {
-    const long g = tile * 32 + j;
-    const bool valid = g < a.G;
-    const long gc = valid ? g : a.G - 1;
+  const int count = *a.cnt;
+  const long ntiles = (count + 31) / 32;
+  // round-robin over workgroups and waves: a few tiles per wave, so balance matters more than locality (rows stream)
+  for (long tile = (long)blockIdx.x * WAVES + wave; tile < ntiles; tile += (long)gridDim.x * WAVES) {
+    const long idx = tile * 32 + j;
+    const bool valid = idx < count;
+    const long gc = a.list[valid ? idx : 0];
     const Ratio r = compute_ratio(a.lb[gc], a.ub[gc]);
     Frag X;
     frag_load_rows(X, a.nb, gc, h);
@@ -407,7 +484,8 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_node_update(UpdArgs a) {
     frag_bias(E, lds + PackUpd::BB, h);
     gemm_w64<32>(lds + PackUpd::WB, lane, E, [&](int s) { return FRAG_AT(H, s); });
     Frag H2;
-    frag_load_tiled(H2, a.P, tile, lane);
+    frag_bias(H2, lds + PackUpd::BC, h);
+    if (r.amb != 0.0f) frag_load_rows(H2, a.P, gc, h);
     gemm_w64<32>(lds + PackUpd::WC, lane, H2, [&](int s) { return FRAG_AT(E, s); });
     frag_relu(H2);
     Frag M;
@@ -416,7 +494,7 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_node_update(UpdArgs a) {
     frag_scale(M, r.live);
     if (valid) {
       if (frag_has_nan(M)) atomicOr(a.status, 1);
-      frag_store_rows(M, a.mu, g, h);
+      frag_store_rows(M, a.mu, gc, h);
     }
   }
 }
@@ -512,31 +590,47 @@ __device__ __forceinline__ void stage_gather(float* lds_cm, int2* lds_ko, const 
   for (int i = threadIdx.x; i < 2 * g.K2; i += blockDim.x) lds_ko[i] = g.koff[i];
 }
 
-struct GUArgs {
-  const float* pack;
+// rows of the gathered fragment (gather channel map) -> row-major (.., 64): lane (j,h) owns channels [16q+8h, 16q+8h+8)
+__device__ __forceinline__ void frag_store_rows_gathered(const Frag& x, float* base, long row, int h) {
+  f32x4* p = reinterpret_cast<f32x4*>(base + row * 64 + 8 * h);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 v0, v1;
+    v0[0] = x.t[0][4 * q + 0]; v0[1] = x.t[1][4 * q + 0]; v0[2] = x.t[0][4 * q + 1]; v0[3] = x.t[1][4 * q + 1];
+    v1[0] = x.t[0][4 * q + 2]; v1[1] = x.t[1][4 * q + 2]; v1[2] = x.t[0][4 * q + 3]; v1[3] = x.t[1][4 * q + 3];
+    p[4 * q] = v0;
+    p[4 * q + 1] = v1;
+  }
+}
+
+struct GArgs {
   const float *lb, *ub;     // bounds of the dst layer, flat (B*N)
+  const float* mask;        // (B, R) BaB mask, used when `need_scored`
   const float* mu_src;      // (B, Ns, 64)
-  const float* P;           // cached feature term, tile-major (tiles of `tm`)
-  float* mu;                // out (B, N, 64)
-  int* status;
+  float* nb;                // out: rows by node id (B*N, 64), written for the lanes that need it
   long ntiles;
+  int need_scored, R, off;  // 0: every live node needs its aggregate; 1: only the scored nodes (last backward step)
   DTileMap tm;
   DGather g;
 };
 
-__global__ __launch_bounds__(WG_MLP, 2) void k_gather_update(GUArgs a) {
+// phase A of a half-pass over a conv edge: nb[g] = sum over the window for the dst nodes that will be updated
+__global__ __launch_bounds__(WG_MLP, 2) void k_gather(GArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* lds_cm = lds + PackUpd::FLOATS;
+  float* lds_cm = lds;
   int2* lds_ko = reinterpret_cast<int2*>(lds_cm + a.g.ncg_k2 * 64);
   stage_gather(lds_cm, lds_ko, a.g);
-  stage_pack(lds, a.pack, PackUpd::FLOATS);
+  __syncthreads();
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
   long t0, t1;
   tile_range(a.ntiles, WAVES_MLP, t0, t1);
   for (long tile = t0 + wave; tile < t1; tile += WAVES_MLP) {
     const TileCtx tc = tile_decode(a.tm, tile, j, 0);
     const long gc = tc.sample * a.tm.N + tc.n;
-    const Ratio r = compute_ratio(a.lb[gc], a.ub[gc]);
+    bool need;
+    if (a.need_scored) need = tc.valid && a.mask[tc.sample * a.R + a.off + tc.n] != 0.0f;
+    else need = tc.valid && compute_ratio(a.lb[gc], a.ub[gc]).live != 0.0f;
+    if (!__any(need)) continue;
     const int wy0 = tc.by * a.g.ystep + a.g.ybase, wx0 = tc.bx * a.g.xstep + a.g.xbase;
     Frag X;
     gather_tile(X, lds_cm + tc.cg * a.g.K2 * 64, lds_ko, a.g.K2, a.mu_src + tc.sample * a.g.Ns * 64 + 2 * j, wy0, wx0,
@@ -548,26 +642,7 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_gather_update(GUArgs a) {
 #pragma unroll
       for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = FRAG_AT(X, R) / freq;
     }
-    Frag H;
-    frag_bias(H, lds + PackUpd::BA, h);
-    const float r0 = r.r0, r1 = r.r1;
-    gemm_w64<64>(lds + PackUpd::WA, lane, H, [&](int s) { return FRAG_AT(X, s & 31) * (s < 32 ? r0 : r1); });
-    frag_relu(H);
-    Frag E;
-    frag_bias(E, lds + PackUpd::BB, h);
-    gemm_w64<32>(lds + PackUpd::WB, lane, E, [&](int s) { return FRAG_AT(H, s); });
-    Frag H2;
-    frag_load_tiled(H2, a.P, tile, lane);
-    gemm_w64<32>(lds + PackUpd::WC, lane, H2, [&](int s) { return FRAG_AT(E, s); });
-    frag_relu(H2);
-    Frag M;
-    frag_bias(M, lds + PackUpd::BD, h);
-    gemm_w64<32>(lds + PackUpd::WD, lane, M, [&](int s) { return FRAG_AT(H2, s); });
-    frag_scale(M, r.live);
-    if (tc.valid) {
-      if (frag_has_nan(M)) atomicOr(a.status, 1);
-      frag_store_rows(M, a.mu, gc, h);
-    }
+    if (need) frag_store_rows_gathered(X, a.nb, gc, h);
   }
 }
 
@@ -602,43 +677,39 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_gather_input_update(GIArgs a) {
 }
 
 struct ScoreArgs {
-  const float* pack; const float* mu; const float* mask; float* scores;
-  long G, ntiles; int N, R, off;   // nodes per sample in this layer, total ReLUs per sample, offset of this layer
+  const float* pack; const float* mu; float* scores; const int* list; const int* cnt;
+  int N, R, off;   // nodes per sample in this layer, total ReLUs per sample, offset of this layer
 };
 
-// score = fscore(relu(fnode(mu))) where the BaB mask is -1, -inf elsewhere    graph_conv.py:445-450
+// score = fscore(relu(fnode(mu_g))) for the nodes g whose BaB mask is -1 (the rest stays -inf)    graph_conv.py:445-450
 __global__ __launch_bounds__(WG_MLP, 2) void k_score(ScoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   stage_pack(lds, a.pack, PackScore::FLOATS);
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
   const float bs = lds[PackScore::BS];
-  for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < a.ntiles; tile += (long)gridDim.x * WAVES_MLP) {
-    const long g = tile * 32 + j;
-    const bool valid = g < a.G;
-    const long gc = valid ? g : a.G - 1;
+  const int count = *a.cnt;
+  const long ntiles = (count + 31) / 32;
+  for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < ntiles; tile += (long)gridDim.x * WAVES_MLP) {
+    const long idx = tile * 32 + j;
+    const bool valid = idx < count;
+    const long gc = a.list[valid ? idx : 0];
     const long b = gc / a.N;
-    const long oidx = b * a.R + a.off + (gc - b * a.N);
-    const bool amb = valid && a.mask[oidx] != 0.0f;
-    float score = -INFINITY;
-    if (__any(amb)) {     // wave-uniform: tiles without an undecided ReLU only write -inf
-      Frag X;
-      frag_load_rows(X, a.mu, gc, h);
-      Frag H;
-      frag_bias(H, lds + PackScore::B1, h);
-      gemm_w64<32>(lds + PackScore::W1, lane, H, [&](int s) { return FRAG_AT(X, s); });
-      frag_relu(H);
-      const f32x4* w4 = reinterpret_cast<const f32x4*>(lds + PackScore::WS + h * 32);
-      float part = 0.0f;
+    Frag X;
+    frag_load_rows(X, a.mu, gc, h);
+    Frag H;
+    frag_bias(H, lds + PackScore::B1, h);
+    gemm_w64<32>(lds + PackScore::W1, lane, H, [&](int s) { return FRAG_AT(X, s); });
+    frag_relu(H);
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(lds + PackScore::WS + h * 32);
+    float part = 0.0f;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const f32x4 w = w4[q];
+    for (int q = 0; q < 8; ++q) {
+      const f32x4 w = w4[q];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) part = fmaf(FRAG_AT(H, 4 * q + c), w[c], part);
-      }
-      part += __shfl_xor(part, 32);
-      if (amb) score = part + bs;
+      for (int c = 0; c < 4; ++c) part = fmaf(FRAG_AT(H, 4 * q + c), w[c], part);
     }
-    if (valid && h == 0) a.scores[oidx] = score;
+    part += __shfl_xor(part, 32);
+    if (valid && h == 0) a.scores[b * a.R + a.off + (gc - b * a.N)] = part + bs;
   }
 }
 
@@ -731,36 +802,63 @@ struct DenseArgs {
 };
 
 // dense edge: out[b, i, :] = sum_k A[i][k] X[b, k, :]   (graph_conv.py:131 forward, :321 backward)
-// one wave per (b, 32-row tile of i, 32-channel half): D[i][ch] on the MFMA, A from L2, X rows coalesced.
+// one workgroup per (b, 32-row tile of i); its 4 waves split K and are summed through LDS in a fixed order.
+// D_it[i][j] on the MFMA for both channel tiles (lane j holds channels 2j, 2j+1 of the source row: one coalesced
+// 256-B row per half-wave and k-step), A from L2; loads run one 8-k-step chunk ahead.
+#define DENSE_CH 8
 __global__ __launch_bounds__(256) void k_dense_agg(DenseArgs a) {
-  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
-  const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wv >= a.B * a.MT * 2) return;
-  const int ft = wv & 1, mt = (wv >> 1) % a.MT, b = (wv >> 1) / a.MT;
+  __shared__ float red[4][32][64];
+  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x;
+  const int mt = tile % a.MT, b = tile / a.MT;
   const int i = mt * 32 + j;
   const bool iok = i < a.M;
   const float* At = a.At + (iok ? i : 0);
-  const float* X = a.X + (long)b * a.K * 64 + ft * 32 + j;
-  f32x16 acc;
+  const float* X = a.X + (long)b * a.K * 64 + 2 * j;
+  f32x16 acc0, acc1;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
   const int ksteps = (a.K + 1) / 2;
-#pragma unroll 8
-  for (int s = 0; s < ksteps; ++s) {
-    const int k = 2 * s + h;
-    const bool kok = k < a.K;
-    const int kc = kok ? k : 0;
-    float av = At[(long)kc * a.ldA];
-    float bv = X[(long)kc * 64];
-    av = (kok && iok) ? av : 0.0f;
-    bv = kok ? bv : 0.0f;
-    acc = mfma32(av, bv, acc);
-  }
-  float* out = a.out + (long)b * a.M * 64 + ft * 32 + j;
+  const int per = (ksteps + 3) / 4;
+  const int s_begin = wave * per, s_end = s_begin + per < ksteps ? s_begin + per : ksteps;
+  float av[DENSE_CH], nav[DENSE_CH];
+  float2 bv[DENSE_CH], nbv[DENSE_CH];
+  auto load = [&](float (&A)[DENSE_CH], float2 (&Bv)[DENSE_CH], int s0) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
+    for (int u = 0; u < DENSE_CH; ++u) {
+      const int k = 2 * (s0 + u) + h;
+      const bool kok = (s0 + u) < s_end && k < a.K;
+      const int kc = kok ? k : 0;
+      const float x = At[(long)kc * a.ldA];
+      const float2 y = *reinterpret_cast<const float2*>(X + (long)kc * 64);
+      A[u] = (kok && iok) ? x : 0.0f;
+      Bv[u].x = kok ? y.x : 0.0f;
+      Bv[u].y = kok ? y.y : 0.0f;
+    }
+  };
+  if (s_begin < s_end) load(av, bv, s_begin);
+  for (int s0 = s_begin; s0 < s_end; s0 += DENSE_CH) {
+    if (s0 + DENSE_CH < s_end) load(nav, nbv, s0 + DENSE_CH);
+#pragma unroll
+    for (int u = 0; u < DENSE_CH; ++u) {
+      acc0 = mfma32(av[u], bv[u].x, acc0);
+      acc1 = mfma32(av[u], bv[u].y, acc1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < DENSE_CH; ++u) { av[u] = nav[u]; bv[u] = nbv[u]; }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { red[wave][r][lane] = acc0[r]; red[wave][16 + r][lane] = acc1[r]; }
+  __syncthreads();
+  float* out = a.out + (long)b * a.M * 64 + 2 * j;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int r = wave * 4 + rr;
+    const float v0 = ((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane];
+    const float v1 = ((red[0][16 + r][lane] + red[1][16 + r][lane]) + red[2][16 + r][lane]) + red[3][16 + r][lane];
     const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-    if (row < a.M) out[(long)row * 64] = acc[r];
+    if (row < a.M) *reinterpret_cast<float2*>(out + (long)row * 64) = make_float2(v0, v1);
   }
 }
 
@@ -868,11 +966,11 @@ static int fail(int code, const char* fmt, ...) {
 
 enum ProfClass {
   PC_EMBED, PC_PRE_FWD, PC_PRE_BWD, PC_PRE_INP, PC_CONV_FWD, PC_CONVT_BWD, PC_DENSE_AGG, PC_PROP_FWD,
-  PC_PROP_BWD_NB, PC_NODE_UPDATE, PC_INPUT_UPDATE, PC_SCORE, PC_ARGMAX, PC_GATHER_UPDATE, PC_GATHER_INPUT, PC_COUNT
+  PC_PROP_BWD_NB, PC_NODE_UPDATE, PC_INPUT_UPDATE, PC_SCORE, PC_ARGMAX, PC_GATHER, PC_GATHER_INPUT, PC_CLASSIFY, PC_COUNT
 };
 static const char* kProfNames[PC_COUNT] = {
     "k_embed", "k_pre_fwd", "k_pre_bwd", "k_pre_inp", "k_conv_fwd", "k_convT_bwd", "k_dense_agg", "k_prop_fwd",
-    "k_prop_bwd_nb", "k_node_update", "k_input_update", "k_score", "k_argmax", "k_gather_update", "k_gather_input_update"};
+    "k_prop_bwd_nb", "k_node_update", "k_input_update", "k_score", "k_argmax", "k_gather", "k_gather_input_update", "k_classify"};
 
 struct DevEdge {
   float *w_fwd = nullptr, *w_bwd = nullptr, *bias = nullptr;   // conv: tap-major copies; linear: W^T padded / W
@@ -889,7 +987,10 @@ struct DevGather {          // one conv edge in one direction, as MFMA gather ta
 #define N_PACKS 12
 struct gnnb_handle {
   int T = 2, p = 64, device = 0, n_cu = 256;
-  bool use_gather = true;       // fused MFMA gather for conv edges (false: VALU gather kernels + k_node_update)
+  bool use_gather = true;       // MFMA gather for conv edges (false: VALU gather kernels)
+  int nu_waves = 8;             // waves per workgroup of k_node_update (one workgroup per CU, weights shared in LDS)
+  int gather_occ = 2;           // workgroups per CU for k_gather (its LDS footprint is only the tap matrix)
+  bool restrict_last = true;    // last backward step of layer 1 only for the scored nodes (nothing else reads it)
   Packs packs;
   float* d_pack[N_PACKS] = {nullptr};
   std::vector<DevGather> gf, gb;   // gf[k]: edge k forward (dst = layer k); gb[k]: edge k transposed (dst = layer k-1)
@@ -948,10 +1049,14 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   HIPCHK(hipFuncSetAttribute((const void*)k_pre_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, PackPreFwd::FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_pre_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, PackPreBwd::FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_pre_inp, hipFuncAttributeMaxDynamicSharedMemorySize, PackPreInp::FLOATS * 4));
-  HIPCHK(hipFuncSetAttribute((const void*)k_node_update, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpd::FLOATS * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<8>, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpd::FLOATS * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<16>, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpd::FLOATS * 4));
+  if (const char* e = getenv("GNNB_NU_WAVES")) h->nu_waves = atoi(e) == 8 ? 8 : 16;
+  if (const char* e = getenv("GNNB_GATHER_OCC")) h->gather_occ = atoi(e) < 1 ? 1 : atoi(e);
   HIPCHK(hipFuncSetAttribute((const void*)k_input_update, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpdInp::FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_score, hipFuncAttributeMaxDynamicSharedMemorySize, PackScore::FLOATS * 4));
-  HIPCHK(hipFuncSetAttribute((const void*)k_gather_update, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  if (const char* e = getenv("GNNB_NO_RESTRICT")) h->restrict_last = !(e[0] == '1');
   HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   if (const char* e = getenv("GNNB_NO_GATHER")) h->use_gather = !(e[0] == '1');
   *out = h;
@@ -1160,7 +1265,7 @@ extern "C" int gnnb_describe(const gnnb_t* h, char* buf, size_t cap) {
       snprintf(t, sizeof t,
                "{\"update\": \"%s\", \"layer\": %d, \"kernel\": \"%s\", \"nodes\": %d, \"tiles_per_sample\": %d, "
                "\"tile\": [%d, %d, %d], \"align\": [%d, %d], \"window\": [%d, %d], \"gather_ksteps\": %d, \"n_src\": %d, \"edge_nnz\": %ld}",
-               what, k, k == 0 ? "k_gather_input_update" : "k_gather_update", h->N[k], g.tm.TPS, g.tm.CT, g.tm.PY, g.tm.PX,
+               what, k, k == 0 ? "k_gather_input_update" : "k_gather+k_node_update", h->N[k], g.tm.TPS, g.tm.CT, g.tm.PY, g.tm.PX,
                g.tm.ay, g.tm.ax, g.WY, g.WX, g.K2, n_src, ez);
     } else {
       snprintf(t, sizeof t, "{\"update\": \"%s\", \"layer\": %d, \"kernel\": \"%s\", \"nodes\": %d, \"n_src\": %d, \"edge_nnz\": %ld}",
@@ -1189,22 +1294,28 @@ extern "C" int gnnb_describe(const gnnb_t* h, char* buf, size_t cap) {
 
 // ---- workspace layout (float offsets, every region 256-B aligned) ----
 struct WsLayout {
-  std::vector<size_t> mu, Pf, Pb;
-  size_t nb = 0, Q = 0, total = 0;
+  std::vector<size_t> mu, Pf, Pb, live, amb, score;
+  size_t cnt = 0, nb = 0, Q = 0, total = 0;
 };
 static size_t align64(size_t nfloats) { return (nfloats + 63) & ~(size_t)63; }
 static WsLayout ws_layout(const gnnb_t* h, int B) {
   WsLayout w;
   const int K = (int)h->N.size() - 1;
   size_t off = 0;
+  w.cnt = off; off += 64;                      // int counters: 4 per ReLU layer (live, amb, score, pad), zeroed every forward
   w.mu.resize(K + 1);
   for (int k = 0; k <= K; ++k) { w.mu[k] = off; off += align64((size_t)B * h->N[k] * 64); }
   size_t maxn = 0;
   for (int k = 0; k < K; ++k) maxn = std::max(maxn, (size_t)h->N[k]);
   w.nb = off; off += align64((size_t)B * maxn * 64);
-  w.Pf.resize(K); w.Pb.resize(K);
-  for (int k = 1; k < K; ++k) { w.Pf[k] = off; off += (size_t)map_tiles(fwd_map(h, k), B) * 2048; }
-  for (int k = 1; k < K; ++k) { w.Pb[k] = off; off += (size_t)map_tiles(bwd_map(h, k), B) * 2048; }
+  w.Pf.resize(K); w.Pb.resize(K); w.live.resize(K); w.amb.resize(K); w.score.resize(K);
+  for (int k = 1; k < K; ++k) { w.Pf[k] = off; off += align64((size_t)B * h->N[k] * 64); }
+  for (int k = 1; k < K; ++k) { w.Pb[k] = off; off += align64((size_t)B * h->N[k] * 64); }
+  for (int k = 1; k < K; ++k) {
+    w.live[k] = off; off += align64((size_t)B * h->N[k]);
+    w.amb[k] = off; off += align64((size_t)B * h->N[k]);
+    w.score[k] = off; off += align64((size_t)B * h->N[k]);
+  }
   w.Q = off; off += (size_t)map_tiles(bwd_map(h, 0), B) * 2048;
   w.total = off;
   return w;
@@ -1334,36 +1445,40 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   float* nb = ws + w.nb;
 
   HIPCHK(hipMemsetAsync(status, 0, sizeof(int32_t), st));
+  HIPCHK(hipMemsetAsync(ws + w.cnt, 0, 64 * sizeof(float), st));
+  int* cnt = reinterpret_cast<int*>(ws + w.cnt);
+  auto ilist = [&](size_t off) { return reinterpret_cast<int*>(ws + off); };
+  std::vector<int> roff(L + 2, 0);          // offset of layer k inside the flat ReLU index
+  for (int k = 2; k <= L + 1; ++k) roff[k] = roff[k - 1] + h->N[k - 1];
 
-  // ---- once per forward: input embedding and the embedding-independent feature chains ----
+  const int total_halfpasses = 2 * h->T;
+  const int limit = h->halfpass_limit > 0 ? std::min(h->halfpass_limit, total_halfpasses) : total_halfpasses;
+  const bool debug_full = h->halfpass_limit > 0;   // with a limit set nothing is restricted or skipped as dead
+
+  // ---- once per forward: classification lists, input embedding, embedding-independent feature chains ----
+  for (int k = 1; k <= L; ++k) {
+    const long G = (long)B * h->N[k];
+    ClassifyArgs a{in->lb[k], in->ub[k], in->mask, mu(k), scores, cnt + 4 * k, ilist(w.live[k]), ilist(w.amb[k]),
+                   ilist(w.score[k]), G, h->N[k], h->R, roff[k]};
+    lz.run(PC_CLASSIFY, [&] { hipLaunchKernelGGL(k_classify, dim3((unsigned)((G + CLS_THREADS - 1) / CLS_THREADS)), dim3(CLS_THREADS), 0, st, a); });
+  }
   {
     const long G = (long)B * h->N[0], nt = (G + 31) / 32;
     EmbedArgs a{h->d_pack[PK_EMBED], in->lb[0], in->x_lp, in->ub[0], mu(0), G, nt};
     lz.run(PC_EMBED, [&] { hipLaunchKernelGGL(k_embed, dim3(mlp_grid(h, nt)), dim3(WG_MLP), PackEmbed::FLOATS * 4, st, a); });
   }
-  const int total_halfpasses = 2 * h->T;
-  const int limit = h->halfpass_limit > 0 ? std::min(h->halfpass_limit, total_halfpasses) : total_halfpasses;
-  const bool debug_full = h->halfpass_limit > 0;   // with a limit set every input-layer update is executed too
   for (int k = 1; k <= L; ++k) {
-    const long G = (long)B * h->N[k];
+    const long G = (long)B * h->N[k], nt = (G + 31) / 32;     // upper bound: the kernels read the real count on the device
     const int q = h->relu_q[k];
     PreArgs a{nullptr, in->lb[k], in->ub[k], in->dual[k - 1], in->primal[q - 1], in->primal[q], h->dev[k].bias,
-              nullptr, G, 0, h->N[k], h->hw[k], DTileMap{}};
-    {
-      const TileMap tm = fwd_map(h, k);
-      a.pack = h->d_pack[PK_PRE_FWD];
-      a.P = ws + w.Pf[k];
-      a.tm = to_dtm(tm);
-      a.ntiles = map_tiles(tm, B);
-      lz.run(PC_PRE_FWD, [&] { hipLaunchKernelGGL(k_pre_fwd, dim3(mlp_grid(h, a.ntiles)), dim3(WG_MLP), PackPreFwd::FLOATS * 4, st, a); });
-    }
+              nullptr, G, nt, h->N[k], h->hw[k], DTileMap{}, ilist(w.amb[k]), cnt + 4 * k + 1};
+    a.pack = h->d_pack[PK_PRE_FWD];
+    a.P = ws + w.Pf[k];
+    lz.run(PC_PRE_FWD, [&] { hipLaunchKernelGGL(k_pre_fwd, dim3(mlp_grid(h, nt)), dim3(WG_MLP), PackPreFwd::FLOATS * 4, st, a); });
     if (limit >= 2) {
-      const TileMap tm = bwd_map(h, k);
       a.pack = h->d_pack[PK_PRE_BWD];
       a.P = ws + w.Pb[k];
-      a.tm = to_dtm(tm);
-      a.ntiles = map_tiles(tm, B);
-      lz.run(PC_PRE_BWD, [&] { hipLaunchKernelGGL(k_pre_bwd, dim3(mlp_grid(h, a.ntiles)), dim3(WG_MLP), PackPreBwd::FLOATS * 4, st, a); });
+      lz.run(PC_PRE_BWD, [&] { hipLaunchKernelGGL(k_pre_bwd, dim3(mlp_grid(h, nt)), dim3(WG_MLP), PackPreBwd::FLOATS * 4, st, a); });
     }
   }
   const bool need_inp = (limit >= 2) && (h->T > 1 || debug_full);
@@ -1371,16 +1486,26 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     const long G = (long)B * h->N[0];
     const TileMap tm = bwd_map(h, 0);
     const long nt = map_tiles(tm, B);
-    PreArgs a{h->d_pack[PK_PRE_INP], in->lb[0], in->ub[0], nullptr, nullptr, nullptr, nullptr, ws + w.Q, G, nt, h->N[0], 1, to_dtm(tm)};
+    PreArgs a{h->d_pack[PK_PRE_INP], in->lb[0], in->ub[0], nullptr, nullptr, nullptr, nullptr, ws + w.Q, G, nt, h->N[0], 1,
+              to_dtm(tm), nullptr, nullptr};
     lz.run(PC_PRE_INP, [&] { hipLaunchKernelGGL(k_pre_inp, dim3(mlp_grid(h, nt)), dim3(WG_MLP), PackPreInp::FLOATS * 4, st, a); });
   }
 
   auto conv_args = [&](const Edge& e, const float* src, float* dst, const float* wt, int normalise) {
     return ConvArgs{src, dst, wt, B, e.c_in, e.h_in, e.w_in, e.c_out, e.h_out, e.w_out, e.kh, e.kw, e.stride, e.pad, normalise};
   };
-  // nb <- A_k mu[k-1]
+  auto gather = [&](const DevGather& d, int k, const float* src, bool scored) {      // phase A over a conv edge, MFMA
+    const long nt = map_tiles(d.g.tm, B);
+    GArgs a{in->lb[k], in->ub[k], in->mask, src, nb, nt, scored ? 1 : 0, h->R, roff[k], to_dtm(d.g.tm), to_dg(d)};
+    const size_t lds = gather_lds_bytes(d, 0);
+    long grid = (nt + WAVES_MLP - 1) / WAVES_MLP;
+    if (grid > (long)h->n_cu * h->gather_occ) grid = (long)h->n_cu * h->gather_occ;
+    lz.run(PC_GATHER, [&] { hipLaunchKernelGGL(k_gather, dim3((unsigned)grid), dim3(WG_MLP), lds, st, a); });
+  };
+  // phase A: nb <- A_k mu[k-1]
   auto agg_fwd = [&](int k) {
     const Edge& e = h->edges[k];
+    if (h->gf[k].ok) { gather(h->gf[k], k, mu(k - 1), false); return; }
     if (e.kind == 0) {
       ConvArgs a = conv_args(e, mu(k - 1), nb, h->dev[k].w_fwd, 0);
       lz.run(PC_CONV_FWD, [&] {
@@ -1393,13 +1518,13 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       });
     } else {
       DenseArgs a{h->dev[k].w_fwd, mu(k - 1), nb, B, e.n_in, e.n_out, h->dev[k].ld_fwd, h->dev[k].mt_fwd};
-      const long waves = (long)B * a.MT * 2;
-      lz.run(PC_DENSE_AGG, [&] { hipLaunchKernelGGL(k_dense_agg, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a); });
+      lz.run(PC_DENSE_AGG, [&] { hipLaunchKernelGGL(k_dense_agg, dim3((unsigned)((long)B * a.MT)), dim3(256), 0, st, a); });
     }
   };
-  // nb <- A_{k+1}^T mu[k+1]  (k+1 <= L), conv case divided by the tap count when `normalise`
-  auto agg_bwd = [&](int k, int normalise) {
+  // phase A: nb <- A_{k+1}^T mu[k+1]  (k+1 <= L), conv case divided by the tap count when `normalise`
+  auto agg_bwd = [&](int k, int normalise, bool scored) {
     const Edge& e = h->edges[k + 1];
+    if (k >= 1 && h->gb[k + 1].ok) { gather(h->gb[k + 1], k, mu(k + 1), scored); return; }
     if (e.kind == 0) {
       ConvArgs a = conv_args(e, mu(k + 1), nb, h->dev[k + 1].w_bwd, normalise);
       lz.run(PC_CONVT_BWD, [&] {
@@ -1412,40 +1537,21 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       });
     } else {
       DenseArgs a{h->dev[k + 1].w_bwd, mu(k + 1), nb, B, e.n_out, e.n_in, e.n_in, h->dev[k + 1].mt_bwd};
-      const long waves = (long)B * a.MT * 2;
-      lz.run(PC_DENSE_AGG, [&] { hipLaunchKernelGGL(k_dense_agg, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a); });
+      lz.run(PC_DENSE_AGG, [&] { hipLaunchKernelGGL(k_dense_agg, dim3((unsigned)((long)B * a.MT)), dim3(256), 0, st, a); });
     }
   };
-  auto node_update = [&](int k, bool fwd) {      // flat tiles, nb already aggregated in HBM
-    const long G = (long)B * h->N[k], nt = (G + 31) / 32;
-    UpdArgs a{h->d_pack[fwd ? PK_UPD_FWD : PK_UPD_BWD], in->lb[k], in->ub[k], nb, ws + (fwd ? w.Pf[k] : w.Pb[k]), mu(k), status, G, nt};
-    lz.run(PC_NODE_UPDATE, [&] { hipLaunchKernelGGL(k_node_update, dim3(mlp_grid(h, nt)), dim3(WG_MLP), PackUpd::FLOATS * 4, st, a); });
-  };
-  auto gather_update = [&](int k, bool fwd) {    // conv edge: aggregate + update in one kernel
-    const DevGather& d = fwd ? h->gf[k] : h->gb[k + 1];
-    const long nt = map_tiles(d.g.tm, B);
-    GUArgs a{h->d_pack[fwd ? PK_UPD_FWD_G : PK_UPD_BWD_G], in->lb[k], in->ub[k], fwd ? mu(k - 1) : mu(k + 1),
-             ws + (fwd ? w.Pf[k] : w.Pb[k]), mu(k), status, nt, to_dtm(d.g.tm), to_dg(d)};
-    const size_t lds = gather_lds_bytes(d, PackUpd::FLOATS);
-    lz.run(PC_GATHER_UPDATE, [&] { hipLaunchKernelGGL(k_gather_update, dim3(mlp_grid(h, nt)), dim3(WG_MLP), lds, st, a); });
-  };
-  auto update_fwd = [&](int k) {
-    if (h->gf[k].ok) { gather_update(k, true); return; }
-    agg_fwd(k);
-    node_update(k, true);
-  };
-  auto update_bwd = [&](int k) {
-    if (k < L && h->gb[k + 1].ok) { gather_update(k, false); return; }
-    if (k == L) {
-      const long rows = (long)B * h->N[L];
-      const float* pw = in->prop_w;
-      const float* mk = mu(K);
-      const int nl = h->N[L];
-      lz.run(PC_PROP_BWD_NB, [&] { hipLaunchKernelGGL(k_prop_bwd_nb, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, pw, mk, nb, rows, nl); });
-    } else {
-      agg_bwd(k, 1);
-    }
-    node_update(k, false);
+  // phase B: node MLP over a compacted list of nodes
+  auto node_update = [&](int k, bool fwd, bool scored) {
+    const long nt = ((long)B * h->N[k] + 31) / 32;
+    UpdArgs a{h->d_pack[fwd ? PK_UPD_FWD : PK_UPD_BWD], in->lb[k], in->ub[k], nb, ws + (fwd ? w.Pf[k] : w.Pb[k]), mu(k), status,
+              ilist(scored ? w.score[k] : w.live[k]), cnt + 4 * k + (scored ? 2 : 0)};
+    const int wv = h->nu_waves;
+    long grid = (nt + wv - 1) / wv;
+    if (grid > h->n_cu) grid = h->n_cu;
+    lz.run(PC_NODE_UPDATE, [&] {
+      if (wv == 8) hipLaunchKernelGGL(k_node_update<8>, dim3((unsigned)grid), dim3(512), PackUpd::FLOATS * 4, st, a);
+      else hipLaunchKernelGGL(k_node_update<16>, dim3((unsigned)grid), dim3(1024), PackUpd::FLOATS * 4, st, a);
+    });
   };
   auto update_input = [&]() {
     if (h->gb[1].ok) {
@@ -1456,7 +1562,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       lz.run(PC_GATHER_INPUT, [&] { hipLaunchKernelGGL(k_gather_input_update, dim3(mlp_grid(h, nt)), dim3(WG_MLP), lds, st, a); });
       return;
     }
-    agg_bwd(0, 0);
+    agg_bwd(0, 0, false);
     const long G = (long)B * h->N[0], nt = (G + 31) / 32;
     UpdInpArgs a{h->d_pack[PK_UPD_INP], nb, ws + w.Q, mu(0), G, nt};
     lz.run(PC_INPUT_UPDATE, [&] { hipLaunchKernelGGL(k_input_update, dim3(mlp_grid(h, nt)), dim3(WG_MLP), PackUpdInp::FLOATS * 4, st, a); });
@@ -1465,28 +1571,42 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   int done = 0;
   for (int t = 0; t < h->T && done < limit; ++t) {
     // forward sweep (graph_conv.py:107-192) + property node (:194-210)
-    for (int k = 1; k <= L; ++k) update_fwd(k);
+    for (int k = 1; k <= L; ++k) {
+      agg_fwd(k);
+      node_update(k, true, false);
+    }
     {
       PropArgs a{h->d_pack[PK_PROP], mu(L), in->prop_w, in->prop_b, in->lb[K], in->ub[K], in->primal[in->n_primal - 1], mu(K), B, h->N[L]};
       lz.run(PC_PROP_FWD, [&] { hipLaunchKernelGGL(k_prop_fwd, dim3((B + 3) / 4), dim3(256), 0, st, a); });
     }
     if (++done >= limit) break;
     // backward sweep (:222-350), Gauss-Seidel order: layer k reads the already-updated mu[k+1]
-    for (int k = L; k >= 1; --k) update_bwd(k);
+    for (int k = L; k >= 1; --k) {
+      // after the last backward step mu[1] is only read by the score head, i.e. at the scored nodes
+      const bool scored = h->restrict_last && !debug_full && t == h->T - 1 && k == 1;
+      if (k == L) {
+        const long rows = (long)B * h->N[L];
+        const float* pw = in->prop_w;
+        const float* mk = mu(K);
+        const int nl = h->N[L];
+        lz.run(PC_PROP_BWD_NB, [&] { hipLaunchKernelGGL(k_prop_bwd_nb, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, pw, mk, nb, rows, nl); });
+      } else {
+        agg_bwd(k, 1, scored);
+      }
+      node_update(k, false, scored);
+    }
     // input layer (:360-385): its last-round result is never read, so it only runs when another round follows
     if (t < h->T - 1 || debug_full) update_input();
     ++done;
   }
 
   // scores (graph_conv.py:442-450) and decision (graph_score.py:41-47)
-  int off = 0;
   ArgmaxArgs am{scores, decisions, B, h->R, L, {0}};
   for (int k = 1; k <= L; ++k) {
-    const long G = (long)B * h->N[k], nt = (G + 31) / 32;
-    ScoreArgs a{h->d_pack[PK_SCORE], mu(k), in->mask, scores, G, nt, h->N[k], h->R, off};
+    const long nt = ((long)B * h->N[k] + 31) / 32;
+    ScoreArgs a{h->d_pack[PK_SCORE], mu(k), scores, ilist(w.score[k]), cnt + 4 * k + 2, h->N[k], h->R, roff[k]};
     lz.run(PC_SCORE, [&] { hipLaunchKernelGGL(k_score, dim3(mlp_grid(h, nt)), dim3(WG_MLP), PackScore::FLOATS * 4, st, a); });
-    off += h->N[k];
-    am.cum[k - 1] = off;
+    am.cum[k - 1] = roff[k] + h->N[k];
   }
   lz.run(PC_ARGMAX, [&] { hipLaunchKernelGGL(k_argmax, dim3(B), dim3(256), 0, st, am); });
   return lz.rc;

@@ -114,7 +114,7 @@ struct PackEmbed { enum { W1 = 0, B1 = W1 + 256, W2 = B1 + 64, B2 = W2 + 4096, F
 // k_pre_fwd: P = fc4[:, :64] (fc1_1(relu(fc1 feat7)) * amb) + fc4.bias    (:153-161, :176-177)
 struct PackPreFwd { enum { W1 = 0, B1 = W1 + 512, W2 = B1 + 64, B2 = W2 + 4096, W3 = B2 + 64, B3 = W3 + 4096, FLOATS = B3 + 64 }; };
 // k_node_update (forward: fc3, fc3_2, fc4[:, 64:], fc4_2; backward: bc3, bc3_1, bc4[:, 64:], bc4_1)
-struct PackUpd { enum { WA = 0, BA = WA + 8192, WB = BA + 64, BB = WB + 4096, WC = BB + 64, WD = WC + 4096, BD = WD + 4096, FLOATS = BD + 64 }; };
+struct PackUpd { enum { WA = 0, BA = WA + 8192, WB = BA + 64, BB = WB + 4096, WC = BB + 64, BC = WC + 4096, WD = BC + 64, BD = WD + 4096, FLOATS = BD + 64 }; };
 // k_pre_bwd: P = bc4[:, :64] (bc2_1(relu(bc2([s, -d2 s, d1 s]))) * amb) + bc4.bias,
 //            s = bc1_2(relu(bc1_1(relu(bc1 feat7'))))                      (:273-293, :344-345)
 struct PackPreBwd {
@@ -159,6 +159,7 @@ inline void build_packs(const float* blob, Packs& pk) {
     pack_w64(&v[PackUpd::WB], W(b), 64, 0, 1);
     pack_vec64(&v[PackUpd::BB], Bv(b));
     pack_w64(&v[PackUpd::WC], W(c), 128, 64, 1);
+    pack_vec64(&v[PackUpd::BC], Bv(c));      // what the cached P reduces to for nodes whose relaxation term is masked out
     pack_w64(&v[PackUpd::WD], W(d), 64, 0, 1);
     pack_vec64(&v[PackUpd::BD], Bv(d));
   };

@@ -107,7 +107,7 @@ def test_node_update_chain(packs):
     w4, b4 = np.asarray(sd[E + "fc4.weight"], np.float64), np.asarray(sd[E + "fc4.bias"], np.float64)
     P = relax @ w4[:, :64].T + b4                      # what k_pre_fwd caches
     p = pk["upd_fwd"]
-    WA, BA, WB, BB, WC, WD, BD = 0, 8192, 8256, 12352, 12416, 16512, 20608
+    WA, BA, WB, BB, WC, BC, WD, BD = 0, 8192, 8256, 12352, 12416, 16512, 16576, 20672
     X = frag_from_rows(nb)
     Hf = frag_bias(p[BA:BA + 64])
     gemm_w64(p[WA:], 64, Hf, lambda s: X[:, s & 31] * (r0[J] if s < 32 else r1[J]))
@@ -123,6 +123,8 @@ def test_node_update_chain(packs):
     e = lin(sd, E + "fc3_2", np.maximum(lin(sd, E + "fc3", np.concatenate([nb * r0[:, None], nb * r1[:, None]], 1)), 0))
     want = lin(sd, E + "fc4_2", np.maximum(lin(sd, E + "fc4", np.concatenate([relax, e], 1)), 0))
     np.testing.assert_allclose(got, want, atol=1e-5)
+    # nodes whose relaxation term is masked (amb = 0): P degenerates to fc4.bias, kept in the pack at BC
+    np.testing.assert_allclose(rows_from_frag(frag_bias(p[BC:BC + 64]))[0], b4, atol=0)
 
 
 def test_pre_bwd_chain(packs):
