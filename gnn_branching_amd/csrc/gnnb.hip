@@ -64,6 +64,7 @@ __device__ __forceinline__ void gemm_w64(const float* wl, int lane, Frag& acc, G
       n0 = w4[((s4 + 1) * 2 + 0) * 64];
       n1 = w4[((s4 + 1) * 2 + 1) * 64];
     }
+    __builtin_amdgcn_sched_barrier(0);      // reads of the next block issue BEFORE this block's MFMAs, not after them
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const float b = getB(s4 * 4 + c);
@@ -114,6 +115,15 @@ __device__ __forceinline__ void frag_scale(Frag& a, float s) {
 // row-major (G, 64) <-> fragment: lane (j, h) owns features [8q+4h, 8q+4h+4) of row `row`, q = 0..7
 __device__ __forceinline__ void frag_load_rows(Frag& x, const float* base, long row, int h) {
   const f32x4* p = reinterpret_cast<const f32x4*>(base + row * 64 + 4 * h);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const f32x4 v = p[2 * q];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) FRAG_AT(x, 4 * q + c) = v[c];
+  }
+}
+__device__ __forceinline__ void frag_load_rowptr(Frag& x, const float* rowptr, int h) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(rowptr + 4 * h);
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const f32x4 v = p[2 * q];
@@ -181,7 +191,7 @@ __device__ __forceinline__ void stage_pack(float* lds, const float* pack, int nf
 }
 
 // ---- tile -> node mapping (gnnb_pack.h TileMap) ----
-struct DTileMap { int mode, N, C, H, W, CT, PY, PX, ay, ax, NBY, NBX, NCG, TPS; };
+struct DTileMap { int mode, N, C, H, W, CT, PY, PX, ay, ax, NBY, NBX, NCG, TPS, lpy, lpx; };
 struct TileCtx { long sample; int n, cg, by, bx, y, x; bool valid; };
 
 // lane j of tile `tile`: which node of which sample.  mode 0: 32 consecutive rows of the flat (B*N) layer;
@@ -212,6 +222,24 @@ __device__ __forceinline__ TileCtx tile_decode(const DTileMap& tm, long tile, in
     c.valid = cl < tm.CT && (unsigned)c.y < (unsigned)tm.H && (unsigned)c.x < (unsigned)tm.W;
     c.n = c.valid ? ((c.cg * tm.CT + cl) * tm.H + c.y) * tm.W + c.x : 0;
   }
+  return c;
+}
+
+// block tiles without integer divisions: ttab[t] = cg | by << 8 | bx << 20 for tile t of a sample (built on the host),
+// PY and PX are powers of two.
+__device__ __forceinline__ TileCtx block_decode(const DTileMap& tm, const int* ttab, long sample, int t, int j) {
+  TileCtx c;
+  c.sample = sample;
+  const int e = ttab[t];
+  c.cg = e & 0xff;
+  c.by = (e >> 8) & 0xfff;
+  c.bx = (e >> 20) & 0xfff;
+  const int cl = j >> (tm.lpy + tm.lpx);
+  const int py = (j >> tm.lpx) & (tm.PY - 1), px = j & (tm.PX - 1);
+  c.y = c.by * tm.PY + tm.ay + py;
+  c.x = c.bx * tm.PX + tm.ax + px;
+  c.valid = cl < tm.CT && (unsigned)c.y < (unsigned)tm.H && (unsigned)c.x < (unsigned)tm.W;
+  c.n = c.valid ? ((c.cg * tm.CT + cl) * tm.H + c.y) * tm.W + c.x : 0;
   return c;
 }
 
@@ -467,14 +495,36 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_node_update(UpdArgs a
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
   const int count = *a.cnt;
   const long ntiles = (count + 31) / 32;
-  // round-robin over workgroups and waves: a few tiles per wave, so balance matters more than locality (rows stream)
-  for (long tile = (long)blockIdx.x * WAVES + wave; tile < ntiles; tile += (long)gridDim.x * WAVES) {
-    const long idx = tile * 32 + j;
-    const bool valid = idx < count;
-    const long gc = a.list[valid ? idx : 0];
-    const Ratio r = compute_ratio(a.lb[gc], a.ub[gc]);
-    Frag X;
-    frag_load_rows(X, a.nb, gc, h);
+  const float* bias_row = a.pack + PackUpd::BCROW;
+  // Only a few tiles per wave, so balance matters more than locality (rows stream): tiles are dealt round-robin over
+  // the SIMDs of the whole grid (4 per workgroup), and the two waves that share a SIMD (w, w+4) take alternate rounds,
+  // so every SIMD's MFMA pipe gets floor or ceil of the average.  The inputs of the next tile (list entry -> bounds ->
+  // aggregate row) are fetched while this tile's MFMA chain runs.
+  static_assert(WAVES == 8, "tile dealing assumes 2 waves per SIMD");
+  const long stride = (long)gridDim.x * 4 * 2;
+  long tile = (long)(wave >> 2) * gridDim.x * 4 + (long)blockIdx.x * 4 + (wave & 3);
+  if (tile >= ntiles) return;
+  long gc, gc_n = 0;
+  bool valid, valid_n = false;
+  float lb, ub, lb_n = 0.0f, ub_n = 0.0f;
+  Frag X, Xn;
+  auto fetch = [&](long tl, long& g_, bool& v_, float& l_, float& u_, Frag& x_) {
+    const long idx = tl * 32 + j;
+    v_ = idx < count;
+    g_ = a.list[v_ ? idx : 0];
+    l_ = a.lb[g_];
+    u_ = a.ub[g_];
+    frag_load_rows(x_, a.nb, g_, h);
+  };
+  fetch(tile, gc, valid, lb, ub, X);
+  for (;;) {
+    const Ratio r = compute_ratio(lb, ub);
+    // nodes without a relaxation term (amb = 0) read the bias row instead of their (never written) P row
+    Frag H2;
+    frag_load_rowptr(H2, r.amb != 0.0f ? a.P + gc * 64 : bias_row, h);
+    const long next = tile + stride;
+    const bool has_next = next < ntiles;
+    if (has_next) fetch(next, gc_n, valid_n, lb_n, ub_n, Xn);
     Frag H;
     frag_bias(H, lds + PackUpd::BA, h);
     const float r0 = r.r0, r1 = r.r1;
@@ -483,9 +533,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_node_update(UpdArgs a
     Frag E;
     frag_bias(E, lds + PackUpd::BB, h);
     gemm_w64<32>(lds + PackUpd::WB, lane, E, [&](int s) { return FRAG_AT(H, s); });
-    Frag H2;
-    frag_bias(H2, lds + PackUpd::BC, h);
-    if (r.amb != 0.0f) frag_load_rows(H2, a.P, gc, h);
     gemm_w64<32>(lds + PackUpd::WC, lane, H2, [&](int s) { return FRAG_AT(E, s); });
     frag_relu(H2);
     Frag M;
@@ -496,6 +543,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_node_update(UpdArgs a
       if (frag_has_nan(M)) atomicOr(a.status, 1);
       frag_store_rows(M, a.mu, gc, h);
     }
+    if (!has_next) break;
+    tile = next; gc = gc_n; valid = valid_n; lb = lb_n; ub = ub_n;
+#pragma unroll
+    for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = FRAG_AT(Xn, R);
   }
 }
 
@@ -533,43 +584,63 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_input_update(UpdInpArgs a) {
 struct DGather {
   const float* cmat;     // [NCG][K2][64]
   const int2* koff;      // [2*K2]: {row offset relative to the window origin, wy | wx << 16}
+  const int* ttab;       // [TPS]: cg | by << 8 | bx << 20
+  const float* zero;     // 64 zero floats
   int K2, ncg_k2, Hs, Ws, Ns, ystep, ybase, xstep, xbase, WY, WX, normalise, kh, kw, stride, pad;
 };
 
 #define GATHER_CH 8   // k-steps per prefetch chunk
+#define KOFF_PAD (2 * GATHER_CH)   // always-masked koff entries behind the table (one chunk is loaded past the end)
 
 __device__ __forceinline__ void gather_tile(Frag& X, const float* cm, const int2* ko, int K2, const float* src,
-                                            int wy0, int wx0, int Hs, int Ws, int lane) {
+                                            const float* zrow, int wy0, int wx0, int Hs, int Ws, int lane) {
   const int h = lane >> 5;
 #pragma unroll
   for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = 0.0f;
   const long origin = (long)wy0 * Ws + wx0;
+  const long zdelta = zrow - src;           // element offset that lands on the zero row
   float2 cur[GATHER_CH], nxt[GATHER_CH];
+  // window nodes outside the source layer (padding) and the k padding read a zero row: nothing is applied to a loaded
+  // value before its MFMA, so the loads of the next chunk really stay in flight behind this chunk's MFMAs
   auto load = [&](float2 (&dst)[GATHER_CH], int s0) {
 #pragma unroll
     for (int u = 0; u < GATHER_CH; ++u) {
-      const int2 e = ko[2 * (s0 + u) + h];
-      const int wy = wy0 + (e.y & 0xffff), wx = wx0 + (e.y >> 16);
+      // one 64-bit LDS read per entry: with two 32-bit halves hipcc branches around the second one, and the
+      // control flow makes its vmcnt bookkeeping fall back to waiting for the loads just issued
+      const unsigned long long ev = reinterpret_cast<const unsigned long long*>(ko)[2 * (s0 + u) + h];
+      const int ex = (int)(unsigned)ev, ey = (int)(unsigned)(ev >> 32);
+      const int wy = wy0 + (ey & 0xffff), wx = wx0 + (ey >> 16);
       const bool ok = (unsigned)wy < (unsigned)Hs && (unsigned)wx < (unsigned)Ws;
-      const long row = ok ? origin + e.x : 0;
-      const float2 v = *reinterpret_cast<const float2*>(src + row * 64);
-      dst[u].x = ok ? v.x : 0.0f;
-      dst[u].y = ok ? v.y : 0.0f;
+      const long o = ok ? (origin + ex) * 64 : zdelta;
+      dst[u] = *reinterpret_cast<const float2*>(src + o);
     }
   };
-  load(cur, 0);
-  for (int s0 = 0; s0 < K2; s0 += GATHER_CH) {
-    if (s0 + GATHER_CH < K2) load(nxt, s0 + GATHER_CH);
+  auto mma = [&](const float2 (&v)[GATHER_CH], int s0) {
 #pragma unroll
     for (int u = 0; u < GATHER_CH; ++u) {
       const float b = cm[(s0 + u) * 64 + lane];
-      X.t[0] = mfma32(cur[u].x, b, X.t[0]);
-      X.t[1] = mfma32(cur[u].y, b, X.t[1]);
+      X.t[0] = mfma32(v[u].x, b, X.t[0]);
+      X.t[1] = mfma32(v[u].y, b, X.t[1]);
     }
+  };
+  // Two register buffers in ping-pong (a rotating copy would have to wait for the data it copies), NO control flow
+  // around the loads (the koff table is padded with 16 always-masked entries, so the one chunk loaded past the end
+  // just reads the zero row), and sched_barriers pinning "issue the next chunk's loads, THEN this chunk's MFMAs":
+  // only then does hipcc keep the next chunk in flight behind counted vmcnt waits.
+  load(cur, 0);
+  const int npairs = K2 / (2 * GATHER_CH);
+  int s0 = 0;
+  for (int pr = 0; pr < npairs; ++pr, s0 += 2 * GATHER_CH) {
+    load(nxt, s0 + GATHER_CH);
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < GATHER_CH; ++u) cur[u] = nxt[u];
+    mma(cur, s0);
+    __builtin_amdgcn_sched_barrier(0);
+    load(cur, s0 + 2 * GATHER_CH);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(nxt, s0 + GATHER_CH);
+    __builtin_amdgcn_sched_barrier(0);
   }
+  if (K2 & GATHER_CH) mma(cur, s0);
 }
 
 // number of kernel taps that touch dst position t along one axis (the reference's `freq`, graph_conv.py:306-311)
@@ -583,11 +654,19 @@ __device__ __forceinline__ int tap_count(int t, int w0, int WN, int Hs, int k, i
   return n;
 }
 
-__device__ __forceinline__ void stage_gather(float* lds_cm, int2* lds_ko, const DGather& g) {
+__device__ __forceinline__ void stage_gather(float* lds_cm, int2* lds_ko, int* lds_tt, const DGather& g, int TPS) {
   const f32x4* src = reinterpret_cast<const f32x4*>(g.cmat);
   f32x4* dst = reinterpret_cast<f32x4*>(lds_cm);
   for (int i = threadIdx.x; i < g.ncg_k2 * 16; i += blockDim.x) dst[i] = src[i];
-  for (int i = threadIdx.x; i < 2 * g.K2; i += blockDim.x) lds_ko[i] = g.koff[i];
+  for (int i = threadIdx.x; i < 2 * g.K2 + KOFF_PAD; i += blockDim.x) lds_ko[i] = g.koff[i];
+  for (int i = threadIdx.x; i < TPS; i += blockDim.x) lds_tt[i] = g.ttab[i];
+}
+
+// [r0 != 0] without the division: r0 = u+/(u+ - l-) is zero iff u+ == 0 and l- != 0 (0/0 is NaN, and NaN != 0)
+__device__ __forceinline__ bool node_is_live(float lb, float ub) {
+  const float lower_temp = lb - relu_nan(lb);
+  const float upper_temp = relu_nan(ub);
+  return !(upper_temp == 0.0f) || lower_temp == 0.0f;
 }
 
 // rows of the gathered fragment (gather channel map) -> row-major (.., 64): lane (j,h) owns channels [16q+8h, 16q+8h+8)
@@ -619,54 +698,96 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_gather(GArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lds_cm = lds;
   int2* lds_ko = reinterpret_cast<int2*>(lds_cm + a.g.ncg_k2 * 64);
-  stage_gather(lds_cm, lds_ko, a.g);
+  int* lds_tt = reinterpret_cast<int*>(lds_ko + 2 * a.g.K2 + KOFF_PAD);
+  stage_gather(lds_cm, lds_ko, lds_tt, a.g, a.tm.TPS);
   __syncthreads();
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
   long t0, t1;
   tile_range(a.ntiles, WAVES_MLP, t0, t1);
-  for (long tile = t0 + wave; tile < t1; tile += WAVES_MLP) {
-    const TileCtx tc = tile_decode(a.tm, tile, j, 0);
+  long tile = t0 + wave;
+  if (tile >= t1) return;
+  long sample = tile / a.tm.TPS;
+  int t = (int)(tile - sample * a.tm.TPS);
+  for (; tile < t1; tile += WAVES_MLP, t += WAVES_MLP) {
+    while (t >= a.tm.TPS) { t -= a.tm.TPS; ++sample; }
+    const TileCtx tc = block_decode(a.tm, lds_tt, sample, t, j);
     const long gc = tc.sample * a.tm.N + tc.n;
     bool need;
     if (a.need_scored) need = tc.valid && a.mask[tc.sample * a.R + a.off + tc.n] != 0.0f;
-    else need = tc.valid && compute_ratio(a.lb[gc], a.ub[gc]).live != 0.0f;
+    else need = tc.valid && node_is_live(a.lb[gc], a.ub[gc]);
     if (!__any(need)) continue;
     const int wy0 = tc.by * a.g.ystep + a.g.ybase, wx0 = tc.bx * a.g.xstep + a.g.xbase;
     Frag X;
-    gather_tile(X, lds_cm + tc.cg * a.g.K2 * 64, lds_ko, a.g.K2, a.mu_src + tc.sample * a.g.Ns * 64 + 2 * j, wy0, wx0,
-                a.g.Hs, a.g.Ws, lane);
+    gather_tile(X, lds_cm + tc.cg * a.g.K2 * 64, lds_ko, a.g.K2, a.mu_src + tc.sample * a.g.Ns * 64 + 2 * j, a.g.zero + 2 * j,
+                wy0, wx0, a.g.Hs, a.g.Ws, lane);
     if (a.g.normalise) {
       const int ny = tap_count(tc.y, wy0, a.g.WY, a.g.Hs, a.g.kh, a.g.stride, a.g.pad);
       const int nx = tap_count(tc.x, wx0, a.g.WX, a.g.Ws, a.g.kw, a.g.stride, a.g.pad);
-      const float freq = tc.valid ? (float)(ny * nx) : 1.0f;
+      const int f = tc.valid ? ny * nx : 1;
+      const float freq = (float)f;
+      if (__all((f & (f - 1)) == 0)) {         // power of two: x * (1/f) is exactly x / f
+        const float inv = 1.0f / freq;
 #pragma unroll
-      for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = FRAG_AT(X, R) / freq;
+        for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = FRAG_AT(X, R) * inv;
+      } else {
+#pragma unroll
+        for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = FRAG_AT(X, R) / freq;
+      }
     }
     if (need) frag_store_rows_gathered(X, a.nb, gc, h);
   }
 }
 
-struct GIArgs { const float* pack; const float* mu_src; const float* Q; float* mu; long ntiles; DTileMap tm; DGather g; };
+struct GIArgs {
+  const float* pack_pre;    // PackPreInp
+  const float* pack;        // PackUpdInp (gather variant)
+  const float *lb, *ub;     // input bounds, flat (B*N0)
+  const float* mu_src; float* mu; long ntiles; DTileMap tm; DGather g;
+};
 
-// input layer: mu_0 = inp_b2_2(relu(Q + inp_b2[:, 64:] . (A_1^T mu_1)))     graph_conv.py:361-385
+// input layer: mu_0 = inp_b2_2(relu(Q + inp_b2[:, 64:] . (A_1^T mu_1))),  Q = inp_b2[:, :64] . inp_b_1(relu(inp_b([l0,u0]))) + b
+// graph_conv.py:361-385; the aggregate, the feature chain and the update stay in registers.
 __global__ __launch_bounds__(WG_MLP, 2) void k_gather_input_update(GIArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* lds_cm = lds + PackUpdInp::FLOATS;
+  float* lds_pre = lds + PackUpdInp::FLOATS;
+  float* lds_cm = lds_pre + PackPreInp::FLOATS;
   int2* lds_ko = reinterpret_cast<int2*>(lds_cm + a.g.ncg_k2 * 64);
-  stage_gather(lds_cm, lds_ko, a.g);
+  int* lds_tt = reinterpret_cast<int*>(lds_ko + 2 * a.g.K2 + KOFF_PAD);
+  stage_gather(lds_cm, lds_ko, lds_tt, a.g, a.tm.TPS);
+  {
+    const f32x4* gsrc = reinterpret_cast<const f32x4*>(a.pack_pre);
+    f32x4* ldst = reinterpret_cast<f32x4*>(lds_pre);
+    for (int i = threadIdx.x; i < PackPreInp::FLOATS / 4; i += blockDim.x) ldst[i] = gsrc[i];
+  }
   stage_pack(lds, a.pack, PackUpdInp::FLOATS);
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
   long t0, t1;
   tile_range(a.ntiles, WAVES_MLP, t0, t1);
-  for (long tile = t0 + wave; tile < t1; tile += WAVES_MLP) {
-    const TileCtx tc = tile_decode(a.tm, tile, j, 0);
+  long tile = t0 + wave;
+  if (tile >= t1) return;
+  long sample = tile / a.tm.TPS;
+  int t = (int)(tile - sample * a.tm.TPS);
+  for (; tile < t1; tile += WAVES_MLP, t += WAVES_MLP) {
+    while (t >= a.tm.TPS) { t -= a.tm.TPS; ++sample; }
+    const TileCtx tc = block_decode(a.tm, lds_tt, sample, t, j);
+    if (!__any(tc.valid)) continue;
     const long gc = tc.sample * a.tm.N + tc.n;
     const int wy0 = tc.by * a.g.ystep + a.g.ybase, wx0 = tc.bx * a.g.xstep + a.g.xbase;
     Frag X;
-    gather_tile(X, lds_cm + tc.cg * a.g.K2 * 64, lds_ko, a.g.K2, a.mu_src + tc.sample * a.g.Ns * 64 + 2 * j, wy0, wx0,
-                a.g.Hs, a.g.Ws, lane);
+    gather_tile(X, lds_cm + tc.cg * a.g.K2 * 64, lds_ko, a.g.K2, a.mu_src + tc.sample * a.g.Ns * 64 + 2 * j, a.g.zero + 2 * j,
+                wy0, wx0, a.g.Hs, a.g.Ws, lane);
+    float x[1];
+    x[0] = h ? a.ub[gc] : a.lb[gc];
+    Frag H0;
+    frag_bias(H0, lds_pre + PackPreInp::B1, h);
+    gemm_small<1>(lds_pre + PackPreInp::W1, lane, H0, x);
+    frag_relu(H0);
+    Frag S;
+    frag_bias(S, lds_pre + PackPreInp::B2, h);
+    gemm_w64<32>(lds_pre + PackPreInp::W2, lane, S, [&](int s) { return FRAG_AT(H0, s); });
     Frag H;
-    frag_load_tiled(H, a.Q, tile, lane);
+    frag_bias(H, lds_pre + PackPreInp::B3, h);
+    gemm_w64<32>(lds_pre + PackPreInp::W3, lane, H, [&](int s) { return FRAG_AT(S, s); });
     gemm_w64<32>(lds + PackUpdInp::WC, lane, H, [&](int s) { return FRAG_AT(X, s); });
     frag_relu(H);
     Frag M;
@@ -795,10 +916,11 @@ __global__ __launch_bounds__(256) void k_convT_bwd(ConvArgs a) {
 }
 
 struct DenseArgs {
-  const float* At;   // (K, ldA): At[k][i] = A[i][k]
+  const float* At;   // (8*ksq, ldA) zero-padded: At[k][i] = A[i][k]
   const float* X;    // (B, K, 64)
   float* out;        // (B, M, 64)
-  int B, K, M, ldA, MT;
+  const float* zero; // 64 zero floats
+  int B, K, M, ldA, MT, ksq;
 };
 
 // dense edge: out[b, i, :] = sum_k A[i][k] X[b, k, :]   (graph_conv.py:131 forward, :321 backward)
@@ -806,59 +928,70 @@ struct DenseArgs {
 // D_it[i][j] on the MFMA for both channel tiles (lane j holds channels 2j, 2j+1 of the source row: one coalesced
 // 256-B row per half-wave and k-step), A from L2; loads run one 8-k-step chunk ahead.
 #define DENSE_CH 8
+// SPLIT = true: the 4 waves of a workgroup share one (b, row tile) and split K (long K, few tiles: the forward edge);
+// SPLIT = false: every wave owns its own (b, row tile) and walks all of K (short K: the transposed edge).
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void k_dense_agg(DenseArgs a) {
-  __shared__ float red[4][32][64];
-  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
-  const int tile = blockIdx.x;
+  __shared__ float red[SPLIT ? 4 : 1][32][64];
+  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // the MT row tiles of one sample all stream the same source rows: keep them on one XCD (blockIdx % 8 labels the
+  // XCD group), so that sample is fetched into one L2 instead of up to MT of them
+  int bid = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+  const int tile = SPLIT ? bid : bid * 4 + wave;
+  if (tile >= a.B * a.MT) return;
   const int mt = tile % a.MT, b = tile / a.MT;
-  const int i = mt * 32 + j;
-  const bool iok = i < a.M;
-  const float* At = a.At + (iok ? i : 0);
+  // At is zero-padded on the host to MT*32 columns and enough rows, the k padding of X reads a zero row: no select
+  // touches a loaded value
+  const float* At = a.At + mt * 32 + j;
   const float* X = a.X + (long)b * a.K * 64 + 2 * j;
+  const long zdelta = (a.zero + 2 * j) - X;
   f32x16 acc0, acc1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
-  const int ksteps = (a.K + 1) / 2;
-  const int per = (ksteps + 3) / 4;
-  const int s_begin = wave * per, s_end = s_begin + per < ksteps ? s_begin + per : ksteps;
-  float av[DENSE_CH], nav[DENSE_CH];
-  float2 bv[DENSE_CH], nbv[DENSE_CH];
-  auto load = [&](float (&A)[DENSE_CH], float2 (&Bv)[DENSE_CH], int s0) {
+  const int nks = SPLIT ? a.ksq : 4 * a.ksq;            // k-steps this wave walks (a multiple of DENSE_CH)
+  const int s_begin = SPLIT ? wave * a.ksq : 0;
+  float av[DENSE_CH];
+  float2 bv[DENSE_CH];
+  // measured: with 16 resident waves per CU the other waves cover a chunk's load latency; keeping a second chunk in
+  // flight per wave made this kernel slower
+  for (int s0 = s_begin; s0 < s_begin + nks; s0 += DENSE_CH) {
 #pragma unroll
     for (int u = 0; u < DENSE_CH; ++u) {
       const int k = 2 * (s0 + u) + h;
-      const bool kok = (s0 + u) < s_end && k < a.K;
-      const int kc = kok ? k : 0;
-      const float x = At[(long)kc * a.ldA];
-      const float2 y = *reinterpret_cast<const float2*>(X + (long)kc * 64);
-      A[u] = (kok && iok) ? x : 0.0f;
-      Bv[u].x = kok ? y.x : 0.0f;
-      Bv[u].y = kok ? y.y : 0.0f;
+      av[u] = At[(long)k * a.ldA];
+      const long o = k < a.K ? (long)k * 64 : zdelta;
+      bv[u] = *reinterpret_cast<const float2*>(X + o);
     }
-  };
-  if (s_begin < s_end) load(av, bv, s_begin);
-  for (int s0 = s_begin; s0 < s_end; s0 += DENSE_CH) {
-    if (s0 + DENSE_CH < s_end) load(nav, nbv, s0 + DENSE_CH);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < DENSE_CH; ++u) {
       acc0 = mfma32(av[u], bv[u].x, acc0);
       acc1 = mfma32(av[u], bv[u].y, acc1);
     }
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < DENSE_CH; ++u) { av[u] = nav[u]; bv[u] = nbv[u]; }
   }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { red[wave][r][lane] = acc0[r]; red[wave][16 + r][lane] = acc1[r]; }
-  __syncthreads();
   float* out = a.out + (long)b * a.M * 64 + 2 * j;
+  if (SPLIT) {
 #pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    const int r = wave * 4 + rr;
-    const float v0 = ((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane];
-    const float v1 = ((red[0][16 + r][lane] + red[1][16 + r][lane]) + red[2][16 + r][lane]) + red[3][16 + r][lane];
-    const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-    if (row < a.M) *reinterpret_cast<float2*>(out + (long)row * 64) = make_float2(v0, v1);
+    for (int r = 0; r < 16; ++r) { red[wave][r][lane] = acc0[r]; red[wave][16 + r][lane] = acc1[r]; }
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int r = wave * 4 + rr;
+      const float v0 = ((red[0][r][lane] + red[SPLIT ? 1 : 0][r][lane]) + red[SPLIT ? 2 : 0][r][lane]) + red[SPLIT ? 3 : 0][r][lane];
+      const float v1 = ((red[0][16 + r][lane] + red[SPLIT ? 1 : 0][16 + r][lane]) + red[SPLIT ? 2 : 0][16 + r][lane]) +
+                       red[SPLIT ? 3 : 0][16 + r][lane];
+      const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < a.M) *reinterpret_cast<float2*>(out + (long)row * 64) = make_float2(v0, v1);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < a.M) *reinterpret_cast<float2*>(out + (long)row * 64) = make_float2(acc0[r], acc1[r]);
+    }
   }
 }
 
@@ -973,8 +1106,8 @@ static const char* kProfNames[PC_COUNT] = {
     "k_prop_bwd_nb", "k_node_update", "k_input_update", "k_score", "k_argmax", "k_gather", "k_gather_input_update", "k_classify"};
 
 struct DevEdge {
-  float *w_fwd = nullptr, *w_bwd = nullptr, *bias = nullptr;   // conv: tap-major copies; linear: W^T padded / W
-  int ld_fwd = 0, mt_fwd = 0, mt_bwd = 0;
+  float *w_fwd = nullptr, *w_bwd = nullptr, *bias = nullptr;   // conv: tap-major copies; linear: W^T / W, zero-padded
+  int ld_fwd = 0, mt_fwd = 0, ksq_fwd = 0, ld_bwd = 0, mt_bwd = 0, ksq_bwd = 0;
 };
 
 struct DevGather {          // one conv edge in one direction, as MFMA gather tables on the device
@@ -982,17 +1115,20 @@ struct DevGather {          // one conv edge in one direction, as MFMA gather ta
   GatherGeom g;
   float* cmat = nullptr;
   int* koff = nullptr;
+  int* ttab = nullptr;
 };
 
 #define N_PACKS 12
 struct gnnb_handle {
   int T = 2, p = 64, device = 0, n_cu = 256;
   bool use_gather = true;       // MFMA gather for conv edges (false: VALU gather kernels)
-  int nu_waves = 8;             // waves per workgroup of k_node_update (one workgroup per CU, weights shared in LDS)
+  int nu_waves = 8;             // waves per workgroup of k_node_update (one workgroup per CU, weights shared in LDS;
+                                // 16 waves measured 27 % slower and no longer fit the register budget)
   int gather_occ = 2;           // workgroups per CU for k_gather (its LDS footprint is only the tap matrix)
   bool restrict_last = true;    // last backward step of layer 1 only for the scored nodes (nothing else reads it)
   Packs packs;
   float* d_pack[N_PACKS] = {nullptr};
+  float* d_zero = nullptr;      // 64 zero floats: where masked gather loads point
   std::vector<DevGather> gf, gb;   // gf[k]: edge k forward (dst = layer k); gb[k]: edge k transposed (dst = layer k-1)
   bool bound = false;
   std::vector<Edge> edges;       // edges[k], k = 1..L (edges[0] unused)
@@ -1044,14 +1180,14 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
                                            &h->packs.upd_fwd_g, &h->packs.upd_bwd_g, &h->packs.upd_inp_g};
   for (int i = 0; i < N_PACKS; ++i)
     if (int rc = upload(&h->d_pack[i], pv[i]->data(), pv[i]->size())) return rc;
+  HIPCHK(hipMalloc((void**)&h->d_zero, 256 * sizeof(float)));
+  HIPCHK(hipMemset(h->d_zero, 0, 256 * sizeof(float)));
   // > 64 KiB of dynamic LDS needs the attribute
   HIPCHK(hipFuncSetAttribute((const void*)k_embed, hipFuncAttributeMaxDynamicSharedMemorySize, PackEmbed::FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_pre_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, PackPreFwd::FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_pre_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, PackPreBwd::FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_pre_inp, hipFuncAttributeMaxDynamicSharedMemorySize, PackPreInp::FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_node_update<8>, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpd::FLOATS * 4));
-  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<16>, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpd::FLOATS * 4));
-  if (const char* e = getenv("GNNB_NU_WAVES")) h->nu_waves = atoi(e) == 8 ? 8 : 16;
   if (const char* e = getenv("GNNB_GATHER_OCC")) h->gather_occ = atoi(e) < 1 ? 1 : atoi(e);
   HIPCHK(hipFuncSetAttribute((const void*)k_input_update, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpdInp::FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_score, hipFuncAttributeMaxDynamicSharedMemorySize, PackScore::FLOATS * 4));
@@ -1073,6 +1209,7 @@ static void free_network(gnnb_t* h) {
     for (auto& d : *v) {
       if (d.cmat) (void)hipFree(d.cmat);
       if (d.koff) (void)hipFree(d.koff);
+      if (d.ttab) (void)hipFree(d.ttab);
     }
   h->gf.clear();
   h->gb.clear();
@@ -1089,6 +1226,7 @@ extern "C" int gnnb_destroy(gnnb_t* h) {
   free_network(h);
   for (int i = 0; i < N_PACKS; ++i)
     if (h->d_pack[i]) (void)hipFree(h->d_pack[i]);
+  if (h->d_zero) (void)hipFree(h->d_zero);
   for (auto& ev : h->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
   for (auto& ev : h->pool) (void)hipEventDestroy(ev);
   delete h;
@@ -1183,14 +1321,22 @@ extern "C" int gnnb_bind_network(gnnb_t* h, const gnnb_layer_desc* L, int n, int
       pack_conv_bwd(t.data(), e);
       if (int rc = upload(&d.w_bwd, t.data(), t.size())) return rc;
     } else {
+      // k_dense_agg operands At[k][i] = A[i][k], zero-padded to 32*MT columns and 8*ksq rows (ksq = k-steps per wave)
+      auto ksq_of = [](int K) { return (((K + 1) / 2 + 3) / 4 + DENSE_CH - 1) / DENSE_CH * DENSE_CH; };
       d.mt_fwd = (e.n_out + 31) / 32;
       d.ld_fwd = d.mt_fwd * 32;
-      d.mt_bwd = (e.n_in + 31) / 32;
-      std::vector<float> t((size_t)e.n_in * d.ld_fwd, 0.f);
+      d.ksq_fwd = ksq_of(e.n_in);
+      std::vector<float> t((size_t)(8 * d.ksq_fwd + 2 * DENSE_CH) * d.ld_fwd, 0.f);           // forward: A = W, k = input node
       for (int o = 0; o < e.n_out; ++o)
         for (int i = 0; i < e.n_in; ++i) t[(size_t)i * d.ld_fwd + o] = e.w[(size_t)o * e.n_in + i];
       if (int rc = upload(&d.w_fwd, t.data(), t.size())) return rc;
-      if (int rc = upload(&d.w_bwd, e.w.data(), e.w.size())) return rc;
+      d.mt_bwd = (e.n_in + 31) / 32;
+      d.ld_bwd = d.mt_bwd * 32;
+      d.ksq_bwd = ksq_of(e.n_out);
+      t.assign((size_t)(8 * d.ksq_bwd + 2 * DENSE_CH) * d.ld_bwd, 0.f);                        // transposed: A = W^T, k = output node
+      for (int o = 0; o < e.n_out; ++o)
+        for (int i = 0; i < e.n_in; ++i) t[(size_t)o * d.ld_bwd + i] = e.w[(size_t)o * e.n_in + i];
+      if (int rc = upload(&d.w_bwd, t.data(), t.size())) return rc;
     }
   }
   // MFMA gather tables for every conv edge, both directions (the input layer's transposed edge is not normalised)
@@ -1201,12 +1347,24 @@ extern "C" int gnnb_bind_network(gnnb_t* h, const gnnb_layer_desc* L, int n, int
       if (h->edges[k].kind != 0) continue;
       for (int dir = 0; dir < 2; ++dir) {
         GatherHost gh;
-        if (!build_gather(h->edges[k], dir, dir == 1 && k > 1, gh)) continue;
+        // the input layer's transposed gather is fused with its feature chain and update (258 MFMAs per tile)
+        if (!build_gather(h->edges[k], dir, dir == 1 && k > 1, gh, (dir == 1 && k == 1) ? 258 : 0)) continue;
         DevGather& d = dir == 0 ? h->gf[k] : h->gb[k];
         d.g = gh.g;
         if (int rc = upload(&d.cmat, gh.cmat.data(), gh.cmat.size())) return rc;
         HIPCHK(hipMalloc((void**)&d.koff, gh.koff.size() * sizeof(int)));
         HIPCHK(hipMemcpy(d.koff, gh.koff.data(), gh.koff.size() * sizeof(int), hipMemcpyHostToDevice));
+        {
+          const TileMap& tm = gh.g.tm;
+          if (tm.NCG > 255 || tm.NBY > 4095 || tm.NBX > 4095) return fail(GNNB_E_INVALID, "layer %d: tile table overflow", k);
+          std::vector<int> tt(tm.TPS);
+          for (int t = 0; t < tm.TPS; ++t) {
+            const int cg = t / (tm.NBY * tm.NBX), rem = t % (tm.NBY * tm.NBX);
+            tt[t] = cg | ((rem / tm.NBX) << 8) | ((rem % tm.NBX) << 20);
+          }
+          HIPCHK(hipMalloc((void**)&d.ttab, tt.size() * sizeof(int)));
+          HIPCHK(hipMemcpy(d.ttab, tt.data(), tt.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
         d.ok = true;
       }
     }
@@ -1223,16 +1381,17 @@ static TileMap bwd_map(const gnnb_t* h, int k) {
   return (k + 1 <= L && h->gb[k + 1].ok) ? h->gb[k + 1].g.tm : flat_map(h->N[k]);
 }
 static long map_tiles(const TileMap& t, int B) { return t.mode ? (long)B * t.TPS : ((long)B * t.N + 31) / 32; }
+static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static DTileMap to_dtm(const TileMap& t) {
-  return DTileMap{t.mode, t.N, t.C, t.H, t.W, t.CT, t.PY, t.PX, t.ay, t.ax, t.NBY, t.NBX, t.NCG, t.TPS};
+  return DTileMap{t.mode, t.N, t.C, t.H, t.W, t.CT, t.PY, t.PX, t.ay, t.ax, t.NBY, t.NBX, t.NCG, t.TPS, ilog2(t.PY), ilog2(t.PX)};
 }
-static DGather to_dg(const DevGather& d) {
+static DGather to_dg(const DevGather& d, const float* zero) {
   const GatherGeom& g = d.g;
-  return DGather{d.cmat, reinterpret_cast<const int2*>(d.koff), g.K2, g.tm.NCG * g.K2, g.Hs, g.Ws, g.Ns, g.ystep, g.ybase,
+  return DGather{d.cmat, reinterpret_cast<const int2*>(d.koff), d.ttab, zero, g.K2, g.tm.NCG * g.K2, g.Hs, g.Ws, g.Ns, g.ystep, g.ybase,
                  g.xstep, g.xbase, g.WY, g.WX, g.normalise, g.kh, g.kw, g.stride, g.pad};
 }
 static size_t gather_lds_bytes(const DevGather& d, size_t pack_floats) {
-  return (pack_floats + (size_t)d.g.tm.NCG * d.g.K2 * 64) * 4 + (size_t)2 * d.g.K2 * 8;
+  return (pack_floats + (size_t)d.g.tm.NCG * d.g.K2 * 64) * 4 + (size_t)(2 * d.g.K2 + KOFF_PAD) * 8 + (size_t)d.g.tm.TPS * 4;
 }
 
 extern "C" int gnnb_graph_info(const gnnb_t* h, int* n_graph, int* sizes, int* n_relu_total) {
@@ -1481,7 +1640,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       lz.run(PC_PRE_BWD, [&] { hipLaunchKernelGGL(k_pre_bwd, dim3(mlp_grid(h, nt)), dim3(WG_MLP), PackPreBwd::FLOATS * 4, st, a); });
     }
   }
-  const bool need_inp = (limit >= 2) && (h->T > 1 || debug_full);
+  const bool need_inp = (limit >= 2) && (h->T > 1 || debug_full) && !h->gb[1].ok;    // the fused input kernel computes Q itself
   if (need_inp) {
     const long G = (long)B * h->N[0];
     const TileMap tm = bwd_map(h, 0);
@@ -1496,7 +1655,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   };
   auto gather = [&](const DevGather& d, int k, const float* src, bool scored) {      // phase A over a conv edge, MFMA
     const long nt = map_tiles(d.g.tm, B);
-    GArgs a{in->lb[k], in->ub[k], in->mask, src, nb, nt, scored ? 1 : 0, h->R, roff[k], to_dtm(d.g.tm), to_dg(d)};
+    GArgs a{in->lb[k], in->ub[k], in->mask, src, nb, nt, scored ? 1 : 0, h->R, roff[k], to_dtm(d.g.tm), to_dg(d, h->d_zero)};
     const size_t lds = gather_lds_bytes(d, 0);
     long grid = (nt + WAVES_MLP - 1) / WAVES_MLP;
     if (grid > (long)h->n_cu * h->gather_occ) grid = (long)h->n_cu * h->gather_occ;
@@ -1517,8 +1676,12 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
         }
       });
     } else {
-      DenseArgs a{h->dev[k].w_fwd, mu(k - 1), nb, B, e.n_in, e.n_out, h->dev[k].ld_fwd, h->dev[k].mt_fwd};
-      lz.run(PC_DENSE_AGG, [&] { hipLaunchKernelGGL(k_dense_agg, dim3((unsigned)((long)B * a.MT)), dim3(256), 0, st, a); });
+      DenseArgs a{h->dev[k].w_fwd, mu(k - 1), nb, h->d_zero, B, e.n_in, e.n_out, h->dev[k].ld_fwd, h->dev[k].mt_fwd, h->dev[k].ksq_fwd};
+      const long tiles = (long)B * a.MT;
+      lz.run(PC_DENSE_AGG, [&] {
+        if (a.K >= 512) hipLaunchKernelGGL(k_dense_agg<true>, dim3((unsigned)tiles), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_dense_agg<false>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, a);
+      });
     }
   };
   // phase A: nb <- A_{k+1}^T mu[k+1]  (k+1 <= L), conv case divided by the tap count when `normalise`
@@ -1536,8 +1699,12 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
         }
       });
     } else {
-      DenseArgs a{h->dev[k + 1].w_bwd, mu(k + 1), nb, B, e.n_out, e.n_in, e.n_in, h->dev[k + 1].mt_bwd};
-      lz.run(PC_DENSE_AGG, [&] { hipLaunchKernelGGL(k_dense_agg, dim3((unsigned)((long)B * a.MT)), dim3(256), 0, st, a); });
+      DenseArgs a{h->dev[k + 1].w_bwd, mu(k + 1), nb, h->d_zero, B, e.n_out, e.n_in, h->dev[k + 1].ld_bwd, h->dev[k + 1].mt_bwd, h->dev[k + 1].ksq_bwd};
+      const long tiles = (long)B * a.MT;
+      lz.run(PC_DENSE_AGG, [&] {
+        if (a.K >= 512) hipLaunchKernelGGL(k_dense_agg<true>, dim3((unsigned)tiles), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_dense_agg<false>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, a);
+      });
     }
   };
   // phase B: node MLP over a compacted list of nodes
@@ -1548,17 +1715,14 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     const int wv = h->nu_waves;
     long grid = (nt + wv - 1) / wv;
     if (grid > h->n_cu) grid = h->n_cu;
-    lz.run(PC_NODE_UPDATE, [&] {
-      if (wv == 8) hipLaunchKernelGGL(k_node_update<8>, dim3((unsigned)grid), dim3(512), PackUpd::FLOATS * 4, st, a);
-      else hipLaunchKernelGGL(k_node_update<16>, dim3((unsigned)grid), dim3(1024), PackUpd::FLOATS * 4, st, a);
-    });
+    lz.run(PC_NODE_UPDATE, [&] { hipLaunchKernelGGL(k_node_update<8>, dim3((unsigned)grid), dim3(512), PackUpd::FLOATS * 4, st, a); });
   };
   auto update_input = [&]() {
     if (h->gb[1].ok) {
       const DevGather& d = h->gb[1];
       const long nt = map_tiles(d.g.tm, B);
-      GIArgs a{h->d_pack[PK_UPD_INP_G], mu(1), ws + w.Q, mu(0), nt, to_dtm(d.g.tm), to_dg(d)};
-      const size_t lds = gather_lds_bytes(d, PackUpdInp::FLOATS);
+      GIArgs a{h->d_pack[PK_PRE_INP], h->d_pack[PK_UPD_INP_G], in->lb[0], in->ub[0], mu(1), mu(0), nt, to_dtm(d.g.tm), to_dg(d, h->d_zero)};
+      const size_t lds = gather_lds_bytes(d, PackUpdInp::FLOATS + PackPreInp::FLOATS);
       lz.run(PC_GATHER_INPUT, [&] { hipLaunchKernelGGL(k_gather_input_update, dim3(mlp_grid(h, nt)), dim3(WG_MLP), lds, st, a); });
       return;
     }

@@ -114,7 +114,7 @@ struct PackEmbed { enum { W1 = 0, B1 = W1 + 256, W2 = B1 + 64, B2 = W2 + 4096, F
 // k_pre_fwd: P = fc4[:, :64] (fc1_1(relu(fc1 feat7)) * amb) + fc4.bias    (:153-161, :176-177)
 struct PackPreFwd { enum { W1 = 0, B1 = W1 + 512, W2 = B1 + 64, B2 = W2 + 4096, W3 = B2 + 64, B3 = W3 + 4096, FLOATS = B3 + 64 }; };
 // k_node_update (forward: fc3, fc3_2, fc4[:, 64:], fc4_2; backward: bc3, bc3_1, bc4[:, 64:], bc4_1)
-struct PackUpd { enum { WA = 0, BA = WA + 8192, WB = BA + 64, BB = WB + 4096, WC = BB + 64, BC = WC + 4096, WD = BC + 64, BD = WD + 4096, FLOATS = BD + 64 }; };
+struct PackUpd { enum { WA = 0, BA = WA + 8192, WB = BA + 64, BB = WB + 4096, WC = BB + 64, BC = WC + 4096, WD = BC + 64, BD = WD + 4096, BCROW = BD + 64, FLOATS = BCROW + 64 }; };
 // k_pre_bwd: P = bc4[:, :64] (bc2_1(relu(bc2([s, -d2 s, d1 s]))) * amb) + bc4.bias,
 //            s = bc1_2(relu(bc1_1(relu(bc1 feat7'))))                      (:273-293, :344-345)
 struct PackPreBwd {
@@ -160,6 +160,7 @@ inline void build_packs(const float* blob, Packs& pk) {
     pack_vec64(&v[PackUpd::BB], Bv(b));
     pack_w64(&v[PackUpd::WC], W(c), 128, 64, 1);
     pack_vec64(&v[PackUpd::BC], Bv(c));      // what the cached P reduces to for nodes whose relaxation term is masked out
+    std::memcpy(&v[PackUpd::BCROW], Bv(c), 64 * sizeof(float));   // the same, row-major: read like a P row by those nodes
     pack_w64(&v[PackUpd::WD], W(d), 64, 0, 1);
     pack_vec64(&v[PackUpd::BD], Bv(d));
   };
@@ -313,7 +314,7 @@ inline void fill_gather_tables(const Edge& e, int dir, GatherHost& out) {
   const GatherGeom& g = out.g;
   const int s = e.stride, p = e.pad;
   const int Cs = dir == 0 ? e.c_in : e.c_out;
-  const int K = Cs * g.WY * g.WX, Kpad = 2 * g.K2;
+  const int K = Cs * g.WY * g.WX, Kpad = 2 * g.K2 + 16;     // 16 always-masked entries behind the table (kernel prefetch)
   out.koff.assign((size_t)Kpad * 2, 0);
   for (int k = 0; k < Kpad; ++k) {
     if (k < K) {
@@ -347,7 +348,8 @@ inline void fill_gather_tables(const Edge& e, int dir, GatherHost& out) {
 }
 
 // pick the tile shape with the fewest MFMAs per sample
-inline bool build_gather(const Edge& e, int dir, bool normalise, GatherHost& best) {
+// `tile_mfma`: MFMAs of whatever runs per tile after the gather in the same kernel (0 for a stand-alone gather)
+inline bool build_gather(const Edge& e, int dir, bool normalise, GatherHost& best, int tile_mfma = 0) {
   const int Cd = dir == 0 ? e.c_out : e.c_in;
   bool found = false;
   long best_cost = 0;
@@ -360,7 +362,8 @@ inline bool build_gather(const Edge& e, int dir, bool normalise, GatherHost& bes
             GatherHost c;
             if (!build_gather_candidate(e, dir, CT, PY, PX, ay, ax, c)) continue;
             if ((size_t)c.g.tm.NCG * c.g.K2 * 64 * 4 > 40 * 1024) continue;   // tap matrix must fit beside the MLP weights in LDS
-            if (!found || c.mfma_per_sample < best_cost) { best = c; best_cost = c.mfma_per_sample; found = true; }
+            const long cost = c.mfma_per_sample + (long)c.g.tm.TPS * tile_mfma;
+            if (!found || cost < best_cost) { best = c; best_cost = cost; found = true; }
           }
   }
   if (!found) return false;

@@ -125,6 +125,7 @@ def test_node_update_chain(packs):
     np.testing.assert_allclose(got, want, atol=1e-5)
     # nodes whose relaxation term is masked (amb = 0): P degenerates to fc4.bias, kept in the pack at BC
     np.testing.assert_allclose(rows_from_frag(frag_bias(p[BC:BC + 64]))[0], b4, atol=0)
+    np.testing.assert_array_equal(p[BD + 64:BD + 128], b4.astype(np.float32))      # BCROW: the same bias, row-major
 
 
 def test_pre_bwd_chain(packs):
@@ -214,6 +215,7 @@ def emulate_gather(g, cmat, koff, mu_src):
         wy0, wx0 = by * g["ystep"] + g["ybase"], bx * g["xstep"] + g["xbase"]
         origin = wy0 * g["Ws"] + wx0
         acc = np.zeros((32, p))
+        assert len(koff) == 2 * g["K2"] + 16 and all(p & 0xffff == 0x7fff for _, p in koff[2 * g["K2"]:])
         for k in range(2 * g["K2"]):
             off, packed = koff[k]
             wy, wx = wy0 + (packed & 0xffff), wx0 + (packed >> 16)
