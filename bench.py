@@ -148,15 +148,12 @@ def main():
         return [t.to(dev).float().contiguous() for t in ts]
     d_args = (dev_list(batch.lower_bounds_all), dev_list(batch.upper_bounds_all), dev_list(batch.dual_vars),
               dev_list(batch.primals), batch.primal_inputs.to(dev), batch.layers, batch.masks.to(dev))
-    gathered = None
+    from gnn_branching_amd import parallel
 
     def step():
-        nonlocal gathered
         res = eng.forward(*d_args)
         if world > 1:
-            if gathered is None:
-                gathered = torch.empty(world * B, eng.R, dtype=torch.float32, device=dev)
-            dist.all_gather_into_tensor(gathered, res.scores)      # the one exchange step: scores -> branch selector
+            parallel.gather_scores(res.scores, world * B)      # the one exchange step: ONE all-gather, scores -> branch selector
         return res
 
     for _ in range(args.warmup):
@@ -208,10 +205,16 @@ def main():
         stats = node_stats(batch)
         alg, issued = plan_flops(plan, B, stats)
         dom_s = prof[dom][0] * 1e-3 / args.steps            # seconds of the dominant kernel class per forward
+        # HBM traffic of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
+        # (tools/pmc.sh + tools/pmc_table.py: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, gfx950 correction applied)
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc_path) and args.net == "cifar_base_kw" and B == 256:
+            traffic = json.load(open(pmc_path)).get(dom, {}).get("hbm_bytes_per_launch")
         ach_tf = alg.get(dom, 0.0) / dom_s / 1e12 if dom_s > 0 else 0.0
         iss_tf = issued.get(dom, 0.0) / dom_s / 1e12 if dom_s > 0 else 0.0
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "avg_launch_us": kern[dom]["avg_us"], "launches_per_step": kern[dom]["launches"] // args.steps,
                     "algorithmic_gflop_per_step": round(alg.get(dom, 0.0) / 1e9, 2),
                     "issued_mfma_tflops": round(iss_tf, 2), "issued_mfma_frac": round(iss_tf / PEAK_F32_MFMA_TFLOPS, 4)}

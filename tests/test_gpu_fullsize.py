@@ -1,0 +1,68 @@
+"""-m gpu: properties at BASELINE.json's full sizes (where the CPU oracle would take minutes):
+batched == re-scored subsets bit for bit, permutation equivariance, decisions == first argmax of the scores,
+plus spot checks of a few samples against the oracle within the 1e-4 budget."""
+import numpy as np
+import pytest
+import torch
+
+from tests.common import SCORE_ATOL, shipped_state
+
+pytestmark = pytest.mark.gpu
+
+
+def model_for(state):
+    from gnn_branching_amd.graphnet.graph_conv import GraphNet
+    m = GraphNet(2, 64)
+    m.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in state.items()})
+    return m.eval()
+
+
+def first_argmax_decisions(scores, sizes):
+    cum = np.cumsum(sizes)
+    out = []
+    for row in scores:
+        if not np.isfinite(row).any():
+            out.append([-1, -1])
+            continue
+        j = int(np.argmax(row))                    # numpy: first maximal index
+        lay = int(np.searchsorted(cum, j, side="right"))
+        out.append([lay, j - (int(cum[lay - 1]) if lay else 0)])
+    return out
+
+
+@pytest.mark.parametrize("net,B", [("cifar_base_kw", 256), ("cifar_wide_kw", 256), ("cifar_deep_kw", 128)])
+def test_full_size_batch_properties(net, B):
+    from gnn_branching_amd import synth
+    from oracle import gnn_oracle
+    state = shipped_state()
+    model = model_for(state)
+    batch = synth.make_batch(net, B, seed=4321, props=[(3, 5) if i % 3 else (1, 7) for i in range(B)])
+    sizes = [int(np.prod(t.shape[1:])) for t in batch.lower_bounds_all[1:-1]]
+    with torch.no_grad():
+        res = model.forward_device(*batch.forward_args()).check()
+        scores = res.scores.cpu()
+        dec = res.decisions.cpu().tolist()
+        # 1. decisions are the first argmax of the padded scores
+        assert dec == first_argmax_decisions(scores.numpy(), sizes)
+        # 2. the mask decides where scores exist
+        assert torch.equal(torch.isfinite(scores), batch.masks != 0)
+        # 3. a re-scored contiguous shard reproduces its rows bit for bit (what data-parallel sharding relies on)
+        lo, hi = B // 3, B // 3 + 16
+        part = model.forward_device(*batch.slice(lo, hi).forward_args()).check()
+        assert torch.equal(part.scores.cpu(), scores[lo:hi])
+        assert part.decisions.cpu().tolist() == dec[lo:hi]
+        # 4. permuting the batch permutes the result
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(0))
+        pb = synth.SubproblemBatch(
+            [t[perm] for t in batch.lower_bounds_all], [t[perm] for t in batch.upper_bounds_all],
+            [t.view(B, -1, 3)[perm].reshape(-1, 3) for t in batch.dual_vars],
+            [t.view(B, -1)[perm].reshape(-1) for t in batch.primals], batch.primal_inputs[perm],
+            {"fixed_layers": batch.layers["fixed_layers"], "prop_layers": [batch.layers["prop_layers"][i] for i in perm.tolist()]},
+            batch.masks[perm])
+        pres = model.forward_device(*pb.forward_args()).check()
+        assert torch.equal(pres.scores.cpu(), scores[perm])
+        # 5. a few samples against the CPU oracle
+        for b in (0, B // 2, B - 1):
+            want = gnn_oracle.oracle_forward(state, *batch.slice(b, b + 1).forward_args())[0]
+            got = scores[b][batch.masks[b] != 0]
+            assert (got - want).abs().max().item() <= SCORE_ATOL

@@ -13,3 +13,23 @@ for k in sorted(vals):
     for c in names:
         v = vals[k].get(c)
         if v: print(f"    {c:28s} mean {sum(v)/len(v):16.1f}  n={len(v)}")
+
+# JSON summary for bench.py's roofline.traffic: HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024
+# (rocprofv3 reports KB; on gfx950 FETCH_SIZE counts half of a wide coalesced stream -- MI355X_MICROARCH.md, HBM section)
+import json
+out = {}
+for k in sorted(vals):
+    name = k.replace('void ', '').split('<')[0]
+    if not name.startswith('k_'): continue
+    v = vals[k]
+    if 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
+        f = sum(v['FETCH_SIZE']) / len(v['FETCH_SIZE']); w = sum(v['WRITE_SIZE']) / len(v['WRITE_SIZE'])
+        e = out.setdefault(name, {})
+        e.update({"fetch_size_kb_per_launch": round(f, 1), "write_size_kb_per_launch": round(w, 1),
+                  "hbm_bytes_per_launch": round((2 * f + w) * 1024), "launches_sampled": len(v['FETCH_SIZE'])})
+    for c in ('SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_INSTS_MFMA', 'SQ_INSTS_VALU', 'SQ_WAVE_CYCLES', 'SQ_WAIT_INST_ANY', 'SQ_WAIT_ANY',
+              'GRBM_GUI_ACTIVE', 'TCC_HIT_sum', 'TCC_MISS_sum', 'SQ_LDS_BANK_CONFLICT'):
+        if c in v: out.setdefault(name, {})[c + "_per_launch"] = round(sum(v[c]) / len(v[c]), 1)
+if len(sys.argv) > 2:
+    json.dump(out, open(sys.argv[2], 'w'), indent=1)
+    print('wrote', sys.argv[2])
