@@ -995,6 +995,150 @@ __global__ __launch_bounds__(256) void k_dense_agg(DenseArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// dense edges, one workgroup per sample: the source rows of the sample are staged in LDS once and shared by all its
+// row tiles (stand-alone tiles re-fetched them through L2 up to MT times: ~40 % L2 misses, 95 us per launch).
+// B operand (source row, channels 2j, 2j+1) = one conflict-free ds_read_b64 per k-step; A operand (weights, shared by
+// all samples) streams from L2 one chunk ahead.
+// ------------------------------------------------------------------------------------------
+struct DenseLArgs {
+  const float* At;    // zero-padded (rows >= K_pad + 16, ldA columns): At[k][i] = A[i][k]
+  const float* X;     // (B, K, 64)
+  float* out;         // (B, M, 64)
+  int B, K, M, ldA, MT, Kpad;
+};
+
+#define DL_CH 8
+// forward edge (long K): 8 waves = 4 row tiles x 2 K-halves; X streams through LDS in double-buffered chunks of
+// 2 x 32 rows (one slab per K-half), the two halves are summed through LDS in a fixed order.  Requires MT <= 4.
+__global__ __launch_bounds__(512, 2) void k_dense_fwd_lds(DenseLArgs a) {
+  __shared__ __attribute__((aligned(16))) float xs[2][2][32][64];      // [buffer][K-half][row][channel]  32 KB
+  __shared__ float red[4][32][64];                                       // 32 KB
+  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int mt = wave & 3, kh = wave >> 2;
+  const int b = blockIdx.x;
+  const int khalf = a.Kpad / 2;                  // rows per K-half, a multiple of 32
+  const int nchunks = khalf / 32;
+  const float* Xb = a.X + (long)b * a.K * 64;
+  // cooperative stage of chunk c: 2 slabs x 32 rows x 256 B = 16 KB, 512 threads x 2 x 16 B
+  auto stage = [&](int buf, int c) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int e = threadIdx.x + 512 * r;        // 16-B piece index, 0..1023
+      const int slab = e >> 9, row = (e >> 4) & 31, piece = e & 15;
+      const int k = slab * khalf + c * 32 + row;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (k < a.K) v = *reinterpret_cast<const f32x4*>(Xb + (long)k * 64 + piece * 4);
+      *reinterpret_cast<f32x4*>(&xs[buf][slab][row][piece * 4]) = v;
+    }
+  };
+  const float* At = a.At + (long)(kh * khalf) * a.ldA + (mt < a.MT ? mt : 0) * 32 + j;   // waves beyond MT idle on tile 0
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+  float av[16], nav[16];
+  auto loadA = [&](float (&A)[16], int c) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) A[u] = At[(long)(c * 32 + 2 * u + h) * a.ldA];
+  };
+  auto mma = [&](const float (&A)[16], int buf) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const float2 bv = *reinterpret_cast<const float2*>(&xs[buf][kh][2 * u + h][2 * j]);
+      acc0 = mfma32(A[u], bv.x, acc0);
+      acc1 = mfma32(A[u], bv.y, acc1);
+    }
+  };
+  stage(0, 0);
+  loadA(av, 0);
+  __syncthreads();
+  for (int c = 0; c < nchunks; c += 2) {
+    if (c + 1 < nchunks) stage(1, c + 1);
+    loadA(nav, c + 1);                      // At carries 32 extra zero rows: reading one chunk past the end is harmless
+    __builtin_amdgcn_sched_barrier(0);
+    mma(av, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    if (c + 1 >= nchunks) break;
+    if (c + 2 < nchunks) stage(0, c + 2);
+    loadA(av, c + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(nav, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+  }
+  if (kh == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { red[mt][r][lane] = acc0[r]; red[mt][16 + r][lane] = acc1[r]; }
+  }
+  __syncthreads();
+  if (kh == 0 && mt < a.MT) {
+    float* out = a.out + (long)b * a.M * 64 + 2 * j;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < a.M) *reinterpret_cast<float2*>(out + (long)row * 64) = make_float2(acc0[r] + red[mt][r][lane], acc1[r] + red[mt][16 + r][lane]);
+    }
+  }
+}
+
+// transposed edge (short K <= 128): the whole source layer of the sample sits in LDS; 8 waves walk the MT row tiles.
+__global__ __launch_bounds__(512, 2) void k_dense_bwd_lds(DenseLArgs a) {
+  __shared__ __attribute__((aligned(16))) float xs[128 + 16][64];       // 36 KB, rows >= K are zero
+  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x;
+  const float* Xb = a.X + (long)b * a.K * 64;
+  for (int e = threadIdx.x; e < (128 + 16) * 16; e += 512) {
+    const int row = e >> 4, piece = e & 15;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < a.K) v = *reinterpret_cast<const f32x4*>(Xb + (long)row * 64 + piece * 4);
+    *reinterpret_cast<f32x4*>(&xs[row][piece * 4]) = v;
+  }
+  __syncthreads();
+  const int nch = a.Kpad / 16;                       // chunks of 8 k-steps
+  for (int mt = wave; mt < a.MT; mt += 8) {
+    const float* At = a.At + mt * 32 + j;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+    float av[DL_CH], nav[DL_CH];
+    auto loadA = [&](float (&A)[DL_CH], int c) {
+#pragma unroll
+      for (int u = 0; u < DL_CH; ++u) A[u] = At[(long)(c * 16 + 2 * u + h) * a.ldA];
+    };
+    auto mma = [&](const float (&A)[DL_CH], int c) {
+#pragma unroll
+      for (int u = 0; u < DL_CH; ++u) {
+        const float2 bv = *reinterpret_cast<const float2*>(&xs[c * 16 + 2 * u + h][2 * j]);
+        acc0 = mfma32(A[u], bv.x, acc0);
+        acc1 = mfma32(A[u], bv.y, acc1);
+      }
+    };
+    loadA(av, 0);
+    const int npairs = nch / 2;
+    int c = 0;
+    for (int pr = 0; pr < npairs; ++pr, c += 2) {
+      loadA(nav, c + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(av, c);
+      __builtin_amdgcn_sched_barrier(0);
+      loadA(av, c + 2);                              // At carries 16 extra zero rows
+      __builtin_amdgcn_sched_barrier(0);
+      mma(nav, c + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (nch & 1) mma(av, c);
+    float* out = a.out + (long)b * a.M * 64 + 2 * j;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < a.M) *reinterpret_cast<float2*>(out + (long)row * 64) = make_float2(acc0[r], acc1[r]);
+    }
+  }
+}
+
 struct PropArgs {
   const float* pack; const float* mu_last; const float* prop_w; const float* prop_b;
   const float *lb, *ub, *z_out; float* mu_prop; int B, N_last;
@@ -1107,7 +1251,7 @@ static const char* kProfNames[PC_COUNT] = {
 
 struct DevEdge {
   float *w_fwd = nullptr, *w_bwd = nullptr, *bias = nullptr;   // conv: tap-major copies; linear: W^T / W, zero-padded
-  int ld_fwd = 0, mt_fwd = 0, ksq_fwd = 0, ld_bwd = 0, mt_bwd = 0, ksq_bwd = 0;
+  int ld_fwd = 0, mt_fwd = 0, ksq_fwd = 0, ld_bwd = 0, mt_bwd = 0, ksq_bwd = 0, kpad_fwd = 0, kpad_bwd = 0;
 };
 
 struct DevGather {          // one conv edge in one direction, as MFMA gather tables on the device
@@ -1125,6 +1269,7 @@ struct gnnb_handle {
   int nu_waves = 8;             // waves per workgroup of k_node_update (one workgroup per CU, weights shared in LDS;
                                 // 16 waves measured 27 % slower and no longer fit the register budget)
   int gather_occ = 2;           // workgroups per CU for k_gather (its LDS footprint is only the tap matrix)
+  bool dense_lds = true;        // Linear edges: one workgroup per sample with the source rows in LDS (false: per-tile kernel)
   bool restrict_last = true;    // last backward step of layer 1 only for the scored nodes (nothing else reads it)
   Packs packs;
   float* d_pack[N_PACKS] = {nullptr};
@@ -1193,6 +1338,7 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   HIPCHK(hipFuncSetAttribute((const void*)k_score, hipFuncAttributeMaxDynamicSharedMemorySize, PackScore::FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_gather, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   if (const char* e = getenv("GNNB_NO_RESTRICT")) h->restrict_last = !(e[0] == '1');
+  if (const char* e = getenv("GNNB_NO_DENSE_LDS")) h->dense_lds = !(e[0] == '1');
   HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   if (const char* e = getenv("GNNB_NO_GATHER")) h->use_gather = !(e[0] == '1');
   *out = h;
@@ -1326,14 +1472,18 @@ extern "C" int gnnb_bind_network(gnnb_t* h, const gnnb_layer_desc* L, int n, int
       d.mt_fwd = (e.n_out + 31) / 32;
       d.ld_fwd = d.mt_fwd * 32;
       d.ksq_fwd = ksq_of(e.n_in);
-      std::vector<float> t((size_t)(8 * d.ksq_fwd + 2 * DENSE_CH) * d.ld_fwd, 0.f);           // forward: A = W, k = input node
+      d.kpad_fwd = (e.n_in + 63) / 64 * 64;
+      d.kpad_bwd = (e.n_out + 15) / 16 * 16;
+      const size_t rows_f = std::max<size_t>(8 * d.ksq_fwd + 2 * DENSE_CH, d.kpad_fwd + 32);
+      std::vector<float> t(rows_f * d.ld_fwd, 0.f);           // forward: A = W, k = input node
       for (int o = 0; o < e.n_out; ++o)
         for (int i = 0; i < e.n_in; ++i) t[(size_t)i * d.ld_fwd + o] = e.w[(size_t)o * e.n_in + i];
       if (int rc = upload(&d.w_fwd, t.data(), t.size())) return rc;
       d.mt_bwd = (e.n_in + 31) / 32;
       d.ld_bwd = d.mt_bwd * 32;
       d.ksq_bwd = ksq_of(e.n_out);
-      t.assign((size_t)(8 * d.ksq_bwd + 2 * DENSE_CH) * d.ld_bwd, 0.f);                        // transposed: A = W^T, k = output node
+      const size_t rows_b = std::max<size_t>(8 * d.ksq_bwd + 2 * DENSE_CH, d.kpad_bwd + 32);
+      t.assign(rows_b * d.ld_bwd, 0.f);                        // transposed: A = W^T, k = output node
       for (int o = 0; o < e.n_out; ++o)
         for (int i = 0; i < e.n_in; ++i) t[(size_t)o * d.ld_bwd + i] = e.w[(size_t)o * e.n_in + i];
       if (int rc = upload(&d.w_bwd, t.data(), t.size())) return rc;
@@ -1676,7 +1826,13 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
         }
       });
     } else {
-      DenseArgs a{h->dev[k].w_fwd, mu(k - 1), nb, h->d_zero, B, e.n_in, e.n_out, h->dev[k].ld_fwd, h->dev[k].mt_fwd, h->dev[k].ksq_fwd};
+      const DevEdge& de = h->dev[k];
+      if (h->dense_lds && de.mt_fwd <= 4) {        // one workgroup per sample, source rows staged in LDS
+        DenseLArgs a{de.w_fwd, mu(k - 1), nb, B, e.n_in, e.n_out, de.ld_fwd, de.mt_fwd, de.kpad_fwd};
+        lz.run(PC_DENSE_AGG, [&] { hipLaunchKernelGGL(k_dense_fwd_lds, dim3(B), dim3(512), 0, st, a); });
+        return;
+      }
+      DenseArgs a{de.w_fwd, mu(k - 1), nb, h->d_zero, B, e.n_in, e.n_out, de.ld_fwd, de.mt_fwd, de.ksq_fwd};
       const long tiles = (long)B * a.MT;
       lz.run(PC_DENSE_AGG, [&] {
         if (a.K >= 512) hipLaunchKernelGGL(k_dense_agg<true>, dim3((unsigned)tiles), dim3(256), 0, st, a);
@@ -1699,7 +1855,13 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
         }
       });
     } else {
-      DenseArgs a{h->dev[k + 1].w_bwd, mu(k + 1), nb, h->d_zero, B, e.n_out, e.n_in, h->dev[k + 1].ld_bwd, h->dev[k + 1].mt_bwd, h->dev[k + 1].ksq_bwd};
+      const DevEdge& de = h->dev[k + 1];
+      if (h->dense_lds && de.kpad_bwd <= 128) {    // one workgroup per sample, the whole source layer in LDS
+        DenseLArgs a{de.w_bwd, mu(k + 1), nb, B, e.n_out, e.n_in, de.ld_bwd, de.mt_bwd, de.kpad_bwd};
+        lz.run(PC_DENSE_AGG, [&] { hipLaunchKernelGGL(k_dense_bwd_lds, dim3(B), dim3(512), 0, st, a); });
+        return;
+      }
+      DenseArgs a{de.w_bwd, mu(k + 1), nb, h->d_zero, B, e.n_out, e.n_in, de.ld_bwd, de.mt_bwd, de.ksq_bwd};
       const long tiles = (long)B * a.MT;
       lz.run(PC_DENSE_AGG, [&] {
         if (a.K >= 512) hipLaunchKernelGGL(k_dense_agg<true>, dim3((unsigned)tiles), dim3(256), 0, st, a);
