@@ -592,27 +592,42 @@ struct DGather {
 #define GATHER_CH 8   // k-steps per prefetch chunk
 #define KOFF_PAD (2 * GATHER_CH)   // always-masked koff entries behind the table (one chunk is loaded past the end)
 
-__device__ __forceinline__ void gather_tile(Frag& X, const float* cm, const int2* ko, int K2, const float* src,
-                                            const float* zrow, int wy0, int wx0, int Hs, int Ws, int lane) {
+// Source rows are read with buffer loads: the descriptor covers exactly this sample's source layer (wave-uniform base
+// in SGPRs), the per-lane part is a 32-bit byte offset, and a masked window node / the k padding simply gets an
+// offset beyond the descriptor's range -- the hardware returns 0 for it without touching memory.  So nothing (no
+// select, no copy) is applied to a loaded value before its MFMA and there is no control flow around the loads, which is
+// what lets hipcc keep the next chunk in flight behind counted vmcnt waits (the koff table carries 16 always-masked
+// entries for the one chunk issued past the end).
+// INTERIOR = the whole window lies inside the source layer (wave-uniform; ~3/4 of the tiles): no bounds arithmetic.
+#define BUF_OOB 0x80000000u
+__device__ __forceinline__ float2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0);
+  return make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
+}
+
+template <bool INTERIOR>
+__device__ __forceinline__ void gather_tile(Frag& X, const float* cm, const int2* ko, int K2, __amdgpu_buffer_rsrc_t rsrc, int j,
+                                            int wy0, int wx0, int Hs, int Ws, int lane) {
   const int h = lane >> 5;
 #pragma unroll
   for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = 0.0f;
-  const long origin = (long)wy0 * Ws + wx0;
-  const long zdelta = zrow - src;           // element offset that lands on the zero row
+  const int origin = wy0 * Ws + wx0;
+  const unsigned lane_off = 8u * (unsigned)j;        // channels 2j, 2j+1 of the row
   float2 cur[GATHER_CH], nxt[GATHER_CH];
-  // window nodes outside the source layer (padding) and the k padding read a zero row: nothing is applied to a loaded
-  // value before its MFMA, so the loads of the next chunk really stay in flight behind this chunk's MFMAs
   auto load = [&](float2 (&dst)[GATHER_CH], int s0) {
 #pragma unroll
     for (int u = 0; u < GATHER_CH; ++u) {
-      // one 64-bit LDS read per entry: with two 32-bit halves hipcc branches around the second one, and the
-      // control flow makes its vmcnt bookkeeping fall back to waiting for the loads just issued
+      // one 64-bit LDS read per entry: with two 32-bit halves hipcc branches around the second one
       const unsigned long long ev = reinterpret_cast<const unsigned long long*>(ko)[2 * (s0 + u) + h];
       const int ex = (int)(unsigned)ev, ey = (int)(unsigned)(ev >> 32);
-      const int wy = wy0 + (ey & 0xffff), wx = wx0 + (ey >> 16);
-      const bool ok = (unsigned)wy < (unsigned)Hs && (unsigned)wx < (unsigned)Ws;
-      const long o = ok ? (origin + ex) * 64 : zdelta;
-      dst[u] = *reinterpret_cast<const float2*>(src + o);
+      unsigned o = (unsigned)(origin + ex) * 256u + lane_off;
+      if (INTERIOR) {
+        o = (ey & 0xffff) == 0x7fff ? BUF_OOB : o;                      // k padding
+      } else {
+        const int wy = wy0 + (ey & 0xffff), wx = wx0 + (ey >> 16);
+        o = ((unsigned)wy < (unsigned)Hs && (unsigned)wx < (unsigned)Ws) ? o : BUF_OOB;
+      }
+      dst[u] = buf_load2(rsrc, o);
     }
   };
   auto mma = [&](const float2 (&v)[GATHER_CH], int s0) {
@@ -623,10 +638,8 @@ __device__ __forceinline__ void gather_tile(Frag& X, const float* cm, const int2
       X.t[1] = mfma32(v[u].y, b, X.t[1]);
     }
   };
-  // Two register buffers in ping-pong (a rotating copy would have to wait for the data it copies), NO control flow
-  // around the loads (the koff table is padded with 16 always-masked entries, so the one chunk loaded past the end
-  // just reads the zero row), and sched_barriers pinning "issue the next chunk's loads, THEN this chunk's MFMAs":
-  // only then does hipcc keep the next chunk in flight behind counted vmcnt waits.
+  // Two register buffers in ping-pong (a rotating copy would have to wait for the data it copies); the sched_barriers
+  // pin "issue the next chunk's loads, THEN this chunk's MFMAs".
   load(cur, 0);
   const int npairs = K2 / (2 * GATHER_CH);
   int s0 = 0;
@@ -641,6 +654,17 @@ __device__ __forceinline__ void gather_tile(Frag& X, const float* cm, const int2
     __builtin_amdgcn_sched_barrier(0);
   }
   if (K2 & GATHER_CH) mma(cur, s0);
+}
+
+// `sbase` = first row of this sample's source layer; must be built from wave-uniform values
+__device__ __forceinline__ void gather_dispatch(Frag& X, const float* cm, const int2* ko, const DGather& g, const float* sbase,
+                                                int j, int wy0, int wx0, int lane) {
+  const int uy = __builtin_amdgcn_readfirstlane(wy0), ux = __builtin_amdgcn_readfirstlane(wx0);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)sbase, 0, g.Ns * 256, 0x00020000);
+  if (uy >= 0 && ux >= 0 && uy + g.WY <= g.Hs && ux + g.WX <= g.Ws)
+    gather_tile<true>(X, cm, ko, g.K2, rsrc, j, uy, ux, g.Hs, g.Ws, lane);
+  else
+    gather_tile<false>(X, cm, ko, g.K2, rsrc, j, uy, ux, g.Hs, g.Ws, lane);
 }
 
 // number of kernel taps that touch dst position t along one axis (the reference's `freq`, graph_conv.py:306-311)
@@ -706,8 +730,9 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_gather(GArgs a) {
   tile_range(a.ntiles, WAVES_MLP, t0, t1);
   long tile = t0 + wave;
   if (tile >= t1) return;
-  long sample = tile / a.tm.TPS;
-  int t = (int)(tile - sample * a.tm.TPS);
+  // tile, sample and t are wave-uniform by construction; make them provably so (scalar registers, scalar base address)
+  int sample = __builtin_amdgcn_readfirstlane((int)(tile / a.tm.TPS));
+  int t = __builtin_amdgcn_readfirstlane((int)(tile - (long)sample * a.tm.TPS));
   for (; tile < t1; tile += WAVES_MLP, t += WAVES_MLP) {
     while (t >= a.tm.TPS) { t -= a.tm.TPS; ++sample; }
     const TileCtx tc = block_decode(a.tm, lds_tt, sample, t, j);
@@ -718,8 +743,7 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_gather(GArgs a) {
     if (!__any(need)) continue;
     const int wy0 = tc.by * a.g.ystep + a.g.ybase, wx0 = tc.bx * a.g.xstep + a.g.xbase;
     Frag X;
-    gather_tile(X, lds_cm + tc.cg * a.g.K2 * 64, lds_ko, a.g.K2, a.mu_src + tc.sample * a.g.Ns * 64 + 2 * j, a.g.zero + 2 * j,
-                wy0, wx0, a.g.Hs, a.g.Ws, lane);
+    gather_dispatch(X, lds_cm + tc.cg * a.g.K2 * 64, lds_ko, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane);
     if (a.g.normalise) {
       const int ny = tap_count(tc.y, wy0, a.g.WY, a.g.Hs, a.g.kh, a.g.stride, a.g.pad);
       const int nx = tap_count(tc.x, wx0, a.g.WX, a.g.Ws, a.g.kw, a.g.stride, a.g.pad);
@@ -765,8 +789,9 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_gather_input_update(GIArgs a) {
   tile_range(a.ntiles, WAVES_MLP, t0, t1);
   long tile = t0 + wave;
   if (tile >= t1) return;
-  long sample = tile / a.tm.TPS;
-  int t = (int)(tile - sample * a.tm.TPS);
+  // tile, sample and t are wave-uniform by construction; make them provably so (scalar registers, scalar base address)
+  int sample = __builtin_amdgcn_readfirstlane((int)(tile / a.tm.TPS));
+  int t = __builtin_amdgcn_readfirstlane((int)(tile - (long)sample * a.tm.TPS));
   for (; tile < t1; tile += WAVES_MLP, t += WAVES_MLP) {
     while (t >= a.tm.TPS) { t -= a.tm.TPS; ++sample; }
     const TileCtx tc = block_decode(a.tm, lds_tt, sample, t, j);
@@ -774,8 +799,7 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_gather_input_update(GIArgs a) {
     const long gc = tc.sample * a.tm.N + tc.n;
     const int wy0 = tc.by * a.g.ystep + a.g.ybase, wx0 = tc.bx * a.g.xstep + a.g.xbase;
     Frag X;
-    gather_tile(X, lds_cm + tc.cg * a.g.K2 * 64, lds_ko, a.g.K2, a.mu_src + tc.sample * a.g.Ns * 64 + 2 * j, a.g.zero + 2 * j,
-                wy0, wx0, a.g.Hs, a.g.Ws, lane);
+    gather_dispatch(X, lds_cm + tc.cg * a.g.K2 * 64, lds_ko, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane);
     float x[1];
     x[0] = h ? a.ub[gc] : a.lb[gc];
     Frag H0;
