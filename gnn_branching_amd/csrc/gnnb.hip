@@ -299,7 +299,7 @@ struct ClassifyArgs {
   const float *lb, *ub, *mask;
   float* mu;       // (B*N, 64) rows of this layer
   float* scores;   // (B, R)
-  int* cnt;        // [3]: live, amb, score
+  int* cnt;        // [3]: plain (live, not ambiguous), ambiguous, scored
   int *live, *amb, *score;
   long G;
   int N, R, off;
@@ -318,8 +318,9 @@ __global__ __launch_bounds__(CLS_THREADS) void k_classify(ClassifyArgs a) {
   const long b = gc / a.N;
   const long sidx = b * a.R + a.off + (gc - b * a.N);
   bool flag[3];
-  flag[0] = valid && r.live != 0.0f;
-  flag[1] = valid && r.amb != 0.0f;
+  const bool live = valid && r.live != 0.0f;
+  flag[1] = valid && r.amb != 0.0f;                 // ambiguous (a subset of live)
+  flag[0] = live && !flag[1];                       // live with r0 == r1: the cheap update path
   flag[2] = valid && a.mask[sidx] != 0.0f;
   if (valid) a.scores[sidx] = -INFINITY;
   unsigned long long bal[3];
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(CLS_THREADS) void k_classify(ClassifyArgs a) {
 #pragma unroll
   for (int c = 0; c < 3; ++c)
     if (flag[c]) lists[c][wbase[c][wave] + __popcll(bal[c] & ((1ull << lane) - 1ull))] = (int)gc;
-  unsigned long long dead = __ballot(valid && !flag[0]);
+  unsigned long long dead = __ballot(valid && !live);
   while (dead) {                       // the whole wave zeroes one dead row per iteration (coalesced 256 B)
     const int l = __ffsll((long long)dead) - 1;
     dead &= dead - 1;
@@ -465,12 +466,9 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_pre_inp(PreArgs a) {
     frag_bias(H, lds + PackPreInp::B1, h);
     gemm_small<1>(lds + PackPreInp::W1, lane, H, x);
     frag_relu(H);
-    Frag S;
-    frag_bias(S, lds + PackPreInp::B2, h);
-    gemm_w64<32>(lds + PackPreInp::W2, lane, S, [&](int s) { return FRAG_AT(H, s); });
-    Frag Q;
-    frag_bias(Q, lds + PackPreInp::B3, h);
-    gemm_w64<32>(lds + PackPreInp::W3, lane, Q, [&](int s) { return FRAG_AT(S, s); });
+    Frag Q;                                  // inp_b_1 and the first half of inp_b2 are folded into one 64x64 map
+    frag_bias(Q, lds + PackPreInp::B2, h);
+    gemm_w64<32>(lds + PackPreInp::W2, lane, Q, [&](int s) { return FRAG_AT(H, s); });
     frag_store_tiled(Q, a.P, tile, lane);
   }
 }
@@ -479,61 +477,68 @@ struct UpdArgs {
   const float* pack;
   const float *lb, *ub;     // pre-activation bounds of this layer, flat (B*N)
   const float* nb;          // aggregated neighbour embeddings, rows by node id (B*N, 64)
-  const float* P;           // cached feature term of the ambiguous nodes, rows by node id
+  const float* P;           // cached P' of the ambiguous nodes, rows by node id
   float* mu;                // out: rows by node id
   int* status;
-  const int* list;          // nodes to update (the live ones; the scored ones for the last backward step of layer 1)
-  const int* cnt;
+  const int *list0, *cnt0;  // nodes with r0 == r1 and no relaxation term (live, not ambiguous): short chain
+  const int *list1, *cnt1;  // general nodes (ambiguous; or the scored nodes for the last backward step of layer 1)
 };
 
-// mu_g = (Wd.relu(P_g + Wc.e) + bd) [r0 != 0],  e = Wb.relu(Wa.[r0*nb_g, r1*nb_g] + ba) + bb,  P_g = bias_c when amb = 0
+// folded node update (gnnb_pack.h PackUpd):  mu_g = (Wd.relu(P'_g + Wcb.h) + bd) [r0 != 0],  h = relu(Wa.[r0 nb_g, r1 nb_g] + ba)
+//   kind 0 tiles (list0): r0 == r1, P' = bcb:  h = relu(WAS.(r0 nb_g) + ba)                      192 MFMAs per 32 nodes
+//   kind 1 tiles (list1): general                                                              256 MFMAs per 32 nodes
 // forward:  fc3, fc3_2, fc4, fc4_2   graph_conv.py:169-181        backward: bc3, bc3_1, bc4, bc4_1   :331-349
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_node_update(UpdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  stage_pack(lds, a.pack, PackUpd::FLOATS);
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
-  const int count = *a.cnt;
-  const long ntiles = (count + 31) / 32;
-  const float* bias_row = a.pack + PackUpd::BCROW;
+  const int c0 = *a.cnt0, c1 = *a.cnt1;
+  const long n0 = (c0 + 31) / 32, ntiles = n0 + (c1 + 31) / 32;
+  const float* bias_row = a.pack + PackUpd::BCBROW;
   // Only a few tiles per wave, so balance matters more than locality (rows stream): tiles are dealt round-robin over
   // the SIMDs of the whole grid (4 per workgroup), and the two waves that share a SIMD (w, w+4) take alternate rounds,
   // so every SIMD's MFMA pipe gets floor or ceil of the average.  The inputs of the next tile (list entry -> bounds ->
-  // aggregate row) are fetched while this tile's MFMA chain runs.
+  // aggregate row) are fetched while this tile's MFMA chain runs; the first fetch overlaps the weight staging.
   static_assert(WAVES == 8, "tile dealing assumes 2 waves per SIMD");
   const long stride = (long)gridDim.x * 4 * 2;
   long tile = (long)(wave >> 2) * gridDim.x * 4 + (long)blockIdx.x * 4 + (wave & 3);
-  if (tile >= ntiles) return;
-  long gc, gc_n = 0;
-  bool valid, valid_n = false;
-  float lb, ub, lb_n = 0.0f, ub_n = 0.0f;
+  long gc = 0, gc_n = 0;
+  bool valid = false, valid_n = false;
+  float lb = 0.0f, ub = 0.0f, lb_n = 0.0f, ub_n = 0.0f;
   Frag X, Xn;
   auto fetch = [&](long tl, long& g_, bool& v_, float& l_, float& u_, Frag& x_) {
-    const long idx = tl * 32 + j;
-    v_ = idx < count;
-    g_ = a.list[v_ ? idx : 0];
+    const bool k0 = tl < n0;
+    const long idx = (k0 ? tl : tl - n0) * 32 + j;
+    v_ = idx < (k0 ? c0 : c1);
+    g_ = (k0 ? a.list0 : a.list1)[v_ ? idx : 0];
     l_ = a.lb[g_];
     u_ = a.ub[g_];
     frag_load_rows(x_, a.nb, g_, h);
   };
-  fetch(tile, gc, valid, lb, ub, X);
+  if (tile < ntiles) fetch(tile, gc, valid, lb, ub, X);
+  stage_pack(lds, a.pack, PackUpd::FLOATS);
+  if (tile >= ntiles) return;
   for (;;) {
     const Ratio r = compute_ratio(lb, ub);
-    // nodes without a relaxation term (amb = 0) read the bias row instead of their (never written) P row
-    Frag H2;
-    frag_load_rowptr(H2, r.amb != 0.0f ? a.P + gc * 64 : bias_row, h);
+    const bool kind0 = tile < n0;              // wave-uniform
     const long next = tile + stride;
     const bool has_next = next < ntiles;
-    if (has_next) fetch(next, gc_n, valid_n, lb_n, ub_n, Xn);
-    Frag H;
+    Frag H, H2;
     frag_bias(H, lds + PackUpd::BA, h);
-    const float r0 = r.r0, r1 = r.r1;
-    gemm_w64<64>(lds + PackUpd::WA, lane, H, [&](int s) { return FRAG_AT(X, s & 31) * (s < 32 ? r0 : r1); });
+    if (kind0) {
+      if (has_next) fetch(next, gc_n, valid_n, lb_n, ub_n, Xn);
+      const float r0 = r.r0;
+      gemm_w64<32>(lds + PackUpd::WAS, lane, H, [&](int s) { return FRAG_AT(X, s) * r0; });
+      frag_bias(H2, lds + PackUpd::BCB, h);
+    } else {
+      // nodes without a relaxation term (amb = 0) read the bias row instead of their (never written) P' row
+      frag_load_rowptr(H2, r.amb != 0.0f ? a.P + gc * 64 : bias_row, h);
+      if (has_next) fetch(next, gc_n, valid_n, lb_n, ub_n, Xn);
+      const float r0 = r.r0, r1 = r.r1;
+      gemm_w64<64>(lds + PackUpd::WA, lane, H, [&](int s) { return FRAG_AT(X, s & 31) * (s < 32 ? r0 : r1); });
+    }
     frag_relu(H);
-    Frag E;
-    frag_bias(E, lds + PackUpd::BB, h);
-    gemm_w64<32>(lds + PackUpd::WB, lane, E, [&](int s) { return FRAG_AT(H, s); });
-    gemm_w64<32>(lds + PackUpd::WC, lane, H2, [&](int s) { return FRAG_AT(E, s); });
+    gemm_w64<32>(lds + PackUpd::WCB, lane, H2, [&](int s) { return FRAG_AT(H, s); });
     frag_relu(H2);
     Frag M;
     frag_bias(M, lds + PackUpd::BD, h);
@@ -806,12 +811,9 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_gather_input_update(GIArgs a) {
     frag_bias(H0, lds_pre + PackPreInp::B1, h);
     gemm_small<1>(lds_pre + PackPreInp::W1, lane, H0, x);
     frag_relu(H0);
-    Frag S;
-    frag_bias(S, lds_pre + PackPreInp::B2, h);
-    gemm_w64<32>(lds_pre + PackPreInp::W2, lane, S, [&](int s) { return FRAG_AT(H0, s); });
-    Frag H;
-    frag_bias(H, lds_pre + PackPreInp::B3, h);
-    gemm_w64<32>(lds_pre + PackPreInp::W3, lane, H, [&](int s) { return FRAG_AT(S, s); });
+    Frag H;                                  // inp_b_1 and the first half of inp_b2 are folded into one 64x64 map
+    frag_bias(H, lds_pre + PackPreInp::B2, h);
+    gemm_w64<32>(lds_pre + PackPreInp::W2, lane, H, [&](int s) { return FRAG_AT(H0, s); });
     gemm_w64<32>(lds + PackUpdInp::WC, lane, H, [&](int s) { return FRAG_AT(X, s); });
     frag_relu(H);
     Frag M;
@@ -1896,8 +1898,9 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   // phase B: node MLP over a compacted list of nodes
   auto node_update = [&](int k, bool fwd, bool scored) {
     const long nt = ((long)B * h->N[k] + 31) / 32;
+    // normal: list0 = live non-ambiguous nodes (short chain), list1 = ambiguous nodes; restricted: the scored nodes, general chain
     UpdArgs a{h->d_pack[fwd ? PK_UPD_FWD : PK_UPD_BWD], in->lb[k], in->ub[k], nb, ws + (fwd ? w.Pf[k] : w.Pb[k]), mu(k), status,
-              ilist(scored ? w.score[k] : w.live[k]), cnt + 4 * k + (scored ? 2 : 0)};
+              ilist(w.live[k]), cnt + 4 * k + (scored ? 3 : 0), ilist(scored ? w.score[k] : w.amb[k]), cnt + 4 * k + (scored ? 2 : 1)};
     const int wv = h->nu_waves;
     long grid = (nt + wv - 1) / wv;
     if (grid > h->n_cu) grid = h->n_cu;

@@ -114,7 +114,13 @@ struct PackEmbed { enum { W1 = 0, B1 = W1 + 256, W2 = B1 + 64, B2 = W2 + 4096, F
 // k_pre_fwd: P = fc4[:, :64] (fc1_1(relu(fc1 feat7)) * amb) + fc4.bias    (:153-161, :176-177)
 struct PackPreFwd { enum { W1 = 0, B1 = W1 + 512, W2 = B1 + 64, B2 = W2 + 4096, W3 = B2 + 64, B3 = W3 + 4096, FLOATS = B3 + 64 }; };
 // k_node_update (forward: fc3, fc3_2, fc4[:, 64:], fc4_2; backward: bc3, bc3_1, bc4[:, 64:], bc4_1)
-struct PackUpd { enum { WA = 0, BA = WA + 8192, WB = BA + 64, BB = WB + 4096, WC = BB + 64, BC = WC + 4096, WD = BC + 64, BD = WD + 4096, BCROW = BD + 64, FLOATS = BCROW + 64 }; };
+// Folded form (exact algebra): e = Wb.h + bb enters the next layer linearly, so
+//   relu(W4.[relax, e] + b4) = relu(P' + Wcb.h),  Wcb = W4[:, 64:].Wb,  P' = W4[:, :64].relax + b4 + W4[:, 64:].bb
+// and for nodes with r0 == r1 (every live node that is not ambiguous)  Wa.[r0 x, r1 x] = WAS.(r0 x),  WAS = Wa[:, :64] + Wa[:, 64:].
+//   WA  : Wa, 128 -> 64 (general nodes)      WAS : summed halves, 64 -> 64 (r0 == r1 nodes)      BA : bias of Wa
+//   WCB : Wcb                                  BCB : b4 + W4[:, 64:].bb  (= P' of a node without relaxation term)
+//   WD, BD : last layer                        BCBROW : BCB again, row-major (read like a P' row)
+struct PackUpd { enum { WA = 0, WAS = WA + 8192, BA = WAS + 4096, WCB = BA + 64, BCB = WCB + 4096, WD = BCB + 64, BD = WD + 4096, BCBROW = BD + 64, FLOATS = BCBROW + 64 }; };
 // k_pre_bwd: P = bc4[:, :64] (bc2_1(relu(bc2([s, -d2 s, d1 s]))) * amb) + bc4.bias,
 //            s = bc1_2(relu(bc1_1(relu(bc1 feat7'))))                      (:273-293, :344-345)
 struct PackPreBwd {
@@ -122,13 +128,32 @@ struct PackPreBwd {
          B4 = W4 + 12288, W5 = B4 + 64, B5 = W5 + 4096, W6 = B5 + 64, B6 = W6 + 4096, FLOATS = B6 + 64 };
 };
 // k_pre_inp: Q = inp_b2[:, :64] inp_b_1(relu(inp_b([l0,u0]))) + inp_b2.bias   (:380-384)
-struct PackPreInp { enum { W1 = 0, B1 = W1 + 128, W2 = B1 + 64, B2 = W2 + 4096, W3 = B2 + 64, B3 = W3 + 4096, FLOATS = B3 + 64 }; };
+// folded: Q = (inp_b2[:, :64].inp_b_1.W) relu(inp_b([l0,u0])) + (inp_b2[:, :64].inp_b_1.b + inp_b2.b)
+struct PackPreInp { enum { W1 = 0, B1 = W1 + 128, W2 = B1 + 64, B2 = W2 + 4096, FLOATS = B2 + 64 }; };
 // k_input_update: mu0 = inp_b2_2(relu(Q + inp_b2[:, 64:] nb))               (:383-385)
 struct PackUpdInp { enum { WC = 0, WD = WC + 4096, BD = WD + 4096, FLOATS = BD + 64 }; };
 // k_score: fscore(relu(fnode(mu)))                                           (:448-449)
 struct PackScore { enum { W1 = 0, B1 = W1 + 4096, WS = B1 + 64, BS = WS + 64, FLOATS = BS + 4 }; };
 // k_prop_fwd (VALU, one wave per sample): transposed row-major copies          (:196-210)
 struct PackProp { enum { W1T = 0, B1 = W1T + 4 * 64, W2T = B1 + 64, B2 = W2T + 128 * 64, W3T = B2 + 64, B3 = W3T + 64 * 64, FLOATS = B3 + 64 }; };
+
+// C (64 x 64) = A (64 x 64, row stride lda, columns [acol0, acol0+64)) . B (64 x 64 row-major), accumulated in double
+inline void matmul64(float* C, const float* A, int lda, int acol0, const float* B) {
+  for (int i = 0; i < 64; ++i)
+    for (int j = 0; j < 64; ++j) {
+      double acc = 0.0;
+      for (int k = 0; k < 64; ++k) acc += (double)A[(size_t)i * lda + acol0 + k] * (double)B[(size_t)k * 64 + j];
+      C[(size_t)i * 64 + j] = (float)acc;
+    }
+}
+// y (64) = A[:, acol0:acol0+64] . x (64) + y0 (64)
+inline void matvec64(float* y, const float* A, int lda, int acol0, const float* x, const float* y0) {
+  for (int i = 0; i < 64; ++i) {
+    double acc = y0 ? (double)y0[i] : 0.0;
+    for (int k = 0; k < 64; ++k) acc += (double)A[(size_t)i * lda + acol0 + k] * (double)x[k];
+    y[i] = (float)acc;
+  }
+}
 
 struct Packs {
   std::vector<float> embed, pre_fwd, upd_fwd, pre_bwd, upd_bwd, pre_inp, upd_inp, score, prop;
@@ -152,20 +177,37 @@ inline void build_packs(const float* blob, Packs& pk) {
   pack_w64(&pk.pre_fwd[PackPreFwd::W3], W(L_FC4), 128, 0, 1);
   pack_vec64(&pk.pre_fwd[PackPreFwd::B3], Bv(L_FC4));
 
-  auto upd = [&](std::vector<float>& v, int a, int b, int c, int d) {
+  // folded bias of the update chain: bcb = b_c + W_c[:, 64:].b_b  (also added to the P' the feature chains cache)
+  auto bcb_of = [&](int b, int c, float* out) { matvec64(out, W(c), 128, 64, Bv(b), Bv(c)); };
+  auto upd = [&](std::vector<float>& v, int a, int b, int c, int d, bool gathered_input) {
     v.assign(PackUpd::FLOATS, 0.f);
-    pack_w64(&v[PackUpd::WA], W(a), 128, 0, 2);
+    std::vector<float> was(64 * 64), wcb(64 * 64);
+    float bcb[64];
+    for (int i = 0; i < 64; ++i)
+      for (int k = 0; k < 64; ++k) was[i * 64 + k] = (float)((double)W(a)[i * 128 + k] + (double)W(a)[i * 128 + 64 + k]);
+    matmul64(wcb.data(), W(c), 128, 64, W(b));
+    bcb_of(b, c, bcb);
+    if (gathered_input) {
+      pack_w64_gather(&v[PackUpd::WA], W(a), 128, 0, 2);
+      pack_w64_gather(&v[PackUpd::WAS], was.data(), 64, 0, 1);
+    } else {
+      pack_w64(&v[PackUpd::WA], W(a), 128, 0, 2);
+      pack_w64(&v[PackUpd::WAS], was.data(), 64, 0, 1);
+    }
     pack_vec64(&v[PackUpd::BA], Bv(a));
-    pack_w64(&v[PackUpd::WB], W(b), 64, 0, 1);
-    pack_vec64(&v[PackUpd::BB], Bv(b));
-    pack_w64(&v[PackUpd::WC], W(c), 128, 64, 1);
-    pack_vec64(&v[PackUpd::BC], Bv(c));      // what the cached P reduces to for nodes whose relaxation term is masked out
-    std::memcpy(&v[PackUpd::BCROW], Bv(c), 64 * sizeof(float));   // the same, row-major: read like a P row by those nodes
+    pack_w64(&v[PackUpd::WCB], wcb.data(), 64, 0, 1);
+    pack_vec64(&v[PackUpd::BCB], bcb);
     pack_w64(&v[PackUpd::WD], W(d), 64, 0, 1);
     pack_vec64(&v[PackUpd::BD], Bv(d));
+    std::memcpy(&v[PackUpd::BCBROW], bcb, 64 * sizeof(float));
   };
-  upd(pk.upd_fwd, L_FC3, L_FC3_2, L_FC4, L_FC4_2);
-  upd(pk.upd_bwd, L_BC3, L_BC3_1, L_BC4, L_BC4_1);
+  upd(pk.upd_fwd, L_FC3, L_FC3_2, L_FC4, L_FC4_2, false);
+  upd(pk.upd_bwd, L_BC3, L_BC3_1, L_BC4, L_BC4_1, false);
+  {   // the feature chains cache P' = W4[:, :64].relax + bcb
+    float bcb[64];
+    bcb_of(L_FC3_2, L_FC4, bcb);
+    pack_vec64(&pk.pre_fwd[PackPreFwd::B3], bcb);
+  }
 
   pk.pre_bwd.assign(PackPreBwd::FLOATS, 0.f);
   pack_wsmall(&pk.pre_bwd[PackPreBwd::W1], W(L_BC1), 7, 4);
@@ -179,15 +221,23 @@ inline void build_packs(const float* blob, Packs& pk) {
   pack_w64(&pk.pre_bwd[PackPreBwd::W5], W(L_BC2_1), 64, 0, 1);
   pack_vec64(&pk.pre_bwd[PackPreBwd::B5], Bv(L_BC2_1));
   pack_w64(&pk.pre_bwd[PackPreBwd::W6], W(L_BC4), 128, 0, 1);
-  pack_vec64(&pk.pre_bwd[PackPreBwd::B6], Bv(L_BC4));
+  {
+    float bcb[64];
+    bcb_of(L_BC3_1, L_BC4, bcb);
+    pack_vec64(&pk.pre_bwd[PackPreBwd::B6], bcb);
+  }
 
   pk.pre_inp.assign(PackPreInp::FLOATS, 0.f);
   pack_wsmall(&pk.pre_inp[PackPreInp::W1], W(L_INP_B), 2, 1);
   pack_vec64(&pk.pre_inp[PackPreInp::B1], Bv(L_INP_B));
-  pack_w64(&pk.pre_inp[PackPreInp::W2], W(L_INP_B_1), 64, 0, 1);
-  pack_vec64(&pk.pre_inp[PackPreInp::B2], Bv(L_INP_B_1));
-  pack_w64(&pk.pre_inp[PackPreInp::W3], W(L_INP_B2), 128, 0, 1);
-  pack_vec64(&pk.pre_inp[PackPreInp::B3], Bv(L_INP_B2));
+  {
+    std::vector<float> w2(64 * 64);
+    float b2[64];
+    matmul64(w2.data(), W(L_INP_B2), 128, 0, W(L_INP_B_1));
+    matvec64(b2, W(L_INP_B2), 128, 0, Bv(L_INP_B_1), Bv(L_INP_B2));
+    pack_w64(&pk.pre_inp[PackPreInp::W2], w2.data(), 64, 0, 1);
+    pack_vec64(&pk.pre_inp[PackPreInp::B2], b2);
+  }
 
   pk.upd_inp.assign(PackUpdInp::FLOATS, 0.f);
   pack_w64(&pk.upd_inp[PackUpdInp::WC], W(L_INP_B2), 128, 64, 1);
@@ -195,10 +245,8 @@ inline void build_packs(const float* blob, Packs& pk) {
   pack_vec64(&pk.upd_inp[PackUpdInp::BD], Bv(L_INP_B2_2));
 
   // variants whose first layer reads the fragment produced by the MFMA gather (gather_feature map)
-  pk.upd_fwd_g = pk.upd_fwd;
-  pack_w64_gather(&pk.upd_fwd_g[PackUpd::WA], W(L_FC3), 128, 0, 2);
-  pk.upd_bwd_g = pk.upd_bwd;
-  pack_w64_gather(&pk.upd_bwd_g[PackUpd::WA], W(L_BC3), 128, 0, 2);
+  upd(pk.upd_fwd_g, L_FC3, L_FC3_2, L_FC4, L_FC4_2, true);
+  upd(pk.upd_bwd_g, L_BC3, L_BC3_1, L_BC4, L_BC4_1, true);
   pk.upd_inp_g = pk.upd_inp;
   pack_w64_gather(&pk.upd_inp_g[PackUpdInp::WC], W(L_INP_B2), 128, 64, 1);
 

@@ -99,33 +99,44 @@ E = "EmbedUpdates.update."
 
 
 def test_node_update_chain(packs):
-    """k_node_update's chain on one tile == fc4_2(relu(fc4([relax, fc3_2(relu(fc3([r0 nb, r1 nb])))])))."""
+    """k_node_update's folded chains on one tile == fc4_2(relu(fc4([relax, fc3_2(relu(fc3([r0 nb, r1 nb])))]))).
+
+    Fold (gnnb_pack.h PackUpd): fc3_2 feeds fc4 linearly, so Wcb = fc4[:, 64:].fc3_2.W and the cached term is
+    P' = fc4[:, :64].relax + fc4.b + fc4[:, 64:].fc3_2.b; nodes with r0 == r1 use the summed halves of fc3."""
     sd, pk = packs
     rng = np.random.RandomState(1)
     nb = rng.standard_normal((32, 64)); relax = rng.standard_normal((32, 64))
     r0 = rng.uniform(0, 1, 32); r1 = 1 - r0
     w4, b4 = np.asarray(sd[E + "fc4.weight"], np.float64), np.asarray(sd[E + "fc4.bias"], np.float64)
-    P = relax @ w4[:, :64].T + b4                      # what k_pre_fwd caches
+    b32 = np.asarray(sd[E + "fc3_2.bias"], np.float64)
+    bcb = b4 + w4[:, 64:] @ b32
+    Pp = relax @ w4[:, :64].T + bcb                      # what k_pre_fwd caches for ambiguous nodes
     p = pk["upd_fwd"]
-    WA, BA, WB, BB, WC, BC, WD, BD = 0, 8192, 8256, 12352, 12416, 16512, 16576, 20672
+    WA, WAS, BA, WCB, BCB, WD, BD, BCBROW = 0, 8192, 12288, 12352, 16448, 16512, 20608, 20672
+    assert p.size == 20736
+    np.testing.assert_allclose(p[BCBROW:BCBROW + 64], bcb, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(rows_from_frag(frag_bias(p[BCB:BCB + 64]))[0], bcb, rtol=1e-6, atol=1e-7)
+
+    def reference(nb_, r0_, r1_, relax_):
+        e = lin(sd, E + "fc3_2", np.maximum(lin(sd, E + "fc3", np.concatenate([nb_ * r0_[:, None], nb_ * r1_[:, None]], 1)), 0))
+        return lin(sd, E + "fc4_2", np.maximum(lin(sd, E + "fc4", np.concatenate([relax_, e], 1)), 0))
+
+    def tail(Hf, H2):
+        Hf = np.maximum(Hf, 0)
+        gemm_w64(p[WCB:], 32, H2, lambda s: Hf[:, s])
+        H2 = np.maximum(H2, 0)
+        M = frag_bias(p[BD:BD + 64])
+        gemm_w64(p[WD:], 32, M, lambda s: H2[:, s])
+        return rows_from_frag(M)
+    # kind 1 (general): K = 128 first layer, P' rows
     X = frag_from_rows(nb)
     Hf = frag_bias(p[BA:BA + 64])
     gemm_w64(p[WA:], 64, Hf, lambda s: X[:, s & 31] * (r0[J] if s < 32 else r1[J]))
-    Hf = np.maximum(Hf, 0)
-    Ef = frag_bias(p[BB:BB + 64])
-    gemm_w64(p[WB:], 32, Ef, lambda s: Hf[:, s])
-    H2 = frag_from_rows(P)
-    gemm_w64(p[WC:], 32, H2, lambda s: Ef[:, s])
-    H2 = np.maximum(H2, 0)
-    M = frag_bias(p[BD:BD + 64])
-    gemm_w64(p[WD:], 32, M, lambda s: H2[:, s])
-    got = rows_from_frag(M)
-    e = lin(sd, E + "fc3_2", np.maximum(lin(sd, E + "fc3", np.concatenate([nb * r0[:, None], nb * r1[:, None]], 1)), 0))
-    want = lin(sd, E + "fc4_2", np.maximum(lin(sd, E + "fc4", np.concatenate([relax, e], 1)), 0))
-    np.testing.assert_allclose(got, want, atol=1e-5)
-    # nodes whose relaxation term is masked (amb = 0): P degenerates to fc4.bias, kept in the pack at BC
-    np.testing.assert_allclose(rows_from_frag(frag_bias(p[BC:BC + 64]))[0], b4, atol=0)
-    np.testing.assert_array_equal(p[BD + 64:BD + 128], b4.astype(np.float32))      # BCROW: the same bias, row-major
+    np.testing.assert_allclose(tail(Hf, frag_from_rows(Pp)), reference(nb, r0, r1, relax), atol=1e-5)
+    # kind 0 (r0 == r1, no relaxation term): summed halves, P' = bcb
+    Hf = frag_bias(p[BA:BA + 64])
+    gemm_w64(p[WAS:], 32, Hf, lambda s: X[:, s] * r0[J])
+    np.testing.assert_allclose(tail(Hf, frag_bias(p[BCB:BCB + 64])), reference(nb, r0, r0, np.zeros_like(relax)), atol=1e-5)
 
 
 def test_pre_bwd_chain(packs):
@@ -149,7 +160,8 @@ def test_pre_bwd_chain(packs):
     s_ = lin(sd, E + "bc1_2", np.maximum(lin(sd, E + "bc1_1", np.maximum(lin(sd, E + "bc1", f7), 0)), 0))
     relax = lin(sd, E + "bc2_1", np.maximum(lin(sd, E + "bc2", np.concatenate([s_, s_ * -d2[:, None], s_ * d1[:, None]], 1)), 0))
     w4, b4 = np.asarray(sd[E + "bc4.weight"], np.float64), np.asarray(sd[E + "bc4.bias"], np.float64)
-    np.testing.assert_allclose(got, relax @ w4[:, :64].T + b4, atol=1e-5)
+    bcb = b4 + w4[:, 64:] @ np.asarray(sd[E + "bc3_1.bias"], np.float64)      # folded bias (PackUpd)
+    np.testing.assert_allclose(got, relax @ w4[:, :64].T + bcb, atol=1e-5)
 
 
 def test_embed_and_score_packs(packs):
@@ -282,7 +294,7 @@ def test_gather_fragment_feeds_first_layer(packs):
         for r in range(16):
             X[:, 16 * it + r] = nb[J, 2 * ((r & 3) + 8 * (r >> 2) + 4 * H) + it]
     p = pk["upd_fwd_g"]
-    Hf = frag_bias(p[8192:8256])
+    Hf = frag_bias(p[12288:12352])
     gemm_w64(p[0:], 64, Hf, lambda s: X[:, s & 31] * (r0[J] if s < 32 else r1[J]))
     want = lin(sd, E + "fc3", np.concatenate([nb * r0[:, None], nb * r1[:, None]], 1))
     np.testing.assert_allclose(rows_from_frag(Hf), want, atol=1e-5)
