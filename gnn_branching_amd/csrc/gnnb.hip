@@ -295,14 +295,18 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_embed(EmbedArgs a) {
 // affect any result: every lane of an MLP tile computes its own column).  Dead rows of mu are zeroed here, once,
 // and scores are preset to -inf.
 // ------------------------------------------------------------------------------------------
-struct ClassifyArgs {
-  const float *lb, *ub, *mask;
-  float* mu;       // (B*N, 64) rows of this layer
-  float* scores;   // (B, R)
-  int* cnt;        // [3]: plain (live, not ambiguous), ambiguous, scored
-  int *live, *amb, *score;
-  long G;
-  int N, R, off;
+#define MAXL 8            // ReLU layers handled by the merged per-layer kernels (bind rejects deeper networks for them)
+struct ClassifyArgs {    // every ReLU layer of the network in one launch
+  int L;
+  const float* lb[MAXL]; const float* ub[MAXL];
+  float* mu[MAXL];                 // (B*N_k, 64) rows of layer k
+  int* live[MAXL]; int* amb[MAXL]; int* score[MAXL];
+  long G[MAXL];
+  int N[MAXL], off[MAXL], blk0[MAXL + 1];   // first workgroup of each layer
+  const float* mask;
+  float* scores;                   // (B, R)
+  int* cnt;                        // 4 ints per layer: plain (live, not ambiguous), ambiguous, scored, 0
+  int R;
 };
 
 #define CLS_THREADS 1024
@@ -311,12 +315,16 @@ __global__ __launch_bounds__(CLS_THREADS) void k_classify(ClassifyArgs a) {
   __shared__ int wcnt[3][CLS_THREADS / 64];
   __shared__ int wbase[3][CLS_THREADS / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long g = (long)blockIdx.x * CLS_THREADS + threadIdx.x;
-  const bool valid = g < a.G;
-  const long gc = valid ? g : a.G - 1;
-  const Ratio r = compute_ratio(a.lb[gc], a.ub[gc]);
-  const long b = gc / a.N;
-  const long sidx = b * a.R + a.off + (gc - b * a.N);
+  int k = 0;
+  while (k + 1 < a.L && (int)blockIdx.x >= a.blk0[k + 1]) ++k;
+  const long G = a.G[k];
+  const int N = a.N[k];
+  const long g = (long)(blockIdx.x - a.blk0[k]) * CLS_THREADS + threadIdx.x;
+  const bool valid = g < G;
+  const long gc = valid ? g : G - 1;
+  const Ratio r = compute_ratio(a.lb[k][gc], a.ub[k][gc]);
+  const long b = gc / N;
+  const long sidx = b * a.R + a.off[k] + (gc - b * N);
   bool flag[3];
   const bool live = valid && r.live != 0.0f;
   flag[1] = valid && r.amb != 0.0f;                 // ambiguous (a subset of live)
@@ -334,20 +342,21 @@ __global__ __launch_bounds__(CLS_THREADS) void k_classify(ClassifyArgs a) {
     const int c = threadIdx.x;
     int total = 0;
     for (int w = 0; w < CLS_THREADS / 64; ++w) { wbase[c][w] = total; total += wcnt[c][w]; }
-    const int base = total ? atomicAdd(a.cnt + c, total) : 0;
+    const int base = total ? atomicAdd(a.cnt + 4 * k + c, total) : 0;
     for (int w = 0; w < CLS_THREADS / 64; ++w) wbase[c][w] += base;
   }
   __syncthreads();
-  int* lists[3] = {a.live, a.amb, a.score};
+  int* lists[3] = {a.live[k], a.amb[k], a.score[k]};
 #pragma unroll
   for (int c = 0; c < 3; ++c)
     if (flag[c]) lists[c][wbase[c][wave] + __popcll(bal[c] & ((1ull << lane) - 1ull))] = (int)gc;
   unsigned long long dead = __ballot(valid && !live);
+  float* mu = a.mu[k];
   while (dead) {                       // the whole wave zeroes one dead row per iteration (coalesced 256 B)
     const int l = __ffsll((long long)dead) - 1;
     dead &= dead - 1;
     const long row = g - lane + l;
-    a.mu[row * 64 + lane] = 0.0f;
+    mu[row * 64 + lane] = 0.0f;
   }
 }
 
@@ -362,93 +371,111 @@ struct PreArgs {
   const int* cnt;
 };
 
-// P_f[g] = fc4[:, :64] . fc1_1(relu(fc1(feat7))) + fc4.bias  for the ambiguous nodes g     graph_conv.py:153-161,176-177
-__global__ __launch_bounds__(WG_MLP, 2) void k_pre_fwd(PreArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  stage_pack(lds, a.pack, PackPreFwd::FLOATS);
-  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
-  const int count = *a.cnt;
-  const long ntiles = (count + 31) / 32;
-  for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < ntiles; tile += (long)gridDim.x * WAVES_MLP) {
-    const long idx = tile * 32 + j;
-    const bool valid = idx < count;
-    const long gc = a.list[valid ? idx : 0];
-    const int n = (int)(gc % a.N);
-    const float lb = a.lb[gc], ub = a.ub[gc];
-    const Ratio r = compute_ratio(lb, ub);
-    const float dd = a.dual[gc * 3 + 1] - a.dual[gc * 3 + 2];
-    const float c = a.bias[n / a.hw];
-    // feat7 = [beta, l, u, d1-d2, z_pre, z_post, c]: even features on half 0, odd on half 1
-    float x[4];
-    x[0] = h ? lb : r.beta;
-    x[1] = h ? dd : ub;
-    x[2] = h ? a.z_post[gc] : a.z_pre[gc];
-    x[3] = h ? 0.0f : c;
-    Frag H;
-    frag_bias(H, lds + PackPreFwd::B1, h);
-    gemm_small<4>(lds + PackPreFwd::W1, lane, H, x);
-    frag_relu(H);
-    Frag S;
-    frag_bias(S, lds + PackPreFwd::B2, h);
-    gemm_w64<32>(lds + PackPreFwd::W2, lane, S, [&](int s) { return FRAG_AT(H, s); });
-    // (layer_relax * ambi_mask, :161: every node of this list has amb = 1)
-    Frag Pf;
-    frag_bias(Pf, lds + PackPreFwd::B3, h);
-    gemm_w64<32>(lds + PackPreFwd::W3, lane, Pf, [&](int s) { return FRAG_AT(S, s); });
-    if (valid) frag_store_rows(Pf, a.P, gc, h);
-  }
-}
+struct PreAllArgs {       // hoisted feature chains of every ReLU layer, forward and backward, in one launch
+  const float* pack_f;   // PackPreFwd
+  const float* pack_b;   // PackPreBwd
+  int L, do_bwd;
+  const float* lb[MAXL]; const float* ub[MAXL]; const float* dual[MAXL];
+  const float* z_pre[MAXL]; const float* z_post[MAXL]; const float* bias[MAXL];
+  float* Pf[MAXL]; float* Pb[MAXL];            // out: P' rows by node id
+  const int* list[MAXL];                       // ambiguous nodes of layer k
+  const int* cnt;                              // cnt[4k + 1] = number of ambiguous nodes of layer k
+  int N[MAXL], hw[MAXL];
+};
 
-// P_b[g] = bc4[:, :64] . bc2_1(relu(bc2([s, -d2 s, d1 s]))) + bc4.bias,
-// s = bc1_2(relu(bc1_1(relu(bc1(feat7')))))     for the ambiguous nodes g                graph_conv.py:273-293,344-345
-__global__ __launch_bounds__(WG_MLP, 2) void k_pre_bwd(PreArgs a) {
+// tile space: for k = 0..L-1: ceil(c_k/32) forward tiles, then (do_bwd) ceil(c_k/32) backward tiles
+//   forward  P'_f[g] = fc4[:, :64] . fc1_1(relu(fc1(feat7))) + bcb_f                           graph_conv.py:153-161,176-177
+//   backward P'_b[g] = bc4[:, :64] . bc2_1(relu(bc2([s, -d2 s, d1 s]))) + bcb_b,
+//            s = bc1_2(relu(bc1_1(relu(bc1(feat7')))))                                        graph_conv.py:273-293,344-345
+// for the ambiguous nodes g (everywhere else the relaxation term is multiplied by amb = 0, :161 / :293)
+__global__ __launch_bounds__(WG_MLP, 2) void k_pre(PreAllArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  stage_pack(lds, a.pack, PackPreBwd::FLOATS);
+  float* lds_b = lds + PackPreFwd::FLOATS;
+  {
+    const f32x4* gsrc = reinterpret_cast<const f32x4*>(a.pack_b);
+    f32x4* ldst = reinterpret_cast<f32x4*>(lds_b);
+    for (int i = threadIdx.x; i < PackPreBwd::FLOATS / 4; i += blockDim.x) ldst[i] = gsrc[i];
+  }
+  stage_pack(lds, a.pack_f, PackPreFwd::FLOATS);
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
-  const int count = *a.cnt;
-  const long ntiles = (count + 31) / 32;
+  long ntiles = 0;
+  for (int k = 0; k < a.L; ++k) ntiles += (long)((a.cnt[4 * k + 1] + 31) / 32) * (a.do_bwd ? 2 : 1);
   for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < ntiles; tile += (long)gridDim.x * WAVES_MLP) {
-    const long idx = tile * 32 + j;
+    // which layer / direction (wave-uniform)
+    int k = 0, count = 0;
+    long t = tile;
+    bool bwd = false;
+    for (; k < a.L; ++k) {
+      count = a.cnt[4 * k + 1];
+      const long tk = (count + 31) / 32;
+      if (t < tk) { bwd = false; break; }
+      t -= tk;
+      if (a.do_bwd) {
+        if (t < tk) { bwd = true; break; }
+        t -= tk;
+      }
+    }
+    const long idx = t * 32 + j;
     const bool valid = idx < count;
-    const long gc = a.list[valid ? idx : 0];
-    const int n = (int)(gc % a.N);
-    const float lb = a.lb[gc], ub = a.ub[gc];
+    const long gc = a.list[k][valid ? idx : 0];
+    const int n = (int)(gc % a.N[k]);
+    const float lb = a.lb[k][gc], ub = a.ub[k][gc];
     const Ratio r = compute_ratio(lb, ub);
-    const float d1 = a.dual[gc * 3 + 1], d2 = a.dual[gc * 3 + 2];
-    const float c = a.bias[n / a.hw];
-    // feat7' = [l, u, beta, -d2+d1, z_post, z_pre, c]
+    const float d1 = a.dual[k][gc * 3 + 1], d2 = a.dual[k][gc * 3 + 2];
+    const float c = a.bias[k][n / a.hw[k]];
+    const float zpre = a.z_pre[k][gc], zpost = a.z_post[k][gc];
     float x[4];
-    x[0] = h ? ub : lb;
-    x[1] = h ? (-d2 + d1) : r.beta;
-    x[2] = h ? a.z_pre[gc] : a.z_post[gc];
-    x[3] = h ? 0.0f : c;
-    Frag H1;
-    frag_bias(H1, lds + PackPreBwd::B1, h);
-    gemm_small<4>(lds + PackPreBwd::W1, lane, H1, x);
-    frag_relu(H1);
-    Frag H2;
-    frag_bias(H2, lds + PackPreBwd::B2, h);
-    gemm_w64<32>(lds + PackPreBwd::W2, lane, H2, [&](int s) { return FRAG_AT(H1, s); });
-    frag_relu(H2);
-    Frag S;
-    frag_bias(S, lds + PackPreBwd::B3, h);
-    gemm_w64<32>(lds + PackPreBwd::W3, lane, S, [&](int s) { return FRAG_AT(H2, s); });
-    // bc2 on [s, s*(-d2), s*d1]  (:287-291)
-    const float nd2 = -d2;
-    Frag H4;
-    frag_bias(H4, lds + PackPreBwd::B4, h);
-    gemm_w64<96>(lds + PackPreBwd::W4, lane, H4, [&](int s) {
-      const float v = FRAG_AT(S, s & 31);
-      return s < 32 ? v : (s < 64 ? v * nd2 : v * d1);
-    });
-    frag_relu(H4);
-    Frag X;
-    frag_bias(X, lds + PackPreBwd::B5, h);
-    gemm_w64<32>(lds + PackPreBwd::W5, lane, X, [&](int s) { return FRAG_AT(H4, s); });
-    Frag Pb;
-    frag_bias(Pb, lds + PackPreBwd::B6, h);
-    gemm_w64<32>(lds + PackPreBwd::W6, lane, Pb, [&](int s) { return FRAG_AT(X, s); });
-    if (valid) frag_store_rows(Pb, a.P, gc, h);
+    if (!bwd) {
+      // feat7 = [beta, l, u, d1-d2, z_pre, z_post, c]: even features on half 0, odd on half 1
+      x[0] = h ? lb : r.beta;
+      x[1] = h ? (d1 - d2) : ub;
+      x[2] = h ? zpost : zpre;
+      x[3] = h ? 0.0f : c;
+      Frag H;
+      frag_bias(H, lds + PackPreFwd::B1, h);
+      gemm_small<4>(lds + PackPreFwd::W1, lane, H, x);
+      frag_relu(H);
+      Frag S;
+      frag_bias(S, lds + PackPreFwd::B2, h);
+      gemm_w64<32>(lds + PackPreFwd::W2, lane, S, [&](int s) { return FRAG_AT(H, s); });
+      Frag Pf;
+      frag_bias(Pf, lds + PackPreFwd::B3, h);
+      gemm_w64<32>(lds + PackPreFwd::W3, lane, Pf, [&](int s) { return FRAG_AT(S, s); });
+      if (valid) frag_store_rows(Pf, a.Pf[k], gc, h);
+    } else {
+      // feat7' = [l, u, beta, -d2+d1, z_post, z_pre, c]
+      x[0] = h ? ub : lb;
+      x[1] = h ? (-d2 + d1) : r.beta;
+      x[2] = h ? zpre : zpost;
+      x[3] = h ? 0.0f : c;
+      Frag H1;
+      frag_bias(H1, lds_b + PackPreBwd::B1, h);
+      gemm_small<4>(lds_b + PackPreBwd::W1, lane, H1, x);
+      frag_relu(H1);
+      Frag H2;
+      frag_bias(H2, lds_b + PackPreBwd::B2, h);
+      gemm_w64<32>(lds_b + PackPreBwd::W2, lane, H2, [&](int s) { return FRAG_AT(H1, s); });
+      frag_relu(H2);
+      Frag S;
+      frag_bias(S, lds_b + PackPreBwd::B3, h);
+      gemm_w64<32>(lds_b + PackPreBwd::W3, lane, S, [&](int s) { return FRAG_AT(H2, s); });
+      // bc2 on [s, s*(-d2), s*d1]  (:287-291)
+      const float nd2 = -d2;
+      Frag H4;
+      frag_bias(H4, lds_b + PackPreBwd::B4, h);
+      gemm_w64<96>(lds_b + PackPreBwd::W4, lane, H4, [&](int s) {
+        const float v = FRAG_AT(S, s & 31);
+        return s < 32 ? v : (s < 64 ? v * nd2 : v * d1);
+      });
+      frag_relu(H4);
+      Frag X;
+      frag_bias(X, lds_b + PackPreBwd::B5, h);
+      gemm_w64<32>(lds_b + PackPreBwd::W5, lane, X, [&](int s) { return FRAG_AT(H4, s); });
+      Frag Pb;
+      frag_bias(Pb, lds_b + PackPreBwd::B6, h);
+      gemm_w64<32>(lds_b + PackPreBwd::W6, lane, Pb, [&](int s) { return FRAG_AT(X, s); });
+      if (valid) frag_store_rows(Pb, a.Pb[k], gc, h);
+    }
   }
 }
 
@@ -823,9 +850,12 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_gather_input_update(GIArgs a) {
   }
 }
 
-struct ScoreArgs {
-  const float* pack; const float* mu; float* scores; const int* list; const int* cnt;
-  int N, R, off;   // nodes per sample in this layer, total ReLUs per sample, offset of this layer
+struct ScoreArgs {        // every ReLU layer in one launch
+  const float* pack; float* scores;
+  int L, R;
+  const float* mu[MAXL]; const int* list[MAXL];
+  const int* cnt;         // cnt[4k + 2] = number of scored nodes of layer k
+  int N[MAXL], off[MAXL]; // nodes per sample in layer k, offset of layer k in the flat ReLU index
 };
 
 // score = fscore(relu(fnode(mu_g))) for the nodes g whose BaB mask is -1 (the rest stays -inf)    graph_conv.py:445-450
@@ -834,15 +864,24 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_score(ScoreArgs a) {
   stage_pack(lds, a.pack, PackScore::FLOATS);
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
   const float bs = lds[PackScore::BS];
-  const int count = *a.cnt;
-  const long ntiles = (count + 31) / 32;
+  long ntiles = 0;
+  for (int k = 0; k < a.L; ++k) ntiles += (a.cnt[4 * k + 2] + 31) / 32;
   for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < ntiles; tile += (long)gridDim.x * WAVES_MLP) {
-    const long idx = tile * 32 + j;
+    int k = 0, count = 0;
+    long t = tile;
+    for (; k < a.L; ++k) {
+      count = a.cnt[4 * k + 2];
+      const long tk = (count + 31) / 32;
+      if (t < tk) break;
+      t -= tk;
+    }
+    const long idx = t * 32 + j;
     const bool valid = idx < count;
-    const long gc = a.list[valid ? idx : 0];
-    const long b = gc / a.N;
+    const long gc = a.list[k][valid ? idx : 0];
+    const int N = a.N[k];
+    const long b = gc / N;
     Frag X;
-    frag_load_rows(X, a.mu, gc, h);
+    frag_load_rows(X, a.mu[k], gc, h);
     Frag H;
     frag_bias(H, lds + PackScore::B1, h);
     gemm_w64<32>(lds + PackScore::W1, lane, H, [&](int s) { return FRAG_AT(X, s); });
@@ -856,7 +895,7 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_score(ScoreArgs a) {
       for (int c = 0; c < 4; ++c) part = fmaf(FRAG_AT(H, 4 * q + c), w[c], part);
     }
     part += __shfl_xor(part, 32);
-    if (valid && h == 0) a.scores[b * a.R + a.off + (gc - b * a.N)] = part + bs;
+    if (valid && h == 0) a.scores[b * a.R + a.off[k] + (gc - b * N)] = part + bs;
   }
 }
 
@@ -1268,11 +1307,11 @@ static int fail(int code, const char* fmt, ...) {
   } while (0)
 
 enum ProfClass {
-  PC_EMBED, PC_PRE_FWD, PC_PRE_BWD, PC_PRE_INP, PC_CONV_FWD, PC_CONVT_BWD, PC_DENSE_AGG, PC_PROP_FWD,
+  PC_EMBED, PC_PRE, PC_PRE_UNUSED, PC_PRE_INP, PC_CONV_FWD, PC_CONVT_BWD, PC_DENSE_AGG, PC_PROP_FWD,
   PC_PROP_BWD_NB, PC_NODE_UPDATE, PC_INPUT_UPDATE, PC_SCORE, PC_ARGMAX, PC_GATHER, PC_GATHER_INPUT, PC_CLASSIFY, PC_COUNT
 };
 static const char* kProfNames[PC_COUNT] = {
-    "k_embed", "k_pre_fwd", "k_pre_bwd", "k_pre_inp", "k_conv_fwd", "k_convT_bwd", "k_dense_agg", "k_prop_fwd",
+    "k_embed", "k_pre", "(unused)", "k_pre_inp", "k_conv_fwd", "k_convT_bwd", "k_dense_agg", "k_prop_fwd",
     "k_prop_bwd_nb", "k_node_update", "k_input_update", "k_score", "k_argmax", "k_gather", "k_gather_input_update", "k_classify"};
 
 struct DevEdge {
@@ -1355,8 +1394,7 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   HIPCHK(hipMemset(h->d_zero, 0, 256 * sizeof(float)));
   // > 64 KiB of dynamic LDS needs the attribute
   HIPCHK(hipFuncSetAttribute((const void*)k_embed, hipFuncAttributeMaxDynamicSharedMemorySize, PackEmbed::FLOATS * 4));
-  HIPCHK(hipFuncSetAttribute((const void*)k_pre_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, PackPreFwd::FLOATS * 4));
-  HIPCHK(hipFuncSetAttribute((const void*)k_pre_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, PackPreBwd::FLOATS * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_pre, hipFuncAttributeMaxDynamicSharedMemorySize, (PackPreFwd::FLOATS + PackPreBwd::FLOATS) * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_pre_inp, hipFuncAttributeMaxDynamicSharedMemorySize, PackPreInp::FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_node_update<8>, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpd::FLOATS * 4));
   if (const char* e = getenv("GNNB_GATHER_OCC")) h->gather_occ = atoi(e) < 1 ? 1 : atoi(e);
@@ -1476,7 +1514,7 @@ extern "C" int gnnb_bind_network(gnnb_t* h, const gnnb_layer_desc* L, int n, int
   }
   if (have) return fail(GNNB_E_INVALID, "fixed layers must end after a ReLU (the property layer is passed per batch)");
   const int Lr = (int)h->N.size() - 1;
-  if (Lr < 1 || Lr > 15) return fail(GNNB_E_INVALID, "unsupported number of ReLU layers %d", Lr);
+  if (Lr < 1 || Lr > MAXL) return fail(GNNB_E_INVALID, "unsupported number of ReLU layers %d (max %d)", Lr, MAXL);
   h->N.push_back(1);   // property node
   h->n_fixed = n;
   h->R = 0;
@@ -1791,30 +1829,41 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   const bool debug_full = h->halfpass_limit > 0;   // with a limit set nothing is restricted or skipped as dead
 
   // ---- once per forward: classification lists, input embedding, embedding-independent feature chains ----
-  for (int k = 1; k <= L; ++k) {
-    const long G = (long)B * h->N[k];
-    ClassifyArgs a{in->lb[k], in->ub[k], in->mask, mu(k), scores, cnt + 4 * k, ilist(w.live[k]), ilist(w.amb[k]),
-                   ilist(w.score[k]), G, h->N[k], h->R, roff[k]};
-    lz.run(PC_CLASSIFY, [&] { hipLaunchKernelGGL(k_classify, dim3((unsigned)((G + CLS_THREADS - 1) / CLS_THREADS)), dim3(CLS_THREADS), 0, st, a); });
+  {
+    ClassifyArgs a{};
+    a.L = L; a.mask = in->mask; a.scores = scores; a.cnt = cnt + 4; a.R = h->R;
+    int blk = 0;
+    for (int k = 1; k <= L; ++k) {
+      const int i = k - 1;
+      a.lb[i] = in->lb[k]; a.ub[i] = in->ub[k]; a.mu[i] = mu(k);
+      a.live[i] = ilist(w.live[k]); a.amb[i] = ilist(w.amb[k]); a.score[i] = ilist(w.score[k]);
+      a.G[i] = (long)B * h->N[k]; a.N[i] = h->N[k]; a.off[i] = roff[k];
+      a.blk0[i] = blk;
+      blk += (int)((a.G[i] + CLS_THREADS - 1) / CLS_THREADS);
+    }
+    a.blk0[L] = blk;
+    lz.run(PC_CLASSIFY, [&] { hipLaunchKernelGGL(k_classify, dim3((unsigned)blk), dim3(CLS_THREADS), 0, st, a); });
   }
   {
     const long G = (long)B * h->N[0], nt = (G + 31) / 32;
     EmbedArgs a{h->d_pack[PK_EMBED], in->lb[0], in->x_lp, in->ub[0], mu(0), G, nt};
     lz.run(PC_EMBED, [&] { hipLaunchKernelGGL(k_embed, dim3(mlp_grid(h, nt)), dim3(WG_MLP), PackEmbed::FLOATS * 4, st, a); });
   }
-  for (int k = 1; k <= L; ++k) {
-    const long G = (long)B * h->N[k], nt = (G + 31) / 32;     // upper bound: the kernels read the real count on the device
-    const int q = h->relu_q[k];
-    PreArgs a{nullptr, in->lb[k], in->ub[k], in->dual[k - 1], in->primal[q - 1], in->primal[q], h->dev[k].bias,
-              nullptr, G, nt, h->N[k], h->hw[k], DTileMap{}, ilist(w.amb[k]), cnt + 4 * k + 1};
-    a.pack = h->d_pack[PK_PRE_FWD];
-    a.P = ws + w.Pf[k];
-    lz.run(PC_PRE_FWD, [&] { hipLaunchKernelGGL(k_pre_fwd, dim3(mlp_grid(h, nt)), dim3(WG_MLP), PackPreFwd::FLOATS * 4, st, a); });
-    if (limit >= 2) {
-      a.pack = h->d_pack[PK_PRE_BWD];
-      a.P = ws + w.Pb[k];
-      lz.run(PC_PRE_BWD, [&] { hipLaunchKernelGGL(k_pre_bwd, dim3(mlp_grid(h, nt)), dim3(WG_MLP), PackPreBwd::FLOATS * 4, st, a); });
+  {
+    PreAllArgs a{};
+    a.pack_f = h->d_pack[PK_PRE_FWD]; a.pack_b = h->d_pack[PK_PRE_BWD];
+    a.L = L; a.do_bwd = limit >= 2 ? 1 : 0; a.cnt = cnt + 4;
+    long nt = 0;                                      // upper bound: the kernel reads the real counts on the device
+    for (int k = 1; k <= L; ++k) {
+      const int i = k - 1, q = h->relu_q[k];
+      a.lb[i] = in->lb[k]; a.ub[i] = in->ub[k]; a.dual[i] = in->dual[k - 1];
+      a.z_pre[i] = in->primal[q - 1]; a.z_post[i] = in->primal[q]; a.bias[i] = h->dev[k].bias;
+      a.Pf[i] = ws + w.Pf[k]; a.Pb[i] = ws + w.Pb[k]; a.list[i] = ilist(w.amb[k]);
+      a.N[i] = h->N[k]; a.hw[i] = h->hw[k];
+      nt += (((long)B * h->N[k] + 31) / 32) * 2;
     }
+    const size_t lds = (PackPreFwd::FLOATS + PackPreBwd::FLOATS) * 4;
+    lz.run(PC_PRE, [&] { hipLaunchKernelGGL(k_pre, dim3(mlp_grid(h, nt / 8)), dim3(WG_MLP), lds, st, a); });
   }
   const bool need_inp = (limit >= 2) && (h->T > 1 || debug_full) && !h->gb[1].ok;    // the fused input kernel computes Q itself
   if (need_inp) {
@@ -1955,11 +2004,17 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
 
   // scores (graph_conv.py:442-450) and decision (graph_score.py:41-47)
   ArgmaxArgs am{scores, decisions, B, h->R, L, {0}};
-  for (int k = 1; k <= L; ++k) {
-    const long nt = ((long)B * h->N[k] + 31) / 32;
-    ScoreArgs a{h->d_pack[PK_SCORE], mu(k), scores, ilist(w.score[k]), cnt + 4 * k + 2, h->N[k], h->R, roff[k]};
-    lz.run(PC_SCORE, [&] { hipLaunchKernelGGL(k_score, dim3(mlp_grid(h, nt)), dim3(WG_MLP), PackScore::FLOATS * 4, st, a); });
-    am.cum[k - 1] = roff[k] + h->N[k];
+  {
+    ScoreArgs a{};
+    a.pack = h->d_pack[PK_SCORE]; a.scores = scores; a.L = L; a.R = h->R; a.cnt = cnt + 4;
+    long nt = 0;
+    for (int k = 1; k <= L; ++k) {
+      const int i = k - 1;
+      a.mu[i] = mu(k); a.list[i] = ilist(w.score[k]); a.N[i] = h->N[k]; a.off[i] = roff[k];
+      nt += ((long)B * h->N[k] + 31) / 32;
+      am.cum[k - 1] = roff[k] + h->N[k];
+    }
+    lz.run(PC_SCORE, [&] { hipLaunchKernelGGL(k_score, dim3(mlp_grid(h, nt / 4)), dim3(WG_MLP), PackScore::FLOATS * 4, st, a); });
   }
   lz.run(PC_ARGMAX, [&] { hipLaunchKernelGGL(k_argmax, dim3(B), dim3(256), 0, st, am); });
   return lz.rc;
