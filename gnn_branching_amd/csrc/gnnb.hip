@@ -1725,8 +1725,8 @@ extern "C" const char* gnnb_profile_class_name(int cls) { return (cls >= 0 && cl
 extern "C" int gnnb_profile_read(gnnb_t* h, double* total_ms, int64_t* launches, int n, int reset) {
   if (!h) return fail(GNNB_E_INVALID, "null handle");
   if (!h->pending.empty()) {
-    HIPCHK(hipStreamSynchronize(h->prof_stream));
     for (auto& ev : h->pending) {
+      HIPCHK(hipEventSynchronize(ev.b));        // launches may sit on several streams (batch pipelining)
       float ms = 0.f;
       HIPCHK(hipEventElapsedTime(&ms, ev.a, ev.b));
       h->prof_ms[ev.cls] += ms;
