@@ -1206,46 +1206,61 @@ __global__ __launch_bounds__(512, 2) void k_dense_bwd_lds(DenseLArgs a) {
 
 struct PropArgs {
   const float* pack; const float* mu_last; const float* prop_w; const float* prop_b;
-  const float *lb, *ub, *z_out; float* mu_prop; int B, N_last;
+  const float *lb, *ub, *z_out; float* mu_prop; float* nb_back; int B, N_last;
 };
 
 // property node (graph_conv.py:194-210): nb = W_prop[b] . mu_L[b];
-// mu_K = out3(relu(out2([relu(out1([l, u, z_out, c])), nb]))).  One wave per sample, lane = channel.
-__global__ __launch_bounds__(256) void k_prop_fwd(PropArgs a) {
-  __shared__ float xs[4][128];
+// mu_K = out3(relu(out2([relu(out1([l, u, z_out, c])), nb]))), then the backward edge from it (:324-326):
+// nb_back[b, n, :] = W_prop[b][n] * mu_K[b, :].  One workgroup (4 waves) per sample, lane = channel: the waves split the
+// rows of mu_L (partial sums combined in a fixed order through LDS), wave 0 runs the three small layers with the
+// transposed weights in LDS (196 dependent FMA steps read LDS, not L2), all waves write the backward aggregate.
+__global__ __launch_bounds__(256) void k_prop(PropArgs a) {
+  __shared__ float wl[PackProp::FLOATS];
+  __shared__ float xs[128];
+  __shared__ float part[4][64];
+  __shared__ float outv[64];
+  for (int i = threadIdx.x; i < PackProp::FLOATS; i += 256) wl[i] = a.pack[i];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int b = blockIdx.x * 4 + w;
-  const bool ok = b < a.B;
-  const int bc = ok ? b : a.B - 1;
-  float nb = 0.0f;
-  const float* mu = a.mu_last + (long)bc * a.N_last * 64 + lane;
-  const float* pw = a.prop_w + (long)bc * a.N_last;
-  for (int n = 0; n < a.N_last; ++n) nb = fmaf(pw[n], mu[(long)n * 64], nb);
-  const float f[4] = {a.lb[bc], a.ub[bc], a.z_out[bc], a.prop_b[bc]};
-  const float* pk = a.pack;
-  float h1 = pk[PackProp::B1 + lane];
+  const int b = blockIdx.x;
+  const float* mu = a.mu_last + (long)b * a.N_last * 64 + lane;
+  const float* pw = a.prop_w + (long)b * a.N_last;
+  float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  for (int n = w; n < a.N_last; n += 16) {             // 4 independent loads in flight per wave
 #pragma unroll
-  for (int k = 0; k < 4; ++k) h1 = fmaf(pk[PackProp::W1T + k * 64 + lane], f[k], h1);
-  xs[w][lane] = relu_nan(h1);
-  xs[w][64 + lane] = nb;
+    for (int u = 0; u < 4; ++u) {
+      const int nn = n + 4 * u;
+      if (nn < a.N_last) acc[u] = fmaf(pw[nn], mu[(long)nn * 64], acc[u]);
+    }
+  }
+  part[w][lane] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
   __syncthreads();
-  float h2 = pk[PackProp::B2 + lane];
-  for (int k = 0; k < 128; ++k) h2 = fmaf(pk[PackProp::W2T + k * 64 + lane], xs[w][k], h2);
+  if (w == 0) {
+    const float nb = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    const float f[4] = {a.lb[b], a.ub[b], a.z_out[b], a.prop_b[b]};
+    float h1 = wl[PackProp::B1 + lane];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) h1 = fmaf(wl[PackProp::W1T + k * 64 + lane], f[k], h1);
+    xs[lane] = relu_nan(h1);
+    xs[64 + lane] = nb;
+    __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): this wave's LDS writes are visible to its own reads
+    float h2 = wl[PackProp::B2 + lane];
+#pragma unroll 8
+    for (int k = 0; k < 128; ++k) h2 = fmaf(wl[PackProp::W2T + k * 64 + lane], xs[k], h2);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    xs[lane] = relu_nan(h2);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    float o = wl[PackProp::B3 + lane];
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) o = fmaf(wl[PackProp::W3T + k * 64 + lane], xs[k], o);
+    a.mu_prop[(long)b * 64 + lane] = o;
+    outv[lane] = o;
+  }
   __syncthreads();
-  xs[w][lane] = relu_nan(h2);
-  __syncthreads();
-  float o = pk[PackProp::B3 + lane];
-  for (int k = 0; k < 64; ++k) o = fmaf(pk[PackProp::W3T + k * 64 + lane], xs[w][k], o);
-  if (ok) a.mu_prop[(long)b * 64 + lane] = o;
-}
-
-// backward edge from the property node (graph_conv.py:324-326): nb[b, n, :] = W_prop[b][n] * mu_K[b, :]
-__global__ __launch_bounds__(256) void k_prop_bwd_nb(const float* prop_w, const float* mu_prop, float* nb, long rows, int N_last) {
-  const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const long b = row / N_last;
-  nb[row * 64 + lane] = prop_w[row] * mu_prop[b * 64 + lane];
+  if (a.nb_back) {
+    const float o = outv[lane];
+    float* nbk = a.nb_back + (long)b * a.N_last * 64 + lane;
+    for (int n = w; n < a.N_last; n += 4) nbk[(long)n * 64] = pw[n] * o;
+  }
 }
 
 struct ArgmaxArgs { const float* scores; int* dec; int B, R, n_relu; int cum[16]; };
@@ -1311,7 +1326,7 @@ enum ProfClass {
   PC_PROP_BWD_NB, PC_NODE_UPDATE, PC_INPUT_UPDATE, PC_SCORE, PC_ARGMAX, PC_GATHER, PC_GATHER_INPUT, PC_CLASSIFY, PC_COUNT
 };
 static const char* kProfNames[PC_COUNT] = {
-    "k_embed", "k_pre", "(unused)", "k_pre_inp", "k_conv_fwd", "k_convT_bwd", "k_dense_agg", "k_prop_fwd",
+    "k_embed", "k_pre", "(unused)", "k_pre_inp", "k_conv_fwd", "k_convT_bwd", "k_dense_agg", "k_prop",
     "k_prop_bwd_nb", "k_node_update", "k_input_update", "k_score", "k_argmax", "k_gather", "k_gather_input_update", "k_classify"};
 
 struct DevEdge {
@@ -1654,7 +1669,7 @@ extern "C" int gnnb_describe(const gnnb_t* h, char* buf, size_t cap) {
   }
   for (int k = L; k >= 1; --k) {
     o += ", ";
-    if (k == L) item("bwd", k, nullptr, "k_prop_bwd_nb+k_node_update", 1);
+    if (k == L) item("bwd", k, nullptr, "k_prop+k_node_update", 1);
     else item("bwd", k, &h->gb[k + 1], h->edges[k + 1].kind == 0 ? "k_convT_bwd+k_node_update" : "k_dense_agg+k_node_update", h->N[k + 1]);
   }
   o += ", ";
@@ -1978,23 +1993,18 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       node_update(k, true, false);
     }
     {
-      PropArgs a{h->d_pack[PK_PROP], mu(L), in->prop_w, in->prop_b, in->lb[K], in->ub[K], in->primal[in->n_primal - 1], mu(K), B, h->N[L]};
-      lz.run(PC_PROP_FWD, [&] { hipLaunchKernelGGL(k_prop_fwd, dim3((B + 3) / 4), dim3(256), 0, st, a); });
+      // the backward sweep starts with the edge from the property node: its aggregate is written by the same kernel
+      const bool bwd_follows = done + 1 < limit;
+      PropArgs a{h->d_pack[PK_PROP], mu(L), in->prop_w, in->prop_b, in->lb[K], in->ub[K], in->primal[in->n_primal - 1], mu(K),
+                 bwd_follows ? nb : nullptr, B, h->N[L]};
+      lz.run(PC_PROP_FWD, [&] { hipLaunchKernelGGL(k_prop, dim3(B), dim3(256), 0, st, a); });
     }
     if (++done >= limit) break;
     // backward sweep (:222-350), Gauss-Seidel order: layer k reads the already-updated mu[k+1]
     for (int k = L; k >= 1; --k) {
       // after the last backward step mu[1] is only read by the score head, i.e. at the scored nodes
       const bool scored = h->restrict_last && !debug_full && t == h->T - 1 && k == 1;
-      if (k == L) {
-        const long rows = (long)B * h->N[L];
-        const float* pw = in->prop_w;
-        const float* mk = mu(K);
-        const int nl = h->N[L];
-        lz.run(PC_PROP_BWD_NB, [&] { hipLaunchKernelGGL(k_prop_bwd_nb, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, pw, mk, nb, rows, nl); });
-      } else {
-        agg_bwd(k, 1, scored);
-      }
+      if (k < L) agg_bwd(k, 1, scored);          // (k == L: k_prop already wrote the aggregate from the property node)
       node_update(k, false, scored);
     }
     // input layer (:360-385): its last-round result is never read, so it only runs when another round follows

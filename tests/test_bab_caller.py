@@ -1,0 +1,57 @@
+"""the batched BaB caller surface.  Collation is checked on the CPU; the batched decisions against the
+reference's own per-subproblem decisions (golden vectors) on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+from gnn_branching_amd import bab_caller
+from tests.common import load_golden
+
+CKPT = __import__("os").path.join(__import__("os").path.dirname(__file__), "..", "models", "cifar_trained_gnn",
+                                  "best_snapshot_None_0_val_acc_0.826_loss_val_0.1036_epoch_57.pt")
+
+
+def subproblems_of(batch):
+    """The golden batch as the BaB loop would hold it: one record per domain, python-list primals, {-1,0,1} masks."""
+    subs = []
+    for b in range(batch.batch_size):
+        one = batch.slice(b, b + 1)
+        subs.append(bab_caller.Subproblem(one.lower_bounds_all, one.upper_bounds_all, one.dual_vars, one.primal_inputs,
+                                          [p.tolist() for p in one.primals], [m[0] for m in one.bab_masks],
+                                          one.layers["prop_layers"][0]))
+    return subs
+
+
+def test_collate_rebuilds_the_batched_arguments():
+    g, batch = load_golden("cifar_base_kw_B3")
+    args, masks = bab_caller.collate(subproblems_of(batch), batch.layers)
+    want = batch.forward_args()
+    for got_list, want_list in zip(args[:4], want[:4]):
+        assert len(got_list) == len(want_list)
+        for a, b in zip(got_list, want_list):
+            assert a.shape == b.shape and torch.equal(a, b)
+    assert torch.equal(args[4], want[4])
+    assert torch.equal(masks, batch.masks)
+    assert [id(p) for p in args[5]["prop_layers"]] == [id(p) for p in batch.layers["prop_layers"]]
+
+
+def test_trace_line_format():
+    line = bab_caller.trace_line(4, [2, 57], 0.31, [2, 57])
+    assert line == "branch 4 decision [2, 57] gnn: improvement 0.31 decision [2, 57] kw: improvement -1 decision None\n"
+    assert bab_caller.gnn_improvement(-1.0, -3.0, -4.0) == (-1.0 - 3.0 + 8.0) / 8.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["cifar_base_kw_B3", "cifar_deep_kw_B2"])
+def test_batched_decisions_equal_reference_decisions(case):
+    g, batch = load_golden(case)
+    subs = subproblems_of(batch)
+    choice = bab_caller.BatchedGraphChoice(subs[0].mask, CKPT)
+    choice.verbose = False
+    got = choice.decision_many(subs, batch.layers)
+    assert got == g["shipped_decisions"].tolist()
+    # the two-children call of one branch, and the inherited single-subproblem surface
+    assert choice.children_decisions(subs[0], subs[1], batch.layers) == got[:2]
+    one = batch.slice(0, 1)
+    assert choice.decision(one.lower_bounds_all, one.upper_bounds_all, one.dual_vars, one.primal_inputs,
+                           [p.tolist() for p in one.primals], one.layers, [m[0] for m in one.bab_masks]) == got[0]
