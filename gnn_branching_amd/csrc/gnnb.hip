@@ -183,10 +183,28 @@ __device__ __forceinline__ Ratio compute_ratio(float lb, float ub) {
   return r;
 }
 
-__device__ __forceinline__ void stage_pack(float* lds, const float* pack, int nfloats) {
-  const f32x4* g = reinterpret_cast<const f32x4*>(pack);
+// global -> LDS copy of a weight pack.  Loads are issued 8 at a time before their LDS stores: a plain copy loop keeps
+// one 16-B load in flight per thread and serialises ~10 L2 round trips per workgroup at the start of every launch.
+__device__ __forceinline__ void copy_to_lds(float* lds, const float* src, int nfloats) {
+  const f32x4* g = reinterpret_cast<const f32x4*>(src);
   f32x4* l = reinterpret_cast<f32x4*>(lds);
-  for (int i = threadIdx.x; i < nfloats / 4; i += blockDim.x) l[i] = g[i];
+  const int n4 = nfloats / 4, stride = blockDim.x;
+  for (int i0 = threadIdx.x; i0 < n4; i0 += 8 * stride) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * stride;
+      v[u] = g[i < n4 ? i : i0];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * stride;
+      if (i < n4) l[i] = v[u];
+    }
+  }
+}
+__device__ __forceinline__ void stage_pack(float* lds, const float* pack, int nfloats) {
+  copy_to_lds(lds, pack, nfloats);
   __syncthreads();
 }
 
@@ -391,11 +409,7 @@ struct PreAllArgs {       // hoisted feature chains of every ReLU layer, forward
 __global__ __launch_bounds__(WG_MLP, 2) void k_pre(PreAllArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lds_b = lds + PackPreFwd::FLOATS;
-  {
-    const f32x4* gsrc = reinterpret_cast<const f32x4*>(a.pack_b);
-    f32x4* ldst = reinterpret_cast<f32x4*>(lds_b);
-    for (int i = threadIdx.x; i < PackPreBwd::FLOATS / 4; i += blockDim.x) ldst[i] = gsrc[i];
-  }
+  copy_to_lds(lds_b, a.pack_b, PackPreBwd::FLOATS);
   stage_pack(lds, a.pack_f, PackPreFwd::FLOATS);
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
   long ntiles = 0;
@@ -711,9 +725,7 @@ __device__ __forceinline__ int tap_count(int t, int w0, int WN, int Hs, int k, i
 }
 
 __device__ __forceinline__ void stage_gather(float* lds_cm, int2* lds_ko, int* lds_tt, const DGather& g, int TPS) {
-  const f32x4* src = reinterpret_cast<const f32x4*>(g.cmat);
-  f32x4* dst = reinterpret_cast<f32x4*>(lds_cm);
-  for (int i = threadIdx.x; i < g.ncg_k2 * 16; i += blockDim.x) dst[i] = src[i];
+  copy_to_lds(lds_cm, g.cmat, g.ncg_k2 * 64);
   for (int i = threadIdx.x; i < 2 * g.K2 + KOFF_PAD; i += blockDim.x) lds_ko[i] = g.koff[i];
   for (int i = threadIdx.x; i < TPS; i += blockDim.x) lds_tt[i] = g.ttab[i];
 }
@@ -810,11 +822,7 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_gather_input_update(GIArgs a) {
   int2* lds_ko = reinterpret_cast<int2*>(lds_cm + a.g.ncg_k2 * 64);
   int* lds_tt = reinterpret_cast<int*>(lds_ko + 2 * a.g.K2 + KOFF_PAD);
   stage_gather(lds_cm, lds_ko, lds_tt, a.g, a.tm.TPS);
-  {
-    const f32x4* gsrc = reinterpret_cast<const f32x4*>(a.pack_pre);
-    f32x4* ldst = reinterpret_cast<f32x4*>(lds_pre);
-    for (int i = threadIdx.x; i < PackPreInp::FLOATS / 4; i += blockDim.x) ldst[i] = gsrc[i];
-  }
+  copy_to_lds(lds_pre, a.pack_pre, PackPreInp::FLOATS);
   stage_pack(lds, a.pack, PackUpdInp::FLOATS);
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
   long t0, t1;
