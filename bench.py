@@ -133,8 +133,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ          # under torchrun the collective path runs even with one rank
+    if use_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     ckpt = os.path.join(ROOT, "models/cifar_trained_gnn/best_snapshot_None_0_val_acc_0.826_loss_val_0.1036_epoch_57.pt")
@@ -156,7 +159,7 @@ def main():
 
     def step():
         res = eng.forward(*d_args)
-        if world > 1:
+        if use_dist:
             parallel.gather_scores(res.scores, world * B)      # the one exchange step: ONE all-gather, scores -> branch selector
         return res
 
@@ -171,7 +174,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -181,7 +184,7 @@ def main():
         res = step()
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -260,7 +263,7 @@ def main():
             "instrumented_ms_per_step": round(1e3 * instrumented / args.steps, 4),
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
