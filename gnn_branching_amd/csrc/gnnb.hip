@@ -1330,12 +1330,12 @@ static int fail(int code, const char* fmt, ...) {
   } while (0)
 
 enum ProfClass {
-  PC_EMBED, PC_PRE, PC_PRE_UNUSED, PC_PRE_INP, PC_CONV_FWD, PC_CONVT_BWD, PC_DENSE_AGG, PC_PROP_FWD,
-  PC_PROP_BWD_NB, PC_NODE_UPDATE, PC_INPUT_UPDATE, PC_SCORE, PC_ARGMAX, PC_GATHER, PC_GATHER_INPUT, PC_CLASSIFY, PC_COUNT
+  PC_EMBED, PC_PRE, PC_PRE_INP, PC_CONV_FWD, PC_CONVT_BWD, PC_DENSE_AGG, PC_PROP_FWD,
+  PC_NODE_UPDATE, PC_INPUT_UPDATE, PC_SCORE, PC_ARGMAX, PC_GATHER, PC_GATHER_INPUT, PC_CLASSIFY, PC_COUNT
 };
 static const char* kProfNames[PC_COUNT] = {
-    "k_embed", "k_pre", "(unused)", "k_pre_inp", "k_conv_fwd", "k_convT_bwd", "k_dense_agg", "k_prop",
-    "k_prop_bwd_nb", "k_node_update", "k_input_update", "k_score", "k_argmax", "k_gather", "k_gather_input_update", "k_classify"};
+    "k_embed", "k_pre", "k_pre_inp", "k_conv_fwd", "k_convT_bwd", "k_dense_agg", "k_prop",
+    "k_node_update", "k_input_update", "k_score", "k_argmax", "k_gather", "k_gather_input_update", "k_classify"};
 
 struct DevEdge {
   float *w_fwd = nullptr, *w_bwd = nullptr, *bias = nullptr;   // conv: tap-major copies; linear: W^T / W, zero-padded
@@ -1354,8 +1354,6 @@ struct DevGather {          // one conv edge in one direction, as MFMA gather ta
 struct gnnb_handle {
   int T = 2, p = 64, device = 0, n_cu = 256;
   bool use_gather = true;       // MFMA gather for conv edges (false: VALU gather kernels)
-  int nu_waves = 8;             // waves per workgroup of k_node_update (one workgroup per CU, weights shared in LDS;
-                                // 16 waves measured 27 % slower and no longer fit the register budget)
   int gather_occ = 2;           // workgroups per CU for k_gather (its LDS footprint is only the tap matrix)
   bool dense_lds = true;        // Linear edges: one workgroup per sample with the source rows in LDS (false: per-tile kernel)
   bool restrict_last = true;    // last backward step of layer 1 only for the scored nodes (nothing else reads it)
@@ -1973,7 +1971,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     // normal: list0 = live non-ambiguous nodes (short chain), list1 = ambiguous nodes; restricted: the scored nodes, general chain
     UpdArgs a{h->d_pack[fwd ? PK_UPD_FWD : PK_UPD_BWD], in->lb[k], in->ub[k], nb, ws + (fwd ? w.Pf[k] : w.Pb[k]), mu(k), status,
               ilist(w.live[k]), cnt + 4 * k + (scored ? 3 : 0), ilist(scored ? w.score[k] : w.amb[k]), cnt + 4 * k + (scored ? 2 : 1)};
-    const int wv = h->nu_waves;
+    const int wv = 8;            // waves per workgroup (one workgroup per CU shares the LDS weights; 16 waves measured 27 % slower)
     long grid = (nt + wv - 1) / wv;
     if (grid > h->n_cu) grid = h->n_cu;
     lz.run(PC_NODE_UPDATE, [&] { hipLaunchKernelGGL(k_node_update<8>, dim3((unsigned)grid), dim3(512), PackUpd::FLOATS * 4, st, a); });

@@ -155,3 +155,33 @@ def test_unfused_valu_gather_path_matches(monkeypatch):
     fin = np.isfinite(want)
     assert np.abs(res.scores.cpu().numpy()[fin] - want[fin]).max() <= SCORE_ATOL
     assert res.decisions.cpu().tolist() == g["random_decisions"].tolist()
+
+
+def test_per_tile_dense_kernel_path_matches(monkeypatch):
+    """GNNB_NO_DENSE_LDS=1 selects the per-tile dense edge kernels (the fallback for Linear layers whose source does
+    not fit the LDS-staged kernels): same scores."""
+    monkeypatch.setenv("GNNB_NO_DENSE_LDS", "1")
+    g, batch = load_golden("cifar_wide_kw_B2")
+    model = make_model("random")
+    with torch.no_grad():
+        res = model.forward_device(*batch.forward_args()).check()
+    want = g["random_scores"]
+    fin = np.isfinite(want)
+    assert np.abs(res.scores.cpu().numpy()[fin] - want[fin]).max() <= SCORE_ATOL
+    assert res.decisions.cpu().tolist() == g["random_decisions"].tolist()
+
+
+def test_two_stream_batch_pipelining_is_bit_identical():
+    """engine.n_streams = 2 cuts a large batch into two chunks on two HIP streams: identical bytes out."""
+    from gnn_branching_amd import synth
+    model = make_model("shipped")
+    batch = synth.make_batch("cifar_base_kw", 160, seed=77)
+    eng = model.engine()
+    with torch.no_grad():
+        one = eng.forward(*batch.forward_args()).check()
+        eng.n_streams = 2
+        try:
+            two = eng.forward(*batch.forward_args()).check()
+        finally:
+            eng.n_streams = 1
+    assert torch.equal(one.scores, two.scores) and torch.equal(one.decisions, two.decisions)
