@@ -12,7 +12,7 @@ import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(CSRC, "libgnnb.so")
+LIB_PATH = os.environ.get("GNNB_LIB", os.path.join(CSRC, "libgnnb.so"))     # GNNB_LIB: dev override (ablation builds)
 SOURCES = ["gnnb.hip", "gnnb_pack.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"]
 
@@ -63,7 +63,7 @@ def needs_build():
 
 def build_library(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 ... -> csrc/libgnnb.so (cross-compiles without a GPU)."""
-    if not force and not needs_build():
+    if "GNNB_LIB" in os.environ or (not force and not needs_build()):
         return LIB_PATH
     cmd = ["hipcc"] + HIPCC_FLAGS + ["-o", LIB_PATH, os.path.join(CSRC, "gnnb.hip")]
     if verbose:

@@ -540,8 +540,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_node_update(UpdArgs a
   // the SIMDs of the whole grid (4 per workgroup), and the two waves that share a SIMD (w, w+4) take alternate rounds,
   // so every SIMD's MFMA pipe gets floor or ceil of the average.  The inputs of the next tile (list entry -> bounds ->
   // aggregate row) are fetched while this tile's MFMA chain runs; the first fetch overlaps the weight staging.
-  static_assert(WAVES == 8, "tile dealing assumes 2 waves per SIMD");
-  const long stride = (long)gridDim.x * 4 * 2;
+  static_assert(WAVES % 4 == 0, "tile dealing assumes whole waves per SIMD");
+  const long stride = (long)gridDim.x * 4 * (WAVES / 4);
   long tile = (long)(wave >> 2) * gridDim.x * 4 + (long)blockIdx.x * 4 + (wave & 3);
   long gc = 0, gc_n = 0;
   bool valid = false, valid_n = false;
@@ -652,28 +652,33 @@ __device__ __forceinline__ float2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned v
 }
 
 template <bool INTERIOR>
-__device__ __forceinline__ void gather_tile(Frag& X, const float* cm, const int2* ko, int K2, __amdgpu_buffer_rsrc_t rsrc, int j,
-                                            int wy0, int wx0, int Hs, int Ws, int lane) {
+__device__ __forceinline__ void gather_tile(Frag& X, const float* cm, const int2* ko, const unsigned* kvo, int K2,
+                                            __amdgpu_buffer_rsrc_t rsrc, int j, int wy0, int wx0, int Hs, int Ws, int lane) {
   const int h = lane >> 5;
 #pragma unroll
   for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = 0.0f;
   const int origin = wy0 * Ws + wx0;
   const unsigned lane_off = 8u * (unsigned)j;        // channels 2j, 2j+1 of the row
+  const unsigned soff = (unsigned)origin * 256u;     // INTERIOR: wave-uniform window origin goes into the scalar offset
   float2 cur[GATHER_CH], nxt[GATHER_CH];
   auto load = [&](float2 (&dst)[GATHER_CH], int s0) {
 #pragma unroll
     for (int u = 0; u < GATHER_CH; ++u) {
-      // one 64-bit LDS read per entry: with two 32-bit halves hipcc branches around the second one
-      const unsigned long long ev = reinterpret_cast<const unsigned long long*>(ko)[2 * (s0 + u) + h];
-      const int ex = (int)(unsigned)ev, ey = (int)(unsigned)(ev >> 32);
-      unsigned o = (unsigned)(origin + ex) * 256u + lane_off;
       if (INTERIOR) {
-        o = (ey & 0xffff) == 0x7fff ? BUF_OOB : o;                      // k padding
+        // per k-step: one LDS read of the tile-invariant byte offset + one add; no bounds arithmetic.  k padding
+        // reads row `origin` (in range for an interior tile; its tap-matrix column is zero)
+        const unsigned vo = kvo[2 * (s0 + u) + h] + lane_off;
+        const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, vo, soff, 0);
+        dst[u] = make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
       } else {
+        // one 64-bit LDS read per entry: with two 32-bit halves hipcc branches around the second one
+        const unsigned long long ev = reinterpret_cast<const unsigned long long*>(ko)[2 * (s0 + u) + h];
+        const int ex = (int)(unsigned)ev, ey = (int)(unsigned)(ev >> 32);
         const int wy = wy0 + (ey & 0xffff), wx = wx0 + (ey >> 16);
+        unsigned o = (unsigned)(origin + ex) * 256u + lane_off;
         o = ((unsigned)wy < (unsigned)Hs && (unsigned)wx < (unsigned)Ws) ? o : BUF_OOB;
+        dst[u] = buf_load2(rsrc, o);
       }
-      dst[u] = buf_load2(rsrc, o);
     }
   };
   auto mma = [&](const float2 (&v)[GATHER_CH], int s0) {
@@ -703,14 +708,14 @@ __device__ __forceinline__ void gather_tile(Frag& X, const float* cm, const int2
 }
 
 // `sbase` = first row of this sample's source layer; must be built from wave-uniform values
-__device__ __forceinline__ void gather_dispatch(Frag& X, const float* cm, const int2* ko, const DGather& g, const float* sbase,
-                                                int j, int wy0, int wx0, int lane) {
+__device__ __forceinline__ void gather_dispatch(Frag& X, const float* cm, const int2* ko, const unsigned* kvo, const DGather& g,
+                                                const float* sbase, int j, int wy0, int wx0, int lane) {
   const int uy = __builtin_amdgcn_readfirstlane(wy0), ux = __builtin_amdgcn_readfirstlane(wx0);
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)sbase, 0, g.Ns * 256, 0x00020000);
   if (uy >= 0 && ux >= 0 && uy + g.WY <= g.Hs && ux + g.WX <= g.Ws)
-    gather_tile<true>(X, cm, ko, g.K2, rsrc, j, uy, ux, g.Hs, g.Ws, lane);
+    gather_tile<true>(X, cm, ko, kvo, g.K2, rsrc, j, uy, ux, g.Hs, g.Ws, lane);
   else
-    gather_tile<false>(X, cm, ko, g.K2, rsrc, j, uy, ux, g.Hs, g.Ws, lane);
+    gather_tile<false>(X, cm, ko, kvo, g.K2, rsrc, j, uy, ux, g.Hs, g.Ws, lane);
 }
 
 // number of kernel taps that touch dst position t along one axis (the reference's `freq`, graph_conv.py:306-311)
@@ -724,9 +729,13 @@ __device__ __forceinline__ int tap_count(int t, int w0, int WN, int Hs, int k, i
   return n;
 }
 
-__device__ __forceinline__ void stage_gather(float* lds_cm, int2* lds_ko, int* lds_tt, const DGather& g, int TPS) {
+__device__ __forceinline__ void stage_gather(float* lds_cm, int2* lds_ko, int* lds_tt, unsigned* lds_kvo, const DGather& g, int TPS) {
   copy_to_lds(lds_cm, g.cmat, g.ncg_k2 * 64);
-  for (int i = threadIdx.x; i < 2 * g.K2 + KOFF_PAD; i += blockDim.x) lds_ko[i] = g.koff[i];
+  for (int i = threadIdx.x; i < 2 * g.K2 + KOFF_PAD; i += blockDim.x) {
+    const int2 e = g.koff[i];
+    lds_ko[i] = e;
+    lds_kvo[i] = (e.y & 0xffff) == 0x7fff ? 0u : (unsigned)e.x * 256u;      // byte offset of window node i from the window origin
+  }
   for (int i = threadIdx.x; i < TPS; i += blockDim.x) lds_tt[i] = g.ttab[i];
 }
 
@@ -767,7 +776,8 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_gather(GArgs a) {
   float* lds_cm = lds;
   int2* lds_ko = reinterpret_cast<int2*>(lds_cm + a.g.ncg_k2 * 64);
   int* lds_tt = reinterpret_cast<int*>(lds_ko + 2 * a.g.K2 + KOFF_PAD);
-  stage_gather(lds_cm, lds_ko, lds_tt, a.g, a.tm.TPS);
+  unsigned* lds_kvo = reinterpret_cast<unsigned*>(lds_tt + ((a.tm.TPS + 3) & ~3));
+  stage_gather(lds_cm, lds_ko, lds_tt, lds_kvo, a.g, a.tm.TPS);
   __syncthreads();
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
   long t0, t1;
@@ -787,7 +797,7 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_gather(GArgs a) {
     if (!__any(need)) continue;
     const int wy0 = tc.by * a.g.ystep + a.g.ybase, wx0 = tc.bx * a.g.xstep + a.g.xbase;
     Frag X;
-    gather_dispatch(X, lds_cm + tc.cg * a.g.K2 * 64, lds_ko, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane);
+    gather_dispatch(X, lds_cm + tc.cg * a.g.K2 * 64, lds_ko, lds_kvo, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane);
     if (a.g.normalise) {
       const int ny = tap_count(tc.y, wy0, a.g.WY, a.g.Hs, a.g.kh, a.g.stride, a.g.pad);
       const int nx = tap_count(tc.x, wx0, a.g.WX, a.g.Ws, a.g.kw, a.g.stride, a.g.pad);
@@ -821,7 +831,8 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_gather_input_update(GIArgs a) {
   float* lds_cm = lds_pre + PackPreInp::FLOATS;
   int2* lds_ko = reinterpret_cast<int2*>(lds_cm + a.g.ncg_k2 * 64);
   int* lds_tt = reinterpret_cast<int*>(lds_ko + 2 * a.g.K2 + KOFF_PAD);
-  stage_gather(lds_cm, lds_ko, lds_tt, a.g, a.tm.TPS);
+  unsigned* lds_kvo = reinterpret_cast<unsigned*>(lds_tt + ((a.tm.TPS + 3) & ~3));
+  stage_gather(lds_cm, lds_ko, lds_tt, lds_kvo, a.g, a.tm.TPS);
   copy_to_lds(lds_pre, a.pack_pre, PackPreInp::FLOATS);
   stage_pack(lds, a.pack, PackUpdInp::FLOATS);
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
@@ -839,7 +850,7 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_gather_input_update(GIArgs a) {
     const long gc = tc.sample * a.tm.N + tc.n;
     const int wy0 = tc.by * a.g.ystep + a.g.ybase, wx0 = tc.bx * a.g.xstep + a.g.xbase;
     Frag X;
-    gather_dispatch(X, lds_cm + tc.cg * a.g.K2 * 64, lds_ko, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane);
+    gather_dispatch(X, lds_cm + tc.cg * a.g.K2 * 64, lds_ko, lds_kvo, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane);
     float x[1];
     x[0] = h ? a.ub[gc] : a.lb[gc];
     Frag H0;
@@ -1354,6 +1365,8 @@ struct DevGather {          // one conv edge in one direction, as MFMA gather ta
 struct gnnb_handle {
   int T = 2, p = 64, device = 0, n_cu = 256;
   bool use_gather = true;       // MFMA gather for conv edges (false: VALU gather kernels)
+  int nu_waves = 12;            // waves per workgroup of k_node_update: 3 per SIMD at 168 VGPRs, measured 6 % faster
+                                // than 8 (16 waves: 27 % slower); k_gather_input_update prefers 8, k_gather 8 x 2 workgroups
   int gather_occ = 2;           // workgroups per CU for k_gather (its LDS footprint is only the tap matrix)
   bool dense_lds = true;        // Linear edges: one workgroup per sample with the source rows in LDS (false: per-tile kernel)
   bool restrict_last = true;    // last backward step of layer 1 only for the scored nodes (nothing else reads it)
@@ -1418,6 +1431,8 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   HIPCHK(hipFuncSetAttribute((const void*)k_pre, hipFuncAttributeMaxDynamicSharedMemorySize, (PackPreFwd::FLOATS + PackPreBwd::FLOATS) * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_pre_inp, hipFuncAttributeMaxDynamicSharedMemorySize, PackPreInp::FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_node_update<8>, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpd::FLOATS * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12>, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpd::FLOATS * 4));
+  if (const char* e = getenv("GNNB_NU_WAVES")) h->nu_waves = atoi(e) == 8 ? 8 : 12;
   if (const char* e = getenv("GNNB_GATHER_OCC")) h->gather_occ = atoi(e) < 1 ? 1 : atoi(e);
   HIPCHK(hipFuncSetAttribute((const void*)k_input_update, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpdInp::FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_score, hipFuncAttributeMaxDynamicSharedMemorySize, PackScore::FLOATS * 4));
@@ -1626,7 +1641,7 @@ static DGather to_dg(const DevGather& d, const float* zero) {
                  g.xstep, g.xbase, g.WY, g.WX, g.normalise, g.kh, g.kw, g.stride, g.pad};
 }
 static size_t gather_lds_bytes(const DevGather& d, size_t pack_floats) {
-  return (pack_floats + (size_t)d.g.tm.NCG * d.g.K2 * 64) * 4 + (size_t)(2 * d.g.K2 + KOFF_PAD) * 8 + (size_t)d.g.tm.TPS * 4;
+  return (pack_floats + (size_t)d.g.tm.NCG * d.g.K2 * 64) * 4 + (size_t)(2 * d.g.K2 + KOFF_PAD) * 12 + (size_t)((d.g.tm.TPS + 3) & ~3) * 4;
 }
 
 extern "C" int gnnb_graph_info(const gnnb_t* h, int* n_graph, int* sizes, int* n_relu_total) {
@@ -1971,10 +1986,13 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     // normal: list0 = live non-ambiguous nodes (short chain), list1 = ambiguous nodes; restricted: the scored nodes, general chain
     UpdArgs a{h->d_pack[fwd ? PK_UPD_FWD : PK_UPD_BWD], in->lb[k], in->ub[k], nb, ws + (fwd ? w.Pf[k] : w.Pb[k]), mu(k), status,
               ilist(w.live[k]), cnt + 4 * k + (scored ? 3 : 0), ilist(scored ? w.score[k] : w.amb[k]), cnt + 4 * k + (scored ? 2 : 1)};
-    const int wv = 8;            // waves per workgroup (one workgroup per CU shares the LDS weights; 16 waves measured 27 % slower)
+    const int wv = h->nu_waves;  // waves per workgroup (one workgroup per CU shares the LDS weights)
     long grid = (nt + wv - 1) / wv;
     if (grid > h->n_cu) grid = h->n_cu;
-    lz.run(PC_NODE_UPDATE, [&] { hipLaunchKernelGGL(k_node_update<8>, dim3((unsigned)grid), dim3(512), PackUpd::FLOATS * 4, st, a); });
+    lz.run(PC_NODE_UPDATE, [&] {
+      if (wv == 12) hipLaunchKernelGGL(k_node_update<12>, dim3((unsigned)grid), dim3(768), PackUpd::FLOATS * 4, st, a);
+      else hipLaunchKernelGGL(k_node_update<8>, dim3((unsigned)grid), dim3(512), PackUpd::FLOATS * 4, st, a);
+    });
   };
   auto update_input = [&]() {
     if (h->gb[1].ok) {
