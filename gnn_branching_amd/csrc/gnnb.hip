@@ -1282,6 +1282,94 @@ __global__ __launch_bounds__(256) void k_prop(PropArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// BaBSR ("KW") branching heuristic -- reference plnn/kw_score_conv.py choose_node_conv :41-113.
+// A scalar `ratio` per node is swept backwards through the verified network (W^T / transposed conv, times the
+// relaxation slope at every ReLU); each ReLU gets |max(b ratio (r0-1), b ratio r0) + min(ratio, 0) intercept| as score.
+// One workgroup per subproblem, the ratio vector of the current layer lives in LDS (two buffers).
+// ------------------------------------------------------------------------------------------
+struct BabsrArgs {
+  int L, R;
+  const float* lb[MAXL]; const float* ub[MAXL]; const float* bias[MAXL];   // ReLU layer k at index k-1
+  int N[MAXL], hw[MAXL], off[MAXL];
+  // edge between layer k and k+1 at index k-1 (k = 1..L-1), walked transposed
+  int ekind[MAXL];              // 0 conv, 1 linear
+  const float* ew[MAXL];        // conv: [co][ky][kx][ci]; linear: W[o][i] with row stride ld
+  int c_in[MAXL], h_in[MAXL], w_in[MAXL], c_out[MAXL], h_out[MAXL], w_out[MAXL], kh[MAXL], kw[MAXL], stride[MAXL], pad[MAXL], ld[MAXL];
+  const float* prop_w;          // (B, N_L)
+  const float* mask;            // (B, R): 1 where the BaB mask is -1
+  float* scores;                // out (B, R): `score` of :103
+  float* icp;                   // out (B, R): `intercept_tb` of :86
+  int maxN;
+};
+
+__global__ __launch_bounds__(256) void k_babsr(BabsrArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* cur = lds;
+  float* nxt = lds + a.maxN;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  {
+    const int NL = a.N[a.L - 1];
+    for (int n = tid; n < NL; n += 256) cur[n] = a.prop_w[(long)b * NL + n];      // Linear(., 1)^T applied to ones(1), :73-77
+  }
+  for (int k = a.L - 1; k >= 0; --k) {
+    __syncthreads();
+    const int N = a.N[k];
+    for (int n = tid; n < N; n += 256) {
+      const long g = (long)b * N + n;
+      const float lb = a.lb[k][g], ub = a.ub[k][g];
+      const float lower_temp = lb - relu_nan(lb), upper_temp = relu_nan(ub);          // compute_ratio :23-27
+      const float slope = upper_temp / (upper_temp - lower_temp);
+      const float intercept = -1.0f * lower_temp * slope;
+      const float rt = cur[n];
+      const float icand = fminf(rt, 0.0f) * intercept;                               // :84-85
+      const float m = a.mask[(long)b * a.R + a.off[k] + n];
+      const float bb = a.bias[k][n / a.hw[k]];
+      const float b1 = bb * (rt * (slope - 1.0f));                                   // :92-93
+      const float rt2 = rt * slope;                                                  // :94
+      const float b2 = bb * rt2;                                                     // :95
+      a.scores[(long)b * a.R + a.off[k] + n] = fabsf(fmaxf(b1, b2) + icand) * m;     // :96-103
+      a.icp[(long)b * a.R + a.off[k] + n] = icand * m;                               // :86
+      cur[n] = rt2;
+    }
+    if (k == 0) break;                       // nothing reads the ratio below the first ReLU layer
+    __syncthreads();
+    const int e = k - 1;                     // edge between ReLU layers k-1+1 and k+1 in 1-based numbering
+    const int Nin = a.N[k - 1];
+    if (a.ekind[e] == 1) {                   // :74-77  ratio <- W^T ratio
+      const int nout = N, ld = a.ld[e];
+      const float* W = a.ew[e];
+      for (int i = tid; i < Nin; i += 256) {
+        float acc = 0.0f;
+        for (int o = 0; o < nout; ++o) acc = fmaf(W[(long)o * ld + i], cur[o], acc);
+        nxt[i] = acc;
+      }
+    } else {                                 // :109-111  ratio <- conv_transpose2d(ratio, W)
+      const int CI = a.c_in[e], HI = a.h_in[e], WI = a.w_in[e], CO = a.c_out[e], HO = a.h_out[e], WO = a.w_out[e];
+      const int KH = a.kh[e], KW = a.kw[e], S = a.stride[e], P = a.pad[e];
+      const float* W = a.ew[e];
+      for (int i = tid; i < Nin; i += 256) {
+        const int x = i % WI, y = (i / WI) % HI, ci = i / (WI * HI);
+        float acc = 0.0f;
+        for (int ky = 0; ky < KH; ++ky) {
+          const int ty = y + P - ky;
+          if (ty < 0 || ty % S != 0 || ty / S >= HO) continue;
+          const int oy = ty / S;
+          for (int kx = 0; kx < KW; ++kx) {
+            const int tx = x + P - kx;
+            if (tx < 0 || tx % S != 0 || tx / S >= WO) continue;
+            const int ox = tx / S;
+            for (int co = 0; co < CO; ++co)
+              acc = fmaf(W[((co * KH + ky) * KW + kx) * CI + ci], cur[(co * HO + oy) * WO + ox], acc);
+          }
+        }
+        nxt[i] = acc;
+      }
+    }
+    float* t = cur; cur = nxt; nxt = t;
+  }
+}
+
 struct ArgmaxArgs { const float* scores; int* dec; int B, R, n_relu; int cum[16]; };
 
 // torch.max(scores, 0) -> first maximal index; flat index -> [layer, idx]      graph_score.py:41-47
@@ -2052,4 +2140,36 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   }
   lz.run(PC_ARGMAX, [&] { hipLaunchKernelGGL(k_argmax, dim3(B), dim3(256), 0, st, am); });
   return lz.rc;
+}
+
+// BaBSR scores of a batch (reference plnn/kw_score_conv.py choose_node_conv :41-113; the decision rule :115-156 stays
+// on the host).  lb/ub: HOST tables of n_graph DEVICE pointers exactly as in gnnb_batch; prop_w (B, N_L), mask (B, R),
+// scores/intercepts (B, R) device.  Stream-ordered, no allocation.
+extern "C" int gnnb_babsr(gnnb_t* h, const float* const* lb, const float* const* ub, int n_graph, const float* prop_w,
+                          const float* mask, int B, float* scores, float* intercepts, void* stream) {
+  if (!h || !lb || !ub || !prop_w || !mask || !scores || !intercepts) return fail(GNNB_E_INVALID, "gnnb_babsr: null argument");
+  if (!h->bound) return fail(GNNB_E_STATE, "gnnb_babsr: call gnnb_bind_network first");
+  const int K = (int)h->N.size() - 1, L = K - 1;
+  if (n_graph != K + 1 || B < 1) return fail(GNNB_E_INVALID, "gnnb_babsr: %d graph layers given, network has %d", n_graph, K + 1);
+  BabsrArgs a{};
+  a.L = L; a.R = h->R; a.prop_w = prop_w; a.mask = mask; a.scores = scores; a.icp = intercepts;
+  int off = 0, maxN = 0;
+  for (int k = 1; k <= L; ++k) {
+    const int i = k - 1;
+    if (!lb[k] || !ub[k]) return fail(GNNB_E_INVALID, "gnnb_babsr: null bounds pointer for graph layer %d", k);
+    a.lb[i] = lb[k]; a.ub[i] = ub[k]; a.bias[i] = h->dev[k].bias; a.N[i] = h->N[k]; a.hw[i] = h->hw[k]; a.off[i] = off;
+    off += h->N[k];
+    maxN = std::max(maxN, h->N[k]);
+    if (k < L) {                              // edge k+1 (between graph layers k and k+1)
+      const Edge& e = h->edges[k + 1];
+      a.ekind[i] = e.kind; a.ew[i] = h->dev[k + 1].w_bwd;
+      a.c_in[i] = e.c_in; a.h_in[i] = e.h_in; a.w_in[i] = e.w_in; a.c_out[i] = e.c_out; a.h_out[i] = e.h_out; a.w_out[i] = e.w_out;
+      a.kh[i] = e.kh; a.kw[i] = e.kw; a.stride[i] = e.stride; a.pad[i] = e.pad; a.ld[i] = h->dev[k + 1].ld_bwd;
+    }
+  }
+  a.maxN = maxN;
+  hipLaunchKernelGGL(k_babsr, dim3(B), dim3(256), (size_t)2 * maxN * sizeof(float), (hipStream_t)stream, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(GNNB_E_HIP, "launch of k_babsr failed: %s", hipGetErrorString(e));
+  return GNNB_OK;
 }

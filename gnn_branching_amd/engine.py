@@ -27,6 +27,22 @@ def state_blob(state_dict):
     return np.ascontiguousarray(np.concatenate(parts))
 
 
+GNN_BLOB_FLOATS = 117825        # the 52 tensors of GraphNet(2, 64) (graph_conv.py:20-76, :281-305, :428-437)
+
+
+class BabsrResult:
+    """Device outputs of one batched BaBSR scoring: `score` and `intercept_tb` of kw_score_conv.py:86, :103, padded
+    (B, R) over the concatenated ReLU layers (already multiplied by the mask)."""
+    __slots__ = ("scores", "intercepts", "masks", "relu_sizes")
+
+    def __init__(self, scores, intercepts, masks, relu_sizes):
+        self.scores, self.intercepts, self.masks, self.relu_sizes = scores, intercepts, masks, relu_sizes
+
+    def per_layer(self, b):
+        """(score list, intercept list, mask list) of subproblem b, one 1-D tensor per ReLU layer."""
+        return tuple(list(torch.split(t[b], self.relu_sizes)) for t in (self.scores, self.intercepts, self.masks))
+
+
 class ForwardResult:
     """Device outputs of one batched forward."""
     __slots__ = ("scores", "decisions", "status", "masks")
@@ -55,7 +71,8 @@ class ScorerEngine:
             raise RuntimeError("gnn_branching_amd needs an AMD GPU (MI355X / gfx950); there is no CPU path")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.T, self.p = T, p
-        blob = state_blob(state_dict)
+        # state_dict None: a handle for the GNN-free entry points only (gnnb_babsr) -- all-zero GNN weights
+        blob = state_blob(state_dict) if state_dict is not None else np.zeros(GNN_BLOB_FLOATS, dtype=np.float32)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.gnnb_create(C.byref(h), blob.ctypes.data_as(C.c_void_p), blob.size, T, p), "gnnb_create")
@@ -231,6 +248,37 @@ class ScorerEngine:
                     # stream and it now waits for the side streams, the caching allocator cannot recycle them early
                     cur.wait_stream(self._streams[c])
         return ForwardResult(scores, dec, status, mask2)
+
+    # ---- BaBSR fallback scorer -------------------------------------------------
+    def babsr(self, lower_bounds_all, upper_bounds_all, layers, masks):
+        """kw_score_conv.py choose_node_conv :41-113 for a batch: same bounds / layers / masks arguments as
+        ``forward``; returns a BabsrResult (device tensors, no synchronisation)."""
+        fixed = layers["fixed_layers"]
+        self.bind(fixed, tuple(lower_bounds_all[0].shape[1:]))
+        B = int(lower_bounds_all[0].shape[0])
+        if len(layers["prop_layers"]) != B:
+            raise ValueError(f"{len(layers['prop_layers'])} property layers for a batch of {B}")
+        ng = len(self.sizes)
+        if len(lower_bounds_all) != ng or len(upper_bounds_all) != ng:
+            raise ValueError(f"{len(lower_bounds_all)} bound tensors, layer graph has {ng} layers")
+        lbs = [self._dev(t) for t in lower_bounds_all]
+        ubs = [self._dev(t) for t in upper_bounds_all]
+        for k, (l, u) in enumerate(zip(lbs, ubs)):
+            if l.numel() != B * self.sizes[k] or u.numel() != B * self.sizes[k]:
+                raise ValueError(f"bounds of graph layer {k}: {tuple(l.shape)} does not hold {B}x{self.sizes[k]} values")
+        mask = self._dev(masks)
+        if mask.numel() != B * self.R:
+            raise ValueError(f"masks has {tuple(mask.shape)}, expected ({B}, {self.R})")
+        pw, _ = self._prop(layers["prop_layers"])
+        scores = torch.empty(B, self.R, dtype=torch.float32, device=self.device)
+        icp = torch.empty(B, self.R, dtype=torch.float32, device=self.device)
+        tl = (C.c_void_p * ng)(*[t.data_ptr() for t in lbs])
+        tu = (C.c_void_p * ng)(*[t.data_ptr() for t in ubs])
+        with torch.cuda.device(self.device):
+            rc = self.lib.gnnb_babsr(self.h, tl, tu, ng, pw.data_ptr(), mask.data_ptr(), B, scores.data_ptr(),
+                                     icp.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(rc, "gnnb_babsr")
+        return BabsrResult(scores, icp, mask.view(B, self.R), self.sizes[1:-1])
 
     def _check_primals(self, fixed, prim, B):
         if len(prim) != len(fixed) + 1:
