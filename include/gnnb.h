@@ -93,7 +93,7 @@ int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* scores_padded, i
 
 /* BaBSR ("KW") branching heuristic for a batch -- the fallback scorer of the BaB loop (reference
  * plnn/kw_score_conv.py choose_node_conv :41-113, called at plnn/relu_conv_gnnkwthreshold.py:157).  lb/ub: HOST tables of
- * n_graph DEVICE pointers as in gnnb_batch (only the ReLU layers 1..L are read); prop_w (B, N_L); mask (B, R) 1.0 where the
+ * n_graph DEVICE pointers laid out like struct gnnb_batch.lb, .ub -- only the ReLU layers 1..L are read; prop_w (B, N_L); mask (B, R) 1.0 where the
  * BaB mask is -1.  Outputs, device (B, R): scores = `score` (:103), intercepts = `intercept_tb` (:86), both already
  * multiplied by the mask.  The decision rule (:115-156, with its counters and random fall-back) stays on the host. */
 int gnnb_babsr(gnnb_t* h, const float* const* lb, const float* const* ub, int n_graph, const float* prop_w,
