@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from .graphnet.graph_score import GraphChoice
+from .plnn.kw_score_conv import BabsrScorer
 
 
 @dataclass
@@ -80,6 +81,39 @@ class BatchedGraphChoice(GraphChoice):
     def children_decisions(self, child0: Subproblem, child1: Subproblem, layers):
         """The two ``graph.decision`` calls of one branch (relu_conv_gnnkwthreshold.py:230, :239) as one B=2 call."""
         return self.decision_many([child0, child1], layers)
+
+
+    def kw_decision_many(self, subs: List[Subproblem], layers, icp_scores, random_order, sparsest_layer,
+                         decision_threshold=0.001):
+        """The BaBSR fall-back decisions (``choose_node_conv`` call of relu_conv_gnnkwthreshold.py:157) of B subproblems
+        in one launch on the engine the GNN already bound.  Only bounds and masks of a Subproblem are read.
+        Returns ([[lay, idx]] * B, [icp_score] * B)."""
+        B = len(subs)
+        ng = len(subs[0].lower_bounds_all)
+        lbs = [torch.cat([torch.as_tensor(s.lower_bounds_all[k]).float().reshape((1,) + tuple(subs[0].lower_bounds_all[k].shape[1:]))
+                          for s in subs]) for k in range(ng)]
+        ubs = [torch.cat([torch.as_tensor(s.upper_bounds_all[k]).float().reshape((1,) + tuple(subs[0].upper_bounds_all[k].shape[1:]))
+                          for s in subs]) for k in range(ng)]
+        masks = torch.stack([torch.cat([(m == -1).float().reshape(-1) for m in s.mask]) for s in subs])
+        props = [s.prop_layer if s.prop_layer is not None else layers["prop_layers"][0] for s in subs]
+        if getattr(self, "_babsr", None) is None:
+            self._babsr = BabsrScorer(self.model.engine())
+        with torch.no_grad():
+            res = self._babsr.scores(lbs, ubs, {"fixed_layers": layers["fixed_layers"], "prop_layers": props}, masks)
+        return self._babsr.decide_many(res, list(icp_scores), random_order, sparsest_layer, decision_threshold)
+
+
+def resolve_branching(gnn_decision, gnn_improvement_value, kw_decision, kw_improvement_value, ineff_kw_dc):
+    """Which decision a branch keeps once both pairs of children are bounded (relu_conv_gnnkwthreshold.py:176-192):
+    a KW point that improves less than the GNN's AND less than 0.05 is counted as inefficient in ``ineff_kw_dc``
+    (mutated, key 'lay-idx'); a KW point that improves more replaces the GNN decision.  Returns (decision, used_kw)."""
+    if kw_improvement_value < gnn_improvement_value and kw_improvement_value < 0.05:
+        key = f'{kw_decision[0]}-{kw_decision[1]}'
+        ineff_kw_dc[key] = ineff_kw_dc.get(key, 0) + 1
+        return gnn_decision, False
+    if kw_improvement_value > gnn_improvement_value:
+        return kw_decision, True
+    return gnn_decision, False
 
 
 def gnn_improvement(dom_lb, dom_lb1, lower_bound):

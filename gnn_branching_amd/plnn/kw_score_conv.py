@@ -34,6 +34,18 @@ class BabsrScorer:
             mask = torch.cat([(torch.as_tensor(m) == -1).float().reshape(m.shape[0], -1) for m in bab_masks], 1)
         return self.engine().babsr(lower_bounds_all, upper_bounds_all, layers, mask)
 
+    def decide_many(self, res, icp_score_counters, random_order, sparsest_layer, decision_threshold=0.001):
+        """The host decision rule for every subproblem of a BabsrResult: ONE device->host copy of the three (B, R)
+        matrices, then ``decide`` per row.  Returns ([[lay, idx]] * B, [icp_score_counter] * B)."""
+        host = torch.stack([res.scores, res.intercepts, res.masks]).cpu()
+        decisions, counters = [], []
+        for b in range(host.shape[1]):
+            score, icp, mask = (list(torch.split(host[i, b], res.relu_sizes)) for i in range(3))
+            d, c = decide(score, icp, mask, icp_score_counters[b], random_order, sparsest_layer, decision_threshold)
+            decisions.append(d)
+            counters.append(c)
+        return decisions, counters
+
 
 def decide(score, intercept_tb, mask, icp_score_counter, random_order, sparsest_layer, decision_threshold=0.001):
     """Decision rule of kw_score_conv.py:115-156 for ONE subproblem from per-layer 1-D tensors (any device)."""

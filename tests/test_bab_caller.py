@@ -55,3 +55,32 @@ def test_batched_decisions_equal_reference_decisions(case):
     one = batch.slice(0, 1)
     assert choice.decision(one.lower_bounds_all, one.upper_bounds_all, one.dual_vars, one.primal_inputs,
                            [p.tolist() for p in one.primals], one.layers, [m[0] for m in one.bab_masks]) == got[0]
+
+
+def test_resolve_branching_rule():
+    ineff = {}
+    # kw worse than gnn and below 0.05: counted as inefficient, gnn kept (reference :176-181)
+    assert bab_caller.resolve_branching([2, 5], 0.10, [1, 7], 0.01, ineff) == ([2, 5], False)
+    assert bab_caller.resolve_branching([2, 5], 0.10, [1, 7], 0.02, ineff) == ([2, 5], False)
+    assert ineff == {"1-7": 2}
+    # kw better: replaces the gnn decision (:182-194)
+    assert bab_caller.resolve_branching([2, 5], 0.10, [1, 7], 0.30, ineff) == ([1, 7], True)
+    # kw worse but not negligible: gnn kept, nothing recorded (:195-196)
+    assert bab_caller.resolve_branching([2, 5], 0.10, [0, 3], 0.07, ineff) == ([2, 5], False)
+    assert ineff == {"1-7": 2}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["cifar_base_kw_B3", "cifar_wide_kw_B2"])
+def test_batched_kw_decisions_equal_reference_decisions(case):
+    import os
+    from tests.common import GOLDEN
+    g, batch = load_golden(case)
+    gb = dict(np.load(os.path.join(GOLDEN, case + "_babsr.npz")))
+    subs = subproblems_of(batch)
+    choice = bab_caller.BatchedGraphChoice(subs[0].mask, CKPT)
+    L = len(subs[0].mask)
+    for si, (sp, cnt, thr) in enumerate(gb["settings"]):
+        dec, counters = choice.kw_decision_many(subs, batch.layers, [int(cnt)] * len(subs), list(range(L)), int(sp), float(thr))
+        want = [gb[f"dec_{b}_{si}"].tolist() for b in range(len(subs))]
+        assert [d + [c] for d, c in zip(dec, counters)] == want, si
