@@ -42,6 +42,7 @@ SYMBOLS = [
                                C.c_void_p, C.c_size_t, C.c_void_p]),
     ("gnnb_babsr", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p,
                              C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("gnnb_mu_projection", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     ("gnnb_destroy", C.c_int, [C.c_void_p]),
     ("gnnb_last_error", C.c_char_p, []),
     ("gnnb_abi_version", C.c_int, []),

@@ -280,7 +280,8 @@ __device__ __forceinline__ void tile_range(long ntiles, int waves, long& begin, 
 // ------------------------------------------------------------------------------------------
 struct EmbedArgs { const float* pack; const float* lb; const float* x; const float* ub; float* mu; long G; long ntiles; };
 
-// mu0 = inp_f_1(relu(inp_f([l0, x_LP, u0])))   graph_conv.py:90-95
+// E0 = relu(inp_f([l0, x_LP, u0])); mu0 = inp_f_1(E0) is deferred into the forward update of ReLU layer 1
+// (gnnb_pack.h "deferred projection")   graph_conv.py:90-95
 __global__ __launch_bounds__(WG_MLP, 2) void k_embed(EmbedArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   stage_pack(lds, a.pack, PackEmbed::FLOATS);
@@ -297,10 +298,7 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_embed(EmbedArgs a) {
     frag_bias(H, lds + PackEmbed::B1, h);
     gemm_small<2>(lds + PackEmbed::W1, lane, H, x);
     frag_relu(H);
-    Frag M;
-    frag_bias(M, lds + PackEmbed::B2, h);
-    gemm_w64<32>(lds + PackEmbed::W2, lane, M, [&](int s) { return FRAG_AT(H, s); });
-    if (valid) frag_store_rows(M, a.mu, g, h);
+    if (valid) frag_store_rows(H, a.mu, g, h);
   }
 }
 
@@ -523,13 +521,15 @@ struct UpdArgs {
   int* status;
   const int *list0, *cnt0;  // nodes with r0 == r1 and no relaxation term (live, not ambiguous): short chain
   const int *list1, *cnt1;  // general nodes (ambiguous; or the scored nodes for the last backward step of layer 1)
+  const float* stab;        // deferred projection of the source layer: s[n] = sum of the edge weights into node n (else null)
+  int N;                    // nodes per sample (index into stab)
 };
 
 // folded node update (gnnb_pack.h PackUpd):  mu_g = (Wd.relu(P'_g + Wcb.h) + bd) [r0 != 0],  h = relu(Wa.[r0 nb_g, r1 nb_g] + ba)
 //   kind 0 tiles (list0): r0 == r1, P' = bcb:  h = relu(WAS.(r0 nb_g) + ba)                      192 MFMAs per 32 nodes
 //   kind 1 tiles (list1): general                                                              256 MFMAs per 32 nodes
 // forward:  fc3, fc3_2, fc4, fc4_2   graph_conv.py:169-181        backward: bc3, bc3_1, bc4, bc4_1   :331-349
-template <int WAVES>
+template <int WAVES, bool DEFERRED>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_node_update(UpdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
@@ -545,18 +545,20 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_node_update(UpdArgs a
   long tile = (long)(wave >> 2) * gridDim.x * 4 + (long)blockIdx.x * 4 + (wave & 3);
   long gc = 0, gc_n = 0;
   bool valid = false, valid_n = false;
-  float lb = 0.0f, ub = 0.0f, lb_n = 0.0f, ub_n = 0.0f;
+  float lb = 0.0f, ub = 0.0f, lb_n = 0.0f, ub_n = 0.0f, sw = 0.0f, sw_n = 0.0f;
   Frag X, Xn;
-  auto fetch = [&](long tl, long& g_, bool& v_, float& l_, float& u_, Frag& x_) {
+  constexpr bool deferred = DEFERRED;            // the aggregate is built from rows with a deferred projection (gnnb_pack.h)
+  auto fetch = [&](long tl, long& g_, bool& v_, float& l_, float& u_, float& s_, Frag& x_) {
     const bool k0 = tl < n0;
     const long idx = (k0 ? tl : tl - n0) * 32 + j;
     v_ = idx < (k0 ? c0 : c1);
     g_ = (k0 ? a.list0 : a.list1)[v_ ? idx : 0];
     l_ = a.lb[g_];
     u_ = a.ub[g_];
+    if (deferred) s_ = a.stab[(unsigned)g_ % (unsigned)a.N];
     frag_load_rows(x_, a.nb, g_, h);
   };
-  if (tile < ntiles) fetch(tile, gc, valid, lb, ub, X);
+  if (tile < ntiles) fetch(tile, gc, valid, lb, ub, sw, X);
   stage_pack(lds, a.pack, PackUpd::FLOATS);
   if (tile >= ntiles) return;
   for (;;) {
@@ -567,15 +569,23 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_node_update(UpdArgs a
     Frag H, H2;
     frag_bias(H, lds + PackUpd::BA, h);
     if (kind0) {
-      if (has_next) fetch(next, gc_n, valid_n, lb_n, ub_n, Xn);
+      if (has_next) fetch(next, gc_n, valid_n, lb_n, ub_n, sw_n, Xn);
       const float r0 = r.r0;
+      if (deferred) {                        // + s.(r0 Wa0.bp + r1 Wa1.bp), r0 == r1: one small k-step
+        const float x[1] = {r0 * sw};
+        gemm_small<1>(lds + PackUpd::VAW, lane, H, x);
+      }
       gemm_w64<32>(lds + PackUpd::WAS, lane, H, [&](int s) { return FRAG_AT(X, s) * r0; });
       frag_bias(H2, lds + PackUpd::BCB, h);
     } else {
       // nodes without a relaxation term (amb = 0) read the bias row instead of their (never written) P' row
       frag_load_rowptr(H2, r.amb != 0.0f ? a.P + gc * 64 : bias_row, h);
-      if (has_next) fetch(next, gc_n, valid_n, lb_n, ub_n, Xn);
+      if (has_next) fetch(next, gc_n, valid_n, lb_n, ub_n, sw_n, Xn);
       const float r0 = r.r0, r1 = r.r1;
+      if (deferred) {
+        const float x[1] = {(h ? r1 : r0) * sw};
+        gemm_small<1>(lds + PackUpd::VAW, lane, H, x);
+      }
       gemm_w64<64>(lds + PackUpd::WA, lane, H, [&](int s) { return FRAG_AT(X, s & 31) * (s < 32 ? r0 : r1); });
     }
     frag_relu(H);
@@ -590,7 +600,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_node_update(UpdArgs a
       frag_store_rows(M, a.mu, gc, h);
     }
     if (!has_next) break;
-    tile = next; gc = gc_n; valid = valid_n; lb = lb_n; ub = ub_n;
+    tile = next; gc = gc_n; valid = valid_n; lb = lb_n; ub = ub_n; sw = sw_n;
 #pragma unroll
     for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = FRAG_AT(Xn, R);
   }
@@ -598,7 +608,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_node_update(UpdArgs a
 
 struct UpdInpArgs { const float* pack; const float* nb; const float* Q; float* mu; long G, ntiles; };
 
-// mu_0 = inp_b2_2(relu(Q + inp_b2[:, 64:] . nb))                          graph_conv.py:383-385
+// E_0 = relu(Q + inp_b2[:, 64:] . nb); mu_0 = inp_b2_2(E_0) is deferred (gnnb_pack.h)         graph_conv.py:383-385
 __global__ __launch_bounds__(WG_MLP, 2) void k_input_update(UpdInpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   stage_pack(lds, a.pack, PackUpdInp::FLOATS);
@@ -613,10 +623,7 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_input_update(UpdInpArgs a) {
     frag_load_tiled(H, a.Q, tile, lane);
     gemm_w64<32>(lds + PackUpdInp::WC, lane, H, [&](int s) { return FRAG_AT(X, s); });
     frag_relu(H);
-    Frag M;
-    frag_bias(M, lds + PackUpdInp::BD, h);
-    gemm_w64<32>(lds + PackUpdInp::WD, lane, M, [&](int s) { return FRAG_AT(H, s); });
-    if (valid) frag_store_rows(M, a.mu, g, h);
+    if (valid) frag_store_rows(H, a.mu, g, h);
   }
 }
 
@@ -823,7 +830,8 @@ struct GIArgs {
   const float* mu_src; float* mu; long ntiles; DTileMap tm; DGather g;
 };
 
-// input layer: mu_0 = inp_b2_2(relu(Q + inp_b2[:, 64:] . (A_1^T mu_1))),  Q = inp_b2[:, :64] . inp_b_1(relu(inp_b([l0,u0]))) + b
+// input layer: E_0 = relu(Q + inp_b2[:, 64:] . (A_1^T mu_1)),  Q = inp_b2[:, :64] . inp_b_1(relu(inp_b([l0,u0]))) + b;
+// mu_0 = inp_b2_2(E_0) is deferred into the next round's forward update of ReLU layer 1 (gnnb_pack.h).
 // graph_conv.py:361-385; the aggregate, the feature chain and the update stay in registers.
 __global__ __launch_bounds__(WG_MLP, 2) void k_gather_input_update(GIArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -862,10 +870,7 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_gather_input_update(GIArgs a) {
     gemm_w64<32>(lds_pre + PackPreInp::W2, lane, H, [&](int s) { return FRAG_AT(H0, s); });
     gemm_w64<32>(lds + PackUpdInp::WC, lane, H, [&](int s) { return FRAG_AT(X, s); });
     frag_relu(H);
-    Frag M;
-    frag_bias(M, lds + PackUpdInp::BD, h);
-    gemm_w64<32>(lds + PackUpdInp::WD, lane, M, [&](int s) { return FRAG_AT(H, s); });
-    if (tc.valid) frag_store_rows(M, a.mu, gc, h);
+    if (tc.valid) frag_store_rows(H, a.mu, gc, h);
   }
 }
 
@@ -1449,7 +1454,7 @@ struct DevGather {          // one conv edge in one direction, as MFMA gather ta
   int* ttab = nullptr;
 };
 
-#define N_PACKS 12
+#define N_PACKS 14
 struct gnnb_handle {
   int T = 2, p = 64, device = 0, n_cu = 256;
   bool use_gather = true;       // MFMA gather for conv edges (false: VALU gather kernels)
@@ -1461,6 +1466,8 @@ struct gnnb_handle {
   Packs packs;
   float* d_pack[N_PACKS] = {nullptr};
   float* d_zero = nullptr;      // 64 zero floats: where masked gather loads point
+  float* d_s1 = nullptr;        // s[n] = sum of the weights of edge 1 into node n of ReLU layer 1 (deferred projection of mu0)
+  int proj0 = -1;               // which Linear the rows of mu[0] still have to go through (LayerId), after the last forward
   std::vector<DevGather> gf, gb;   // gf[k]: edge k forward (dst = layer k); gb[k]: edge k transposed (dst = layer k-1)
   bool bound = false;
   std::vector<Edge> edges;       // edges[k], k = 1..L (edges[0] unused)
@@ -1480,7 +1487,7 @@ struct gnnb_handle {
 };
 
 enum { PK_EMBED, PK_PRE_FWD, PK_UPD_FWD, PK_PRE_BWD, PK_UPD_BWD, PK_PRE_INP, PK_UPD_INP, PK_SCORE, PK_PROP,
-       PK_UPD_FWD_G, PK_UPD_BWD_G, PK_UPD_INP_G };
+       PK_UPD_FWD_G, PK_UPD_BWD_G, PK_UPD_INP_G, PK_UPD_FWD_E, PK_UPD_FWD_I, PK_COUNT };
 
 static int upload(float** d, const float* h, size_t n) {
   HIPCHK(hipMalloc((void**)d, n * sizeof(float)));
@@ -1509,7 +1516,8 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   build_packs(w_blob, h->packs);
   const std::vector<float>* pv[N_PACKS] = {&h->packs.embed, &h->packs.pre_fwd, &h->packs.upd_fwd, &h->packs.pre_bwd, &h->packs.upd_bwd,
                                            &h->packs.pre_inp, &h->packs.upd_inp, &h->packs.score, &h->packs.prop,
-                                           &h->packs.upd_fwd_g, &h->packs.upd_bwd_g, &h->packs.upd_inp_g};
+                                           &h->packs.upd_fwd_g, &h->packs.upd_bwd_g, &h->packs.upd_inp_g,
+                                           &h->packs.upd_fwd_e, &h->packs.upd_fwd_i};
   for (int i = 0; i < N_PACKS; ++i)
     if (int rc = upload(&h->d_pack[i], pv[i]->data(), pv[i]->size())) return rc;
   HIPCHK(hipMalloc((void**)&h->d_zero, 256 * sizeof(float)));
@@ -1518,8 +1526,10 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   HIPCHK(hipFuncSetAttribute((const void*)k_embed, hipFuncAttributeMaxDynamicSharedMemorySize, PackEmbed::FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_pre, hipFuncAttributeMaxDynamicSharedMemorySize, (PackPreFwd::FLOATS + PackPreBwd::FLOATS) * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_pre_inp, hipFuncAttributeMaxDynamicSharedMemorySize, PackPreInp::FLOATS * 4));
-  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<8>, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpd::FLOATS * 4));
-  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12>, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpd::FLOATS * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpd::FLOATS * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpd::FLOATS * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpd::FLOATS * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpd::FLOATS * 4));
   if (const char* e = getenv("GNNB_NU_WAVES")) h->nu_waves = atoi(e) == 8 ? 8 : 12;
   if (const char* e = getenv("GNNB_GATHER_OCC")) h->gather_occ = atoi(e) < 1 ? 1 : atoi(e);
   HIPCHK(hipFuncSetAttribute((const void*)k_input_update, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpdInp::FLOATS * 4));
@@ -1534,6 +1544,7 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
 }
 
 static void free_network(gnnb_t* h) {
+  if (h->d_s1) { (void)hipFree(h->d_s1); h->d_s1 = nullptr; }
   for (auto& d : h->dev) {
     if (d.w_fwd) (void)hipFree(d.w_fwd);
     if (d.w_bwd) (void)hipFree(d.w_bwd);
@@ -1676,6 +1687,35 @@ extern "C" int gnnb_bind_network(gnnb_t* h, const gnnb_layer_desc* L, int n, int
         for (int i = 0; i < e.n_in; ++i) t[(size_t)o * d.ld_bwd + i] = e.w[(size_t)o * e.n_in + i];
       if (int rc = upload(&d.w_bwd, t.data(), t.size())) return rc;
     }
+  }
+  {   // static bias-sum table of edge 1: every input node is live, so sum_n A[n',n] does not depend on the batch
+    const Edge& e = h->edges[1];
+    std::vector<float> s1(h->N[1], 0.f);
+    if (e.kind == 0) {
+      for (int co = 0; co < e.c_out; ++co)
+        for (int y = 0; y < e.h_out; ++y)
+          for (int x = 0; x < e.w_out; ++x) {
+            double acc = 0.0;
+            for (int ci = 0; ci < e.c_in; ++ci)
+              for (int ky = 0; ky < e.kh; ++ky) {
+                const int iy = y * e.stride - e.pad + ky;
+                if (iy < 0 || iy >= e.h_in) continue;
+                for (int kx = 0; kx < e.kw; ++kx) {
+                  const int ix = x * e.stride - e.pad + kx;
+                  if (ix < 0 || ix >= e.w_in) continue;
+                  acc += (double)e.w[(((size_t)co * e.c_in + ci) * e.kh + ky) * e.kw + kx];
+                }
+              }
+            s1[((size_t)co * e.h_out + y) * e.w_out + x] = (float)acc;
+          }
+    } else {
+      for (int o = 0; o < e.n_out; ++o) {
+        double acc = 0.0;
+        for (int i = 0; i < e.n_in; ++i) acc += (double)e.w[(size_t)o * e.n_in + i];
+        s1[o] = (float)acc;
+      }
+    }
+    if (int rc = upload(&h->d_s1, s1.data(), s1.size())) return rc;
   }
   // MFMA gather tables for every conv edge, both directions (the input layer's transposed edge is not normalised)
   h->gf.assign(Lr + 1, DevGather());
@@ -1832,6 +1872,15 @@ extern "C" int gnnb_mu_location(const gnnb_t* h, int B, int k, size_t* offset_by
   return GNNB_OK;
 }
 
+// Inspection: the rows of mu[k] written by the last forward are E with mu = W.E + b for the Linear `*linear_id`
+// (index into the checkpoint's 26 Linear layers in state-dict order), or final embeddings when *linear_id = -1.
+extern "C" int gnnb_mu_projection(const gnnb_t* h, int k, int* linear_id) {
+  if (!h || !linear_id) return fail(GNNB_E_INVALID, "gnnb_mu_projection: null argument");
+  if (k < 0 || k >= (int)h->N.size()) return fail(GNNB_E_INVALID, "gnnb_mu_projection: bad layer");
+  *linear_id = k == 0 ? h->proj0 : -1;
+  return GNNB_OK;
+}
+
 extern "C" int gnnb_set_halfpass_limit(gnnb_t* h, int n) {
   if (!h) return fail(GNNB_E_INVALID, "null handle");
   h->halfpass_limit = n;
@@ -1972,6 +2021,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     const long G = (long)B * h->N[0], nt = (G + 31) / 32;
     EmbedArgs a{h->d_pack[PK_EMBED], in->lb[0], in->x_lp, in->ub[0], mu(0), G, nt};
     lz.run(PC_EMBED, [&] { hipLaunchKernelGGL(k_embed, dim3(mlp_grid(h, nt)), dim3(WG_MLP), PackEmbed::FLOATS * 4, st, a); });
+    h->proj0 = L_INP_F_1;
   }
   {
     PreAllArgs a{};
@@ -2071,18 +2121,25 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   // phase B: node MLP over a compacted list of nodes
   auto node_update = [&](int k, bool fwd, bool scored) {
     const long nt = ((long)B * h->N[k] + 31) / 32;
+    // the forward update of layer 1 reads an aggregate of mu[0] rows whose last Linear is deferred (gnnb_pack.h)
+    const bool deferred = fwd && k == 1;
+    const int pack = !fwd ? PK_UPD_BWD : (!deferred ? PK_UPD_FWD : (h->proj0 == L_INP_F_1 ? PK_UPD_FWD_E : PK_UPD_FWD_I));
     // normal: list0 = live non-ambiguous nodes (short chain), list1 = ambiguous nodes; restricted: the scored nodes, general chain
-    UpdArgs a{h->d_pack[fwd ? PK_UPD_FWD : PK_UPD_BWD], in->lb[k], in->ub[k], nb, ws + (fwd ? w.Pf[k] : w.Pb[k]), mu(k), status,
-              ilist(w.live[k]), cnt + 4 * k + (scored ? 3 : 0), ilist(scored ? w.score[k] : w.amb[k]), cnt + 4 * k + (scored ? 2 : 1)};
+    UpdArgs a{h->d_pack[pack], in->lb[k], in->ub[k], nb, ws + (fwd ? w.Pf[k] : w.Pb[k]), mu(k), status,
+              ilist(w.live[k]), cnt + 4 * k + (scored ? 3 : 0), ilist(scored ? w.score[k] : w.amb[k]), cnt + 4 * k + (scored ? 2 : 1),
+              deferred ? h->d_s1 : nullptr, h->N[k]};
     const int wv = h->nu_waves;  // waves per workgroup (one workgroup per CU shares the LDS weights)
     long grid = (nt + wv - 1) / wv;
     if (grid > h->n_cu) grid = h->n_cu;
     lz.run(PC_NODE_UPDATE, [&] {
-      if (wv == 12) hipLaunchKernelGGL(k_node_update<12>, dim3((unsigned)grid), dim3(768), PackUpd::FLOATS * 4, st, a);
-      else hipLaunchKernelGGL(k_node_update<8>, dim3((unsigned)grid), dim3(512), PackUpd::FLOATS * 4, st, a);
+      if (wv == 12 && deferred) hipLaunchKernelGGL((k_node_update<12, true>), dim3((unsigned)grid), dim3(768), PackUpd::FLOATS * 4, st, a);
+      else if (wv == 12) hipLaunchKernelGGL((k_node_update<12, false>), dim3((unsigned)grid), dim3(768), PackUpd::FLOATS * 4, st, a);
+      else if (deferred) hipLaunchKernelGGL((k_node_update<8, true>), dim3((unsigned)grid), dim3(512), PackUpd::FLOATS * 4, st, a);
+      else hipLaunchKernelGGL((k_node_update<8, false>), dim3((unsigned)grid), dim3(512), PackUpd::FLOATS * 4, st, a);
     });
   };
   auto update_input = [&]() {
+    h->proj0 = L_INP_B2_2;
     if (h->gb[1].ok) {
       const DevGather& d = h->gb[1];
       const long nt = map_tiles(d.g.tm, B);

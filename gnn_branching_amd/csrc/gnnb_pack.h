@@ -109,8 +109,14 @@ inline void pack_transposed(float* dst, const float* W, int out, int in) {
 }
 
 // ---- per-kernel weight packs: float offsets inside each pack (LDS image == global image) ----
-// k_embed: mu0 = inp_f_1(relu(inp_f([l0, x, u0])))                       (graph_conv.py:90-95)
-struct PackEmbed { enum { W1 = 0, B1 = W1 + 256, W2 = B1 + 64, B2 = W2 + 4096, FLOATS = B2 + 64 }; };
+// Deferred projection (exact algebra): a producer whose last layer is a plain Linear, mu = Wp.E + bp,
+// stores E; the edge aggregate commutes with Wp (sum_n A[n',n] mu_n = Wp.(sum_n A[n',n] E_n) + bp.sum_n A[n',n]), so
+// Wp is folded into the FIRST layer of the consumer: Wa.[r0 nb, r1 nb] = (Wa0.Wp).(r0 G) + (Wa1.Wp).(r1 G) +
+// s.(r0.Wa0.bp + r1.Wa1.bp) with G the aggregate of the stored E rows and s = sum_n A[n',n] a per-node scalar.
+// Used for the input layer (every node is live there, so s is a static table): its 3072 nodes per sample lose one
+// 64x64 GEMM each, the 2048 consumers' GEMM count is unchanged.
+// k_embed: E0 = relu(inp_f([l0, x, u0])); mu0 = inp_f_1(E0) is deferred       (graph_conv.py:90-95)
+struct PackEmbed { enum { W1 = 0, B1 = W1 + 256, FLOATS = B1 + 64 }; };
 // k_pre_fwd: P = fc4[:, :64] (fc1_1(relu(fc1 feat7)) * amb) + fc4.bias    (:153-161, :176-177)
 struct PackPreFwd { enum { W1 = 0, B1 = W1 + 512, W2 = B1 + 64, B2 = W2 + 4096, W3 = B2 + 64, B3 = W3 + 4096, FLOATS = B3 + 64 }; };
 // k_node_update (forward: fc3, fc3_2, fc4[:, 64:], fc4_2; backward: bc3, bc3_1, bc4[:, 64:], bc4_1)
@@ -120,7 +126,10 @@ struct PackPreFwd { enum { W1 = 0, B1 = W1 + 512, W2 = B1 + 64, B2 = W2 + 4096, 
 //   WA  : Wa, 128 -> 64 (general nodes)      WAS : summed halves, 64 -> 64 (r0 == r1 nodes)      BA : bias of Wa
 //   WCB : Wcb                                  BCB : b4 + W4[:, 64:].bb  (= P' of a node without relaxation term)
 //   WD, BD : last layer                        BCBROW : BCB again, row-major (read like a P' row)
-struct PackUpd { enum { WA = 0, WAS = WA + 8192, BA = WAS + 4096, WCB = BA + 64, BCB = WCB + 4096, WD = BCB + 64, BD = WD + 4096, BCBROW = BD + 64, FLOATS = BCBROW + 64 }; };
+//   VAW : the 64 x 2 matrix [Wa[:, :64].bp, Wa[:, 64:].bp] as one small k-step -- bias terms of a deferred projection:
+//         H += VAW.[r0 s, r1 s] costs 2 MFMAs and no registers (zero without a deferred projection)
+struct PackUpd { enum { WA = 0, WAS = WA + 8192, BA = WAS + 4096, WCB = BA + 64, BCB = WCB + 4096, WD = BCB + 64, BD = WD + 4096, BCBROW = BD + 64,
+                        VAW = BCBROW + 64, FLOATS = VAW + 128 }; };
 // k_pre_bwd: P = bc4[:, :64] (bc2_1(relu(bc2([s, -d2 s, d1 s]))) * amb) + bc4.bias,
 //            s = bc1_2(relu(bc1_1(relu(bc1 feat7'))))                      (:273-293, :344-345)
 struct PackPreBwd {
@@ -130,8 +139,8 @@ struct PackPreBwd {
 // k_pre_inp: Q = inp_b2[:, :64] inp_b_1(relu(inp_b([l0,u0]))) + inp_b2.bias   (:380-384)
 // folded: Q = (inp_b2[:, :64].inp_b_1.W) relu(inp_b([l0,u0])) + (inp_b2[:, :64].inp_b_1.b + inp_b2.b)
 struct PackPreInp { enum { W1 = 0, B1 = W1 + 128, W2 = B1 + 64, B2 = W2 + 4096, FLOATS = B2 + 64 }; };
-// k_input_update: mu0 = inp_b2_2(relu(Q + inp_b2[:, 64:] nb))               (:383-385)
-struct PackUpdInp { enum { WC = 0, WD = WC + 4096, BD = WD + 4096, FLOATS = BD + 64 }; };
+// k_input_update: E0 = relu(Q + inp_b2[:, 64:] nb); mu0 = inp_b2_2(E0) is deferred   (:383-385)
+struct PackUpdInp { enum { WC = 0, FLOATS = WC + 4096 }; };
 // k_score: fscore(relu(fnode(mu)))                                           (:448-449)
 struct PackScore { enum { W1 = 0, B1 = W1 + 4096, WS = B1 + 64, BS = WS + 64, FLOATS = BS + 4 }; };
 // k_prop_fwd (VALU, one wave per sample): transposed row-major copies          (:196-210)
@@ -158,6 +167,7 @@ inline void matvec64(float* y, const float* A, int lda, int acol0, const float* 
 struct Packs {
   std::vector<float> embed, pre_fwd, upd_fwd, pre_bwd, upd_bwd, pre_inp, upd_inp, score, prop;
   std::vector<float> upd_fwd_g, upd_bwd_g, upd_inp_g;   // first layer permuted for a gathered (MFMA) input fragment
+  std::vector<float> upd_fwd_e, upd_fwd_i;              // forward update of ReLU layer 1: inp_f_1 / inp_b2_2 folded in
 };
 
 inline void build_packs(const float* blob, Packs& pk) {
@@ -166,8 +176,6 @@ inline void build_packs(const float* blob, Packs& pk) {
   pk.embed.assign(PackEmbed::FLOATS, 0.f);
   pack_wsmall(&pk.embed[PackEmbed::W1], W(L_INP_F), 3, 2);
   pack_vec64(&pk.embed[PackEmbed::B1], Bv(L_INP_F));
-  pack_w64(&pk.embed[PackEmbed::W2], W(L_INP_F_1), 64, 0, 1);
-  pack_vec64(&pk.embed[PackEmbed::B2], Bv(L_INP_F_1));
 
   pk.pre_fwd.assign(PackPreFwd::FLOATS, 0.f);
   pack_wsmall(&pk.pre_fwd[PackPreFwd::W1], W(L_FC1), 7, 4);
@@ -179,19 +187,43 @@ inline void build_packs(const float* blob, Packs& pk) {
 
   // folded bias of the update chain: bcb = b_c + W_c[:, 64:].b_b  (also added to the P' the feature chains cache)
   auto bcb_of = [&](int b, int c, float* out) { matvec64(out, W(c), 128, 64, Bv(b), Bv(c)); };
-  auto upd = [&](std::vector<float>& v, int a, int b, int c, int d, bool gathered_input) {
+  // proj >= 0: the aggregate this update reads is built from rows whose projection Linear `proj` is deferred
+  auto upd = [&](std::vector<float>& v, int a, int b, int c, int d, bool gathered_input, int proj = -1) {
     v.assign(PackUpd::FLOATS, 0.f);
-    std::vector<float> was(64 * 64), wcb(64 * 64);
+    std::vector<float> was(64 * 64), wcb(64 * 64), wa(64 * 128);
     float bcb[64];
-    for (int i = 0; i < 64; ++i)
-      for (int k = 0; k < 64; ++k) was[i * 64 + k] = (float)((double)W(a)[i * 128 + k] + (double)W(a)[i * 128 + 64 + k]);
+    std::memcpy(wa.data(), W(a), sizeof(float) * 64 * 128);
+    if (proj >= 0) {
+      std::vector<double> t(64 * 128);
+      float vaw[128];
+      for (int i = 0; i < 64; ++i) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int k = 0; k < 64; ++k) {
+          s0 += (double)W(a)[i * 128 + k] * (double)Bv(proj)[k];
+          s1 += (double)W(a)[i * 128 + 64 + k] * (double)Bv(proj)[k];
+        }
+        vaw[2 * i] = (float)s0; vaw[2 * i + 1] = (float)s1;
+        for (int half = 0; half < 2; ++half)
+          for (int j = 0; j < 64; ++j) {
+            double acc = 0.0;
+            for (int k = 0; k < 64; ++k) acc += (double)W(a)[i * 128 + 64 * half + k] * (double)W(proj)[k * 64 + j];
+            t[i * 128 + 64 * half + j] = acc;
+          }
+        for (int j = 0; j < 64; ++j) was[i * 64 + j] = (float)(t[i * 128 + j] + t[i * 128 + 64 + j]);
+      }
+      for (size_t q = 0; q < t.size(); ++q) wa[q] = (float)t[q];
+      pack_wsmall(&v[PackUpd::VAW], vaw, 2, 1);
+    } else {
+      for (int i = 0; i < 64; ++i)
+        for (int k = 0; k < 64; ++k) was[i * 64 + k] = (float)((double)W(a)[i * 128 + k] + (double)W(a)[i * 128 + 64 + k]);
+    }
     matmul64(wcb.data(), W(c), 128, 64, W(b));
     bcb_of(b, c, bcb);
     if (gathered_input) {
-      pack_w64_gather(&v[PackUpd::WA], W(a), 128, 0, 2);
+      pack_w64_gather(&v[PackUpd::WA], wa.data(), 128, 0, 2);
       pack_w64_gather(&v[PackUpd::WAS], was.data(), 64, 0, 1);
     } else {
-      pack_w64(&v[PackUpd::WA], W(a), 128, 0, 2);
+      pack_w64(&v[PackUpd::WA], wa.data(), 128, 0, 2);
       pack_w64(&v[PackUpd::WAS], was.data(), 64, 0, 1);
     }
     pack_vec64(&v[PackUpd::BA], Bv(a));
@@ -203,6 +235,8 @@ inline void build_packs(const float* blob, Packs& pk) {
   };
   upd(pk.upd_fwd, L_FC3, L_FC3_2, L_FC4, L_FC4_2, false);
   upd(pk.upd_bwd, L_BC3, L_BC3_1, L_BC4, L_BC4_1, false);
+  upd(pk.upd_fwd_e, L_FC3, L_FC3_2, L_FC4, L_FC4_2, false, L_INP_F_1);      // round 0: mu0 comes from the embedding
+  upd(pk.upd_fwd_i, L_FC3, L_FC3_2, L_FC4, L_FC4_2, false, L_INP_B2_2);     // later rounds: from the input-layer update
   {   // the feature chains cache P' = W4[:, :64].relax + bcb
     float bcb[64];
     bcb_of(L_FC3_2, L_FC4, bcb);
@@ -241,8 +275,6 @@ inline void build_packs(const float* blob, Packs& pk) {
 
   pk.upd_inp.assign(PackUpdInp::FLOATS, 0.f);
   pack_w64(&pk.upd_inp[PackUpdInp::WC], W(L_INP_B2), 128, 64, 1);
-  pack_w64(&pk.upd_inp[PackUpdInp::WD], W(L_INP_B2_2), 64, 0, 1);
-  pack_vec64(&pk.upd_inp[PackUpdInp::BD], Bv(L_INP_B2_2));
 
   // variants whose first layer reads the fragment produced by the MFMA gather (gather_feature map)
   upd(pk.upd_fwd_g, L_FC3, L_FC3_2, L_FC4, L_FC4_2, true);

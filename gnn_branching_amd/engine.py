@@ -27,6 +27,10 @@ def state_blob(state_dict):
     return np.ascontiguousarray(np.concatenate(parts))
 
 
+# (out, in) of the 26 Linear layers in state-dict order (graph_conv.py:26-74, :428-437)
+GNN_LINEARS = [(64, 3), (64, 64), (64, 2), (64, 64), (64, 128), (64, 64), (64, 7), (64, 64), (64, 128), (64, 64), (64, 128),
+               (64, 64), (64, 4), (64, 128), (64, 64), (64, 7), (64, 64), (64, 64), (64, 192), (64, 64), (64, 128), (64, 64),
+               (64, 128), (64, 64), (64, 64), (1, 64)]
 GNN_BLOB_FLOATS = 117825        # the 52 tensors of GraphNet(2, 64) (graph_conv.py:20-76, :281-305, :428-437)
 
 
@@ -73,6 +77,7 @@ class ScorerEngine:
         self.T, self.p = T, p
         # state_dict None: a handle for the GNN-free entry points only (gnnb_babsr) -- all-zero GNN weights
         blob = state_blob(state_dict) if state_dict is not None else np.zeros(GNN_BLOB_FLOATS, dtype=np.float32)
+        self._blob = blob
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.gnnb_create(C.byref(h), blob.ctypes.data_as(C.c_void_p), blob.size, T, p), "gnnb_create")
@@ -301,7 +306,22 @@ class ScorerEngine:
         if self.n_streams > 1 and B >= self.n_streams * self.min_chunk:
             raise RuntimeError("mu() inspects a single-chunk forward: set engine.n_streams = 1 first")
         ws = self.workspace(B)
-        return ws[off.value:off.value + 4 * n.value].view(torch.float32).view(B, self.sizes[k], self.p)
+        rows = ws[off.value:off.value + 4 * n.value].view(torch.float32).view(B, self.sizes[k], self.p)
+        # some producers leave their last Linear to the consumer: apply it here, for inspection
+        lid = C.c_int(-1)
+        _lib.check(self.lib.gnnb_mu_projection(self.h, k, C.byref(lid)), "gnnb_mu_projection")
+        if lid.value < 0:
+            return rows
+        W, b = self._linear(lid.value)
+        return rows @ W.t() + b
+
+    def _linear(self, idx):
+        """(weight, bias) of the idx-th Linear of the checkpoint (state-dict order) as device tensors."""
+        off = sum(o * i + o for o, i in GNN_LINEARS[:idx])
+        o, i = GNN_LINEARS[idx]
+        W = torch.from_numpy(self._blob[off:off + o * i].reshape(o, i).copy()).to(self.device)
+        b = torch.from_numpy(self._blob[off + o * i:off + o * i + o].copy()).to(self.device)
+        return W, b
 
     def describe(self):
         """The launch plan of one forward on the bound network (dict parsed from gnnb_describe's JSON)."""

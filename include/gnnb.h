@@ -113,6 +113,11 @@ int gnnb_describe(const gnnb_t* h, char* buf, size_t cap);
 /* Location of embedding mu[k] inside the workspace: row-major (B, N_k, p) fp32. */
 int gnnb_mu_location(const gnnb_t* h, int B, int k, size_t* offset_bytes, size_t* n_floats);
 
+/* Inspection: some producers store their embedding rows before their last Linear layer (the projection is folded into
+ * the consumer): the rows of mu[k] left by the last forward are E with mu = W.E + b for Linear
+ * `*linear_id` (index into the checkpoint's 26 Linear layers, state-dict order), or final when *linear_id = -1. */
+int gnnb_mu_projection(const gnnb_t* h, int k, int* linear_id);
+
 /* Stop after `n` half-passes (1 = round-0 forward sweep, 2 = + round-0 backward sweep, ...;
  * <= 0 = run everything).  With a limit set the scores are computed from the embeddings so far. */
 int gnnb_set_halfpass_limit(gnnb_t* h, int n);

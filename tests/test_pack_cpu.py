@@ -33,7 +33,7 @@ def packs(packlib):
     assert blob.size == packlib.gnnb_pt_blob_floats() == 117825
     out = {}
     for which, name in enumerate(["embed", "pre_fwd", "upd_fwd", "pre_bwd", "upd_bwd", "pre_inp", "upd_inp", "score", "prop",
-                                  "upd_fwd_g", "upd_bwd_g", "upd_inp_g"]):
+                                  "upd_fwd_g", "upd_bwd_g", "upd_inp_g", "upd_fwd_e", "upd_fwd_i"]):
         n = packlib.gnnb_pt_pack(blob.ctypes.data, which, None, 0)
         buf = np.zeros(n, np.float32)
         assert packlib.gnnb_pt_pack(blob.ctypes.data, which, buf.ctypes.data, n) == n
@@ -113,7 +113,7 @@ def test_node_update_chain(packs):
     Pp = relax @ w4[:, :64].T + bcb                      # what k_pre_fwd caches for ambiguous nodes
     p = pk["upd_fwd"]
     WA, WAS, BA, WCB, BCB, WD, BD, BCBROW = 0, 8192, 12288, 12352, 16448, 16512, 20608, 20672
-    assert p.size == 20736
+    assert p.size == 20864
     np.testing.assert_allclose(p[BCBROW:BCBROW + 64], bcb, rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(rows_from_frag(frag_bias(p[BCB:BCB + 64]))[0], bcb, rtol=1e-6, atol=1e-7)
 
@@ -137,6 +137,49 @@ def test_node_update_chain(packs):
     Hf = frag_bias(p[BA:BA + 64])
     gemm_w64(p[WAS:], 32, Hf, lambda s: X[:, s] * r0[J])
     np.testing.assert_allclose(tail(Hf, frag_bias(p[BCB:BCB + 64])), reference(nb, r0, r0, np.zeros_like(relax)), atol=1e-5)
+
+
+@pytest.mark.parametrize("pack,proj", [("upd_fwd_e", "inp_f_1"), ("upd_fwd_i", "inp_b2_2")])
+def test_node_update_chain_with_deferred_projection(packs, pack, proj):
+    """Forward update of ReLU layer 1: the aggregate G is built from the input layer's rows BEFORE their last Linear
+    (mu0 = Wp.E + bp), so nb = Wp.G + s.bp with s = sum of the edge weights into the node; Wp is folded into fc3 and the
+    s-term enters as one small k-step (gnnb_pack.h "deferred projection")."""
+    sd, pk = packs
+    rng = np.random.RandomState(7)
+    G = rng.standard_normal((32, 64)); relax = rng.standard_normal((32, 64)); sw = rng.standard_normal(32)
+    r0 = rng.uniform(0, 1, 32); r1 = 1 - r0
+    wp, bp = np.asarray(sd[E + proj + ".weight"], np.float64), np.asarray(sd[E + proj + ".bias"], np.float64)
+    nb = G @ wp.T + sw[:, None] * bp[None, :]
+    w4, b4 = np.asarray(sd[E + "fc4.weight"], np.float64), np.asarray(sd[E + "fc4.bias"], np.float64)
+    bcb = b4 + w4[:, 64:] @ np.asarray(sd[E + "fc3_2.bias"], np.float64)
+    Pp = relax @ w4[:, :64].T + bcb
+    p = pk[pack]
+    WA, WAS, BA, WCB, BCB, WD, BD, BCBROW, VAW = 0, 8192, 12288, 12352, 16448, 16512, 20608, 20672, 20736
+
+    def reference(nb_, r0_, r1_, relax_):
+        e = lin(sd, E + "fc3_2", np.maximum(lin(sd, E + "fc3", np.concatenate([nb_ * r0_[:, None], nb_ * r1_[:, None]], 1)), 0))
+        return lin(sd, E + "fc4_2", np.maximum(lin(sd, E + "fc4", np.concatenate([relax_, e], 1)), 0))
+
+    def tail(Hf, H2):
+        Hf = np.maximum(Hf, 0)
+        gemm_w64(p[WCB:], 32, H2, lambda s: Hf[:, s])
+        H2 = np.maximum(H2, 0)
+        M = frag_bias(p[BD:BD + 64])
+        gemm_w64(p[WD:], 32, M, lambda s: H2[:, s])
+        return rows_from_frag(M)
+    X = frag_from_rows(G)
+    # general nodes: lane half 0 feeds r0.s, half 1 feeds r1.s into the small k-step
+    Hf = frag_bias(p[BA:BA + 64])
+    gemm_small(p[VAW:], 1, Hf, [np.where(H == 0, r0[J], r1[J]) * sw[J]])
+    gemm_w64(p[WA:], 64, Hf, lambda s: X[:, s & 31] * (r0[J] if s < 32 else r1[J]))
+    np.testing.assert_allclose(tail(Hf, frag_from_rows(Pp)), reference(nb, r0, r1, relax), atol=2e-5)
+    # r0 == r1 nodes: both halves feed r0.s
+    Hf = frag_bias(p[BA:BA + 64])
+    gemm_small(p[VAW:], 1, Hf, [r0[J] * sw[J]])
+    gemm_w64(p[WAS:], 32, Hf, lambda s: X[:, s] * r0[J])
+    np.testing.assert_allclose(tail(Hf, frag_bias(p[BCB:BCB + 64])), reference(nb, r0, r0, np.zeros_like(relax)), atol=2e-5)
+    # packs without a deferred projection carry a zero small k-step
+    assert not pk["upd_fwd"][VAW:VAW + 128].any() and not pk["upd_bwd"][VAW:VAW + 128].any()
 
 
 def test_pre_bwd_chain(packs):
@@ -170,9 +213,9 @@ def test_embed_and_score_packs(packs):
     f3 = rng.standard_normal((32, 3))
     p = pk["embed"]
     f4 = np.concatenate([f3, np.zeros((32, 1))], 1)
+    assert p.size == 320                      # inp_f only: inp_f_1 is deferred into the forward update of ReLU layer 1
     Hf = frag_bias(p[256:320]); gemm_small(p[0:], 2, Hf, [f4[J, 2 * s + H] for s in range(2)]); Hf = np.maximum(Hf, 0)
-    M = frag_bias(p[4416:4480]); gemm_w64(p[320:], 32, M, lambda s: Hf[:, s])
-    np.testing.assert_allclose(rows_from_frag(M), lin(sd, E + "inp_f_1", np.maximum(lin(sd, E + "inp_f", f3), 0)), atol=1e-5)
+    np.testing.assert_allclose(rows_from_frag(Hf), np.maximum(lin(sd, E + "inp_f", f3), 0), atol=1e-5)
     # score head: per-lane partial dot over the lane's 32 features + the other half
     mu = rng.standard_normal((32, 64))
     p = pk["score"]
