@@ -65,7 +65,7 @@ def plan_flops(plan, B, stats, restrict_last=True):
             reps, nodes = T - 1, u["nodes"] * B
             if u["kernel"] == "k_gather_input_update":
                 add(alg, u["kernel"], reps * 2.0 * (2 * 64 * 64 * nodes + nnz * 64))
-                add(issued, u["kernel"], reps * MFMA_FLOP * u["tiles_per_sample"] * B * (2 * u["gather_ksteps"] + 130))   # inp_b2_2 is deferred
+                add(issued, u["kernel"], reps * MFMA_FLOP * u["tiles_per_sample"] * B * (2 * u["gather_ksteps"] + 132))   # inp_b2_2 is deferred
             else:
                 agg, upd = u["kernel"].split("+")
                 add(alg, upd, reps * 2.0 * 2 * 64 * 64 * nodes)
@@ -77,11 +77,11 @@ def plan_flops(plan, B, stats, restrict_last=True):
             restricted = restrict_last and u["update"] == "bwd" and k == 1 and t == T - 1
             n_upd = stats[k]["scored"] if restricted else stats[k]["live"]
             add(alg, upd, 2.0 * MLP_MACS_PER_NODE * n_upd)
-            # folded chains: 192 MFMAs per tile of live non-ambiguous nodes, 256 per tile of general nodes
+            # folded chains, last layer deferred: 128 (+2) MFMAs per tile of live non-ambiguous nodes, 192 (+2) per tile of general nodes
             if restricted:
-                add(issued, upd, MFMA_FLOP * tiles(n_upd) * 256)
+                add(issued, upd, MFMA_FLOP * tiles(n_upd) * 194)
             else:
-                add(issued, upd, MFMA_FLOP * (tiles(stats[k]["live"] - stats[k]["amb"]) * 192 + tiles(stats[k]["amb"]) * 256))
+                add(issued, upd, MFMA_FLOP * (tiles(stats[k]["live"] - stats[k]["amb"]) * 130 + tiles(stats[k]["amb"]) * 194))
             frac = n_upd / max(stats[k]["nodes"], 1)
             add(alg, agg, 2.0 * nnz * 64 * frac)
             if agg == "k_gather":

@@ -278,27 +278,44 @@ __device__ __forceinline__ void tile_range(long ntiles, int waves, long& begin, 
 // ------------------------------------------------------------------------------------------
 // MFMA node-MLP kernels.  One wave = one tile of 32 consecutive nodes of a (B*N_k) flat layer.
 // ------------------------------------------------------------------------------------------
-struct EmbedArgs { const float* pack; const float* lb; const float* x; const float* ub; float* mu; long G; long ntiles; };
+struct EmbedArgs { const float* w; const float* b; const float* lb; const float* x; const float* ub; float* mu; long G; };
 
 // E0 = relu(inp_f([l0, x_LP, u0])); mu0 = inp_f_1(E0) is deferred into the forward update of ReLU layer 1
 // (gnnb_pack.h "deferred projection")   graph_conv.py:90-95
-__global__ __launch_bounds__(WG_MLP, 2) void k_embed(EmbedArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  stage_pack(lds, a.pack, PackEmbed::FLOATS);
-  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
-  for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < a.ntiles; tile += (long)gridDim.x * WAVES_MLP) {
-    const long g = tile * 32 + j;
-    const bool valid = g < a.G;
-    const long gc = valid ? g : a.G - 1;
-    // features [l, x, u]: half 0 holds even features (l, u), half 1 odd (x, pad)
-    float x[2];
-    x[0] = h ? a.x[gc] : a.lb[gc];
-    x[1] = h ? 0.0f : a.ub[gc];
-    Frag H;
-    frag_bias(H, lds + PackEmbed::B1, h);
-    gemm_small<2>(lds + PackEmbed::W1, lane, H, x);
-    frag_relu(H);
-    if (valid) frag_store_rows(H, a.mu, g, h);
+// 3 -> 64 features per node: 192 FMAs against a 256-B row written, i.e. HBM-write-bound VALU work, not an MFMA job.
+// A thread owns 4 consecutive features (its 12 weights + 4 biases stay in registers) and walks nodes; 16 threads
+// write one 256-B row, one wave instruction writes 1 KiB contiguous.
+#define EMBED_UNROLL 4
+__global__ __launch_bounds__(256) void k_embed(EmbedArgs a) {
+  const int q = threadIdx.x & 15;                       // feature quad
+  float w[4][3], bias[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    bias[c] = a.b[4 * q + c];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) w[c][i] = a.w[(4 * q + c) * 3 + i];
+  }
+  const long nodes_per_pass = (long)gridDim.x * 16;      // 16 nodes per workgroup and pass
+  long g = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  for (; g < a.G; g += nodes_per_pass * EMBED_UNROLL) {
+    float l[EMBED_UNROLL], x[EMBED_UNROLL], u[EMBED_UNROLL];
+#pragma unroll
+    for (int r = 0; r < EMBED_UNROLL; ++r) {
+      const long gg = g + r * nodes_per_pass;
+      const long gc = gg < a.G ? gg : a.G - 1;
+      l[r] = a.lb[gc]; x[r] = a.x[gc]; u[r] = a.ub[gc];
+    }
+#pragma unroll
+    for (int r = 0; r < EMBED_UNROLL; ++r) {
+      const long gg = g + r * nodes_per_pass;
+      f32x4 o;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        // torch addmm order: bias + sum_k in_k w_k
+        o[c] = relu_nan(fmaf(u[r], w[c][2], fmaf(x[r], w[c][1], fmaf(l[r], w[c][0], bias[c]))));
+      }
+      if (gg < a.G) *reinterpret_cast<f32x4*>(a.mu + gg * 64 + 4 * q) = o;
+    }
   }
 }
 
@@ -521,13 +538,15 @@ struct UpdArgs {
   int* status;
   const int *list0, *cnt0;  // nodes with r0 == r1 and no relaxation term (live, not ambiguous): short chain
   const int *list1, *cnt1;  // general nodes (ambiguous; or the scored nodes for the last backward step of layer 1)
-  const float* stab;        // deferred projection of the source layer: s[n] = sum of the edge weights into node n (else null)
-  int N;                    // nodes per sample (index into stab)
+  const float* sarr;        // DEFERRED: s[g] = sum over the edge of live_src (k_livesum), the bias term of the source rows' projection
 };
 
-// folded node update (gnnb_pack.h PackUpd):  mu_g = (Wd.relu(P'_g + Wcb.h) + bd) [r0 != 0],  h = relu(Wa.[r0 nb_g, r1 nb_g] + ba)
-//   kind 0 tiles (list0): r0 == r1, P' = bcb:  h = relu(WAS.(r0 nb_g) + ba)                      192 MFMAs per 32 nodes
-//   kind 1 tiles (list1): general                                                              256 MFMAs per 32 nodes
+// folded node update (gnnb_pack.h PackUpd):  E_g = relu(P'_g + Wcb.h) [r0 != 0],  h = relu(Wa.[r0 nb_g, r1 nb_g] + ba);
+// the last layer, mu_g = (Wd.E_g + bd) [r0 != 0], is deferred into the consumers of the rows ("deferred projection").
+//   kind 0 tiles (list0): r0 == r1, P' = bcb:  h = relu(WAS.(r0 nb_g) + ba)                      128 MFMAs per 32 nodes
+//   kind 1 tiles (list1): general                                                              192 MFMAs per 32 nodes
+// DEFERRED: nb is an aggregate G of rows whose own last layer Wp is deferred: Wa is pre-multiplied by Wp and the bias
+// term s.(r0 Wa0.bp + r1 Wa1.bp) enters as one small k-step.
 // forward:  fc3, fc3_2, fc4, fc4_2   graph_conv.py:169-181        backward: bc3, bc3_1, bc4, bc4_1   :331-349
 template <int WAVES, bool DEFERRED>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_node_update(UpdArgs a) {
@@ -555,7 +574,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_node_update(UpdArgs a
     g_ = (k0 ? a.list0 : a.list1)[v_ ? idx : 0];
     l_ = a.lb[g_];
     u_ = a.ub[g_];
-    if (deferred) s_ = a.stab[(unsigned)g_ % (unsigned)a.N];
+    if (deferred) s_ = a.sarr[g_];
     frag_load_rows(x_, a.nb, g_, h);
   };
   if (tile < ntiles) fetch(tile, gc, valid, lb, ub, sw, X);
@@ -591,13 +610,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_node_update(UpdArgs a
     frag_relu(H);
     gemm_w64<32>(lds + PackUpd::WCB, lane, H2, [&](int s) { return FRAG_AT(H, s); });
     frag_relu(H2);
-    Frag M;
-    frag_bias(M, lds + PackUpd::BD, h);
-    gemm_w64<32>(lds + PackUpd::WD, lane, M, [&](int s) { return FRAG_AT(H2, s); });
-    frag_scale(M, r.live);
+    frag_scale(H2, r.live);
     if (valid) {
-      if (frag_has_nan(M)) atomicOr(a.status, 1);
-      frag_store_rows(M, a.mu, gc, h);
+      if (frag_has_nan(H2)) atomicOr(a.status, 1);      // a NaN here is a NaN in mu = Wd.E + bd (:184-186, :339-341)
+      frag_store_rows(H2, a.mu, gc, h);
     }
     if (!has_next) break;
     tile = next; gc = gc_n; valid = valid_n; lb = lb_n; ub = ub_n; sw = sw_n;
@@ -606,7 +622,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_node_update(UpdArgs a
   }
 }
 
-struct UpdInpArgs { const float* pack; const float* nb; const float* Q; float* mu; long G, ntiles; };
+struct UpdInpArgs { const float* pack; const float* nb; const float* Q; const float* sarr; float* mu; long G, ntiles; };
 
 // E_0 = relu(Q + inp_b2[:, 64:] . nb); mu_0 = inp_b2_2(E_0) is deferred (gnnb_pack.h)         graph_conv.py:383-385
 __global__ __launch_bounds__(WG_MLP, 2) void k_input_update(UpdInpArgs a) {
@@ -621,6 +637,10 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_input_update(UpdInpArgs a) {
     frag_load_rows(X, a.nb, gc, h);
     Frag H;
     frag_load_tiled(H, a.Q, tile, lane);
+    {                                          // bias term of the projection deferred in the rows of mu_1
+      const float x[1] = {h ? 0.0f : a.sarr[gc]};
+      gemm_small<1>(lds + PackUpdInp::VC, lane, H, x);
+    }
     gemm_w64<32>(lds + PackUpdInp::WC, lane, H, [&](int s) { return FRAG_AT(X, s); });
     frag_relu(H);
     if (valid) frag_store_rows(H, a.mu, g, h);
@@ -827,7 +847,7 @@ struct GIArgs {
   const float* pack_pre;    // PackPreInp
   const float* pack;        // PackUpdInp (gather variant)
   const float *lb, *ub;     // input bounds, flat (B*N0)
-  const float* mu_src; float* mu; long ntiles; DTileMap tm; DGather g;
+  const float* mu_src; const float* sarr; float* mu; long ntiles; DTileMap tm; DGather g;
 };
 
 // input layer: E_0 = relu(Q + inp_b2[:, 64:] . (A_1^T mu_1)),  Q = inp_b2[:, :64] . inp_b_1(relu(inp_b([l0,u0]))) + b;
@@ -868,6 +888,10 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_gather_input_update(GIArgs a) {
     Frag H;                                  // inp_b_1 and the first half of inp_b2 are folded into one 64x64 map
     frag_bias(H, lds_pre + PackPreInp::B2, h);
     gemm_w64<32>(lds_pre + PackPreInp::W2, lane, H, [&](int s) { return FRAG_AT(H0, s); });
+    {                                          // bias term of the projection deferred in the rows of mu_1
+      const float xs[1] = {h ? 0.0f : a.sarr[gc]};
+      gemm_small<1>(lds + PackUpdInp::VC, lane, H, xs);
+    }
     gemm_w64<32>(lds + PackUpdInp::WC, lane, H, [&](int s) { return FRAG_AT(X, s); });
     frag_relu(H);
     if (tc.valid) frag_store_rows(H, a.mu, gc, h);
@@ -878,11 +902,13 @@ struct ScoreArgs {        // every ReLU layer in one launch
   const float* pack; float* scores;
   int L, R;
   const float* mu[MAXL]; const int* list[MAXL];
+  const float* lb[MAXL]; const float* ub[MAXL];
   const int* cnt;         // cnt[4k + 2] = number of scored nodes of layer k
   int N[MAXL], off[MAXL]; // nodes per sample in layer k, offset of layer k in the flat ReLU index
 };
 
 // score = fscore(relu(fnode(mu_g))) for the nodes g whose BaB mask is -1 (the rest stays -inf)    graph_conv.py:445-450
+// the rows hold E_g with mu_g = (Wp.E_g + bp).live: fnode is pre-multiplied by Wp, fnode.bp.live enters as a small k-step
 __global__ __launch_bounds__(WG_MLP, 2) void k_score(ScoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   stage_pack(lds, a.pack, PackScore::FLOATS);
@@ -908,6 +934,11 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_score(ScoreArgs a) {
     frag_load_rows(X, a.mu[k], gc, h);
     Frag H;
     frag_bias(H, lds + PackScore::B1, h);
+    {
+      const float live = node_is_live(a.lb[k][gc], a.ub[k][gc]) ? 1.0f : 0.0f;
+      const float x[1] = {h ? 0.0f : live};
+      gemm_small<1>(lds + PackScore::V1, lane, H, x);
+    }
     gemm_w64<32>(lds + PackScore::W1, lane, H, [&](int s) { return FRAG_AT(X, s); });
     frag_relu(H);
     const f32x4* w4 = reinterpret_cast<const f32x4*>(lds + PackScore::WS + h * 32);
@@ -1231,6 +1262,7 @@ __global__ __launch_bounds__(512, 2) void k_dense_bwd_lds(DenseLArgs a) {
 struct PropArgs {
   const float* pack; const float* mu_last; const float* prop_w; const float* prop_b;
   const float *lb, *ub, *z_out; float* mu_prop; float* nb_back; int B, N_last;
+  const float *lbl, *ubl;   // bounds of the top ReLU layer (its rows have fc4_2 deferred: the bias term needs live_n)
 };
 
 // property node (graph_conv.py:194-210): nb = W_prop[b] . mu_L[b];
@@ -1243,6 +1275,7 @@ __global__ __launch_bounds__(256) void k_prop(PropArgs a) {
   __shared__ float xs[128];
   __shared__ float part[4][64];
   __shared__ float outv[64];
+  __shared__ float spart[4];
   for (int i = threadIdx.x; i < PackProp::FLOATS; i += 256) wl[i] = a.pack[i];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int b = blockIdx.x;
@@ -1257,9 +1290,20 @@ __global__ __launch_bounds__(256) void k_prop(PropArgs a) {
     }
   }
   part[w][lane] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  // sp = sum_n W_prop[n] live_n: the rows of mu_L hold E with mu = (fc4_2.E + b).live, so
+  // out2[:, 64:].nb = (out2[:, 64:].fc4_2.W).(sum_n W_prop[n] E_n) + sp.(out2[:, 64:].fc4_2.b)   (folded in PackProp)
+  float sp = 0.0f;
+  for (int n = threadIdx.x; n < a.N_last; n += 256) {
+    const long g = (long)b * a.N_last + n;
+    sp += node_is_live(a.lbl[g], a.ubl[g]) ? pw[n] : 0.0f;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sp += __shfl_xor(sp, o);
+  if (lane == 0) spart[w] = sp;
   __syncthreads();
   if (w == 0) {
     const float nb = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    const float spt = (spart[0] + spart[1]) + (spart[2] + spart[3]);
     const float f[4] = {a.lb[b], a.ub[b], a.z_out[b], a.prop_b[b]};
     float h1 = wl[PackProp::B1 + lane];
 #pragma unroll
@@ -1267,7 +1311,7 @@ __global__ __launch_bounds__(256) void k_prop(PropArgs a) {
     xs[lane] = relu_nan(h1);
     xs[64 + lane] = nb;
     __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): this wave's LDS writes are visible to its own reads
-    float h2 = wl[PackProp::B2 + lane];
+    float h2 = fmaf(spt, wl[PackProp::V2 + lane], wl[PackProp::B2 + lane]);
 #pragma unroll 8
     for (int k = 0; k < 128; ++k) h2 = fmaf(wl[PackProp::W2T + k * 64 + lane], xs[k], h2);
     __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -1285,6 +1329,77 @@ __global__ __launch_bounds__(256) void k_prop(PropArgs a) {
     float* nbk = a.nb_back + (long)b * a.N_last * 64 + lane;
     for (int n = w; n < a.N_last; n += 4) nbk[(long)n * 64] = pw[n] * o;
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_livesum: s[b, n'] = sum_n A[n', n] live[b, n] for every edge and direction (gnnb_pack.h "deferred projection"):
+// the bias of a producer's deferred last layer reaches a consumer multiplied by this scalar.  Static over the rounds
+// (live depends on the bounds only), so it runs once per forward.  Scalar stencil work (HBM/L2-bound, one thread per
+// destination node), all edges in one launch.  Transposed conv edges are divided by the tap count exactly like their
+// aggregate (graph_conv.py:306-312) unless the destination is the input layer (:361-372).
+// ------------------------------------------------------------------------------------------
+struct LiveSumJob {
+  int kind;                 // 0 conv forward, 1 dense forward, 2 conv transposed, 3 dense transposed
+  const float* w;           // conv fwd [ci][ky][kx][co]; conv bwd [co][ky][kx][ci]; dense fwd [i][ld]; dense bwd [o][ld]
+  const float *lbs, *ubs;   // bounds of the SOURCE layer (null: every source node is live -- the input layer)
+  float* out;               // (B, Ndst)
+  int Ndst, Nsrc, ld, normalise;
+  int c_in, h_in, w_in, c_out, h_out, w_out, kh, kw, stride, pad;   // geometry of the conv edge (forward orientation)
+  int blk0;
+};
+struct LiveSumArgs { int njobs, B; LiveSumJob job[2 * MAXL]; };
+
+__global__ __launch_bounds__(256) void k_livesum(LiveSumArgs a) {
+  int q = 0;
+  while (q + 1 < a.njobs && (int)blockIdx.x >= a.job[q + 1].blk0) ++q;
+  const LiveSumJob& jb = a.job[q];
+  const long g = (long)(blockIdx.x - jb.blk0) * 256 + threadIdx.x;
+  if (g >= (long)a.B * jb.Ndst) return;
+  const long b = g / jb.Ndst;
+  const int n = (int)(g - b * jb.Ndst);
+  const float* lbs = jb.lbs ? jb.lbs + b * jb.Nsrc : nullptr;
+  const float* ubs = jb.ubs ? jb.ubs + b * jb.Nsrc : nullptr;
+  auto live = [&](int m) { return !lbs || node_is_live(lbs[m], ubs[m]); };
+  float acc = 0.0f;
+  if (jb.kind == 0) {
+    const int x = n % jb.w_out, y = (n / jb.w_out) % jb.h_out, co = n / (jb.w_out * jb.h_out);
+    for (int ci = 0; ci < jb.c_in; ++ci)
+      for (int ky = 0; ky < jb.kh; ++ky) {
+        const int iy = y * jb.stride - jb.pad + ky;
+        if ((unsigned)iy >= (unsigned)jb.h_in) continue;
+        for (int kx = 0; kx < jb.kw; ++kx) {
+          const int ix = x * jb.stride - jb.pad + kx;
+          if ((unsigned)ix >= (unsigned)jb.w_in) continue;
+          if (live((ci * jb.h_in + iy) * jb.w_in + ix)) acc += jb.w[((ci * jb.kh + ky) * jb.kw + kx) * jb.c_out + co];
+        }
+      }
+  } else if (jb.kind == 1) {
+    for (int i = 0; i < jb.Nsrc; ++i)
+      if (live(i)) acc += jb.w[(long)i * jb.ld + n];
+  } else if (jb.kind == 2) {
+    const int x = n % jb.w_in, y = (n / jb.w_in) % jb.h_in, ci = n / (jb.w_in * jb.h_in);
+    int ny = 0, nx = 0;
+    for (int ky = 0; ky < jb.kh; ++ky) {
+      const int ty = y + jb.pad - ky;
+      if (ty < 0 || ty % jb.stride != 0 || ty / jb.stride >= jb.h_out) continue;
+      ++ny;
+      const int oy = ty / jb.stride;
+      nx = 0;
+      for (int kx = 0; kx < jb.kw; ++kx) {
+        const int tx = x + jb.pad - kx;
+        if (tx < 0 || tx % jb.stride != 0 || tx / jb.stride >= jb.w_out) continue;
+        ++nx;
+        const int ox = tx / jb.stride;
+        for (int co = 0; co < jb.c_out; ++co)
+          if (live((co * jb.h_out + oy) * jb.w_out + ox)) acc += jb.w[((co * jb.kh + ky) * jb.kw + kx) * jb.c_in + ci];
+      }
+    }
+    if (jb.normalise) acc = acc / (float)(ny * nx);
+  } else {
+    for (int o = 0; o < jb.Nsrc; ++o)
+      if (live(o)) acc += jb.w[(long)o * jb.ld + n];
+  }
+  jb.out[g] = acc;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1435,11 +1550,11 @@ static int fail(int code, const char* fmt, ...) {
 
 enum ProfClass {
   PC_EMBED, PC_PRE, PC_PRE_INP, PC_CONV_FWD, PC_CONVT_BWD, PC_DENSE_AGG, PC_PROP_FWD,
-  PC_NODE_UPDATE, PC_INPUT_UPDATE, PC_SCORE, PC_ARGMAX, PC_GATHER, PC_GATHER_INPUT, PC_CLASSIFY, PC_COUNT
+  PC_NODE_UPDATE, PC_INPUT_UPDATE, PC_SCORE, PC_ARGMAX, PC_GATHER, PC_GATHER_INPUT, PC_CLASSIFY, PC_LIVESUM, PC_COUNT
 };
 static const char* kProfNames[PC_COUNT] = {
     "k_embed", "k_pre", "k_pre_inp", "k_conv_fwd", "k_convT_bwd", "k_dense_agg", "k_prop",
-    "k_node_update", "k_input_update", "k_score", "k_argmax", "k_gather", "k_gather_input_update", "k_classify"};
+    "k_node_update", "k_input_update", "k_score", "k_argmax", "k_gather", "k_gather_input_update", "k_classify", "k_livesum"};
 
 struct DevEdge {
   float *w_fwd = nullptr, *w_bwd = nullptr, *bias = nullptr;   // conv: tap-major copies; linear: W^T / W, zero-padded
@@ -1454,7 +1569,7 @@ struct DevGather {          // one conv edge in one direction, as MFMA gather ta
   int* ttab = nullptr;
 };
 
-#define N_PACKS 14
+#define N_PACKS 14   // == PK_COUNT
 struct gnnb_handle {
   int T = 2, p = 64, device = 0, n_cu = 256;
   bool use_gather = true;       // MFMA gather for conv edges (false: VALU gather kernels)
@@ -1466,8 +1581,8 @@ struct gnnb_handle {
   Packs packs;
   float* d_pack[N_PACKS] = {nullptr};
   float* d_zero = nullptr;      // 64 zero floats: where masked gather loads point
-  float* d_s1 = nullptr;        // s[n] = sum of the weights of edge 1 into node n of ReLU layer 1 (deferred projection of mu0)
-  int proj0 = -1;               // which Linear the rows of mu[0] still have to go through (LayerId), after the last forward
+  std::vector<int> proj;        // per graph layer: which Linear (LayerId) the rows of mu[k] still have to go through after
+                                // the last enqueued kernel (-1: the rows are final) -- the "deferred projection" of gnnb_pack.h
   std::vector<DevGather> gf, gb;   // gf[k]: edge k forward (dst = layer k); gb[k]: edge k transposed (dst = layer k-1)
   bool bound = false;
   std::vector<Edge> edges;       // edges[k], k = 1..L (edges[0] unused)
@@ -1486,8 +1601,9 @@ struct gnnb_handle {
   hipStream_t prof_stream = nullptr;
 };
 
-enum { PK_EMBED, PK_PRE_FWD, PK_UPD_FWD, PK_PRE_BWD, PK_UPD_BWD, PK_PRE_INP, PK_UPD_INP, PK_SCORE, PK_PROP,
-       PK_UPD_FWD_G, PK_UPD_BWD_G, PK_UPD_INP_G, PK_UPD_FWD_E, PK_UPD_FWD_I, PK_COUNT };
+enum { PK_EMBED, PK_PRE_FWD, PK_PRE_BWD, PK_PRE_INP, PK_PROP, PK_UPD_FWD_E, PK_UPD_FWD_I, PK_UPD_FWD_F, PK_UPD_BWD, PK_UPD_BWD_B,
+       PK_UPD_INP, PK_UPD_INP_G, PK_SCORE_B, PK_SCORE_F, PK_COUNT };
+static_assert(PK_COUNT == N_PACKS, "pack table");
 
 static int upload(float** d, const float* h, size_t n) {
   HIPCHK(hipMalloc((void**)d, n * sizeof(float)));
@@ -1514,16 +1630,15 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   HIPCHK(hipGetDeviceProperties(&prop, h->device));
   h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   build_packs(w_blob, h->packs);
-  const std::vector<float>* pv[N_PACKS] = {&h->packs.embed, &h->packs.pre_fwd, &h->packs.upd_fwd, &h->packs.pre_bwd, &h->packs.upd_bwd,
-                                           &h->packs.pre_inp, &h->packs.upd_inp, &h->packs.score, &h->packs.prop,
-                                           &h->packs.upd_fwd_g, &h->packs.upd_bwd_g, &h->packs.upd_inp_g,
-                                           &h->packs.upd_fwd_e, &h->packs.upd_fwd_i};
+  const std::vector<float>* pv[N_PACKS] = {&h->packs.embed, &h->packs.pre_fwd, &h->packs.pre_bwd, &h->packs.pre_inp, &h->packs.prop,
+                                           &h->packs.upd_fwd_e, &h->packs.upd_fwd_i, &h->packs.upd_fwd_f, &h->packs.upd_bwd,
+                                           &h->packs.upd_bwd_b, &h->packs.upd_inp, &h->packs.upd_inp_g, &h->packs.score_b,
+                                           &h->packs.score_f};
   for (int i = 0; i < N_PACKS; ++i)
     if (int rc = upload(&h->d_pack[i], pv[i]->data(), pv[i]->size())) return rc;
   HIPCHK(hipMalloc((void**)&h->d_zero, 256 * sizeof(float)));
   HIPCHK(hipMemset(h->d_zero, 0, 256 * sizeof(float)));
   // > 64 KiB of dynamic LDS needs the attribute
-  HIPCHK(hipFuncSetAttribute((const void*)k_embed, hipFuncAttributeMaxDynamicSharedMemorySize, PackEmbed::FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_pre, hipFuncAttributeMaxDynamicSharedMemorySize, (PackPreFwd::FLOATS + PackPreBwd::FLOATS) * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_pre_inp, hipFuncAttributeMaxDynamicSharedMemorySize, PackPreInp::FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_node_update<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpd::FLOATS * 4));
@@ -1544,7 +1659,6 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
 }
 
 static void free_network(gnnb_t* h) {
-  if (h->d_s1) { (void)hipFree(h->d_s1); h->d_s1 = nullptr; }
   for (auto& d : h->dev) {
     if (d.w_fwd) (void)hipFree(d.w_fwd);
     if (d.w_bwd) (void)hipFree(d.w_bwd);
@@ -1655,6 +1769,7 @@ extern "C" int gnnb_bind_network(gnnb_t* h, const gnnb_layer_desc* L, int n, int
   h->R = 0;
   for (int k = 1; k <= Lr; ++k) h->R += h->N[k];
   h->dev.resize(Lr + 1);
+  h->proj.assign(Lr + 2, -1);
   for (int k = 1; k <= Lr; ++k) {
     const Edge& e = h->edges[k];
     DevEdge& d = h->dev[k];
@@ -1687,35 +1802,6 @@ extern "C" int gnnb_bind_network(gnnb_t* h, const gnnb_layer_desc* L, int n, int
         for (int i = 0; i < e.n_in; ++i) t[(size_t)o * d.ld_bwd + i] = e.w[(size_t)o * e.n_in + i];
       if (int rc = upload(&d.w_bwd, t.data(), t.size())) return rc;
     }
-  }
-  {   // static bias-sum table of edge 1: every input node is live, so sum_n A[n',n] does not depend on the batch
-    const Edge& e = h->edges[1];
-    std::vector<float> s1(h->N[1], 0.f);
-    if (e.kind == 0) {
-      for (int co = 0; co < e.c_out; ++co)
-        for (int y = 0; y < e.h_out; ++y)
-          for (int x = 0; x < e.w_out; ++x) {
-            double acc = 0.0;
-            for (int ci = 0; ci < e.c_in; ++ci)
-              for (int ky = 0; ky < e.kh; ++ky) {
-                const int iy = y * e.stride - e.pad + ky;
-                if (iy < 0 || iy >= e.h_in) continue;
-                for (int kx = 0; kx < e.kw; ++kx) {
-                  const int ix = x * e.stride - e.pad + kx;
-                  if (ix < 0 || ix >= e.w_in) continue;
-                  acc += (double)e.w[(((size_t)co * e.c_in + ci) * e.kh + ky) * e.kw + kx];
-                }
-              }
-            s1[((size_t)co * e.h_out + y) * e.w_out + x] = (float)acc;
-          }
-    } else {
-      for (int o = 0; o < e.n_out; ++o) {
-        double acc = 0.0;
-        for (int i = 0; i < e.n_in; ++i) acc += (double)e.w[(size_t)o * e.n_in + i];
-        s1[o] = (float)acc;
-      }
-    }
-    if (int rc = upload(&h->d_s1, s1.data(), s1.size())) return rc;
   }
   // MFMA gather tables for every conv edge, both directions (the input layer's transposed edge is not normalised)
   h->gf.assign(Lr + 1, DevGather());
@@ -1832,6 +1918,7 @@ extern "C" int gnnb_describe(const gnnb_t* h, char* buf, size_t cap) {
 // ---- workspace layout (float offsets, every region 256-B aligned) ----
 struct WsLayout {
   std::vector<size_t> mu, Pf, Pb, live, amb, score;
+  std::vector<size_t> sf, sb;   // k_livesum outputs: sf[k] (B, N_k) over edge k, sb[k] (B, N_k) over edge k+1 transposed
   size_t cnt = 0, nb = 0, Q = 0, total = 0;
 };
 static size_t align64(size_t nfloats) { return (nfloats + 63) & ~(size_t)63; }
@@ -1853,6 +1940,9 @@ static WsLayout ws_layout(const gnnb_t* h, int B) {
     w.amb[k] = off; off += align64((size_t)B * h->N[k]);
     w.score[k] = off; off += align64((size_t)B * h->N[k]);
   }
+  w.sf.assign(K, 0); w.sb.assign(K, 0);
+  for (int k = 1; k < K; ++k) { w.sf[k] = off; off += align64((size_t)B * h->N[k]); }
+  for (int k = 0; k < K - 1; ++k) { w.sb[k] = off; off += align64((size_t)B * h->N[k]); }
   w.Q = off; off += (size_t)map_tiles(bwd_map(h, 0), B) * 2048;
   w.total = off;
   return w;
@@ -1877,7 +1967,7 @@ extern "C" int gnnb_mu_location(const gnnb_t* h, int B, int k, size_t* offset_by
 extern "C" int gnnb_mu_projection(const gnnb_t* h, int k, int* linear_id) {
   if (!h || !linear_id) return fail(GNNB_E_INVALID, "gnnb_mu_projection: null argument");
   if (k < 0 || k >= (int)h->N.size()) return fail(GNNB_E_INVALID, "gnnb_mu_projection: bad layer");
-  *linear_id = k == 0 ? h->proj0 : -1;
+  *linear_id = k < (int)h->proj.size() ? h->proj[k] : -1;
   return GNNB_OK;
 }
 
@@ -2017,11 +2107,39 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     a.blk0[L] = blk;
     lz.run(PC_CLASSIFY, [&] { hipLaunchKernelGGL(k_classify, dim3((unsigned)blk), dim3(CLS_THREADS), 0, st, a); });
   }
+  {   // bias-sum scalars of every edge and direction (the rows carry deferred projections)
+    LiveSumArgs a{};
+    a.B = B;
+    int blk = 0, q = 0;
+    auto push = [&](int kind, const Edge& e, const float* wt, int ld, const float* lbs, const float* ubs, float* out, int Ndst, int Nsrc, int normalise) {
+      LiveSumJob& j = a.job[q++];
+      j.kind = kind; j.w = wt; j.lbs = lbs; j.ubs = ubs; j.out = out; j.Ndst = Ndst; j.Nsrc = Nsrc; j.ld = ld; j.normalise = normalise;
+      j.c_in = e.c_in; j.h_in = e.h_in; j.w_in = e.w_in; j.c_out = e.c_out; j.h_out = e.h_out; j.w_out = e.w_out;
+      j.kh = e.kh; j.kw = e.kw; j.stride = e.stride; j.pad = e.pad; j.blk0 = blk;
+      blk += (int)(((long)B * Ndst + 255) / 256);
+    };
+    for (int k = 1; k <= L; ++k) {            // forward edge k: source layer k-1 (the input layer is all live)
+      const Edge& e = h->edges[k];
+      push(e.kind == 0 ? 0 : 1, e, h->dev[k].w_fwd, h->dev[k].ld_fwd, k > 1 ? in->lb[k - 1] : nullptr, k > 1 ? in->ub[k - 1] : nullptr,
+           ws + w.sf[k], h->N[k], h->N[k - 1], 0);
+    }
+    if (limit >= 2)
+      for (int k = 0; k < L; ++k) {           // edge k+1 transposed: source layer k+1
+        const Edge& e = h->edges[k + 1];
+        push(e.kind == 0 ? 2 : 3, e, h->dev[k + 1].w_bwd, h->dev[k + 1].ld_bwd, in->lb[k + 1], in->ub[k + 1], ws + w.sb[k], h->N[k], h->N[k + 1],
+             k >= 1 ? 1 : 0);
+      }
+    a.njobs = q;
+    lz.run(PC_LIVESUM, [&] { hipLaunchKernelGGL(k_livesum, dim3((unsigned)blk), dim3(256), 0, st, a); });
+  }
   {
-    const long G = (long)B * h->N[0], nt = (G + 31) / 32;
-    EmbedArgs a{h->d_pack[PK_EMBED], in->lb[0], in->x_lp, in->ub[0], mu(0), G, nt};
-    lz.run(PC_EMBED, [&] { hipLaunchKernelGGL(k_embed, dim3(mlp_grid(h, nt)), dim3(WG_MLP), PackEmbed::FLOATS * 4, st, a); });
-    h->proj0 = L_INP_F_1;
+    const long G = (long)B * h->N[0];
+    EmbedArgs a{h->d_pack[PK_EMBED] + PackEmbed::W, h->d_pack[PK_EMBED] + PackEmbed::B, in->lb[0], in->x_lp, in->ub[0], mu(0), G};
+    long grid = (G + 16 * EMBED_UNROLL - 1) / (16 * EMBED_UNROLL);
+    if (grid > (long)h->n_cu * 16) grid = (long)h->n_cu * 16;
+    lz.run(PC_EMBED, [&] { hipLaunchKernelGGL(k_embed, dim3((unsigned)grid), dim3(256), 0, st, a); });
+    for (auto& pj : h->proj) pj = -1;
+    h->proj[0] = L_INP_F_1;
   }
   {
     PreAllArgs a{};
@@ -2121,13 +2239,21 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   // phase B: node MLP over a compacted list of nodes
   auto node_update = [&](int k, bool fwd, bool scored) {
     const long nt = ((long)B * h->N[k] + 31) / 32;
-    // the forward update of layer 1 reads an aggregate of mu[0] rows whose last Linear is deferred (gnnb_pack.h)
-    const bool deferred = fwd && k == 1;
-    const int pack = !fwd ? PK_UPD_BWD : (!deferred ? PK_UPD_FWD : (h->proj0 == L_INP_F_1 ? PK_UPD_FWD_E : PK_UPD_FWD_I));
+    // the aggregate in `nb` was built from rows whose last Linear is deferred (gnnb_pack.h), except the one k_prop writes
+    const int src_proj = fwd ? h->proj[k - 1] : (k < L ? h->proj[k + 1] : -1);
+    int pack = PK_UPD_BWD;
+    const float* sarr = nullptr;
+    if (fwd) {
+      pack = src_proj == L_INP_F_1 ? PK_UPD_FWD_E : (src_proj == L_INP_B2_2 ? PK_UPD_FWD_I : PK_UPD_FWD_F);
+      sarr = ws + w.sf[k];
+    } else if (k < L) {
+      pack = PK_UPD_BWD_B;
+      sarr = ws + w.sb[k];
+    }
+    const bool deferred = sarr != nullptr;
     // normal: list0 = live non-ambiguous nodes (short chain), list1 = ambiguous nodes; restricted: the scored nodes, general chain
     UpdArgs a{h->d_pack[pack], in->lb[k], in->ub[k], nb, ws + (fwd ? w.Pf[k] : w.Pb[k]), mu(k), status,
-              ilist(w.live[k]), cnt + 4 * k + (scored ? 3 : 0), ilist(scored ? w.score[k] : w.amb[k]), cnt + 4 * k + (scored ? 2 : 1),
-              deferred ? h->d_s1 : nullptr, h->N[k]};
+              ilist(w.live[k]), cnt + 4 * k + (scored ? 3 : 0), ilist(scored ? w.score[k] : w.amb[k]), cnt + 4 * k + (scored ? 2 : 1), sarr};
     const int wv = h->nu_waves;  // waves per workgroup (one workgroup per CU shares the LDS weights)
     long grid = (nt + wv - 1) / wv;
     if (grid > h->n_cu) grid = h->n_cu;
@@ -2137,20 +2263,21 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       else if (deferred) hipLaunchKernelGGL((k_node_update<8, true>), dim3((unsigned)grid), dim3(512), PackUpd::FLOATS * 4, st, a);
       else hipLaunchKernelGGL((k_node_update<8, false>), dim3((unsigned)grid), dim3(512), PackUpd::FLOATS * 4, st, a);
     });
+    h->proj[k] = fwd ? L_FC4_2 : L_BC4_1;
   };
   auto update_input = [&]() {
-    h->proj0 = L_INP_B2_2;
+    h->proj[0] = L_INP_B2_2;
     if (h->gb[1].ok) {
       const DevGather& d = h->gb[1];
       const long nt = map_tiles(d.g.tm, B);
-      GIArgs a{h->d_pack[PK_PRE_INP], h->d_pack[PK_UPD_INP_G], in->lb[0], in->ub[0], mu(1), mu(0), nt, to_dtm(d.g.tm), to_dg(d, h->d_zero)};
+      GIArgs a{h->d_pack[PK_PRE_INP], h->d_pack[PK_UPD_INP_G], in->lb[0], in->ub[0], mu(1), ws + w.sb[0], mu(0), nt, to_dtm(d.g.tm), to_dg(d, h->d_zero)};
       const size_t lds = gather_lds_bytes(d, PackUpdInp::FLOATS + PackPreInp::FLOATS);
       lz.run(PC_GATHER_INPUT, [&] { hipLaunchKernelGGL(k_gather_input_update, dim3(mlp_grid(h, nt)), dim3(WG_MLP), lds, st, a); });
       return;
     }
     agg_bwd(0, 0, false);
     const long G = (long)B * h->N[0], nt = (G + 31) / 32;
-    UpdInpArgs a{h->d_pack[PK_UPD_INP], nb, ws + w.Q, mu(0), G, nt};
+    UpdInpArgs a{h->d_pack[PK_UPD_INP], nb, ws + w.Q, ws + w.sb[0], mu(0), G, nt};
     lz.run(PC_INPUT_UPDATE, [&] { hipLaunchKernelGGL(k_input_update, dim3(mlp_grid(h, nt)), dim3(WG_MLP), PackUpdInp::FLOATS * 4, st, a); });
   };
 
@@ -2165,7 +2292,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       // the backward sweep starts with the edge from the property node: its aggregate is written by the same kernel
       const bool bwd_follows = done + 1 < limit;
       PropArgs a{h->d_pack[PK_PROP], mu(L), in->prop_w, in->prop_b, in->lb[K], in->ub[K], in->primal[in->n_primal - 1], mu(K),
-                 bwd_follows ? nb : nullptr, B, h->N[L]};
+                 bwd_follows ? nb : nullptr, B, h->N[L], in->lb[L], in->ub[L]};
       lz.run(PC_PROP_FWD, [&] { hipLaunchKernelGGL(k_prop, dim3(B), dim3(256), 0, st, a); });
     }
     if (++done >= limit) break;
@@ -2185,11 +2312,12 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   ArgmaxArgs am{scores, decisions, B, h->R, L, {0}};
   {
     ScoreArgs a{};
-    a.pack = h->d_pack[PK_SCORE]; a.scores = scores; a.L = L; a.R = h->R; a.cnt = cnt + 4;
+    a.pack = h->d_pack[h->proj[1] == L_FC4_2 ? PK_SCORE_F : PK_SCORE_B]; a.scores = scores; a.L = L; a.R = h->R; a.cnt = cnt + 4;
     long nt = 0;
     for (int k = 1; k <= L; ++k) {
       const int i = k - 1;
       a.mu[i] = mu(k); a.list[i] = ilist(w.score[k]); a.N[i] = h->N[k]; a.off[i] = roff[k];
+      a.lb[i] = in->lb[k]; a.ub[i] = in->ub[k];
       nt += ((long)B * h->N[k] + 31) / 32;
       am.cum[k - 1] = roff[k] + h->N[k];
     }

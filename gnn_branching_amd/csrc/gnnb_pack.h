@@ -109,14 +109,15 @@ inline void pack_transposed(float* dst, const float* W, int out, int in) {
 }
 
 // ---- per-kernel weight packs: float offsets inside each pack (LDS image == global image) ----
-// Deferred projection (exact algebra): a producer whose last layer is a plain Linear, mu = Wp.E + bp,
-// stores E; the edge aggregate commutes with Wp (sum_n A[n',n] mu_n = Wp.(sum_n A[n',n] E_n) + bp.sum_n A[n',n]), so
-// Wp is folded into the FIRST layer of the consumer: Wa.[r0 nb, r1 nb] = (Wa0.Wp).(r0 G) + (Wa1.Wp).(r1 G) +
-// s.(r0.Wa0.bp + r1.Wa1.bp) with G the aggregate of the stored E rows and s = sum_n A[n',n] a per-node scalar.
-// Used for the input layer (every node is live there, so s is a static table): its 3072 nodes per sample lose one
-// 64x64 GEMM each, the 2048 consumers' GEMM count is unchanged.
+// Deferred projection (exact algebra).  Every producer ends in a plain Linear, mu = (Wp.E + bp).live
+// (live = 1 on the input layer).  It stores E.live instead; the edge aggregate commutes with Wp,
+//   sum_n A[n',n] mu_n = Wp.(sum_n A[n',n] E_n) + bp.s[n'],   s[n'] = sum_n A[n',n] live_n   (k_livesum, once per forward),
+// so Wp is folded into the FIRST layer of the consumer: Wa.[r0 nb, r1 nb] = (Wa0.Wp).(r0 G) + (Wa1.Wp).(r1 G) +
+// s.(r0.Wa0.bp + r1.Wa1.bp) with G the aggregate of the stored rows.  Every node update thereby loses its last 64x64
+// GEMM; the consumers' GEMM count is unchanged (the s-term is one small k-step, 2 MFMAs).
 // k_embed: E0 = relu(inp_f([l0, x, u0])); mu0 = inp_f_1(E0) is deferred       (graph_conv.py:90-95)
-struct PackEmbed { enum { W1 = 0, B1 = W1 + 256, FLOATS = B1 + 64 }; };
+// (VALU kernel: plain row-major inp_f.weight (64 x 3) and bias)
+struct PackEmbed { enum { W = 0, B = W + 192, FLOATS = B + 64 }; };
 // k_pre_fwd: P = fc4[:, :64] (fc1_1(relu(fc1 feat7)) * amb) + fc4.bias    (:153-161, :176-177)
 struct PackPreFwd { enum { W1 = 0, B1 = W1 + 512, W2 = B1 + 64, B2 = W2 + 4096, W3 = B2 + 64, B3 = W3 + 4096, FLOATS = B3 + 64 }; };
 // k_node_update (forward: fc3, fc3_2, fc4[:, 64:], fc4_2; backward: bc3, bc3_1, bc4[:, 64:], bc4_1)
@@ -125,10 +126,11 @@ struct PackPreFwd { enum { W1 = 0, B1 = W1 + 512, W2 = B1 + 64, B2 = W2 + 4096, 
 // and for nodes with r0 == r1 (every live node that is not ambiguous)  Wa.[r0 x, r1 x] = WAS.(r0 x),  WAS = Wa[:, :64] + Wa[:, 64:].
 //   WA  : Wa, 128 -> 64 (general nodes)      WAS : summed halves, 64 -> 64 (r0 == r1 nodes)      BA : bias of Wa
 //   WCB : Wcb                                  BCB : b4 + W4[:, 64:].bb  (= P' of a node without relaxation term)
-//   WD, BD : last layer                        BCBROW : BCB again, row-major (read like a P' row)
-//   VAW : the 64 x 2 matrix [Wa[:, :64].bp, Wa[:, 64:].bp] as one small k-step -- bias terms of a deferred projection:
-//         H += VAW.[r0 s, r1 s] costs 2 MFMAs and no registers (zero without a deferred projection)
-struct PackUpd { enum { WA = 0, WAS = WA + 8192, BA = WAS + 4096, WCB = BA + 64, BCB = WCB + 4096, WD = BCB + 64, BD = WD + 4096, BCBROW = BD + 64,
+//   BCBROW : BCB again, row-major (read like a P' row)
+//   VAW : the 64 x 2 matrix [Wa[:, :64].bp, Wa[:, 64:].bp] as one small k-step -- bias terms of the deferred projection of
+//         the SOURCE rows: H += VAW.[r0 s, r1 s] costs 2 MFMAs and no registers (zero when the aggregate is final)
+// The last layer (fc4_2 / bc4_1) is not here: it is deferred into whoever consumes the rows this kernel writes.
+struct PackUpd { enum { WA = 0, WAS = WA + 8192, BA = WAS + 4096, WCB = BA + 64, BCB = WCB + 4096, BCBROW = BCB + 64,
                         VAW = BCBROW + 64, FLOATS = VAW + 128 }; };
 // k_pre_bwd: P = bc4[:, :64] (bc2_1(relu(bc2([s, -d2 s, d1 s]))) * amb) + bc4.bias,
 //            s = bc1_2(relu(bc1_1(relu(bc1 feat7'))))                      (:273-293, :344-345)
@@ -140,11 +142,15 @@ struct PackPreBwd {
 // folded: Q = (inp_b2[:, :64].inp_b_1.W) relu(inp_b([l0,u0])) + (inp_b2[:, :64].inp_b_1.b + inp_b2.b)
 struct PackPreInp { enum { W1 = 0, B1 = W1 + 128, W2 = B1 + 64, B2 = W2 + 4096, FLOATS = B2 + 64 }; };
 // k_input_update: E0 = relu(Q + inp_b2[:, 64:] nb); mu0 = inp_b2_2(E0) is deferred   (:383-385)
-struct PackUpdInp { enum { WC = 0, FLOATS = WC + 4096 }; };
+// WC = inp_b2[:, 64:].bc4_1.W (the rows of mu_1 it aggregates have bc4_1 deferred), VC = [inp_b2[:, 64:].bc4_1.b, 0] small k-step
+struct PackUpdInp { enum { WC = 0, VC = WC + 4096, FLOATS = VC + 128 }; };
 // k_score: fscore(relu(fnode(mu)))                                           (:448-449)
-struct PackScore { enum { W1 = 0, B1 = W1 + 4096, WS = B1 + 64, BS = WS + 64, FLOATS = BS + 4 }; };
+// W1 = fnode.Wp, V1 = [fnode.bp, 0] small k-step fed with live (the scored rows have their last Linear Wp deferred)
+struct PackScore { enum { W1 = 0, B1 = W1 + 4096, WS = B1 + 64, BS = WS + 64, V1 = BS + 4, FLOATS = V1 + 128 }; };
 // k_prop_fwd (VALU, one wave per sample): transposed row-major copies          (:196-210)
-struct PackProp { enum { W1T = 0, B1 = W1T + 4 * 64, W2T = B1 + 64, B2 = W2T + 128 * 64, W3T = B2 + 64, B3 = W3T + 64 * 64, FLOATS = B3 + 64 }; };
+// the second half of out2 is folded with fc4_2 (deferred in the rows of mu_L): W2T rows 64.. = (out2[:, 64:].fc4_2.W)^T,
+// V2 = out2[:, 64:].fc4_2.b multiplies sum_n W_prop[n] live_n
+struct PackProp { enum { W1T = 0, B1 = W1T + 4 * 64, W2T = B1 + 64, B2 = W2T + 128 * 64, W3T = B2 + 64, B3 = W3T + 64 * 64, V2 = B3 + 64, FLOATS = V2 + 64 }; };
 
 // C (64 x 64) = A (64 x 64, row stride lda, columns [acol0, acol0+64)) . B (64 x 64 row-major), accumulated in double
 inline void matmul64(float* C, const float* A, int lda, int acol0, const float* B) {
@@ -165,17 +171,20 @@ inline void matvec64(float* y, const float* A, int lda, int acol0, const float* 
 }
 
 struct Packs {
-  std::vector<float> embed, pre_fwd, upd_fwd, pre_bwd, upd_bwd, pre_inp, upd_inp, score, prop;
-  std::vector<float> upd_fwd_g, upd_bwd_g, upd_inp_g;   // first layer permuted for a gathered (MFMA) input fragment
-  std::vector<float> upd_fwd_e, upd_fwd_i;              // forward update of ReLU layer 1: inp_f_1 / inp_b2_2 folded in
+  std::vector<float> embed, pre_fwd, pre_bwd, pre_inp, prop;
+  // node updates by the projection deferred in the rows they aggregate:
+  std::vector<float> upd_fwd_e, upd_fwd_i, upd_fwd_f;   // forward: inp_f_1 (layer 1, round 0) / inp_b2_2 (layer 1, later) / fc4_2
+  std::vector<float> upd_bwd, upd_bwd_b;                // backward: none (top layer: aggregate from the property node) / bc4_1
+  std::vector<float> upd_inp, upd_inp_g;                // input layer (bc4_1 folded); _g: first layer permuted for a gathered fragment
+  std::vector<float> score_b, score_f;                  // score head on rows with bc4_1 / fc4_2 deferred
 };
 
 inline void build_packs(const float* blob, Packs& pk) {
   auto W = [&](int id) { return blob + weight_offset(id); };
   auto Bv = [&](int id) { return blob + bias_offset(id); };
   pk.embed.assign(PackEmbed::FLOATS, 0.f);
-  pack_wsmall(&pk.embed[PackEmbed::W1], W(L_INP_F), 3, 2);
-  pack_vec64(&pk.embed[PackEmbed::B1], Bv(L_INP_F));
+  std::memcpy(&pk.embed[PackEmbed::W], W(L_INP_F), 192 * sizeof(float));
+  std::memcpy(&pk.embed[PackEmbed::B], Bv(L_INP_F), 64 * sizeof(float));
 
   pk.pre_fwd.assign(PackPreFwd::FLOATS, 0.f);
   pack_wsmall(&pk.pre_fwd[PackPreFwd::W1], W(L_FC1), 7, 4);
@@ -229,14 +238,14 @@ inline void build_packs(const float* blob, Packs& pk) {
     pack_vec64(&v[PackUpd::BA], Bv(a));
     pack_w64(&v[PackUpd::WCB], wcb.data(), 64, 0, 1);
     pack_vec64(&v[PackUpd::BCB], bcb);
-    pack_w64(&v[PackUpd::WD], W(d), 64, 0, 1);
-    pack_vec64(&v[PackUpd::BD], Bv(d));
+    (void)d;   // the last layer is folded into the consumers of the rows
     std::memcpy(&v[PackUpd::BCBROW], bcb, 64 * sizeof(float));
   };
-  upd(pk.upd_fwd, L_FC3, L_FC3_2, L_FC4, L_FC4_2, false);
-  upd(pk.upd_bwd, L_BC3, L_BC3_1, L_BC4, L_BC4_1, false);
-  upd(pk.upd_fwd_e, L_FC3, L_FC3_2, L_FC4, L_FC4_2, false, L_INP_F_1);      // round 0: mu0 comes from the embedding
-  upd(pk.upd_fwd_i, L_FC3, L_FC3_2, L_FC4, L_FC4_2, false, L_INP_B2_2);     // later rounds: from the input-layer update
+  upd(pk.upd_fwd_e, L_FC3, L_FC3_2, L_FC4, L_FC4_2, false, L_INP_F_1);      // layer 1, round 0: mu0 comes from the embedding
+  upd(pk.upd_fwd_i, L_FC3, L_FC3_2, L_FC4, L_FC4_2, false, L_INP_B2_2);     // layer 1, later rounds: from the input-layer update
+  upd(pk.upd_fwd_f, L_FC3, L_FC3_2, L_FC4, L_FC4_2, false, L_FC4_2);        // layers >= 2: from the forward update below
+  upd(pk.upd_bwd, L_BC3, L_BC3_1, L_BC4, L_BC4_1, false);                   // top layer: final aggregate from the property node
+  upd(pk.upd_bwd_b, L_BC3, L_BC3_1, L_BC4, L_BC4_1, false, L_BC4_1);        // below: from the backward update above
   {   // the feature chains cache P' = W4[:, :64].relax + bcb
     float bcb[64];
     bcb_of(L_FC3_2, L_FC4, bcb);
@@ -274,24 +283,49 @@ inline void build_packs(const float* blob, Packs& pk) {
   }
 
   pk.upd_inp.assign(PackUpdInp::FLOATS, 0.f);
-  pack_w64(&pk.upd_inp[PackUpdInp::WC], W(L_INP_B2), 128, 64, 1);
+  std::vector<float> wc(64 * 64);
+  {
+    float vc[128];
+    matmul64(wc.data(), W(L_INP_B2), 128, 64, W(L_BC4_1));
+    float t[64];
+    matvec64(t, W(L_INP_B2), 128, 64, Bv(L_BC4_1), nullptr);
+    for (int i = 0; i < 64; ++i) { vc[2 * i] = t[i]; vc[2 * i + 1] = 0.f; }
+    pack_w64(&pk.upd_inp[PackUpdInp::WC], wc.data(), 64, 0, 1);
+    pack_wsmall(&pk.upd_inp[PackUpdInp::VC], vc, 2, 1);
+  }
 
-  // variants whose first layer reads the fragment produced by the MFMA gather (gather_feature map)
-  upd(pk.upd_fwd_g, L_FC3, L_FC3_2, L_FC4, L_FC4_2, true);
-  upd(pk.upd_bwd_g, L_BC3, L_BC3_1, L_BC4, L_BC4_1, true);
+  // variant whose first layer reads the fragment produced by the MFMA gather (gather_feature map)
   pk.upd_inp_g = pk.upd_inp;
-  pack_w64_gather(&pk.upd_inp_g[PackUpdInp::WC], W(L_INP_B2), 128, 64, 1);
+  pack_w64_gather(&pk.upd_inp_g[PackUpdInp::WC], wc.data(), 64, 0, 1);
 
-  pk.score.assign(PackScore::FLOATS, 0.f);
-  pack_w64(&pk.score[PackScore::W1], W(L_FNODE), 64, 0, 1);
-  pack_vec64(&pk.score[PackScore::B1], Bv(L_FNODE));
-  pack_vec64(&pk.score[PackScore::WS], W(L_FSCORE));
-  pk.score[PackScore::BS] = Bv(L_FSCORE)[0];
+  auto score = [&](std::vector<float>& v, int proj) {
+    v.assign(PackScore::FLOATS, 0.f);
+    std::vector<float> w1(64 * 64);
+    float t[64], v1[128];
+    matmul64(w1.data(), W(L_FNODE), 64, 0, W(proj));
+    matvec64(t, W(L_FNODE), 64, 0, Bv(proj), nullptr);
+    for (int i = 0; i < 64; ++i) { v1[2 * i] = t[i]; v1[2 * i + 1] = 0.f; }
+    pack_w64(&v[PackScore::W1], w1.data(), 64, 0, 1);
+    pack_vec64(&v[PackScore::B1], Bv(L_FNODE));
+    pack_vec64(&v[PackScore::WS], W(L_FSCORE));
+    v[PackScore::BS] = Bv(L_FSCORE)[0];
+    pack_wsmall(&v[PackScore::V1], v1, 2, 1);
+  };
+  score(pk.score_b, L_BC4_1);
+  score(pk.score_f, L_FC4_2);      // only reached when a half-pass limit stops the forward after a forward sweep
 
   pk.prop.assign(PackProp::FLOATS, 0.f);
   pack_transposed(&pk.prop[PackProp::W1T], W(L_OUT1), 64, 4);
   std::memcpy(&pk.prop[PackProp::B1], Bv(L_OUT1), 64 * sizeof(float));
-  pack_transposed(&pk.prop[PackProp::W2T], W(L_OUT2), 64, 128);
+  {
+    std::vector<float> w2(64 * 128), w2b(64 * 64);
+    std::memcpy(w2.data(), W(L_OUT2), sizeof(float) * 64 * 128);
+    matmul64(w2b.data(), W(L_OUT2), 128, 64, W(L_FC4_2));
+    for (int i = 0; i < 64; ++i)
+      for (int j = 0; j < 64; ++j) w2[i * 128 + 64 + j] = w2b[i * 64 + j];
+    pack_transposed(&pk.prop[PackProp::W2T], w2.data(), 64, 128);
+    matvec64(&pk.prop[PackProp::V2], W(L_OUT2), 128, 64, Bv(L_FC4_2), nullptr);
+  }
   std::memcpy(&pk.prop[PackProp::B2], Bv(L_OUT2), 64 * sizeof(float));
   pack_transposed(&pk.prop[PackProp::W3T], W(L_OUT3), 64, 64);
   std::memcpy(&pk.prop[PackProp::B3], Bv(L_OUT3), 64 * sizeof(float));

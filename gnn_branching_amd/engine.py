@@ -213,6 +213,7 @@ class ScorerEngine:
             raise ValueError("primal_inputs has the wrong size")
         self._check_primals(fixed, prim, B)
         pw, pb = self._prop(layers["prop_layers"])
+        self._last_bounds = list(zip(lbs, ubs))           # for mu() (inspection)
 
         scores = torch.empty(B, self.R, dtype=torch.float32, device=self.device)
         dec = torch.empty(B, 2, dtype=torch.int32, device=self.device)
@@ -307,13 +308,20 @@ class ScorerEngine:
             raise RuntimeError("mu() inspects a single-chunk forward: set engine.n_streams = 1 first")
         ws = self.workspace(B)
         rows = ws[off.value:off.value + 4 * n.value].view(torch.float32).view(B, self.sizes[k], self.p)
-        # some producers leave their last Linear to the consumer: apply it here, for inspection
+        # producers leave their last Linear to the consumer: mu = (W.E + b).[r0 != 0]; apply it here,
+        # for inspection only
         lid = C.c_int(-1)
         _lib.check(self.lib.gnnb_mu_projection(self.h, k, C.byref(lid)), "gnnb_mu_projection")
         if lid.value < 0:
             return rows
         W, b = self._linear(lid.value)
-        return rows @ W.t() + b
+        out = rows @ W.t() + b
+        if 1 <= k < len(self.sizes) - 1:
+            lb, ub = (t.reshape(B, -1) for t in self._last_bounds[k])
+            lower_temp, upper_temp = lb - torch.relu(lb), torch.relu(ub)
+            live = (upper_temp / (upper_temp - lower_temp)) != 0          # graph_conv.py:178 / :347
+            out = out * live.unsqueeze(-1)
+        return out
 
     def _linear(self, idx):
         """(weight, bias) of the idx-th Linear of the checkpoint (state-dict order) as device tensors."""

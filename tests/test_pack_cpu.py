@@ -32,8 +32,8 @@ def packs(packlib):
     blob = np.concatenate([np.asarray(v, np.float32).reshape(-1) for v in sd.values()])
     assert blob.size == packlib.gnnb_pt_blob_floats() == 117825
     out = {}
-    for which, name in enumerate(["embed", "pre_fwd", "upd_fwd", "pre_bwd", "upd_bwd", "pre_inp", "upd_inp", "score", "prop",
-                                  "upd_fwd_g", "upd_bwd_g", "upd_inp_g", "upd_fwd_e", "upd_fwd_i"]):
+    for which, name in enumerate(["embed", "pre_fwd", "pre_bwd", "pre_inp", "prop", "upd_fwd_e", "upd_fwd_i", "upd_fwd_f", "upd_bwd",
+                                  "upd_bwd_b", "upd_inp", "upd_inp_g", "score_b", "score_f"]):
         n = packlib.gnnb_pt_pack(blob.ctypes.data, which, None, 0)
         buf = np.zeros(n, np.float32)
         assert packlib.gnnb_pt_pack(blob.ctypes.data, which, buf.ctypes.data, n) == n
@@ -98,88 +98,79 @@ def lin(sd, name, x):
 E = "EmbedUpdates.update."
 
 
-def test_node_update_chain(packs):
-    """k_node_update's folded chains on one tile == fc4_2(relu(fc4([relax, fc3_2(relu(fc3([r0 nb, r1 nb])))]))).
+UPD = dict(WA=0, WAS=8192, BA=12288, WCB=12352, BCB=16448, BCBROW=16512, VAW=16576, FLOATS=16704)
 
-    Fold (gnnb_pack.h PackUpd): fc3_2 feeds fc4 linearly, so Wcb = fc4[:, 64:].fc3_2.W and the cached term is
-    P' = fc4[:, :64].relax + fc4.b + fc4[:, 64:].fc3_2.b; nodes with r0 == r1 use the summed halves of fc3."""
+
+@pytest.mark.parametrize("pack,chain,proj", [
+    ("upd_fwd_e", ("fc3", "fc3_2", "fc4", "fc4_2"), "inp_f_1"), ("upd_fwd_i", ("fc3", "fc3_2", "fc4", "fc4_2"), "inp_b2_2"),
+    ("upd_fwd_f", ("fc3", "fc3_2", "fc4", "fc4_2"), "fc4_2"), ("upd_bwd_b", ("bc3", "bc3_1", "bc4", "bc4_1"), "bc4_1"),
+    ("upd_bwd", ("bc3", "bc3_1", "bc4", "bc4_1"), None)])
+def test_node_update_chain(packs, pack, chain, proj):
+    """k_node_update's folded chain on one tile.  Reference: mu = d(relu(c([relax, b(relu(a([r0 nb, r1 nb])))]))).
+
+    Folds (gnnb_pack.h PackUpd): b feeds c linearly, so Wcb = c[:, 64:].b.W and the cached term is
+    P' = c[:, :64].relax + c.b + c[:, 64:].b.b; nodes with r0 == r1 use the summed halves of a; the last layer d is NOT
+    applied (the kernel stores E with mu = d(E), deferred into the consumers); and when the aggregate was built from
+    rows with a deferred projection p (nb = p.W.G + s.p.b), p.W is folded into a and the s-term is one small k-step."""
     sd, pk = packs
-    rng = np.random.RandomState(1)
-    nb = rng.standard_normal((32, 64)); relax = rng.standard_normal((32, 64))
-    r0 = rng.uniform(0, 1, 32); r1 = 1 - r0
-    w4, b4 = np.asarray(sd[E + "fc4.weight"], np.float64), np.asarray(sd[E + "fc4.bias"], np.float64)
-    b32 = np.asarray(sd[E + "fc3_2.bias"], np.float64)
-    bcb = b4 + w4[:, 64:] @ b32
-    Pp = relax @ w4[:, :64].T + bcb                      # what k_pre_fwd caches for ambiguous nodes
-    p = pk["upd_fwd"]
-    WA, WAS, BA, WCB, BCB, WD, BD, BCBROW = 0, 8192, 12288, 12352, 16448, 16512, 20608, 20672
-    assert p.size == 20864
-    np.testing.assert_allclose(p[BCBROW:BCBROW + 64], bcb, rtol=1e-6, atol=1e-7)
-    np.testing.assert_allclose(rows_from_frag(frag_bias(p[BCB:BCB + 64]))[0], bcb, rtol=1e-6, atol=1e-7)
-
-    def reference(nb_, r0_, r1_, relax_):
-        e = lin(sd, E + "fc3_2", np.maximum(lin(sd, E + "fc3", np.concatenate([nb_ * r0_[:, None], nb_ * r1_[:, None]], 1)), 0))
-        return lin(sd, E + "fc4_2", np.maximum(lin(sd, E + "fc4", np.concatenate([relax_, e], 1)), 0))
-
-    def tail(Hf, H2):
-        Hf = np.maximum(Hf, 0)
-        gemm_w64(p[WCB:], 32, H2, lambda s: Hf[:, s])
-        H2 = np.maximum(H2, 0)
-        M = frag_bias(p[BD:BD + 64])
-        gemm_w64(p[WD:], 32, M, lambda s: H2[:, s])
-        return rows_from_frag(M)
-    # kind 1 (general): K = 128 first layer, P' rows
-    X = frag_from_rows(nb)
-    Hf = frag_bias(p[BA:BA + 64])
-    gemm_w64(p[WA:], 64, Hf, lambda s: X[:, s & 31] * (r0[J] if s < 32 else r1[J]))
-    np.testing.assert_allclose(tail(Hf, frag_from_rows(Pp)), reference(nb, r0, r1, relax), atol=1e-5)
-    # kind 0 (r0 == r1, no relaxation term): summed halves, P' = bcb
-    Hf = frag_bias(p[BA:BA + 64])
-    gemm_w64(p[WAS:], 32, Hf, lambda s: X[:, s] * r0[J])
-    np.testing.assert_allclose(tail(Hf, frag_bias(p[BCB:BCB + 64])), reference(nb, r0, r0, np.zeros_like(relax)), atol=1e-5)
-
-
-@pytest.mark.parametrize("pack,proj", [("upd_fwd_e", "inp_f_1"), ("upd_fwd_i", "inp_b2_2")])
-def test_node_update_chain_with_deferred_projection(packs, pack, proj):
-    """Forward update of ReLU layer 1: the aggregate G is built from the input layer's rows BEFORE their last Linear
-    (mu0 = Wp.E + bp), so nb = Wp.G + s.bp with s = sum of the edge weights into the node; Wp is folded into fc3 and the
-    s-term enters as one small k-step (gnnb_pack.h "deferred projection")."""
-    sd, pk = packs
+    la, lb_, lc, ld = chain
     rng = np.random.RandomState(7)
     G = rng.standard_normal((32, 64)); relax = rng.standard_normal((32, 64)); sw = rng.standard_normal(32)
     r0 = rng.uniform(0, 1, 32); r1 = 1 - r0
-    wp, bp = np.asarray(sd[E + proj + ".weight"], np.float64), np.asarray(sd[E + proj + ".bias"], np.float64)
-    nb = G @ wp.T + sw[:, None] * bp[None, :]
-    w4, b4 = np.asarray(sd[E + "fc4.weight"], np.float64), np.asarray(sd[E + "fc4.bias"], np.float64)
-    bcb = b4 + w4[:, 64:] @ np.asarray(sd[E + "fc3_2.bias"], np.float64)
-    Pp = relax @ w4[:, :64].T + bcb
+    if proj is None:
+        nb = G
+    else:
+        wp, bp = np.asarray(sd[E + proj + ".weight"], np.float64), np.asarray(sd[E + proj + ".bias"], np.float64)
+        nb = G @ wp.T + sw[:, None] * bp[None, :]
+    w4, b4 = np.asarray(sd[E + lc + ".weight"], np.float64), np.asarray(sd[E + lc + ".bias"], np.float64)
+    bcb = b4 + w4[:, 64:] @ np.asarray(sd[E + lb_ + ".bias"], np.float64)
+    Pp = relax @ w4[:, :64].T + bcb                      # what k_pre caches for ambiguous nodes
     p = pk[pack]
-    WA, WAS, BA, WCB, BCB, WD, BD, BCBROW, VAW = 0, 8192, 12288, 12352, 16448, 16512, 20608, 20672, 20736
+    assert p.size == UPD["FLOATS"]
+    WA, WAS, BA, WCB, BCB, BCBROW, VAW = (UPD[k] for k in ("WA", "WAS", "BA", "WCB", "BCB", "BCBROW", "VAW"))
+    np.testing.assert_allclose(p[BCBROW:BCBROW + 64], bcb, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(rows_from_frag(frag_bias(p[BCB:BCB + 64]))[0], bcb, rtol=1e-6, atol=1e-7)
+    if proj is None:
+        assert not p[VAW:VAW + 128].any()
 
     def reference(nb_, r0_, r1_, relax_):
-        e = lin(sd, E + "fc3_2", np.maximum(lin(sd, E + "fc3", np.concatenate([nb_ * r0_[:, None], nb_ * r1_[:, None]], 1)), 0))
-        return lin(sd, E + "fc4_2", np.maximum(lin(sd, E + "fc4", np.concatenate([relax_, e], 1)), 0))
+        """the rows the reference would hold BEFORE its last Linear d"""
+        e = lin(sd, E + lb_, np.maximum(lin(sd, E + la, np.concatenate([nb_ * r0_[:, None], nb_ * r1_[:, None]], 1)), 0))
+        return np.maximum(lin(sd, E + lc, np.concatenate([relax_, e], 1)), 0)
 
     def tail(Hf, H2):
         Hf = np.maximum(Hf, 0)
         gemm_w64(p[WCB:], 32, H2, lambda s: Hf[:, s])
-        H2 = np.maximum(H2, 0)
-        M = frag_bias(p[BD:BD + 64])
-        gemm_w64(p[WD:], 32, M, lambda s: H2[:, s])
-        return rows_from_frag(M)
+        return rows_from_frag(np.maximum(H2, 0))
     X = frag_from_rows(G)
     # general nodes: lane half 0 feeds r0.s, half 1 feeds r1.s into the small k-step
     Hf = frag_bias(p[BA:BA + 64])
     gemm_small(p[VAW:], 1, Hf, [np.where(H == 0, r0[J], r1[J]) * sw[J]])
     gemm_w64(p[WA:], 64, Hf, lambda s: X[:, s & 31] * (r0[J] if s < 32 else r1[J]))
     np.testing.assert_allclose(tail(Hf, frag_from_rows(Pp)), reference(nb, r0, r1, relax), atol=2e-5)
-    # r0 == r1 nodes: both halves feed r0.s
+    # r0 == r1 nodes without relaxation term: summed halves, P' = bcb, both lane halves feed r0.s
     Hf = frag_bias(p[BA:BA + 64])
     gemm_small(p[VAW:], 1, Hf, [r0[J] * sw[J]])
     gemm_w64(p[WAS:], 32, Hf, lambda s: X[:, s] * r0[J])
     np.testing.assert_allclose(tail(Hf, frag_bias(p[BCB:BCB + 64])), reference(nb, r0, r0, np.zeros_like(relax)), atol=2e-5)
-    # packs without a deferred projection carry a zero small k-step
-    assert not pk["upd_fwd"][VAW:VAW + 128].any() and not pk["upd_bwd"][VAW:VAW + 128].any()
+
+
+def test_input_update_pack(packs):
+    """E_0 = relu(Q + inp_b2[:, 64:].nb) with nb = bc4_1.W.G + s.bc4_1.b folded (PackUpdInp WC, VC)."""
+    sd, pk = packs
+    rng = np.random.RandomState(11)
+    G = rng.standard_normal((32, 64)); Q = rng.standard_normal((32, 64)); sw = rng.standard_normal(32)
+    wp, bp = np.asarray(sd[E + "bc4_1.weight"], np.float64), np.asarray(sd[E + "bc4_1.bias"], np.float64)
+    nb = G @ wp.T + sw[:, None] * bp[None, :]
+    w2 = np.asarray(sd[E + "inp_b2.weight"], np.float64)
+    want = np.maximum(Q + nb @ w2[:, 64:].T, 0)
+    p = pk["upd_inp"]
+    assert p.size == 4096 + 128
+    Hf = frag_from_rows(Q)
+    gemm_small(p[4096:], 1, Hf, [np.where(H == 0, sw[J], 0.0)])
+    X = frag_from_rows(G)
+    gemm_w64(p[0:], 32, Hf, lambda s: X[:, s])
+    np.testing.assert_allclose(rows_from_frag(np.maximum(Hf, 0)), want, atol=2e-5)
 
 
 def test_pre_bwd_chain(packs):
@@ -212,27 +203,40 @@ def test_embed_and_score_packs(packs):
     rng = np.random.RandomState(3)
     f3 = rng.standard_normal((32, 3))
     p = pk["embed"]
-    f4 = np.concatenate([f3, np.zeros((32, 1))], 1)
-    assert p.size == 320                      # inp_f only: inp_f_1 is deferred into the forward update of ReLU layer 1
-    Hf = frag_bias(p[256:320]); gemm_small(p[0:], 2, Hf, [f4[J, 2 * s + H] for s in range(2)]); Hf = np.maximum(Hf, 0)
-    np.testing.assert_allclose(rows_from_frag(Hf), np.maximum(lin(sd, E + "inp_f", f3), 0), atol=1e-5)
+    # inp_f only, row-major for the VALU kernel: inp_f_1 is deferred into the forward update of ReLU layer 1
+    assert p.size == 256
+    np.testing.assert_array_equal(p[:192].reshape(64, 3), np.asarray(sd[E + "inp_f.weight"]))
+    np.testing.assert_array_equal(p[192:256], np.asarray(sd[E + "inp_f.bias"]))
     # score head: per-lane partial dot over the lane's 32 features + the other half
     mu = rng.standard_normal((32, 64))
-    p = pk["score"]
-    X = frag_from_rows(mu)
-    Hs = frag_bias(p[4096:4160]); gemm_w64(p[0:], 32, Hs, lambda s: X[:, s]); Hs = np.maximum(Hs, 0)
-    ws = p[4160:4224]
-    part = np.array([sum(Hs[l, R] * ws[H[l] * 32 + R] for R in range(32)) for l in range(64)])
-    score = part[:32] + part[32:] + p[4224]
-    want = lin(sd, "ComputeFinalScore.fscore", np.maximum(lin(sd, "ComputeFinalScore.fnode", mu), 0))[:, 0]
-    np.testing.assert_allclose(score, want, atol=1e-5)
+    live = (rng.uniform(0, 1, 32) > 0.3).astype(np.float64)
+    for name, proj in (("score_b", "bc4_1"), ("score_f", "fc4_2")):
+        # the rows hold E with mu = (Wp.E + bp).live
+        wp, bp = np.asarray(sd[E + proj + ".weight"], np.float64), np.asarray(sd[E + proj + ".bias"], np.float64)
+        Erows = mu * live[:, None]
+        mu_true = (Erows @ wp.T + bp) * live[:, None]
+        p = pk[name]
+        X = frag_from_rows(Erows)
+        Hs = frag_bias(p[4096:4160])
+        gemm_small(p[4228:], 1, Hs, [np.where(H == 0, live[J], 0.0)])
+        gemm_w64(p[0:], 32, Hs, lambda s: X[:, s]); Hs = np.maximum(Hs, 0)
+        ws = p[4160:4224]
+        part = np.array([sum(Hs[l, R] * ws[H[l] * 32 + R] for R in range(32)) for l in range(64)])
+        score = part[:32] + part[32:] + p[4224]
+        want = lin(sd, "ComputeFinalScore.fscore", np.maximum(lin(sd, "ComputeFinalScore.fnode", mu_true), 0))[:, 0]
+        np.testing.assert_allclose(score, want, atol=2e-5)
 
 
 def test_prop_pack_is_transposed(packs):
     sd, pk = packs
     p = pk["prop"]
     w2 = np.asarray(sd[E + "out2.weight"])
-    np.testing.assert_array_equal(p[320:320 + 128 * 64].reshape(128, 64), w2.T)
+    np.testing.assert_array_equal(p[320:320 + 64 * 64].reshape(64, 64), w2[:, :64].T)
+    # second half: folded with fc4_2 (deferred in the rows of the top ReLU layer), bias vector V2
+    wp, bp = np.asarray(sd[E + "fc4_2.weight"], np.float64), np.asarray(sd[E + "fc4_2.bias"], np.float64)
+    np.testing.assert_allclose(p[320 + 64 * 64:320 + 128 * 64].reshape(64, 64), (w2[:, 64:].astype(np.float64) @ wp).T, atol=1e-6)
+    v2 = p[320 + 128 * 64 + 64 + 64 * 64 + 64:][:64]
+    np.testing.assert_allclose(v2, w2[:, 64:].astype(np.float64) @ bp, atol=1e-6)
     np.testing.assert_array_equal(p[0:256].reshape(4, 64), np.asarray(sd[E + "out1.weight"]).T)
 
 
@@ -336,8 +340,8 @@ def test_gather_fragment_feeds_first_layer(packs):
     for it in range(2):
         for r in range(16):
             X[:, 16 * it + r] = nb[J, 2 * ((r & 3) + 8 * (r >> 2) + 4 * H) + it]
-    p = pk["upd_fwd_g"]
-    Hf = frag_bias(p[12288:12352])
-    gemm_w64(p[0:], 64, Hf, lambda s: X[:, s & 31] * (r0[J] if s < 32 else r1[J]))
-    want = lin(sd, E + "fc3", np.concatenate([nb * r0[:, None], nb * r1[:, None]], 1))
-    np.testing.assert_allclose(rows_from_frag(Hf), want, atol=1e-5)
+    p = pk["upd_inp_g"]
+    Hf = np.zeros((64, 32))
+    gemm_w64(p[0:], 32, Hf, lambda s: X[:, s])
+    want = nb @ (np.asarray(sd[E + "inp_b2.weight"], np.float64)[:, 64:] @ np.asarray(sd[E + "bc4_1.weight"], np.float64)).T
+    np.testing.assert_allclose(rows_from_frag(Hf), want, atol=2e-5)
