@@ -334,6 +334,7 @@ struct ClassifyArgs {    // every ReLU layer of the network in one launch
   const float* lb[MAXL]; const float* ub[MAXL];
   float* mu[MAXL];                 // (B*N_k, 64) rows of layer k
   int* live[MAXL]; int* amb[MAXL]; int* score[MAXL];
+  float* livef[MAXL];              // (B*N_k) 1.0 / 0.0: [r0 != 0], read by k_livesum
   long G[MAXL];
   int N[MAXL], off[MAXL], blk0[MAXL + 1];   // first workgroup of each layer
   const float* mask;
@@ -363,7 +364,10 @@ __global__ __launch_bounds__(CLS_THREADS) void k_classify(ClassifyArgs a) {
   flag[1] = valid && r.amb != 0.0f;                 // ambiguous (a subset of live)
   flag[0] = live && !flag[1];                       // live with r0 == r1: the cheap update path
   flag[2] = valid && a.mask[sidx] != 0.0f;
-  if (valid) a.scores[sidx] = -INFINITY;
+  if (valid) {
+    a.scores[sidx] = -INFINITY;
+    a.livef[k][g] = live ? 1.0f : 0.0f;
+  }
   unsigned long long bal[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -1340,66 +1344,170 @@ __global__ __launch_bounds__(256) void k_prop(PropArgs a) {
 // ------------------------------------------------------------------------------------------
 struct LiveSumJob {
   int kind;                 // 0 conv forward, 1 dense forward, 2 conv transposed, 3 dense transposed
-  const float* w;           // conv fwd [ci][ky][kx][co]; conv bwd [co][ky][kx][ci]; dense fwd [i][ld]; dense bwd [o][ld]
-  const float *lbs, *ubs;   // bounds of the SOURCE layer (null: every source node is live -- the input layer)
+  const float* w;           // conv fwd [ci][ky][kx][co]; conv bwd [co][ky][kx][ci]; dense (both directions) W[o][ld]
+  const float* lf;          // live flags of the SOURCE layer (B, Nsrc), written by k_classify; null: all live (input layer)
   float* out;               // (B, Ndst)
   int Ndst, Nsrc, ld, normalise;
   int c_in, h_in, w_in, c_out, h_out, w_out, kh, kw, stride, pad;   // geometry of the conv edge (forward orientation)
-  int blk0;
+  int wlds;                 // conv: number of weights to stage in LDS (0: read them from global memory)
 };
-struct LiveSumArgs { int njobs, B; LiveSumJob job[2 * MAXL]; };
+struct LiveSumArgs { int njobs, B, lv_floats; LiveSumJob job[2 * MAXL]; };
+#define LIVESUM_MAXW 16384    // conv weights staged in LDS (64 KB)
 
-__global__ __launch_bounds__(256) void k_livesum(LiveSumArgs a) {
-  int q = 0;
-  while (q + 1 < a.njobs && (int)blockIdx.x >= a.job[q + 1].blk0) ++q;
-  const LiveSumJob& jb = a.job[q];
-  const long g = (long)(blockIdx.x - jb.blk0) * 256 + threadIdx.x;
-  if (g >= (long)a.B * jb.Ndst) return;
-  const long b = g / jb.Ndst;
-  const int n = (int)(g - b * jb.Ndst);
-  const float* lbs = jb.lbs ? jb.lbs + b * jb.Nsrc : nullptr;
-  const float* ubs = jb.ubs ? jb.ubs + b * jb.Nsrc : nullptr;
-  auto live = [&](int m) { return !lbs || node_is_live(lbs[m], ubs[m]); };
-  float acc = 0.0f;
-  if (jb.kind == 0) {
-    const int x = n % jb.w_out, y = (n / jb.w_out) % jb.h_out, co = n / (jb.w_out * jb.h_out);
-    for (int ci = 0; ci < jb.c_in; ++ci)
-      for (int ky = 0; ky < jb.kh; ++ky) {
-        const int iy = y * jb.stride - jb.pad + ky;
-        if ((unsigned)iy >= (unsigned)jb.h_in) continue;
-        for (int kx = 0; kx < jb.kw; ++kx) {
-          const int ix = x * jb.stride - jb.pad + kx;
-          if ((unsigned)ix >= (unsigned)jb.w_in) continue;
-          if (live((ci * jb.h_in + iy) * jb.w_in + ix)) acc += jb.w[((ci * jb.kh + ky) * jb.kw + kx) * jb.c_out + co];
+#define LIVESUM_MAXSRC 40000  // source nodes per sample that fit the 160 KB LDS (bind rejects larger layers)
+#define LS_CC 4
+#define LS_DO 9
+// conv / transposed-conv stencil of one sample out of LDS.  KH, KW, S > 0: compile-time kernel size and stride, so the tap
+// loops unroll completely and all LDS reads of a source channel are issued before their FMAs (masked, no branches);
+// KH = 0: run-time geometry (any other conv).
+template <int KH, int KW, int S, bool FWD>
+__device__ __forceinline__ void livesum_conv(const LiveSumJob& jb, const float* lv, const float* W, float* out, int tid) {
+  const int kh = KH ? KH : jb.kh, kw = KH ? KW : jb.kw, st = KH ? S : jb.stride;
+  const int Hd = FWD ? jb.h_out : jb.h_in, Wd = FWD ? jb.w_out : jb.w_in, Cd = FWD ? jb.c_out : jb.c_in;   // destination side
+  const int Hs = FWD ? jb.h_in : jb.h_out, Ws = FWD ? jb.w_in : jb.w_out, Cs = FWD ? jb.c_in : jb.c_out;   // source side
+  const int npos = Hd * Wd;
+  const int P = npos < 256 ? npos : 256;               // positions handled per pass
+  const int ngrp = 256 / P;                            // thread groups that split the channel chunks
+  const int grp = tid / P;
+  if (grp >= ngrp) return;
+  const int nchunk = (Cd + LS_CC - 1) / LS_CC;
+  // taps walked per axis.  forward: every ky, source row sy = y*s - p + ky; transposed: ky = ky0 + s*t, sy = sy0 - t
+  const int TY = FWD ? kh : (kh + st - 1) / st, TX = FWD ? kw : (kw + st - 1) / st;
+  constexpr int TYC = KH ? (FWD ? KH : (KH + S - 1) / S) : 1, TXC = KH ? (FWD ? KW : (KW + S - 1) / S) : 1;
+  for (int pos = tid - grp * P; pos < npos; pos += 256) {     // one pass unless the layer has more than 256 positions
+    const int y = pos / Wd, x = pos - y * Wd;
+    int ky0 = 0, kx0 = 0, sy0, sx0;
+    if (FWD) {
+      sy0 = y * st - jb.pad; sx0 = x * st - jb.pad;
+    } else {
+      ky0 = (y + jb.pad) % st; kx0 = (x + jb.pad) % st;
+      sy0 = (y + jb.pad - ky0) / st; sx0 = (x + jb.pad - kx0) / st;
+    }
+    const int kstep = FWD ? 1 : st, sstep = FWD ? 1 : -1;
+    int cnt_y = 0, cnt_x = 0;
+    for (int t = 0; t < TY; ++t) cnt_y += ((unsigned)(sy0 + sstep * t) < (unsigned)Hs && ky0 + kstep * t < kh) ? 1 : 0;
+    for (int t = 0; t < TX; ++t) cnt_x += ((unsigned)(sx0 + sstep * t) < (unsigned)Ws && kx0 + kstep * t < kw) ? 1 : 0;
+    for (int ch = grp; ch < nchunk; ch += ngrp) {
+      const int c0 = ch * LS_CC;
+      float acc[LS_CC];
+#pragma unroll
+      for (int u = 0; u < LS_CC; ++u) acc[u] = 0.0f;
+      for (int cs = 0; cs < Cs; ++cs) {
+        if (KH) {
+#pragma unroll
+          for (int t = 0; t < TYC; ++t)
+#pragma unroll
+            for (int u2 = 0; u2 < TXC; ++u2) {
+              const int sy = sy0 + sstep * t, ky = ky0 + kstep * t, sx = sx0 + sstep * u2, kx = kx0 + kstep * u2;
+              const bool v = (unsigned)sy < (unsigned)Hs && (unsigned)sx < (unsigned)Ws && ky < kh && kx < kw;
+              const float l = v ? lv[(cs * Hs + (v ? sy : 0)) * Ws + (v ? sx : 0)] : 0.0f;
+              const float* wr = W + ((cs * kh + (v ? ky : 0)) * kw + (v ? kx : 0)) * Cd + c0;
+#pragma unroll
+              for (int u = 0; u < LS_CC; ++u) acc[u] = fmaf(c0 + u < Cd ? wr[u] : 0.0f, l, acc[u]);
+            }
+        } else {
+          for (int t = 0; t < TY; ++t) {
+            const int sy = sy0 + sstep * t, ky = ky0 + kstep * t;
+            if ((unsigned)sy >= (unsigned)Hs || ky >= kh) continue;
+            for (int u2 = 0; u2 < TX; ++u2) {
+              const int sx = sx0 + sstep * u2, kx = kx0 + kstep * u2;
+              if ((unsigned)sx >= (unsigned)Ws || kx >= kw) continue;
+              const float l = lv[(cs * Hs + sy) * Ws + sx];
+              const float* wr = W + ((cs * kh + ky) * kw + kx) * Cd + c0;
+#pragma unroll
+              for (int u = 0; u < LS_CC; ++u) acc[u] = fmaf(c0 + u < Cd ? wr[u] : 0.0f, l, acc[u]);
+            }
+          }
         }
       }
+#pragma unroll
+      for (int u = 0; u < LS_CC; ++u)
+        if (c0 + u < Cd) {
+          float v = acc[u];
+          if (!FWD && jb.normalise) v = v / (float)(cnt_y * cnt_x);
+          out[(c0 + u) * npos + pos] = v;
+        }
+    }
+  }
+}
+
+// grid (sample, job): the live flags of the sample's source layer and the conv weights are staged in LDS once.  The stencil
+// is ALU-bound (an FMA per tap), so the loops are built to spend few instructions per FMA: a thread owns one pixel position
+// and 8 channels at a time (one LDS read of the flag + two 16-B reads of 8 consecutive weights feed 8 FMAs), positions and
+// tap ranges are decoded once per thread, transposed edges walk only the taps of the lane's stride phase.
+__global__ __launch_bounds__(256) void k_livesum(LiveSumArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lv[];     // [lv_floats] flags, then the conv weights
+  const LiveSumJob& jb = a.job[blockIdx.y];
+  const long b = blockIdx.x;
+  const int tid = threadIdx.x;
+  if (jb.lf && (jb.Nsrc & 3) == 0) {
+    copy_to_lds(lv, jb.lf + b * jb.Nsrc, jb.Nsrc);       // (B, Nsrc) rows stay 16-B aligned when Nsrc % 4 == 0
+  } else if (jb.lf) {
+    const float* lf = jb.lf + b * jb.Nsrc;
+    for (int i = tid; i < jb.Nsrc; i += 256) lv[i] = lf[i];
+  } else {
+    for (int i = tid; i < jb.Nsrc; i += 256) lv[i] = 1.0f;
+  }
+  float* wl = lv + a.lv_floats;
+  if ((jb.wlds & 3) == 0) copy_to_lds(wl, jb.w, jb.wlds);
+  else for (int i = tid; i < jb.wlds; i += 256) wl[i] = jb.w[i];
+  const float* W = jb.wlds ? wl : jb.w;
+  __syncthreads();
+  float* out = jb.out + b * jb.Ndst;
+  if (jb.kind == 0 || jb.kind == 2) {
+    const bool fwd = jb.kind == 0;
+    const int key = jb.kh * 100 + jb.kw * 10 + jb.stride;
+    if (fwd) {
+      if (key == 442) livesum_conv<4, 4, 2, true>(jb, lv, W, out, tid);
+      else if (key == 331) livesum_conv<3, 3, 1, true>(jb, lv, W, out, tid);
+      else livesum_conv<0, 0, 0, true>(jb, lv, W, out, tid);
+    } else {
+      if (key == 442) livesum_conv<4, 4, 2, false>(jb, lv, W, out, tid);
+      else if (key == 331) livesum_conv<3, 3, 1, false>(jb, lv, W, out, tid);
+      else livesum_conv<0, 0, 0, false>(jb, lv, W, out, tid);
+    }
   } else if (jb.kind == 1) {
-    for (int i = 0; i < jb.Nsrc; ++i)
-      if (live(i)) acc += jb.w[(long)i * jb.ld + n];
-  } else if (jb.kind == 2) {
-    const int x = n % jb.w_in, y = (n / jb.w_in) % jb.h_in, ci = n / (jb.w_in * jb.h_in);
-    int ny = 0, nx = 0;
-    for (int ky = 0; ky < jb.kh; ++ky) {
-      const int ty = y + jb.pad - ky;
-      if (ty < 0 || ty % jb.stride != 0 || ty / jb.stride >= jb.h_out) continue;
-      ++ny;
-      const int oy = ty / jb.stride;
-      nx = 0;
-      for (int kx = 0; kx < jb.kw; ++kx) {
-        const int tx = x + jb.pad - kx;
-        if (tx < 0 || tx % jb.stride != 0 || tx / jb.stride >= jb.w_out) continue;
-        ++nx;
-        const int ox = tx / jb.stride;
-        for (int co = 0; co < jb.c_out; ++co)
-          if (live((co * jb.h_out + oy) * jb.w_out + ox)) acc += jb.w[((co * jb.kh + ky) * jb.kw + kx) * jb.c_in + ci];
+    // few outputs, long K: a wave per LS_DO outputs at a time (that many x 4 independent loads in flight), lanes stride over
+    // the sources, shuffle reduction
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int o0 = wv * LS_DO; o0 < jb.Ndst; o0 += 4 * LS_DO) {
+      float acc[LS_DO];
+      const float* wrow[LS_DO];
+#pragma unroll
+      for (int u = 0; u < LS_DO; ++u) { acc[u] = 0.0f; wrow[u] = jb.w + (long)(o0 + u < jb.Ndst ? o0 + u : o0) * jb.ld; }
+#pragma unroll 4
+      for (int i = lane; i < jb.Nsrc; i += 64) {
+        const float l = lv[i];
+#pragma unroll
+        for (int u = 0; u < LS_DO; ++u) acc[u] = fmaf(wrow[u][i], l, acc[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < LS_DO; ++u) {
+        float v = acc[u];
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
+        if (lane == 0 && o0 + u < jb.Ndst) out[o0 + u] = v;
       }
     }
-    if (jb.normalise) acc = acc / (float)(ny * nx);
   } else {
-    for (int o = 0; o < jb.Nsrc; ++o)
-      if (live(o)) acc += jb.w[(long)o * jb.ld + n];
+    // dense transposed: thread per input node, coalesced weight rows, broadcast live flags
+    for (int n0 = tid; n0 < jb.Ndst; n0 += 1024) {         // 4 nodes per thread at a time: 40 independent loads in flight
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      int nn[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) nn[u] = n0 + 256 * u < jb.Ndst ? n0 + 256 * u : n0;
+#pragma unroll 10
+      for (int o = 0; o < jb.Nsrc; ++o) {
+        const float l = lv[o];
+        const float* wr = jb.w + (long)o * jb.ld;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = fmaf(wr[nn[u]], l, acc[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (n0 + 256 * u < jb.Ndst) out[n0 + 256 * u] = acc[u];
+    }
   }
-  jb.out[g] = acc;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1650,6 +1758,7 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   HIPCHK(hipFuncSetAttribute((const void*)k_input_update, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpdInp::FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_score, hipFuncAttributeMaxDynamicSharedMemorySize, PackScore::FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_gather, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_livesum, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   if (const char* e = getenv("GNNB_NO_RESTRICT")) h->restrict_last = !(e[0] == '1');
   if (const char* e = getenv("GNNB_NO_DENSE_LDS")) h->dense_lds = !(e[0] == '1');
   HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1770,6 +1879,8 @@ extern "C" int gnnb_bind_network(gnnb_t* h, const gnnb_layer_desc* L, int n, int
   for (int k = 1; k <= Lr; ++k) h->R += h->N[k];
   h->dev.resize(Lr + 1);
   h->proj.assign(Lr + 2, -1);
+  for (int k = 0; k <= Lr; ++k)
+    if (h->N[k] > LIVESUM_MAXSRC) return fail(GNNB_E_INVALID, "graph layer %d has %d nodes, more than the %d k_livesum holds in LDS", k, h->N[k], LIVESUM_MAXSRC);
   for (int k = 1; k <= Lr; ++k) {
     const Edge& e = h->edges[k];
     DevEdge& d = h->dev[k];
@@ -1918,6 +2029,7 @@ extern "C" int gnnb_describe(const gnnb_t* h, char* buf, size_t cap) {
 // ---- workspace layout (float offsets, every region 256-B aligned) ----
 struct WsLayout {
   std::vector<size_t> mu, Pf, Pb, live, amb, score;
+  std::vector<size_t> lf;       // live flags (B, N_k) as floats
   std::vector<size_t> sf, sb;   // k_livesum outputs: sf[k] (B, N_k) over edge k, sb[k] (B, N_k) over edge k+1 transposed
   size_t cnt = 0, nb = 0, Q = 0, total = 0;
 };
@@ -1940,7 +2052,8 @@ static WsLayout ws_layout(const gnnb_t* h, int B) {
     w.amb[k] = off; off += align64((size_t)B * h->N[k]);
     w.score[k] = off; off += align64((size_t)B * h->N[k]);
   }
-  w.sf.assign(K, 0); w.sb.assign(K, 0);
+  w.sf.assign(K, 0); w.sb.assign(K, 0); w.lf.assign(K, 0);
+  for (int k = 1; k < K; ++k) { w.lf[k] = off; off += align64((size_t)B * h->N[k]); }
   for (int k = 1; k < K; ++k) { w.sf[k] = off; off += align64((size_t)B * h->N[k]); }
   for (int k = 0; k < K - 1; ++k) { w.sb[k] = off; off += align64((size_t)B * h->N[k]); }
   w.Q = off; off += (size_t)map_tiles(bwd_map(h, 0), B) * 2048;
@@ -2100,6 +2213,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       const int i = k - 1;
       a.lb[i] = in->lb[k]; a.ub[i] = in->ub[k]; a.mu[i] = mu(k);
       a.live[i] = ilist(w.live[k]); a.amb[i] = ilist(w.amb[k]); a.score[i] = ilist(w.score[k]);
+      a.livef[i] = ws + w.lf[k];
       a.G[i] = (long)B * h->N[k]; a.N[i] = h->N[k]; a.off[i] = roff[k];
       a.blk0[i] = blk;
       blk += (int)((a.G[i] + CLS_THREADS - 1) / CLS_THREADS);
@@ -2107,30 +2221,45 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     a.blk0[L] = blk;
     lz.run(PC_CLASSIFY, [&] { hipLaunchKernelGGL(k_classify, dim3((unsigned)blk), dim3(CLS_THREADS), 0, st, a); });
   }
+
   {   // bias-sum scalars of every edge and direction (the rows carry deferred projections)
     LiveSumArgs a{};
     a.B = B;
-    int blk = 0, q = 0;
-    auto push = [&](int kind, const Edge& e, const float* wt, int ld, const float* lbs, const float* ubs, float* out, int Ndst, int Nsrc, int normalise) {
+    int q = 0, maxw = 0;
+    auto push = [&](int kind, const Edge& e, const float* wt, int ld, const float* lf, float* out, int Ndst, int Nsrc, int normalise) {
       LiveSumJob& j = a.job[q++];
-      j.kind = kind; j.w = wt; j.lbs = lbs; j.ubs = ubs; j.out = out; j.Ndst = Ndst; j.Nsrc = Nsrc; j.ld = ld; j.normalise = normalise;
+      j.kind = kind; j.w = wt; j.lf = lf; j.out = out; j.Ndst = Ndst; j.Nsrc = Nsrc; j.ld = ld; j.normalise = normalise;
       j.c_in = e.c_in; j.h_in = e.h_in; j.w_in = e.w_in; j.c_out = e.c_out; j.h_out = e.h_out; j.w_out = e.w_out;
-      j.kh = e.kh; j.kw = e.kw; j.stride = e.stride; j.pad = e.pad; j.blk0 = blk;
-      blk += (int)(((long)B * Ndst + 255) / 256);
+      j.kh = e.kh; j.kw = e.kw; j.stride = e.stride; j.pad = e.pad;
+      const long nw = (long)e.c_in * e.c_out * e.kh * e.kw;
+      j.wlds = (e.kind == 0 && nw <= LIVESUM_MAXW) ? (int)nw : 0;
+      maxw = std::max(maxw, j.wlds);
     };
     for (int k = 1; k <= L; ++k) {            // forward edge k: source layer k-1 (the input layer is all live)
       const Edge& e = h->edges[k];
-      push(e.kind == 0 ? 0 : 1, e, h->dev[k].w_fwd, h->dev[k].ld_fwd, k > 1 ? in->lb[k - 1] : nullptr, k > 1 ? in->ub[k - 1] : nullptr,
+      push(e.kind == 0 ? 0 : 1, e, e.kind == 0 ? h->dev[k].w_fwd : h->dev[k].w_bwd, h->dev[k].ld_bwd, k > 1 ? ws + w.lf[k - 1] : nullptr,
            ws + w.sf[k], h->N[k], h->N[k - 1], 0);
     }
     if (limit >= 2)
       for (int k = 0; k < L; ++k) {           // edge k+1 transposed: source layer k+1
         const Edge& e = h->edges[k + 1];
-        push(e.kind == 0 ? 2 : 3, e, h->dev[k + 1].w_bwd, h->dev[k + 1].ld_bwd, in->lb[k + 1], in->ub[k + 1], ws + w.sb[k], h->N[k], h->N[k + 1],
+        push(e.kind == 0 ? 2 : 3, e, h->dev[k + 1].w_bwd, h->dev[k + 1].ld_bwd, ws + w.lf[k + 1], ws + w.sb[k], h->N[k], h->N[k + 1],
              k >= 1 ? 1 : 0);
       }
     a.njobs = q;
-    lz.run(PC_LIVESUM, [&] { hipLaunchKernelGGL(k_livesum, dim3((unsigned)blk), dim3(256), 0, st, a); });
+    if (const char* e = getenv("GNNB_LS_ONLY")) {       // dev: time one job (results are wrong)
+      const int only = atoi(e);
+      if (only >= 0 && only < q) { a.job[0] = a.job[only]; q = 1; a.njobs = 1; }
+    }
+    int maxn = 0;
+    for (int k = 0; k <= L; ++k) maxn = std::max(maxn, h->N[k]);
+    a.lv_floats = (maxn + 3) & ~3;
+    if ((size_t)(a.lv_floats + maxw) * 4 > 160 * 1024) {      // very wide layers: leave the weights in global memory
+      for (int i = 0; i < q; ++i) a.job[i].wlds = 0;
+      maxw = 0;
+    }
+    // (running this and k_pre on a side stream under k_embed / the first aggregation was measured: 1.72 ms vs 1.59 ms in-line)
+    lz.run(PC_LIVESUM, [&] { hipLaunchKernelGGL(k_livesum, dim3((unsigned)B, (unsigned)q), dim3(256), (size_t)(a.lv_floats + maxw) * sizeof(float), st, a); });
   }
   {
     const long G = (long)B * h->N[0];
