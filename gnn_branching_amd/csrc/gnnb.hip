@@ -420,7 +420,9 @@ struct PreAllArgs {       // hoisted feature chains of every ReLU layer, forward
   int N[MAXL], hw[MAXL];
 };
 
-// tile space: for k = 0..L-1: ceil(c_k/32) forward tiles, then (do_bwd) ceil(c_k/32) backward tiles
+// tile space: (do_bwd) the backward tiles of all layers, ceil(c_k/32) each, then the forward tiles of all layers: a
+// backward tile is 456 MFMAs, a forward tile 136, and there are only a few tiles per wave, so the strided dealing below
+// hands every wave its share of the long ones first
 //   forward  P'_f[g] = fc4[:, :64] . fc1_1(relu(fc1(feat7))) + bcb_f                           graph_conv.py:153-161,176-177
 //   backward P'_b[g] = bc4[:, :64] . bc2_1(relu(bc2([s, -d2 s, d1 s]))) + bcb_b,
 //            s = bc1_2(relu(bc1_1(relu(bc1(feat7')))))                                        graph_conv.py:273-293,344-345
@@ -431,22 +433,19 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_pre(PreAllArgs a) {
   copy_to_lds(lds_b, a.pack_b, PackPreBwd::FLOATS);
   stage_pack(lds, a.pack_f, PackPreFwd::FLOATS);
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
-  long ntiles = 0;
-  for (int k = 0; k < a.L; ++k) ntiles += (long)((a.cnt[4 * k + 1] + 31) / 32) * (a.do_bwd ? 2 : 1);
-  for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < ntiles; tile += (long)gridDim.x * WAVES_MLP) {
+  long nhalf = 0;
+  for (int k = 0; k < a.L; ++k) nhalf += (long)((a.cnt[4 * k + 1] + 31) / 32);
+  const long ntiles = nhalf * (a.do_bwd ? 2 : 1);
+  for (long tile = (long)wave * gridDim.x + blockIdx.x; tile < ntiles; tile += (long)gridDim.x * WAVES_MLP) {
     // which layer / direction (wave-uniform)
+    const bool bwd = a.do_bwd && tile < nhalf;
     int k = 0, count = 0;
-    long t = tile;
-    bool bwd = false;
+    long t = (a.do_bwd && !bwd) ? tile - nhalf : tile;
     for (; k < a.L; ++k) {
       count = a.cnt[4 * k + 1];
       const long tk = (count + 31) / 32;
-      if (t < tk) { bwd = false; break; }
+      if (t < tk) break;
       t -= tk;
-      if (a.do_bwd) {
-        if (t < tk) { bwd = true; break; }
-        t -= tk;
-      }
     }
     const long idx = t * 32 + j;
     const bool valid = idx < count;
