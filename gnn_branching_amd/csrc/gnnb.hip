@@ -1132,15 +1132,18 @@ struct DenseLArgs {
 };
 
 #define DL_CH 8
-// forward edge (long K): 8 waves = 4 row tiles x 2 K-halves; X streams through LDS in double-buffered chunks of
-// 2 x 32 rows (one slab per K-half), the two halves are summed through LDS in a fixed order.  Requires MT <= 4.
-__global__ __launch_bounds__(512, 2) void k_dense_fwd_lds(DenseLArgs a) {
-  __shared__ __attribute__((aligned(16))) float xs[2][2][32][64];      // [buffer][K-half][row][channel]  32 KB
-  __shared__ float red[4][32][64];                                       // 32 KB
+#define DENSE_FWD_LDS_FLOATS (2 * 2 * 32 * 64 + 4 * 32 * 64)     // xs + red = 64 KB
+#define DENSE_BWD_ROWS (128 + 16)
+// forward edge (long K) of sample b: 8 waves = 4 row tiles x 2 K-halves; X streams through LDS in double-buffered chunks
+// of 2 x 32 rows (one slab per K-half), the two halves are summed through LDS in a fixed order.  Requires MT <= 4 and 512
+// threads.  `scratch`: DENSE_FWD_LDS_FLOATS floats of LDS; store(row, channel pair index j, value pair).
+template <class Store>
+__device__ __forceinline__ void dense_fwd_sample(const DenseLArgs& a, int b, float* scratch, Store store) {
+  float (*xs)[2][32][64] = reinterpret_cast<float (*)[2][32][64]>(scratch);                 // [buffer][K-half][row][channel]  32 KB
+  float (*red)[32][64] = reinterpret_cast<float (*)[32][64]>(scratch + 2 * 2 * 32 * 64);    // 32 KB
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int mt = wave & 3, kh = wave >> 2;
-  const int b = blockIdx.x;
   const int khalf = a.Kpad / 2;                  // rows per K-half, a multiple of 32
   const int nchunks = khalf / 32;
   const float* Xb = a.X + (long)b * a.K * 64;
@@ -1197,29 +1200,28 @@ __global__ __launch_bounds__(512, 2) void k_dense_fwd_lds(DenseLArgs a) {
   }
   __syncthreads();
   if (kh == 0 && mt < a.MT) {
-    float* out = a.out + (long)b * a.M * 64 + 2 * j;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (row < a.M) *reinterpret_cast<float2*>(out + (long)row * 64) = make_float2(acc0[r] + red[mt][r][lane], acc1[r] + red[mt][16 + r][lane]);
+      if (row < a.M) store(row, j, make_float2(acc0[r] + red[mt][r][lane], acc1[r] + red[mt][16 + r][lane]));
     }
   }
 }
 
-// transposed edge (short K <= 128): the whole source layer of the sample sits in LDS; 8 waves walk the MT row tiles.
-__global__ __launch_bounds__(512, 2) void k_dense_bwd_lds(DenseLArgs a) {
-  __shared__ __attribute__((aligned(16))) float xs[128 + 16][64];       // 36 KB, rows >= K are zero
+__global__ __launch_bounds__(512, 2) void k_dense_fwd_lds(DenseLArgs a) {
+  __shared__ __attribute__((aligned(16))) float scratch[DENSE_FWD_LDS_FLOATS];
+  const int b = blockIdx.x;
+  float* out = a.out + (long)b * a.M * 64;
+  dense_fwd_sample(a, b, scratch, [&](int row, int j, float2 v) { *reinterpret_cast<float2*>(out + (long)row * 64 + 2 * j) = v; });
+}
+
+// transposed edge (short K <= 128) of one sample whose source rows sit in LDS (`xs`: DENSE_BWD_ROWS x 64, rows >= K zero);
+// 8 waves walk the MT row tiles.
+template <class Store>
+__device__ __forceinline__ void dense_bwd_sample(const DenseLArgs& a, const float* xs_raw, Store store) {
+  const float (*xs)[64] = reinterpret_cast<const float (*)[64]>(xs_raw);
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int b = blockIdx.x;
-  const float* Xb = a.X + (long)b * a.K * 64;
-  for (int e = threadIdx.x; e < (128 + 16) * 16; e += 512) {
-    const int row = e >> 4, piece = e & 15;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (row < a.K) v = *reinterpret_cast<const f32x4*>(Xb + (long)row * 64 + piece * 4);
-    *reinterpret_cast<f32x4*>(&xs[row][piece * 4]) = v;
-  }
-  __syncthreads();
   const int nch = a.Kpad / 16;                       // chunks of 8 k-steps
   for (int mt = wave; mt < a.MT; mt += 8) {
     const float* At = a.At + mt * 32 + j;
@@ -1253,13 +1255,27 @@ __global__ __launch_bounds__(512, 2) void k_dense_bwd_lds(DenseLArgs a) {
       __builtin_amdgcn_sched_barrier(0);
     }
     if (nch & 1) mma(av, c);
-    float* out = a.out + (long)b * a.M * 64 + 2 * j;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (row < a.M) *reinterpret_cast<float2*>(out + (long)row * 64) = make_float2(acc0[r], acc1[r]);
+      if (row < a.M) store(row, j, make_float2(acc0[r], acc1[r]));
     }
   }
+}
+
+__global__ __launch_bounds__(512, 2) void k_dense_bwd_lds(DenseLArgs a) {
+  __shared__ __attribute__((aligned(16))) float xs[DENSE_BWD_ROWS][64];       // 36 KB, rows >= K are zero
+  const int b = blockIdx.x;
+  const float* Xb = a.X + (long)b * a.K * 64;
+  for (int e = threadIdx.x; e < DENSE_BWD_ROWS * 16; e += 512) {
+    const int row = e >> 4, piece = e & 15;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < a.K) v = *reinterpret_cast<const f32x4*>(Xb + (long)row * 64 + piece * 4);
+    *reinterpret_cast<f32x4*>(&xs[row][piece * 4]) = v;
+  }
+  __syncthreads();
+  float* out = a.out + (long)b * a.M * 64;
+  dense_bwd_sample(a, &xs[0][0], [&](int row, int j, float2 v) { *reinterpret_cast<float2*>(out + (long)row * 64 + 2 * j) = v; });
 }
 
 struct PropArgs {
@@ -1332,6 +1348,200 @@ __global__ __launch_bounds__(256) void k_prop(PropArgs a) {
     float* nbk = a.nb_back + (long)b * a.N_last * 64 + lane;
     for (int n = w; n < a.N_last; n += 4) nbk[(long)n * 64] = pw[n] * o;
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_top: the top of the network in one launch per round, one workgroup (8 waves) per sample.  When the last ReLU layer
+// hangs on a Linear edge and has <= 128 nodes, everything between "layer L-1 forward-updated" and "layer L-1 can be
+// backward-updated" is local to a sample and tiny:
+//   F1  nb_L   = W_L . mu_{L-1}                        (dense forward edge, graph_conv.py:130-137)
+//   F2  mu_L   <- forward node update                  (:139-186)
+//   F3  mu_K   <- property node, nb_back = W_prop^T mu_K  (:194-210, :324-326)
+//   B1  mu_L   <- backward node update                 (:253-350)
+//   B2  nb_{L-1} = W_L^T . mu_L                        (dense transposed edge, :320-322)
+// As five launches these cost ~160 us of mostly launch ramps, weight staging and latency; here the layer's rows never
+// leave LDS.  LDS map (floats): A = weight pack of the running phase (first the dense-forward staging buffers),
+// Bp = PackProp, C = the rows of layer L (DENSE_BWD_ROWS x 64, rows >= N zero), sm = small vectors.
+// ------------------------------------------------------------------------------------------
+struct TopArgs {
+  DenseLArgs df;            // forward edge L (out unused)
+  DenseLArgs db;            // transposed edge L (X unused: the rows come from LDS), out = aggregate rows of layer L-1
+  const float *pack_f, *pack_b, *pack_p;
+  const float *Pf, *Pb;     // cached P' rows of layer L (by node id), forward / backward
+  const float* sf;          // bias-sum scalars of the forward edge (B, N)
+  const float *lb, *ub;     // bounds of layer L, flat (B*N)
+  const float *prop_w, *prop_b, *lbK, *ubK, *z_out;
+  float* mu_prop;           // (B, 64)
+  float* mu;                // (B, N, 64) rows of layer L (backward-produced)
+  int* status;
+  int N;
+};
+#define TOP_A_FLOATS (PackUpd::FLOATS > DENSE_FWD_LDS_FLOATS ? PackUpd::FLOATS : DENSE_FWD_LDS_FLOATS)
+#define TOP_LDS_FLOATS (TOP_A_FLOATS + PackProp::FLOATS + DENSE_BWD_ROWS * 64 + 8 * 64 + 128 + 64 + 64)
+
+__device__ __forceinline__ void copy_to_lds_part(float* lds, const float* src, int nfloats, int tid, int nthr) {
+  const f32x4* g = reinterpret_cast<const f32x4*>(src);
+  f32x4* l = reinterpret_cast<f32x4*>(lds);
+  const int n4 = nfloats / 4;
+  for (int i0 = tid; i0 < n4; i0 += 8 * nthr) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * nthr;
+      v[u] = g[i < n4 ? i : i0];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * nthr;
+      if (i < n4) l[i] = v[u];
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 1) void k_top(TopArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* A = lds;
+  float* Bp = A + TOP_A_FLOATS;
+  float* Cr = Bp + PackProp::FLOATS;
+  float* part = Cr + DENSE_BWD_ROWS * 64;     // [8][64]
+  float* xs = part + 8 * 64;                  // [128]
+  float* outv = xs + 128;                     // [64]
+  float* spart = outv + 64;                   // [8]
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x, N = a.N;
+  for (int i = tid; i < DENSE_BWD_ROWS * 16; i += 512) reinterpret_cast<f32x4*>(Cr)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  copy_to_lds(Bp, a.pack_p, PackProp::FLOATS);
+  __syncthreads();
+
+  // ---- F1: rows of C <- W_L . mu_{L-1}
+  dense_fwd_sample(a.df, b, A, [&](int row, int jj, float2 v) { *reinterpret_cast<float2*>(Cr + row * 64 + 2 * jj) = v; });
+  __syncthreads();
+
+  // per-lane node of the update phases (waves 0..3: one tile of 32 nodes each)
+  const int n = wave * 32 + j;
+  const bool upd_wave = wave * 32 < N;
+  const bool valid = n < N;
+  const long g = (long)b * N + (valid ? n : 0);
+  const float* pw = a.prop_w + (long)b * N;
+  Ratio r{};
+  if (upd_wave) r = compute_ratio(a.lb[g], a.ub[g]);
+  auto load_row = [&](Frag& x_, int row) {       // fragment <- LDS row (row-major 64 floats)
+    const f32x4* p = reinterpret_cast<const f32x4*>(Cr + row * 64 + 4 * h);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const f32x4 v = p[2 * q];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) FRAG_AT(x_, 4 * q + c) = v[c];
+    }
+  };
+  auto store_row = [&](const Frag& x_, float* base) {
+    f32x4* p = reinterpret_cast<f32x4*>(base + 4 * h);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      f32x4 v;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = FRAG_AT(x_, 4 * q + c);
+      p[2 * q] = v;
+    }
+  };
+  // general folded node chain on fragment X (k_node_update, kind 1); `sx`: small k-step input of a deferred projection
+  auto chain = [&](const Frag& X, const float* Prow, bool deferred, float sx, Frag& H2) {
+    Frag H;
+    frag_bias(H, A + PackUpd::BA, h);
+    if (deferred) {
+      const float x1[1] = {sx};
+      gemm_small<1>(A + PackUpd::VAW, lane, H, x1);
+    }
+    const float r0 = r.r0, r1 = r.r1;
+    gemm_w64<64>(A + PackUpd::WA, lane, H, [&](int s) { return FRAG_AT(X, s & 31) * (s < 32 ? r0 : r1); });
+    frag_relu(H);
+    frag_load_rowptr(H2, Prow, h);
+    gemm_w64<32>(A + PackUpd::WCB, lane, H2, [&](int s) { return FRAG_AT(H, s); });
+    frag_relu(H2);
+    frag_scale(H2, r.live);
+  };
+
+  // ---- F2: forward node update of layer L (rows stay in C)
+  stage_pack(A, a.pack_f, PackUpd::FLOATS);
+  if (upd_wave) {
+    Frag X, E;
+    load_row(X, valid ? n : 0);
+    chain(X, r.amb != 0.0f ? a.Pf + g * 64 : a.pack_f + PackUpd::BCBROW, true, (h ? r.r1 : r.r0) * a.sf[g], E);
+    if (valid) {
+      if (frag_has_nan(E)) atomicOr(a.status, 1);
+      store_row(E, Cr + n * 64);
+    }
+  }
+  __syncthreads();
+
+  // ---- F3: property node (k_prop) on the rows in C; meanwhile waves 1..7 stage the backward pack
+  {
+    float acc = 0.0f;
+    for (int m = wave; m < N; m += 8) acc = fmaf(pw[m], Cr[m * 64 + lane], acc);
+    part[wave * 64 + lane] = acc;
+    float sp = 0.0f;
+    for (int m = tid; m < N; m += 512) {
+      const long gm = (long)b * N + m;
+      sp += node_is_live(a.lb[gm], a.ub[gm]) ? pw[m] : 0.0f;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sp += __shfl_xor(sp, o);
+    if (lane == 0) spart[wave] = sp;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float nbv = 0.0f, spt = 0.0f;
+#pragma unroll
+    for (int w8 = 0; w8 < 8; ++w8) { nbv += part[w8 * 64 + lane]; spt += spart[w8]; }
+    const float f[4] = {a.lbK[b], a.ubK[b], a.z_out[b], a.prop_b[b]};
+    float h1 = Bp[PackProp::B1 + lane];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) h1 = fmaf(Bp[PackProp::W1T + k * 64 + lane], f[k], h1);
+    xs[lane] = relu_nan(h1);
+    xs[64 + lane] = nbv;
+    __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): this wave's LDS writes are visible to its own reads
+    float h2 = fmaf(spt, Bp[PackProp::V2 + lane], Bp[PackProp::B2 + lane]);
+#pragma unroll 8
+    for (int k = 0; k < 128; ++k) h2 = fmaf(Bp[PackProp::W2T + k * 64 + lane], xs[k], h2);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    xs[lane] = relu_nan(h2);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    float o = Bp[PackProp::B3 + lane];
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) o = fmaf(Bp[PackProp::W3T + k * 64 + lane], xs[k], o);
+    a.mu_prop[(long)b * 64 + lane] = o;
+    outv[lane] = o;
+  } else {
+    copy_to_lds_part(A, a.pack_b, PackUpd::FLOATS, tid - 64, 448);
+  }
+  __syncthreads();
+
+  // ---- B1: backward node update of layer L; its aggregate is the rank-1 edge from the property node
+  if (upd_wave) {
+    Frag X, E;
+    const float wn = valid ? pw[n] : 0.0f;
+    {
+      const f32x4* o4 = reinterpret_cast<const f32x4*>(outv + 4 * h);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const f32x4 v = o4[2 * q];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) FRAG_AT(X, 4 * q + c) = wn * v[c];
+      }
+    }
+    chain(X, r.amb != 0.0f ? a.Pb + g * 64 : a.pack_b + PackUpd::BCBROW, false, 0.0f, E);
+    if (valid) {
+      if (frag_has_nan(E)) atomicOr(a.status, 1);
+      store_row(E, Cr + n * 64);
+      store_row(E, a.mu + g * 64);
+    }
+  }
+  __syncthreads();
+
+  // ---- B2: aggregate rows of layer L-1 <- W_L^T . rows of C
+  float* out = a.db.out + (long)b * a.db.M * 64;
+  dense_bwd_sample(a.db, Cr, [&](int row, int jj, float2 v) { *reinterpret_cast<float2*>(out + (long)row * 64 + 2 * jj) = v; });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1657,11 +1867,11 @@ static int fail(int code, const char* fmt, ...) {
 
 enum ProfClass {
   PC_EMBED, PC_PRE, PC_PRE_INP, PC_CONV_FWD, PC_CONVT_BWD, PC_DENSE_AGG, PC_PROP_FWD,
-  PC_NODE_UPDATE, PC_INPUT_UPDATE, PC_SCORE, PC_ARGMAX, PC_GATHER, PC_GATHER_INPUT, PC_CLASSIFY, PC_LIVESUM, PC_COUNT
+  PC_NODE_UPDATE, PC_INPUT_UPDATE, PC_SCORE, PC_ARGMAX, PC_GATHER, PC_GATHER_INPUT, PC_CLASSIFY, PC_LIVESUM, PC_TOP, PC_COUNT
 };
 static const char* kProfNames[PC_COUNT] = {
     "k_embed", "k_pre", "k_pre_inp", "k_conv_fwd", "k_convT_bwd", "k_dense_agg", "k_prop",
-    "k_node_update", "k_input_update", "k_score", "k_argmax", "k_gather", "k_gather_input_update", "k_classify", "k_livesum"};
+    "k_node_update", "k_input_update", "k_score", "k_argmax", "k_gather", "k_gather_input_update", "k_classify", "k_livesum", "k_top"};
 
 struct DevEdge {
   float *w_fwd = nullptr, *w_bwd = nullptr, *bias = nullptr;   // conv: tap-major copies; linear: W^T / W, zero-padded
@@ -1685,6 +1895,7 @@ struct gnnb_handle {
   int gather_occ = 2;           // workgroups per CU for k_gather (its LDS footprint is only the tap matrix)
   bool dense_lds = true;        // Linear edges: one workgroup per sample with the source rows in LDS (false: per-tile kernel)
   bool restrict_last = true;    // last backward step of layer 1 only for the scored nodes (nothing else reads it)
+  bool use_top = true;          // fuse the top of the network (last Linear edge, last ReLU layer, property node) into k_top
   Packs packs;
   float* d_pack[N_PACKS] = {nullptr};
   float* d_zero = nullptr;      // 64 zero floats: where masked gather loads point
@@ -1762,6 +1973,8 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   if (const char* e = getenv("GNNB_NO_DENSE_LDS")) h->dense_lds = !(e[0] == '1');
   HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   if (const char* e = getenv("GNNB_NO_GATHER")) h->use_gather = !(e[0] == '1');
+  if (const char* e = getenv("GNNB_NO_TOP")) h->use_top = !(e[0] == '1');
+  HIPCHK(hipFuncSetAttribute((const void*)k_top, hipFuncAttributeMaxDynamicSharedMemorySize, TOP_LDS_FLOATS * 4));
   *out = h;
   return GNNB_OK;
 }
@@ -2409,8 +2622,41 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     lz.run(PC_INPUT_UPDATE, [&] { hipLaunchKernelGGL(k_input_update, dim3(mlp_grid(h, nt)), dim3(WG_MLP), PackUpdInp::FLOATS * 4, st, a); });
   };
 
+  // the top of the network as one launch per round (k_top); with a half-pass limit (inspection) the separate kernels run
+  const bool top_fused = h->use_top && !debug_full && L >= 2 && h->edges[L].kind == 1 && h->N[L] <= 128 && h->dense_lds &&
+                         h->dev[L].mt_fwd <= 4 && h->dev[L].kpad_bwd <= 128;
+  auto top = [&]() {
+    const Edge& e = h->edges[L];
+    const DevEdge& de = h->dev[L];
+    TopArgs a{};
+    a.df = DenseLArgs{de.w_fwd, mu(L - 1), nullptr, B, e.n_in, e.n_out, de.ld_fwd, de.mt_fwd, de.kpad_fwd};
+    a.db = DenseLArgs{de.w_bwd, nullptr, nb, B, e.n_out, e.n_in, de.ld_bwd, de.mt_bwd, de.kpad_bwd};
+    a.pack_f = h->d_pack[PK_UPD_FWD_F]; a.pack_b = h->d_pack[PK_UPD_BWD]; a.pack_p = h->d_pack[PK_PROP];
+    a.Pf = ws + w.Pf[L]; a.Pb = ws + w.Pb[L]; a.sf = ws + w.sf[L];
+    a.lb = in->lb[L]; a.ub = in->ub[L];
+    a.prop_w = in->prop_w; a.prop_b = in->prop_b; a.lbK = in->lb[K]; a.ubK = in->ub[K]; a.z_out = in->primal[in->n_primal - 1];
+    a.mu_prop = mu(K); a.mu = mu(L); a.status = status; a.N = h->N[L];
+    lz.run(PC_TOP, [&] { hipLaunchKernelGGL(k_top, dim3(B), dim3(512), TOP_LDS_FLOATS * 4, st, a); });
+    h->proj[L] = L_BC4_1;
+  };
+
   int done = 0;
   for (int t = 0; t < h->T && done < limit; ++t) {
+    if (top_fused) {
+      for (int k = 1; k < L; ++k) {
+        agg_fwd(k);
+        node_update(k, true, false);
+      }
+      top();                                     // F1 .. B2: both half-passes of layer L, aggregate of layer L-1 in `nb`
+      for (int k = L - 1; k >= 1; --k) {
+        const bool scored = h->restrict_last && t == h->T - 1 && k == 1;
+        if (k < L - 1) agg_bwd(k, 1, scored);
+        node_update(k, false, scored);
+      }
+      if (t < h->T - 1) update_input();
+      done += 2;
+      continue;
+    }
     // forward sweep (graph_conv.py:107-192) + property node (:194-210)
     for (int k = 1; k <= L; ++k) {
       agg_fwd(k);

@@ -171,6 +171,21 @@ def test_per_tile_dense_kernel_path_matches(monkeypatch):
     assert res.decisions.cpu().tolist() == g["random_decisions"].tolist()
 
 
+@pytest.mark.parametrize("case", ["cifar_base_kw_B3", "cifar_deep_kw_B2"])
+def test_separate_top_kernels_path_matches(monkeypatch, case):
+    """GNNB_NO_TOP=1 runs the top of the network (last Linear edge, last ReLU layer, property node) as its separate
+    kernels instead of the fused k_top: same scores (the embeddings-after-every-half-pass test also takes this path)."""
+    monkeypatch.setenv("GNNB_NO_TOP", "1")
+    g, batch = load_golden(case)
+    model = make_model("random")
+    with torch.no_grad():
+        res = model.forward_device(*batch.forward_args()).check()
+    want = g["random_scores"]
+    fin = np.isfinite(want)
+    assert np.abs(res.scores.cpu().numpy()[fin] - want[fin]).max() <= SCORE_ATOL
+    assert res.decisions.cpu().tolist() == g["random_decisions"].tolist()
+
+
 def test_two_stream_batch_pipelining_is_bit_identical():
     """engine.n_streams = 2 cuts a large batch into two chunks on two HIP streams: identical bytes out."""
     from gnn_branching_amd import synth
