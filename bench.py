@@ -30,6 +30,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32, same guide
 
 MFMA_FLOP = 2 * 32 * 32 * 2          # one v_mfma_f32_32x32x2_f32
 MLP_MACS_PER_NODE = 128 * 64 + 3 * 64 * 64   # fc3|bc3, fc3_2|bc3_1, 2nd half of fc4|bc4, fc4_2|bc4_1 (SURVEY 8(d) minus the hoisted feature chains)
+AGGREGATION_KERNELS = ("k_gather", "k_conv_fwd", "k_convT_bwd", "k_dense_agg")   # edge aggregation = message passing: HBM-bound
 
 
 def node_stats(batch):
@@ -51,7 +52,7 @@ def plan_flops(plan, B, stats, restrict_last=True):
     are updated, sparse edge sums 2*nnz*p) and issued MFMA flops (instructions x 4096, incl. tile padding and the
     zeros of the dense gather blocks)."""
     T = plan["T"]
-    alg, issued = {}, {}
+    alg, issued, agg_bytes = {}, {}, {}
 
     def add(d, k, v):
         d[k] = d.get(k, 0.0) + v
@@ -77,8 +78,12 @@ def plan_flops(plan, B, stats, restrict_last=True):
             restricted = restrict_last and u["update"] == "bwd" and k == 1 and t == T - 1
             n_upd = stats[k]["scored"] if restricted else stats[k]["live"]
             add(alg, upd, 2.0 * MLP_MACS_PER_NODE * n_upd)
+            # message passing of this half-pass: every source row read once, every updated row written once
+            add(agg_bytes, agg, 4.0 * 64 * (B * u["n_src"] + n_upd))
             # folded chains, last layer deferred: 128 (+2) MFMAs per tile of live non-ambiguous nodes, 192 (+2) per tile of general nodes
-            if restricted:
+            if upd == "k_top":                   # one workgroup per sample: every node of the layer through the general chain
+                add(issued, upd, MFMA_FLOP * B * tiles(u["nodes"]) * 194)
+            elif restricted:
                 add(issued, upd, MFMA_FLOP * tiles(n_upd) * 194)
             else:
                 add(issued, upd, MFMA_FLOP * (tiles(stats[k]["live"] - stats[k]["amb"]) * 130 + tiles(stats[k]["amb"]) * 194))
@@ -86,6 +91,8 @@ def plan_flops(plan, B, stats, restrict_last=True):
             add(alg, agg, 2.0 * nnz * 64 * frac)
             if agg == "k_gather":
                 add(issued, agg, MFMA_FLOP * u["tiles_per_sample"] * B * 2 * u["gather_ksteps"])
+            elif agg == "k_top" and u["n_src"] > 1:      # dense edge on the MFMA: row tiles x k-steps x 2 channel halves
+                add(issued, agg, MFMA_FLOP * B * tiles(u["nodes"]) * ((u["n_src"] + 1) // 2) * 2)
     for k, st in stats.items():
         add(alg, "k_pre_fwd", 2.0 * (7 * 64 + 2 * 64 * 64) * st["amb"])
         add(issued, "k_pre_fwd", MFMA_FLOP * tiles(st["amb"]) * 136)
@@ -93,7 +100,7 @@ def plan_flops(plan, B, stats, restrict_last=True):
         add(issued, "k_pre_bwd", MFMA_FLOP * tiles(st["amb"]) * 456)
         add(alg, "k_score", 2.0 * (64 * 64 + 64) * st["scored"])
         add(issued, "k_score", MFMA_FLOP * tiles(st["scored"]) * 64)
-    return alg, issued
+    return alg, issued, agg_bytes
 
 
 def message_passing_bytes(sizes, B, T):
@@ -214,7 +221,7 @@ def main():
         dom = max(kern, key=lambda k: kern[k]["ms_total"])
         plan = eng.describe()
         stats = node_stats(batch)
-        alg, issued = plan_flops(plan, B, stats)
+        alg, issued, agg_bytes = plan_flops(plan, B, stats)
         dom_s = prof[dom][0] * 1e-3 / args.steps            # seconds of the dominant kernel class per forward
         # HBM traffic of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
         # (tools/pmc.sh + tools/pmc_table.py: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, gfx950 correction applied)
@@ -224,15 +231,36 @@ def main():
             traffic = json.load(open(pmc_path)).get(dom, {}).get("hbm_bytes_per_launch")
         ach_tf = alg.get(dom, 0.0) / dom_s / 1e12 if dom_s > 0 else 0.0
         iss_tf = issued.get(dom, 0.0) / dom_s / 1e12 if dom_s > 0 else 0.0
-        roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                    "avg_launch_us": kern[dom]["avg_us"], "launches_per_step": kern[dom]["launches"] // args.steps,
-                    "algorithmic_gflop_per_step": round(alg.get(dom, 0.0) / 1e9, 2),
-                    "issued_mfma_tflops": round(iss_tf, 2), "issued_mfma_frac": round(iss_tf / PEAK_F32_MFMA_TFLOPS, 4)}
+        launches = kern[dom]["launches"] // args.steps
+        if dom in AGGREGATION_KERNELS:
+            # an edge-aggregation (message-passing) kernel: HBM-bound by SURVEY 8(d).  Algorithmic bytes per launch =
+            # 4*p*(source rows read once + updated destination rows written once), averaged over the class's launches.
+            ach_gbs = agg_bytes.get(dom, 0.0) / dom_s / 1e9 if dom_s > 0 else 0.0
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(ach_gbs / PEAK_HBM_GBS, 4), "traffic": traffic,
+                        "avg_launch_us": kern[dom]["avg_us"], "launches_per_step": launches,
+                        "algorithmic_bytes_per_launch": round(agg_bytes.get(dom, 0.0) / max(launches, 1)),
+                        "issued_mfma_tflops": round(iss_tf, 2), "issued_mfma_frac": round(iss_tf / PEAK_F32_MFMA_TFLOPS, 4)}
+        else:
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                        "avg_launch_us": kern[dom]["avg_us"], "launches_per_step": launches,
+                        "algorithmic_gflop_per_step": round(alg.get(dom, 0.0) / 1e9, 2),
+                        "issued_mfma_tflops": round(iss_tf, 2), "issued_mfma_frac": round(iss_tf / PEAK_F32_MFMA_TFLOPS, 4)}
+        # the node-update class next to it (fp32 MFMA bound), whichever of the two is dominant
+        nu_s = prof.get("k_node_update", (0.0, 0))[0] * 1e-3 / args.steps
+        roofline_nu = None
+        if nu_s > 0:
+            nu_tf = alg.get("k_node_update", 0.0) / nu_s / 1e12
+            nu_iss = issued.get("k_node_update", 0.0) / nu_s / 1e12
+            roofline_nu = {"kernel": "k_node_update", "bound": "mfma", "achieved": round(nu_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                           "unit": "TFLOP/s", "frac": round(nu_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                           "issued_mfma_tflops": round(nu_iss, 2), "issued_mfma_frac": round(nu_iss / PEAK_F32_MFMA_TFLOPS, 4),
+                           "note": "achieved = the reference's MACs for the updated nodes / time; issued = MFMA instructions after the folds"}
         # message passing is fused into the update kernels (the aggregate never reaches HBM): its algorithmic bytes
         # 4*p*(N_src+N_dst) per half-pass over the time of every kernel that performs an update
-        mp_names = ("k_gather", "k_gather_input_update", "k_conv_fwd", "k_convT_bwd", "k_dense_agg", "k_prop_fwd",
-                    "k_prop_bwd_nb", "k_node_update", "k_input_update")
+        mp_names = ("k_gather", "k_gather_input_update", "k_conv_fwd", "k_convT_bwd", "k_dense_agg", "k_prop", "k_top",
+                    "k_node_update", "k_input_update")
         mp_ms = sum(prof[k][0] for k in mp_names if k in prof)
         mp_bytes = message_passing_bytes(sizes, B, T) * args.steps
         mp_gbs = mp_bytes / (mp_ms * 1e-3) / 1e9 if mp_ms > 0 else 0.0
@@ -255,6 +283,7 @@ def main():
                        "ambiguous_per_subproblem": round(total_amb / (world * B), 1),
                        "parallelism": f"dp{world}" + (" + 1 all-gather(scores)/step" if world > 1 else "")},
             "roofline": roofline,
+            "roofline_node_update": roofline_nu,
             "roofline_message_passing": roofline_mp,
             "cpu_baseline": cpu,
             "kernels": kern,

@@ -823,7 +823,7 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_gather(GArgs a) {
     const long gc = tc.sample * a.tm.N + tc.n;
     bool need;
     if (a.need_scored) need = tc.valid && a.mask[tc.sample * a.R + a.off + tc.n] != 0.0f;
-    else need = tc.valid && node_is_live(a.lb[gc], a.ub[gc]);
+    else need = tc.valid && node_is_live(a.lb[gc], a.ub[gc]);    // (one load of k_classify's live flag instead: measured 1.7 % slower)
     if (!__any(need)) continue;
     const int wy0 = tc.by * a.g.ystep + a.g.ybase, wx0 = tc.bx * a.g.xstep + a.g.xbase;
     Frag X;
@@ -1896,6 +1896,7 @@ struct gnnb_handle {
   bool dense_lds = true;        // Linear edges: one workgroup per sample with the source rows in LDS (false: per-tile kernel)
   bool restrict_last = true;    // last backward step of layer 1 only for the scored nodes (nothing else reads it)
   bool use_top = true;          // fuse the top of the network (last Linear edge, last ReLU layer, property node) into k_top
+  bool top_ok = false;          // ... which the bound network allows (set by gnnb_bind_network)
   Packs packs;
   float* d_pack[N_PACKS] = {nullptr};
   float* d_zero = nullptr;      // 64 zero floats: where masked gather loads point
@@ -2126,6 +2127,7 @@ extern "C" int gnnb_bind_network(gnnb_t* h, const gnnb_layer_desc* L, int n, int
       if (int rc = upload(&d.w_bwd, t.data(), t.size())) return rc;
     }
   }
+  h->top_ok = Lr >= 2 && h->edges[Lr].kind == 1 && h->N[Lr] <= 128 && h->dense_lds && h->dev[Lr].mt_fwd <= 4 && h->dev[Lr].kpad_bwd <= 128;
   // MFMA gather tables for every conv edge, both directions (the input layer's transposed edge is not normalised)
   h->gf.assign(Lr + 1, DevGather());
   h->gb.assign(Lr + 1, DevGather());
@@ -2219,15 +2221,18 @@ extern "C" int gnnb_describe(const gnnb_t* h, char* buf, size_t cap) {
     }
     o += t;
   };
+  const bool top = h->use_top && h->top_ok;     // k_top covers the edge into layer L, both updates of layer L and the edge back
   bool first = true;
   for (int k = 1; k <= L; ++k) {
     if (!first) o += ", ";
     first = false;
-    item("fwd", k, &h->gf[k], h->edges[k].kind == 0 ? "k_conv_fwd+k_node_update" : "k_dense_agg+k_node_update", h->N[k - 1]);
+    if (top && k == L) item("fwd", k, nullptr, "k_top+k_top", h->N[k - 1]);
+    else item("fwd", k, &h->gf[k], h->edges[k].kind == 0 ? "k_conv_fwd+k_node_update" : "k_dense_agg+k_node_update", h->N[k - 1]);
   }
   for (int k = L; k >= 1; --k) {
     o += ", ";
-    if (k == L) item("bwd", k, nullptr, "k_prop+k_node_update", 1);
+    if (k == L) item("bwd", k, nullptr, top ? "k_top+k_top" : "k_prop+k_node_update", 1);
+    else if (top && k == L - 1) item("bwd", k, nullptr, "k_top+k_node_update", h->N[k + 1]);
     else item("bwd", k, &h->gb[k + 1], h->edges[k + 1].kind == 0 ? "k_convT_bwd+k_node_update" : "k_dense_agg+k_node_update", h->N[k + 1]);
   }
   o += ", ";
@@ -2623,8 +2628,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   };
 
   // the top of the network as one launch per round (k_top); with a half-pass limit (inspection) the separate kernels run
-  const bool top_fused = h->use_top && !debug_full && L >= 2 && h->edges[L].kind == 1 && h->N[L] <= 128 && h->dense_lds &&
-                         h->dev[L].mt_fwd <= 4 && h->dev[L].kpad_bwd <= 128;
+  const bool top_fused = h->use_top && h->top_ok && !debug_full;
   auto top = [&]() {
     const Edge& e = h->edges[L];
     const DevEdge& de = h->dev[L];
