@@ -1,6 +1,7 @@
 #!/bin/bash
 # dev helper (GPU box): collect SQ/TCC counters per dispatch in separate passes -> gpurun_out/pmc_<tag>/
 R=$GRAFT_REPO_ROOT; TAG=${1:-x}
+mkdir -p $R/gpurun_out/pmc_$TAG
 cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA" \
