@@ -748,6 +748,76 @@ __device__ __forceinline__ void gather_dispatch(Frag& X, const float* cm, const 
     gather_tile<false>(X, cm, ko, kvo, g.K2, rsrc, j, uy, ux, g.Hs, g.Ws, lane);
 }
 
+// Round 0, forward edge into ReLU layer 1: the source rows are the input embedding E0 = relu(inp_f([l0, x, u0]))
+// (graph_conv.py:90-95), 6 FMAs per row and channel pair -- cheaper to recompute per k-step under the MFMAs than to write
+// 201 MB of rows (k_embed) and read them back.  Same structure as gather_tile; the three scalars of a window node come
+// from buffer loads (out-of-range -> masked explicitly, since relu(bias) of a zero input is not zero).
+struct EmbedSrc { const float *lb, *x, *ub; const float* wb; };     // (B, Ns) scalars; inp_f weight (64 x 3) then bias (64)
+
+template <bool INTERIOR>
+__device__ __forceinline__ void gather_tile_embed(Frag& X, const float* cm, const int2* ko, const unsigned* kvo, int K2,
+                                                  __amdgpu_buffer_rsrc_t rl, __amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t ru,
+                                                  const float (&w)[2][3], const float (&bias)[2], int wy0, int wx0, int Hs, int Ws, int lane) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = 0.0f;
+  const int origin = wy0 * Ws + wx0;
+  const unsigned soff = (unsigned)origin * 4u;
+  struct Chunk { float l[GATHER_CH], x[GATHER_CH], u[GATHER_CH]; unsigned o[GATHER_CH]; };
+  Chunk cur, nxt;
+  auto load = [&](Chunk& c, int s0) {
+#pragma unroll
+    for (int q = 0; q < GATHER_CH; ++q) {
+      unsigned o;
+      if (INTERIOR) {
+        o = kvo[2 * (s0 + q) + h] >> 6;                 // byte offset of the window node in a float array
+        c.l[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rl, o, soff, 0));
+        c.x[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, o, soff, 0));
+        c.u[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, o, soff, 0));
+      } else {
+        const unsigned long long ev = reinterpret_cast<const unsigned long long*>(ko)[2 * (s0 + q) + h];
+        const int ex = (int)(unsigned)ev, ey = (int)(unsigned)(ev >> 32);
+        const int wy = wy0 + (ey & 0xffff), wx = wx0 + (ey >> 16);
+        o = (unsigned)(origin + ex) * 4u;
+        o = ((unsigned)wy < (unsigned)Hs && (unsigned)wx < (unsigned)Ws) ? o : BUF_OOB;
+        c.l[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rl, o, 0, 0));
+        c.x[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, 0));
+        c.u[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, o, 0, 0));
+      }
+      c.o[q] = o;
+    }
+  };
+  auto mma = [&](const Chunk& c, int s0) {
+#pragma unroll
+    for (int q = 0; q < GATHER_CH; ++q) {
+      const float b = cm[(s0 + q) * 64 + lane];
+      float e0 = relu_nan(fmaf(c.u[q], w[0][2], fmaf(c.x[q], w[0][1], fmaf(c.l[q], w[0][0], bias[0]))));
+      float e1 = relu_nan(fmaf(c.u[q], w[1][2], fmaf(c.x[q], w[1][1], fmaf(c.l[q], w[1][0], bias[1]))));
+      if (!INTERIOR) {
+        const bool v = c.o[q] != BUF_OOB;
+        e0 = v ? e0 : 0.0f;
+        e1 = v ? e1 : 0.0f;
+      }
+      X.t[0] = mfma32(e0, b, X.t[0]);
+      X.t[1] = mfma32(e1, b, X.t[1]);
+    }
+  };
+  load(cur, 0);
+  const int npairs = K2 / (2 * GATHER_CH);
+  int s0 = 0;
+  for (int pr = 0; pr < npairs; ++pr, s0 += 2 * GATHER_CH) {
+    load(nxt, s0 + GATHER_CH);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(cur, s0);
+    __builtin_amdgcn_sched_barrier(0);
+    load(cur, s0 + 2 * GATHER_CH);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(nxt, s0 + GATHER_CH);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (K2 & GATHER_CH) mma(cur, s0);
+}
+
 // number of kernel taps that touch dst position t along one axis (the reference's `freq`, graph_conv.py:306-311)
 __device__ __forceinline__ int tap_count(int t, int w0, int WN, int Hs, int k, int stride, int pad) {
   int n = 0;
@@ -798,9 +868,11 @@ struct GArgs {
   int need_scored, R, off;  // 0: every live node needs its aggregate; 1: only the scored nodes (last backward step)
   DTileMap tm;
   DGather g;
+  EmbedSrc es;              // EMBED: the source rows are computed from the input scalars (mu_src unused)
 };
 
 // phase A of a half-pass over a conv edge: nb[g] = sum over the window for the dst nodes that will be updated
+template <bool EMBED>
 __global__ __launch_bounds__(WG_MLP, 2) void k_gather(GArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lds_cm = lds;
@@ -810,6 +882,15 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_gather(GArgs a) {
   stage_gather(lds_cm, lds_ko, lds_tt, lds_kvo, a.g, a.tm.TPS);
   __syncthreads();
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
+  float ew[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, eb[2] = {0.f, 0.f};   // EMBED: inp_f rows of this lane's channels 2j, 2j+1
+  if (EMBED) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      eb[c] = a.es.wb[192 + 2 * j + c];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) ew[c][i] = a.es.wb[(2 * j + c) * 3 + i];
+    }
+  }
   long t0, t1;
   tile_range(a.ntiles, WAVES_MLP, t0, t1);
   long tile = t0 + wave;
@@ -827,7 +908,20 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_gather(GArgs a) {
     if (!__any(need)) continue;
     const int wy0 = tc.by * a.g.ystep + a.g.ybase, wx0 = tc.bx * a.g.xstep + a.g.xbase;
     Frag X;
-    gather_dispatch(X, lds_cm + tc.cg * a.g.K2 * 64, lds_ko, lds_kvo, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane);
+    if (EMBED) {
+      const int uy = __builtin_amdgcn_readfirstlane(wy0), ux = __builtin_amdgcn_readfirstlane(wx0);
+      const long sb = (long)sample * a.g.Ns;
+      const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(a.es.lb + sb), 0, a.g.Ns * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.es.x + sb), 0, a.g.Ns * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)(a.es.ub + sb), 0, a.g.Ns * 4, 0x00020000);
+      const float* cmt = lds_cm + tc.cg * a.g.K2 * 64;
+      if (uy >= 0 && ux >= 0 && uy + a.g.WY <= a.g.Hs && ux + a.g.WX <= a.g.Ws)
+        gather_tile_embed<true>(X, cmt, lds_ko, lds_kvo, a.g.K2, rl, rx, ru, ew, eb, uy, ux, a.g.Hs, a.g.Ws, lane);
+      else
+        gather_tile_embed<false>(X, cmt, lds_ko, lds_kvo, a.g.K2, rl, rx, ru, ew, eb, uy, ux, a.g.Hs, a.g.Ws, lane);
+    } else {
+      gather_dispatch(X, lds_cm + tc.cg * a.g.K2 * 64, lds_ko, lds_kvo, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane);
+    }
     if (a.g.normalise) {
       const int ny = tap_count(tc.y, wy0, a.g.WY, a.g.Hs, a.g.kh, a.g.stride, a.g.pad);
       const int nx = tap_count(tc.x, wx0, a.g.WX, a.g.Ws, a.g.kw, a.g.stride, a.g.pad);
@@ -1895,6 +1989,7 @@ struct gnnb_handle {
   int gather_occ = 2;           // workgroups per CU for k_gather (its LDS footprint is only the tap matrix)
   bool dense_lds = true;        // Linear edges: one workgroup per sample with the source rows in LDS (false: per-tile kernel)
   bool restrict_last = true;    // last backward step of layer 1 only for the scored nodes (nothing else reads it)
+  bool embed_fuse = true;       // round 0: the first forward gather computes the input embedding itself (no k_embed, no mu[0] rows)
   bool use_top = true;          // fuse the top of the network (last Linear edge, last ReLU layer, property node) into k_top
   bool top_ok = false;          // ... which the bound network allows (set by gnnb_bind_network)
   Packs packs;
@@ -1968,7 +2063,9 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   if (const char* e = getenv("GNNB_GATHER_OCC")) h->gather_occ = atoi(e) < 1 ? 1 : atoi(e);
   HIPCHK(hipFuncSetAttribute((const void*)k_input_update, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpdInp::FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_score, hipFuncAttributeMaxDynamicSharedMemorySize, PackScore::FLOATS * 4));
-  HIPCHK(hipFuncSetAttribute((const void*)k_gather, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  if (const char* e = getenv("GNNB_NO_EMBED_FUSE")) h->embed_fuse = !(e[0] == '1');
   HIPCHK(hipFuncSetAttribute((const void*)k_livesum, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   if (const char* e = getenv("GNNB_NO_RESTRICT")) h->restrict_last = !(e[0] == '1');
   if (const char* e = getenv("GNNB_NO_DENSE_LDS")) h->dense_lds = !(e[0] == '1');
@@ -2136,8 +2233,8 @@ extern "C" int gnnb_bind_network(gnnb_t* h, const gnnb_layer_desc* L, int n, int
       if (h->edges[k].kind != 0) continue;
       for (int dir = 0; dir < 2; ++dir) {
         GatherHost gh;
-        // the input layer's transposed gather is fused with its feature chain and update (258 MFMAs per tile)
-        if (!build_gather(h->edges[k], dir, dir == 1 && k > 1, gh, (dir == 1 && k == 1) ? 258 : 0)) continue;
+        // the input layer's transposed gather is fused with its feature chain and update (132 MFMAs per tile)
+        if (!build_gather(h->edges[k], dir, dir == 1 && k > 1, gh, (dir == 1 && k == 1) ? 132 : 0)) continue;
         DevGather& d = dir == 0 ? h->gf[k] : h->gb[k];
         d.g = gh.g;
         if (int rc = upload(&d.cmat, gh.cmat.data(), gh.cmat.size())) return rc;
@@ -2421,6 +2518,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   const int limit = h->halfpass_limit > 0 ? std::min(h->halfpass_limit, total_halfpasses) : total_halfpasses;
   const bool debug_full = h->halfpass_limit > 0;   // with a limit set nothing is restricted or skipped as dead
 
+  const bool embed_in_gather = h->embed_fuse && !debug_full && h->gf[1].ok;
   // ---- once per forward: classification lists, input embedding, embedding-independent feature chains ----
   {
     ClassifyArgs a{};
@@ -2483,7 +2581,9 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     EmbedArgs a{h->d_pack[PK_EMBED] + PackEmbed::W, h->d_pack[PK_EMBED] + PackEmbed::B, in->lb[0], in->x_lp, in->ub[0], mu(0), G};
     long grid = (G + 16 * EMBED_UNROLL - 1) / (16 * EMBED_UNROLL);
     if (grid > (long)h->n_cu * 16) grid = (long)h->n_cu * 16;
-    lz.run(PC_EMBED, [&] { hipLaunchKernelGGL(k_embed, dim3((unsigned)grid), dim3(256), 0, st, a); });
+    // with the MFMA gather on the first edge, round 0 computes the embedding inside that gather (k_gather<true>): nothing
+    // else reads mu[0] before the input-layer update overwrites it.  Inspection runs keep the rows.
+    if (!embed_in_gather) lz.run(PC_EMBED, [&] { hipLaunchKernelGGL(k_embed, dim3((unsigned)grid), dim3(256), 0, st, a); });
     for (auto& pj : h->proj) pj = -1;
     h->proj[0] = L_INP_F_1;
   }
@@ -2516,18 +2616,22 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   auto conv_args = [&](const Edge& e, const float* src, float* dst, const float* wt, int normalise) {
     return ConvArgs{src, dst, wt, B, e.c_in, e.h_in, e.w_in, e.c_out, e.h_out, e.w_out, e.kh, e.kw, e.stride, e.pad, normalise};
   };
-  auto gather = [&](const DevGather& d, int k, const float* src, bool scored) {      // phase A over a conv edge, MFMA
+  auto gather = [&](const DevGather& d, int k, const float* src, bool scored, bool embed_src) {      // phase A over a conv edge, MFMA
     const long nt = map_tiles(d.g.tm, B);
-    GArgs a{in->lb[k], in->ub[k], in->mask, src, nb, nt, scored ? 1 : 0, h->R, roff[k], to_dtm(d.g.tm), to_dg(d, h->d_zero)};
+    GArgs a{in->lb[k], in->ub[k], in->mask, src, nb, nt, scored ? 1 : 0, h->R, roff[k], to_dtm(d.g.tm), to_dg(d, h->d_zero),
+            EmbedSrc{in->lb[0], in->x_lp, in->ub[0], h->d_pack[PK_EMBED]}};
     const size_t lds = gather_lds_bytes(d, 0);
     long grid = (nt + WAVES_MLP - 1) / WAVES_MLP;
     if (grid > (long)h->n_cu * h->gather_occ) grid = (long)h->n_cu * h->gather_occ;
-    lz.run(PC_GATHER, [&] { hipLaunchKernelGGL(k_gather, dim3((unsigned)grid), dim3(WG_MLP), lds, st, a); });
+    lz.run(PC_GATHER, [&] {
+      if (embed_src) hipLaunchKernelGGL(k_gather<true>, dim3((unsigned)grid), dim3(WG_MLP), lds, st, a);
+      else hipLaunchKernelGGL(k_gather<false>, dim3((unsigned)grid), dim3(WG_MLP), lds, st, a);
+    });
   };
   // phase A: nb <- A_k mu[k-1]
   auto agg_fwd = [&](int k) {
     const Edge& e = h->edges[k];
-    if (h->gf[k].ok) { gather(h->gf[k], k, mu(k - 1), false); return; }
+    if (h->gf[k].ok) { gather(h->gf[k], k, mu(k - 1), false, k == 1 && embed_in_gather && h->proj[0] == L_INP_F_1); return; }
     if (e.kind == 0) {
       ConvArgs a = conv_args(e, mu(k - 1), nb, h->dev[k].w_fwd, 0);
       lz.run(PC_CONV_FWD, [&] {
@@ -2556,7 +2660,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   // phase A: nb <- A_{k+1}^T mu[k+1]  (k+1 <= L), conv case divided by the tap count when `normalise`
   auto agg_bwd = [&](int k, int normalise, bool scored) {
     const Edge& e = h->edges[k + 1];
-    if (k >= 1 && h->gb[k + 1].ok) { gather(h->gb[k + 1], k, mu(k + 1), scored); return; }
+    if (k >= 1 && h->gb[k + 1].ok) { gather(h->gb[k + 1], k, mu(k + 1), scored, false); return; }
     if (e.kind == 0) {
       ConvArgs a = conv_args(e, mu(k + 1), nb, h->dev[k + 1].w_bwd, normalise);
       lz.run(PC_CONVT_BWD, [&] {
