@@ -1241,16 +1241,27 @@ __device__ __forceinline__ void dense_fwd_sample(const DenseLArgs& a, int b, flo
   const int khalf = a.Kpad / 2;                  // rows per K-half, a multiple of 32
   const int nchunks = khalf / 32;
   const float* Xb = a.X + (long)b * a.K * 64;
-  // cooperative stage of chunk c: 2 slabs x 32 rows x 256 B = 16 KB, 512 threads x 2 x 16 B
-  auto stage = [&](int buf, int c) {
+  // cooperative stage of chunk c: 2 slabs x 32 rows x 256 B = 16 KB, 512 threads x 2 x 16 B.  The global loads are issued
+  // BEFORE the MFMAs of the running chunk and written to LDS after them, so their latency is not exposed once per chunk
+  // (as one load-then-store step this kernel ran at half its MFMA rate).
+  f32x4 sv[2];
+  auto gload = [&](int c) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const int e = threadIdx.x + 512 * r;        // 16-B piece index, 0..1023
       const int slab = e >> 9, row = (e >> 4) & 31, piece = e & 15;
       const int k = slab * khalf + c * 32 + row;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (k < a.K) v = *reinterpret_cast<const f32x4*>(Xb + (long)k * 64 + piece * 4);
-      *reinterpret_cast<f32x4*>(&xs[buf][slab][row][piece * 4]) = v;
+      const f32x4* src = reinterpret_cast<const f32x4*>(Xb + (long)(k < a.K ? k : 0) * 64 + piece * 4);
+      const f32x4 v = *src;
+      sv[r] = k < a.K ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int e = threadIdx.x + 512 * r;
+      const int slab = e >> 9, row = (e >> 4) & 31, piece = e & 15;
+      *reinterpret_cast<f32x4*>(&xs[buf][slab][row][piece * 4]) = sv[r];
     }
   };
   const float* At = a.At + (long)(kh * khalf) * a.ldA + (mt < a.MT ? mt : 0) * 32 + j;   // waves beyond MT idle on tile 0
@@ -1270,22 +1281,27 @@ __device__ __forceinline__ void dense_fwd_sample(const DenseLArgs& a, int b, flo
       acc1 = mfma32(A[u], bv.y, acc1);
     }
   };
-  stage(0, 0);
+  gload(0);
+  lstore(0);
   loadA(av, 0);
   __syncthreads();
   for (int c = 0; c < nchunks; c += 2) {
-    if (c + 1 < nchunks) stage(1, c + 1);
+    const bool more1 = c + 1 < nchunks;
+    if (more1) gload(c + 1);
     loadA(nav, c + 1);                      // At carries 32 extra zero rows: reading one chunk past the end is harmless
     __builtin_amdgcn_sched_barrier(0);
     mma(av, 0);
     __builtin_amdgcn_sched_barrier(0);
+    if (more1) lstore(1);
     __syncthreads();
-    if (c + 1 >= nchunks) break;
-    if (c + 2 < nchunks) stage(0, c + 2);
+    if (!more1) break;
+    const bool more2 = c + 2 < nchunks;
+    if (more2) gload(c + 2);
     loadA(av, c + 2);
     __builtin_amdgcn_sched_barrier(0);
     mma(nav, 1);
     __builtin_amdgcn_sched_barrier(0);
+    if (more2) lstore(0);
     __syncthreads();
   }
   if (kh == 1) {
@@ -1322,7 +1338,9 @@ __device__ __forceinline__ void dense_bwd_sample(const DenseLArgs& a, const floa
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
-    float av[DL_CH], nav[DL_CH];
+    // three A buffers in rotation: a chunk of 8 k-steps is only 16 MFMAs (~0.4 us), less than an L2 round trip, so the
+    // weights are fetched TWO chunks ahead.  At carries 48 extra zero rows for the loads issued past the end.
+    float a0[DL_CH], a1[DL_CH], a2[DL_CH];
     auto loadA = [&](float (&A)[DL_CH], int c) {
 #pragma unroll
       for (int u = 0; u < DL_CH; ++u) A[u] = At[(long)(c * 16 + 2 * u + h) * a.ldA];
@@ -1335,20 +1353,24 @@ __device__ __forceinline__ void dense_bwd_sample(const DenseLArgs& a, const floa
         acc1 = mfma32(A[u], bv.y, acc1);
       }
     };
-    loadA(av, 0);
-    const int npairs = nch / 2;
-    int c = 0;
-    for (int pr = 0; pr < npairs; ++pr, c += 2) {
-      loadA(nav, c + 1);
+    loadA(a0, 0);
+    loadA(a1, 1);
+    for (int c = 0; c < nch; c += 3) {
+      loadA(a2, c + 2);
       __builtin_amdgcn_sched_barrier(0);
-      mma(av, c);
+      mma(a0, c);
       __builtin_amdgcn_sched_barrier(0);
-      loadA(av, c + 2);                              // At carries 16 extra zero rows
+      if (c + 1 >= nch) break;
+      loadA(a0, c + 3);
       __builtin_amdgcn_sched_barrier(0);
-      mma(nav, c + 1);
+      mma(a1, c + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 2 >= nch) break;
+      loadA(a1, c + 4);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a2, c + 2);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (nch & 1) mma(av, c);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -2217,7 +2239,7 @@ extern "C" int gnnb_bind_network(gnnb_t* h, const gnnb_layer_desc* L, int n, int
       d.mt_bwd = (e.n_in + 31) / 32;
       d.ld_bwd = d.mt_bwd * 32;
       d.ksq_bwd = ksq_of(e.n_out);
-      const size_t rows_b = std::max<size_t>(8 * d.ksq_bwd + 2 * DENSE_CH, d.kpad_bwd + 32);
+      const size_t rows_b = std::max<size_t>(8 * d.ksq_bwd + 2 * DENSE_CH, d.kpad_bwd + 64);   // k_dense_bwd_lds reads up to 3 chunks past kpad
       t.assign(rows_b * d.ld_bwd, 0.f);                        // transposed: A = W^T, k = output node
       for (int o = 0; o < e.n_out; ++o)
         for (int i = 0; i < e.n_in; ++i) t[(size_t)o * d.ld_bwd + i] = e.w[(size_t)o * e.n_in + i];

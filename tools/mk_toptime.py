@@ -1,0 +1,18 @@
+"""dev helper: build tools/ablate/toptime.so = libgnnb with wall-clock stamps at the phase boundaries of k_top (printf)."""
+import subprocess
+src = open('/root/repo/gnn_branching_amd/csrc/gnnb.hip').read()
+src = src.replace('"../../include/gnnb.h"', '"/root/repo/include/gnnb.h"').replace('"gnnb_pack.h"', '"/root/repo/gnn_branching_amd/csrc/gnnb_pack.h"')
+a = src.index('__global__ __launch_bounds__(512, 1) void k_top(TopArgs a) {')
+b = src.index('// ------------------------------------------------------------------------------------------\n// k_livesum')
+body = src[a:b]
+marks = ['  // ---- F1: rows of C', '  // per-lane node of the update phases', '  // ---- F2: forward node update', '  // ---- F3: property node',
+         '  // ---- B1: backward node update', '  // ---- B2: aggregate rows']
+body = body.replace('  const int b = blockIdx.x, N = a.N;', '  const int b = blockIdx.x, N = a.N;\n  long long tt[8]; int ti = 0;\n  tt[ti++] = wall_clock64();')
+for m in marks:
+    assert m in body, m
+    body = body.replace(m, '  __syncthreads(); tt[ti++] = wall_clock64();\n' + m)
+i = body.rindex('}')
+body = body[:i] + ('  __syncthreads(); tt[ti++] = wall_clock64();\n  if (blockIdx.x == 7 && threadIdx.x == 0) printf("k_top phases (10ns ticks): stage %lld F1 %lld setup %lld '
+                   'F2 %lld F3 %lld B1 %lld B2 %lld\\n", tt[1]-tt[0], tt[2]-tt[1], tt[3]-tt[2], tt[4]-tt[3], tt[5]-tt[4], tt[6]-tt[5], tt[7]-tt[6]);\n}\n\n')
+open('/tmp/gnnb_t.hip', 'w').write(src[:a] + body + src[b:])
+subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-o', '/root/repo/tools/ablate/toptime.so', '/tmp/gnnb_t.hip'])
