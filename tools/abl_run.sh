@@ -1,0 +1,5 @@
+for n in none noflag nonorm nomfma noload; do
+  GNNB_LIB=$GRAFT_REPO_ROOT/tools/ablate/abl_$n.so bash tools/timeline.sh abl_$n > /dev/null 2>&1
+  echo "== $n: $(grep 'k_gather<' gpurun_out/timeline_abl_$n.txt | awk '{print $6}' | tr '\n' ' ')"
+done
+bash tools/timeline.sh full > /dev/null 2>&1; echo "== full: $(grep 'k_gather<' gpurun_out/timeline_full.txt | awk '{print $6}' | tr '\n' ' ')"
