@@ -427,29 +427,14 @@ struct PreAllArgs {       // hoisted feature chains of every ReLU layer, forward
 //   backward P'_b[g] = bc4[:, :64] . bc2_1(relu(bc2([s, -d2 s, d1 s]))) + bcb_b,
 //            s = bc1_2(relu(bc1_1(relu(bc1(feat7')))))                                        graph_conv.py:273-293,344-345
 // for the ambiguous nodes g (everywhere else the relaxation term is multiplied by amb = 0, :161 / :293)
-__global__ __launch_bounds__(WG_MLP, 2) void k_pre(PreAllArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* lds_b = lds + PackPreFwd::FLOATS;
-  copy_to_lds(lds_b, a.pack_b, PackPreBwd::FLOATS);
-  stage_pack(lds, a.pack_f, PackPreFwd::FLOATS);
-  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
-  long nhalf = 0;
-  for (int k = 0; k < a.L; ++k) nhalf += (long)((a.cnt[4 * k + 1] + 31) / 32);
-  const long ntiles = nhalf * (a.do_bwd ? 2 : 1);
-  for (long tile = (long)wave * gridDim.x + blockIdx.x; tile < ntiles; tile += (long)gridDim.x * WAVES_MLP) {
-    // which layer / direction (wave-uniform)
-    const bool bwd = a.do_bwd && tile < nhalf;
-    int k = 0, count = 0;
-    long t = (a.do_bwd && !bwd) ? tile - nhalf : tile;
-    for (; k < a.L; ++k) {
-      count = a.cnt[4 * k + 1];
-      const long tk = (count + 31) / 32;
-      if (t < tk) break;
-      t -= tk;
-    }
+// one tile (32 ambiguous nodes `list[32 t ..]` of layer k) of the hoisted chains; lds / lds_b: PackPreFwd / PackPreBwd in LDS
+__device__ __forceinline__ void pre_tile(const PreAllArgs& a, const float* lds, const float* lds_b, int k, bool bwd, const int* list, int count,
+                                         long t, int lane) {
+  const int h = lane >> 5, j = lane & 31;
+  {
     const long idx = t * 32 + j;
     const bool valid = idx < count;
-    const long gc = a.list[k][valid ? idx : 0];
+    const long gc = list[valid ? idx : 0];
     const int n = (int)(gc % a.N[k]);
     const float lb = a.lb[k][gc], ub = a.ub[k][gc];
     const Ratio r = compute_ratio(lb, ub);
@@ -511,6 +496,30 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_pre(PreAllArgs a) {
   }
 }
 
+__global__ __launch_bounds__(WG_MLP, 2) void k_pre(PreAllArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* lds_b = lds + PackPreFwd::FLOATS;
+  copy_to_lds(lds_b, a.pack_b, PackPreBwd::FLOATS);
+  stage_pack(lds, a.pack_f, PackPreFwd::FLOATS);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long nhalf = 0;
+  for (int k = 0; k < a.L; ++k) nhalf += (long)((a.cnt[4 * k + 1] + 31) / 32);
+  const long ntiles = nhalf * (a.do_bwd ? 2 : 1);
+  for (long tile = (long)wave * gridDim.x + blockIdx.x; tile < ntiles; tile += (long)gridDim.x * WAVES_MLP) {
+    // which layer / direction (wave-uniform)
+    const bool bwd = a.do_bwd && tile < nhalf;
+    int k = 0, count = 0;
+    long t = (a.do_bwd && !bwd) ? tile - nhalf : tile;
+    for (; k < a.L; ++k) {
+      count = a.cnt[4 * k + 1];
+      const long tk = (count + 31) / 32;
+      if (t < tk) break;
+      t -= tk;
+    }
+    pre_tile(a, lds, lds_b, k, bwd, a.list[k], count, t, lane);
+  }
+}
+
 // Q = inp_b2[:, :64] . inp_b_1(relu(inp_b([l0, u0]))) + inp_b2.bias       graph_conv.py:380-384
 __global__ __launch_bounds__(WG_MLP, 2) void k_pre_inp(PreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -551,20 +560,13 @@ struct UpdArgs {
 // DEFERRED: nb is an aggregate G of rows whose own last layer Wp is deferred: Wa is pre-multiplied by Wp and the bias
 // term s.(r0 Wa0.bp + r1 Wa1.bp) enters as one small k-step.
 // forward:  fc3, fc3_2, fc4, fc4_2   graph_conv.py:169-181        backward: bc3, bc3_1, bc4, bc4_1   :331-349
-template <int WAVES, bool DEFERRED>
-__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_node_update(UpdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
-  const int c0 = *a.cnt0, c1 = *a.cnt1;
+// The tile loop of the node update: tiles `tile`, `tile + stride`, ... of the lists in `a` (c0 / c1 entries); the weight
+// pack is staged into `lds` here (the first fetch overlaps it).
+template <bool DEFERRED>
+__device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, int c0, int c1, long tile, long stride, int lane) {
+  const int h = lane >> 5, j = lane & 31;
   const long n0 = (c0 + 31) / 32, ntiles = n0 + (c1 + 31) / 32;
   const float* bias_row = a.pack + PackUpd::BCBROW;
-  // Only a few tiles per wave, so balance matters more than locality (rows stream): tiles are dealt round-robin over
-  // the SIMDs of the whole grid (4 per workgroup), and the two waves that share a SIMD (w, w+4) take alternate rounds,
-  // so every SIMD's MFMA pipe gets floor or ceil of the average.  The inputs of the next tile (list entry -> bounds ->
-  // aggregate row) are fetched while this tile's MFMA chain runs; the first fetch overlaps the weight staging.
-  static_assert(WAVES % 4 == 0, "tile dealing assumes whole waves per SIMD");
-  const long stride = (long)gridDim.x * 4 * (WAVES / 4);
-  long tile = (long)(wave >> 2) * gridDim.x * 4 + (long)blockIdx.x * 4 + (wave & 3);
   long gc = 0, gc_n = 0;
   bool valid = false, valid_n = false;
   float lb = 0.0f, ub = 0.0f, lb_n = 0.0f, ub_n = 0.0f, sw = 0.0f, sw_n = 0.0f;
@@ -623,6 +625,20 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_node_update(UpdArgs a
 #pragma unroll
     for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = FRAG_AT(Xn, R);
   }
+}
+
+template <int WAVES, bool DEFERRED>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_node_update(UpdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // Only a few tiles per wave, so balance matters more than locality (rows stream): tiles are dealt round-robin over
+  // the SIMDs of the whole grid (4 per workgroup), and the two waves that share a SIMD (w, w+4) take alternate rounds,
+  // so every SIMD's MFMA pipe gets floor or ceil of the average.  The inputs of the next tile (list entry -> bounds ->
+  // aggregate row) are fetched while this tile's MFMA chain runs; the first fetch overlaps the weight staging.
+  static_assert(WAVES % 4 == 0, "tile dealing assumes whole waves per SIMD");
+  const long stride = (long)gridDim.x * 4 * (WAVES / 4);
+  const long tile = (long)(wave >> 2) * gridDim.x * 4 + (long)blockIdx.x * 4 + (wave & 3);
+  node_update_loop<DEFERRED>(a, lds, *a.cnt0, *a.cnt1, tile, stride, lane);
 }
 
 struct UpdInpArgs { const float* pack; const float* nb; const float* Q; const float* sarr; float* mu; long G, ntiles; };
@@ -871,26 +887,85 @@ struct GArgs {
   EmbedSrc es;              // EMBED: the source rows are computed from the input scalars (mu_src unused)
 };
 
+// EMBED: inp_f rows of this lane's channels 2j, 2j+1
+struct EmbedLane { float w[2][3], b[2]; };
+template <bool EMBED>
+__device__ __forceinline__ EmbedLane embed_lane(const GArgs& a, int j) {
+  EmbedLane e{};
+  if (EMBED) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      e.b[c] = a.es.wb[192 + 2 * j + c];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) e.w[c][i] = a.es.wb[(2 * j + c) * 3 + i];
+    }
+  }
+  return e;
+}
+
+// one tile of phase A: the aggregate rows of the tile's dst nodes that will be updated
+template <bool EMBED>
+__device__ __forceinline__ void gather_process_tile(const GArgs& a, const TileCtx& tc, int sample, const float* lds_cm, const int2* lds_ko,
+                                                    const unsigned* lds_kvo, const EmbedLane& el, int lane) {
+  const int h = lane >> 5, j = lane & 31;
+  const long gc = tc.sample * a.tm.N + tc.n;
+  bool need;
+  if (a.need_scored) need = tc.valid && a.mask[tc.sample * a.R + a.off + tc.n] != 0.0f;
+  else need = tc.valid && node_is_live(a.lb[gc], a.ub[gc]);    // (one load of k_classify's live flag instead: measured 1.7 % slower)
+  if (!__any(need)) return;
+  const int wy0 = tc.by * a.g.ystep + a.g.ybase, wx0 = tc.bx * a.g.xstep + a.g.xbase;
+  Frag X;
+  if (EMBED) {
+    const int uy = __builtin_amdgcn_readfirstlane(wy0), ux = __builtin_amdgcn_readfirstlane(wx0);
+    const long sb = (long)sample * a.g.Ns;
+    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(a.es.lb + sb), 0, a.g.Ns * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.es.x + sb), 0, a.g.Ns * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)(a.es.ub + sb), 0, a.g.Ns * 4, 0x00020000);
+    const float* cmt = lds_cm + tc.cg * a.g.K2 * 64;
+    if (uy >= 0 && ux >= 0 && uy + a.g.WY <= a.g.Hs && ux + a.g.WX <= a.g.Ws)
+      gather_tile_embed<true>(X, cmt, lds_ko, lds_kvo, a.g.K2, rl, rx, ru, el.w, el.b, uy, ux, a.g.Hs, a.g.Ws, lane);
+    else
+      gather_tile_embed<false>(X, cmt, lds_ko, lds_kvo, a.g.K2, rl, rx, ru, el.w, el.b, uy, ux, a.g.Hs, a.g.Ws, lane);
+  } else {
+    gather_dispatch(X, lds_cm + tc.cg * a.g.K2 * 64, lds_ko, lds_kvo, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane);
+  }
+  if (a.g.normalise) {
+    const int ny = tap_count(tc.y, wy0, a.g.WY, a.g.Hs, a.g.kh, a.g.stride, a.g.pad);
+    const int nx = tap_count(tc.x, wx0, a.g.WX, a.g.Ws, a.g.kw, a.g.stride, a.g.pad);
+    const int f = tc.valid ? ny * nx : 1;
+    const float freq = (float)f;
+    if (__all((f & (f - 1)) == 0)) {         // power of two: x * (1/f) is exactly x / f
+      const float inv = 1.0f / freq;
+#pragma unroll
+      for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = FRAG_AT(X, R) * inv;
+    } else {
+#pragma unroll
+      for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = FRAG_AT(X, R) / freq;
+    }
+  }
+  if (need) frag_store_rows_gathered(X, a.nb, gc, h);
+}
+
+// LDS image of a gather's tables: tap matrix, window offsets (two forms), tile table
+struct GatherLds { float* cm; int2* ko; int* tt; unsigned* kvo; };
+__device__ __forceinline__ GatherLds gather_lds(float* base, const DGather& g, int TPS) {
+  GatherLds l;
+  l.cm = base;
+  l.ko = reinterpret_cast<int2*>(l.cm + g.ncg_k2 * 64);
+  l.tt = reinterpret_cast<int*>(l.ko + 2 * g.K2 + KOFF_PAD);
+  l.kvo = reinterpret_cast<unsigned*>(l.tt + ((TPS + 3) & ~3));
+  return l;
+}
+
 // phase A of a half-pass over a conv edge: nb[g] = sum over the window for the dst nodes that will be updated
 template <bool EMBED>
 __global__ __launch_bounds__(WG_MLP, 2) void k_gather(GArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* lds_cm = lds;
-  int2* lds_ko = reinterpret_cast<int2*>(lds_cm + a.g.ncg_k2 * 64);
-  int* lds_tt = reinterpret_cast<int*>(lds_ko + 2 * a.g.K2 + KOFF_PAD);
-  unsigned* lds_kvo = reinterpret_cast<unsigned*>(lds_tt + ((a.tm.TPS + 3) & ~3));
-  stage_gather(lds_cm, lds_ko, lds_tt, lds_kvo, a.g, a.tm.TPS);
+  const GatherLds gl = gather_lds(lds, a.g, a.tm.TPS);
+  stage_gather(gl.cm, gl.ko, gl.tt, gl.kvo, a.g, a.tm.TPS);
   __syncthreads();
-  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
-  float ew[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, eb[2] = {0.f, 0.f};   // EMBED: inp_f rows of this lane's channels 2j, 2j+1
-  if (EMBED) {
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      eb[c] = a.es.wb[192 + 2 * j + c];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) ew[c][i] = a.es.wb[(2 * j + c) * 3 + i];
-    }
-  }
+  const int lane = threadIdx.x & 63, j = lane & 31, wave = threadIdx.x >> 6;
+  const EmbedLane el = embed_lane<EMBED>(a, j);
   long t0, t1;
   tile_range(a.ntiles, WAVES_MLP, t0, t1);
   long tile = t0 + wave;
@@ -900,43 +975,8 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_gather(GArgs a) {
   int t = __builtin_amdgcn_readfirstlane((int)(tile - (long)sample * a.tm.TPS));
   for (; tile < t1; tile += WAVES_MLP, t += WAVES_MLP) {
     while (t >= a.tm.TPS) { t -= a.tm.TPS; ++sample; }
-    const TileCtx tc = block_decode(a.tm, lds_tt, sample, t, j);
-    const long gc = tc.sample * a.tm.N + tc.n;
-    bool need;
-    if (a.need_scored) need = tc.valid && a.mask[tc.sample * a.R + a.off + tc.n] != 0.0f;
-    else need = tc.valid && node_is_live(a.lb[gc], a.ub[gc]);    // (one load of k_classify's live flag instead: measured 1.7 % slower)
-    if (!__any(need)) continue;
-    const int wy0 = tc.by * a.g.ystep + a.g.ybase, wx0 = tc.bx * a.g.xstep + a.g.xbase;
-    Frag X;
-    if (EMBED) {
-      const int uy = __builtin_amdgcn_readfirstlane(wy0), ux = __builtin_amdgcn_readfirstlane(wx0);
-      const long sb = (long)sample * a.g.Ns;
-      const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(a.es.lb + sb), 0, a.g.Ns * 4, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.es.x + sb), 0, a.g.Ns * 4, 0x00020000);
-      const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)(a.es.ub + sb), 0, a.g.Ns * 4, 0x00020000);
-      const float* cmt = lds_cm + tc.cg * a.g.K2 * 64;
-      if (uy >= 0 && ux >= 0 && uy + a.g.WY <= a.g.Hs && ux + a.g.WX <= a.g.Ws)
-        gather_tile_embed<true>(X, cmt, lds_ko, lds_kvo, a.g.K2, rl, rx, ru, ew, eb, uy, ux, a.g.Hs, a.g.Ws, lane);
-      else
-        gather_tile_embed<false>(X, cmt, lds_ko, lds_kvo, a.g.K2, rl, rx, ru, ew, eb, uy, ux, a.g.Hs, a.g.Ws, lane);
-    } else {
-      gather_dispatch(X, lds_cm + tc.cg * a.g.K2 * 64, lds_ko, lds_kvo, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane);
-    }
-    if (a.g.normalise) {
-      const int ny = tap_count(tc.y, wy0, a.g.WY, a.g.Hs, a.g.kh, a.g.stride, a.g.pad);
-      const int nx = tap_count(tc.x, wx0, a.g.WX, a.g.Ws, a.g.kw, a.g.stride, a.g.pad);
-      const int f = tc.valid ? ny * nx : 1;
-      const float freq = (float)f;
-      if (__all((f & (f - 1)) == 0)) {         // power of two: x * (1/f) is exactly x / f
-        const float inv = 1.0f / freq;
-#pragma unroll
-        for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = FRAG_AT(X, R) * inv;
-      } else {
-#pragma unroll
-        for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = FRAG_AT(X, R) / freq;
-      }
-    }
-    if (need) frag_store_rows_gathered(X, a.nb, gc, h);
+    const TileCtx tc = block_decode(a.tm, gl.tt, sample, t, j);
+    gather_process_tile<EMBED>(a, tc, sample, gl.cm, gl.ko, gl.kvo, el, lane);
   }
 }
 
@@ -950,17 +990,41 @@ struct GIArgs {
 // input layer: E_0 = relu(Q + inp_b2[:, 64:] . (A_1^T mu_1)),  Q = inp_b2[:, :64] . inp_b_1(relu(inp_b([l0,u0]))) + b;
 // mu_0 = inp_b2_2(E_0) is deferred into the next round's forward update of ReLU layer 1 (gnnb_pack.h).
 // graph_conv.py:361-385; the aggregate, the feature chain and the update stay in registers.
+// one tile of the fused input-layer update; lds_upd / lds_pre: PackUpdInp / PackPreInp in LDS
+__device__ __forceinline__ void input_update_tile(const GIArgs& a, const TileCtx& tc, int sample, const float* lds_upd, const float* lds_pre,
+                                                  const GatherLds& gl, int lane) {
+  const int h = lane >> 5, j = lane & 31;
+  if (!__any(tc.valid)) return;
+  const long gc = tc.sample * a.tm.N + tc.n;
+  const int wy0 = tc.by * a.g.ystep + a.g.ybase, wx0 = tc.bx * a.g.xstep + a.g.xbase;
+  Frag X;
+  gather_dispatch(X, gl.cm + tc.cg * a.g.K2 * 64, gl.ko, gl.kvo, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane);
+  float x[1];
+  x[0] = h ? a.ub[gc] : a.lb[gc];
+  Frag H0;
+  frag_bias(H0, lds_pre + PackPreInp::B1, h);
+  gemm_small<1>(lds_pre + PackPreInp::W1, lane, H0, x);
+  frag_relu(H0);
+  Frag H;                                  // inp_b_1 and the first half of inp_b2 are folded into one 64x64 map
+  frag_bias(H, lds_pre + PackPreInp::B2, h);
+  gemm_w64<32>(lds_pre + PackPreInp::W2, lane, H, [&](int s) { return FRAG_AT(H0, s); });
+  {                                          // bias term of the projection deferred in the rows of mu_1
+    const float xs[1] = {h ? 0.0f : a.sarr[gc]};
+    gemm_small<1>(lds_upd + PackUpdInp::VC, lane, H, xs);
+  }
+  gemm_w64<32>(lds_upd + PackUpdInp::WC, lane, H, [&](int s) { return FRAG_AT(X, s); });
+  frag_relu(H);
+  if (tc.valid) frag_store_rows(H, a.mu, gc, h);
+}
+
 __global__ __launch_bounds__(WG_MLP, 2) void k_gather_input_update(GIArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lds_pre = lds + PackUpdInp::FLOATS;
-  float* lds_cm = lds_pre + PackPreInp::FLOATS;
-  int2* lds_ko = reinterpret_cast<int2*>(lds_cm + a.g.ncg_k2 * 64);
-  int* lds_tt = reinterpret_cast<int*>(lds_ko + 2 * a.g.K2 + KOFF_PAD);
-  unsigned* lds_kvo = reinterpret_cast<unsigned*>(lds_tt + ((a.tm.TPS + 3) & ~3));
-  stage_gather(lds_cm, lds_ko, lds_tt, lds_kvo, a.g, a.tm.TPS);
+  const GatherLds gl = gather_lds(lds_pre + PackPreInp::FLOATS, a.g, a.tm.TPS);
+  stage_gather(gl.cm, gl.ko, gl.tt, gl.kvo, a.g, a.tm.TPS);
   copy_to_lds(lds_pre, a.pack_pre, PackPreInp::FLOATS);
   stage_pack(lds, a.pack, PackUpdInp::FLOATS);
-  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, j = lane & 31, wave = threadIdx.x >> 6;
   long t0, t1;
   tile_range(a.ntiles, WAVES_MLP, t0, t1);
   long tile = t0 + wave;
@@ -970,28 +1034,8 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_gather_input_update(GIArgs a) {
   int t = __builtin_amdgcn_readfirstlane((int)(tile - (long)sample * a.tm.TPS));
   for (; tile < t1; tile += WAVES_MLP, t += WAVES_MLP) {
     while (t >= a.tm.TPS) { t -= a.tm.TPS; ++sample; }
-    const TileCtx tc = block_decode(a.tm, lds_tt, sample, t, j);
-    if (!__any(tc.valid)) continue;
-    const long gc = tc.sample * a.tm.N + tc.n;
-    const int wy0 = tc.by * a.g.ystep + a.g.ybase, wx0 = tc.bx * a.g.xstep + a.g.xbase;
-    Frag X;
-    gather_dispatch(X, lds_cm + tc.cg * a.g.K2 * 64, lds_ko, lds_kvo, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane);
-    float x[1];
-    x[0] = h ? a.ub[gc] : a.lb[gc];
-    Frag H0;
-    frag_bias(H0, lds_pre + PackPreInp::B1, h);
-    gemm_small<1>(lds_pre + PackPreInp::W1, lane, H0, x);
-    frag_relu(H0);
-    Frag H;                                  // inp_b_1 and the first half of inp_b2 are folded into one 64x64 map
-    frag_bias(H, lds_pre + PackPreInp::B2, h);
-    gemm_w64<32>(lds_pre + PackPreInp::W2, lane, H, [&](int s) { return FRAG_AT(H0, s); });
-    {                                          // bias term of the projection deferred in the rows of mu_1
-      const float xs[1] = {h ? 0.0f : a.sarr[gc]};
-      gemm_small<1>(lds + PackUpdInp::VC, lane, H, xs);
-    }
-    gemm_w64<32>(lds + PackUpdInp::WC, lane, H, [&](int s) { return FRAG_AT(X, s); });
-    frag_relu(H);
-    if (tc.valid) frag_store_rows(H, a.mu, gc, h);
+    const TileCtx tc = block_decode(a.tm, gl.tt, sample, t, j);
+    input_update_tile(a, tc, sample, lds, lds_pre, gl, lane);
   }
 }
 
