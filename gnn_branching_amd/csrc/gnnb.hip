@@ -2035,276 +2035,6 @@ enum { PK_EMBED, PK_PRE_FWD, PK_PRE_BWD, PK_PRE_INP, PK_PROP, PK_UPD_FWD_E, PK_U
 static_assert(PK_COUNT == N_PACKS, "pack table");
 
 // ------------------------------------------------------------------------------------------
-// k_forward: the whole forward of one subproblem in ONE workgroup, the batch in ONE launch.
-//
-// Nothing in graph_conv.py couples two subproblems, and a subproblem's state (6-10 k embedding rows) streams through one
-// CU's LDS/L1/L2 comfortably, so a workgroup can walk all phases of its sample -- classification, bias sums, feature
-// chains, T x (forward sweep, top, backward sweep, input update), score head, argmax -- with __syncthreads() between
-// phases instead of kernel boundaries.  At the benchmark's batch (256 subproblems on 256 CUs) the 23 dependent launches
-// of the multi-kernel schedule spend a third of their time in launch ramps, weight staging and tails; here every CU
-// is busy with its own sample from the first to the last instruction.  The per-tile device functions are the ones
-// the multi-kernel path uses (that path stays for small batches, inspection runs and networks the MFMA gather tables or
-// k_top do not cover).  Writes of one phase are read by other waves of the SAME workgroup after a barrier: workgroup
-// scope, same CU, same L1 -- no cross-CU visibility is ever needed.
-// ------------------------------------------------------------------------------------------
-struct GatherDesc { DTileMap tm; DGather g; };
-struct FwdStatic {                 // per bound network, in device memory
-  int L, T, R, njobs;
-  int N[MAXL + 2], roff[MAXL + 2];
-  GatherDesc gf[MAXL + 1];         // gf[k]: forward edge into ReLU layer k (k = 1..L-1)
-  GatherDesc gb[MAXL + 1];         // gb[k]: transposed edge k+1 into layer k (k = 0..L-2)
-  LiveSumJob job[2 * MAXL];        // lf / out are filled per call
-  int job_src[2 * MAXL], job_dst[2 * MAXL], job_fwd[2 * MAXL], job_woff[2 * MAXL];
-  int w_floats;                    // conv weights of all jobs staged in LDS
-  const float* pack[N_PACKS];
-};
-struct FwdArgs {
-  const FwdStatic* S;
-  ClassifyArgs cls;                // per ReLU layer: lb, ub, mu, lists (B*N_k slices per sample), N, off; scores, mask, R
-  PreAllArgs pre;
-  ScoreArgs sc;
-  TopArgs top;
-  ArgmaxArgs am;
-  EmbedSrc es;
-  const float *lb0, *ub0;          // input layer bounds
-  float* mu0; float* muK; float* nb;
-  float* sf[MAXL + 1]; float* sb[MAXL + 1];
-  int* status;
-  int B, restrict_last;
-};
-
-// wave-uniform copy of a POD descriptor out of device memory: the loads are vector loads (the kernel also writes global
-// memory, so nothing proves them scalar), readfirstlane puts every word into an SGPR
-template <class T>
-__device__ __forceinline__ T uniform_load(const T* p) {
-  static_assert(sizeof(T) % 4 == 0, "word-sized descriptor");
-  T out;
-  const int* src = reinterpret_cast<const int*>(p);
-  int* dst = reinterpret_cast<int*>(&out);
-#pragma unroll
-  for (unsigned i = 0; i < sizeof(T) / 4; ++i) dst[i] = __builtin_amdgcn_readfirstlane(src[i]);
-  return out;
-}
-__device__ __forceinline__ int uniform_int(const int* p) { return __builtin_amdgcn_readfirstlane(*p); }
-
-static_assert(sizeof(FwdArgs) <= 4096, "kernel arguments are limited to 4 KB");
-#define FWD_THREADS 512
-#define FWD_WAVES 8
-#define FWD_LDS_FLOATS 40960       // 160 KB
-#define FWD_PERSIST (FWD_LDS_FLOATS - 256)   // per-sample state that survives the phases: list counts
-
-__global__ __launch_bounds__(FWD_THREADS, 1) void k_forward(FwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const FwdStatic& S = *a.S;
-  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int L = uniform_int(&S.L), T = uniform_int(&S.T), R = uniform_int(&S.R), njobs = uniform_int(&S.njobs);
-  auto SN = [&](int k) { return uniform_int(&S.N[k]); };
-  auto Sroff = [&](int k) { return uniform_int(&S.roff[k]); };
-  auto Spack = [&](int id) { return uniform_load(&S.pack[id]); };
-  int* cntl = reinterpret_cast<int*>(lds + FWD_PERSIST);        // cntl[4 k + c], k = 1..L: plain-live, ambiguous, scored
-  for (int sample = blockIdx.x; sample < a.B; sample += gridDim.x) {
-    __syncthreads();
-    // ================= classification (k_classify for one sample) =================
-    int* wc = reinterpret_cast<int*>(lds);                      // [3][FWD_WAVES]
-    float* lvall = lds + 64;                                    // live flags of the ReLU layers, by flat ReLU index
-    for (int k = 1; k <= L; ++k) {
-      const int i = k - 1, N = SN(k);
-      const long g0 = (long)sample * N;
-      int run[3] = {0, 0, 0};
-      for (int n0 = 0; n0 < N; n0 += FWD_THREADS) {
-        const int n = n0 + tid;
-        const bool valid = n < N;
-        const long gc = g0 + (valid ? n : 0);
-        const Ratio r = compute_ratio(a.cls.lb[i][gc], a.cls.ub[i][gc]);
-        const long sidx = (long)sample * a.cls.R + a.cls.off[i] + (valid ? n : 0);
-        bool flag[3];
-        const bool live = valid && r.live != 0.0f;
-        flag[1] = valid && r.amb != 0.0f;
-        flag[0] = live && !flag[1];
-        flag[2] = valid && a.cls.mask[sidx] != 0.0f;
-        if (valid) {
-          a.cls.scores[sidx] = -INFINITY;
-          lvall[a.cls.off[i] + n] = live ? 1.0f : 0.0f;
-        }
-        unsigned long long bal[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          bal[c] = __ballot(flag[c]);
-          if (lane == 0) wc[c * FWD_WAVES + wave] = __popcll(bal[c]);
-        }
-        __syncthreads();
-        int* lists[3] = {a.cls.live[i] + g0, a.cls.amb[i] + g0, a.cls.score[i] + g0};
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          int before = 0, total = 0;
-#pragma unroll
-          for (int w = 0; w < FWD_WAVES; ++w) {
-            const int v = wc[c * FWD_WAVES + w];
-            before += w < wave ? v : 0;
-            total += v;
-          }
-          if (flag[c]) lists[c][run[c] + before + __popcll(bal[c] & ((1ull << lane) - 1ull))] = (int)gc;
-          run[c] += total;
-        }
-        unsigned long long dead = __ballot(valid && !live);
-        float* mu = a.cls.mu[i];
-        while (dead) {                       // the whole wave zeroes one dead row per iteration (coalesced 256 B)
-          const int l = __ffsll((long long)dead) - 1;
-          dead &= dead - 1;
-          const long row = gc - lane + l;
-          mu[row * 64 + lane] = 0.0f;
-        }
-        __syncthreads();
-      }
-      if (tid < 3) cntl[4 * k + tid] = run[tid];
-    }
-    __syncthreads();
-
-    // ================= bias-sum scalars (k_livesum for one sample) =================
-    {
-      float* wl = lvall + ((R + 3) & ~3);
-      for (int q = 0; q < njobs; ++q) {
-        const int nw = uniform_int(&S.job[q].wlds), wo = uniform_int(&S.job_woff[q]);
-        const float* w = uniform_load(&S.job[q].w);
-        for (int t = tid; t < nw; t += FWD_THREADS) wl[wo + t] = w[t];
-      }
-      __syncthreads();
-      for (int q = 0; q < njobs; ++q) {
-        const LiveSumJob jb = uniform_load(&S.job[q]);
-        const int src = uniform_int(&S.job_src[q]), dst = uniform_int(&S.job_dst[q]), wo = uniform_int(&S.job_woff[q]);
-        const float* lv = src == 0 ? nullptr : lvall + Sroff(src);
-        float* out = (uniform_int(&S.job_fwd[q]) ? a.sf[dst] : a.sb[dst]) + (long)sample * jb.Ndst;
-        livesum_job<FWD_THREADS>(jb, lv, jb.wlds ? wl + wo : jb.w, out, tid);
-      }
-    }
-    __syncthreads();
-
-    // ================= hoisted feature chains (k_pre for one sample) =================
-    {
-      float* lds_b = lds + PackPreFwd::FLOATS;
-      copy_to_lds(lds_b, a.pre.pack_b, PackPreBwd::FLOATS);
-      stage_pack(lds, a.pre.pack_f, PackPreFwd::FLOATS);
-      int nhalf = 0;
-      for (int k = 1; k <= L; ++k) nhalf += (cntl[4 * k + 1] + 31) / 32;
-      for (int tile = wave; tile < 2 * nhalf; tile += FWD_WAVES) {
-        const bool bwd = tile < nhalf;
-        int t = bwd ? tile : tile - nhalf, k = 1, count = 0;
-        for (; k <= L; ++k) {
-          count = cntl[4 * k + 1];
-          const int tk = (count + 31) / 32;
-          if (t < tk) break;
-          t -= tk;
-        }
-        pre_tile(a.pre, lds, lds_b, k - 1, bwd, a.cls.amb[k - 1] + (long)sample * SN(k), count, t, lane);
-      }
-    }
-    __syncthreads();
-
-    // ================= T rounds =================
-    auto gather_phase = [&](const GatherDesc& gd, int k, const float* src, bool scored, bool embed, float* tab) {
-      // tables staged by the caller into `tab`; tiles of this sample
-      GArgs ga{a.cls.lb[k - 1], a.cls.ub[k - 1], a.cls.mask, src, a.nb, 0, scored ? 1 : 0, R, Sroff(k), gd.tm, gd.g, a.es};
-      const GatherLds gl = gather_lds(tab, gd.g, gd.tm.TPS);
-      if (embed) {
-        const EmbedLane el = embed_lane<true>(ga, j);
-        for (int t = wave; t < gd.tm.TPS; t += FWD_WAVES)
-          gather_process_tile<true>(ga, block_decode(gd.tm, gl.tt, sample, t, j), sample, gl.cm, gl.ko, gl.kvo, el, lane);
-      } else {
-        const EmbedLane el{};
-        for (int t = wave; t < gd.tm.TPS; t += FWD_WAVES)
-          gather_process_tile<false>(ga, block_decode(gd.tm, gl.tt, sample, t, j), sample, gl.cm, gl.ko, gl.kvo, el, lane);
-      }
-    };
-    auto stage_tables = [&](const GatherDesc& gd, float* tab) {
-      const GatherLds gl = gather_lds(tab, gd.g, gd.tm.TPS);
-      stage_gather(gl.cm, gl.ko, gl.tt, gl.kvo, gd.g, gd.tm.TPS);
-    };
-    auto update_phase = [&](int k, bool fwd, bool scored, int src_proj) {
-      // weight pack staged inside node_update_loop (first fetch overlaps it); lists of this sample
-      const long g0 = (long)sample * SN(k);
-      int pack = PK_UPD_BWD;
-      const float* sarr = nullptr;
-      if (fwd) {
-        pack = src_proj == L_INP_F_1 ? PK_UPD_FWD_E : (src_proj == L_INP_B2_2 ? PK_UPD_FWD_I : PK_UPD_FWD_F);
-        sarr = a.sf[k];
-      } else if (k < L) {
-        pack = PK_UPD_BWD_B;
-        sarr = a.sb[k];
-      }
-      UpdArgs ua{Spack(pack), a.cls.lb[k - 1], a.cls.ub[k - 1], a.nb, fwd ? a.pre.Pf[k - 1] : a.pre.Pb[k - 1], a.cls.mu[k - 1], a.status,
-                 a.cls.live[k - 1] + g0, nullptr, (scored ? a.cls.score[k - 1] : a.cls.amb[k - 1]) + g0, nullptr, sarr};
-      const int c0 = scored ? 0 : cntl[4 * k + 0], c1 = scored ? cntl[4 * k + 2] : cntl[4 * k + 1];
-      if (sarr) node_update_loop<true>(ua, lds, c0, c1, wave, FWD_WAVES, lane);
-      else node_update_loop<false>(ua, lds, c0, c1, wave, FWD_WAVES, lane);
-    };
-    float* tab = lds + PackUpd::FLOATS;        // gather tables live behind the node-update pack
-    int proj0 = L_INP_F_1;
-    for (int t = 0; t < T; ++t) {
-      // forward sweep over the conv layers
-      for (int k = 1; k < L; ++k) {
-        const GatherDesc gd = uniform_load(&S.gf[k]);
-        stage_tables(gd, tab);
-        __syncthreads();
-        gather_phase(gd, k, k == 1 ? a.mu0 : a.cls.mu[k - 2], false, k == 1 && t == 0, tab);
-        __syncthreads();
-        update_phase(k, true, false, k == 1 ? proj0 : L_FC4_2);
-        __syncthreads();
-      }
-      // top of the network: both half-passes of layer L, aggregate of layer L-1 in nb
-      top_sample(a.top, sample, lds);
-      __syncthreads();
-      // backward sweep
-      for (int k = L - 1; k >= 1; --k) {
-        const bool scored = a.restrict_last && t == T - 1 && k == 1;
-        if (k < L - 1) {
-          const GatherDesc gd = uniform_load(&S.gb[k]);
-          stage_tables(gd, tab);
-          __syncthreads();
-          gather_phase(gd, k, a.cls.mu[k], scored, false, tab);
-          __syncthreads();
-        }
-        update_phase(k, false, scored, L_BC4_1);
-        __syncthreads();
-      }
-      // input layer, when another round follows
-      if (t < T - 1) {
-        const GatherDesc gd = uniform_load(&S.gb[0]);
-        GIArgs gi{Spack(PK_PRE_INP), Spack(PK_UPD_INP_G), a.lb0, a.ub0, a.cls.mu[0], a.sb[0], a.mu0, 0, gd.tm, gd.g};
-        float* lds_pre = lds + PackUpdInp::FLOATS;
-        const GatherLds gl = gather_lds(lds_pre + PackPreInp::FLOATS, gd.g, gd.tm.TPS);
-        stage_gather(gl.cm, gl.ko, gl.tt, gl.kvo, gd.g, gd.tm.TPS);
-        copy_to_lds(lds_pre, gi.pack_pre, PackPreInp::FLOATS);
-        stage_pack(lds, gi.pack, PackUpdInp::FLOATS);
-        for (int tt = wave; tt < gd.tm.TPS; tt += FWD_WAVES)
-          input_update_tile(gi, block_decode(gd.tm, gl.tt, sample, tt, j), sample, lds, lds_pre, gl, lane);
-        proj0 = L_INP_B2_2;
-        __syncthreads();
-      }
-    }
-
-    // ================= score head and decision =================
-    {
-      stage_pack(lds, a.sc.pack, PackScore::FLOATS);
-      int ntiles = 0;
-      for (int k = 1; k <= L; ++k) ntiles += (cntl[4 * k + 2] + 31) / 32;
-      for (int tile = wave; tile < ntiles; tile += FWD_WAVES) {
-        int t = tile, k = 1, count = 0;
-        for (; k <= L; ++k) {
-          count = cntl[4 * k + 2];
-          const int tk = (count + 31) / 32;
-          if (t < tk) break;
-          t -= tk;
-        }
-        score_tile(a.sc, lds, k - 1, a.cls.score[k - 1] + (long)sample * SN(k), count, t, lane);
-      }
-      __syncthreads();
-      argmax_sample<FWD_THREADS>(a.am, sample, lds + 8192, reinterpret_cast<int*>(lds + 8192 + FWD_THREADS));
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
@@ -2326,11 +2056,11 @@ static int fail(int code, const char* fmt, ...) {
 
 enum ProfClass {
   PC_EMBED, PC_PRE, PC_PRE_INP, PC_CONV_FWD, PC_CONVT_BWD, PC_DENSE_AGG, PC_PROP_FWD,
-  PC_NODE_UPDATE, PC_INPUT_UPDATE, PC_SCORE, PC_ARGMAX, PC_GATHER, PC_GATHER_INPUT, PC_CLASSIFY, PC_LIVESUM, PC_TOP, PC_FORWARD, PC_COUNT
+  PC_NODE_UPDATE, PC_INPUT_UPDATE, PC_SCORE, PC_ARGMAX, PC_GATHER, PC_GATHER_INPUT, PC_CLASSIFY, PC_LIVESUM, PC_TOP, PC_COUNT
 };
 static const char* kProfNames[PC_COUNT] = {
     "k_embed", "k_pre", "k_pre_inp", "k_conv_fwd", "k_convT_bwd", "k_dense_agg", "k_prop",
-    "k_node_update", "k_input_update", "k_score", "k_argmax", "k_gather", "k_gather_input_update", "k_classify", "k_livesum", "k_top", "k_forward"};
+    "k_node_update", "k_input_update", "k_score", "k_argmax", "k_gather", "k_gather_input_update", "k_classify", "k_livesum", "k_top"};
 
 struct DevEdge {
   float *w_fwd = nullptr, *w_bwd = nullptr, *bias = nullptr;   // conv: tap-major copies; linear: W^T / W, zero-padded
@@ -2354,10 +2084,6 @@ struct gnnb_handle {
   bool dense_lds = true;        // Linear edges: one workgroup per sample with the source rows in LDS (false: per-tile kernel)
   bool restrict_last = true;    // last backward step of layer 1 only for the scored nodes (nothing else reads it)
   bool embed_fuse = true;       // round 0: the first forward gather computes the input embedding itself (no k_embed, no mu[0] rows)
-  bool use_mega = false;        // one workgroup per subproblem, one launch per forward (k_forward) when the batch fills the chip
-  bool mega_ok = false;         // ... and the bound network is covered (MFMA gather tables on every conv edge, k_top on the last)
-  int mega_min_b = 0;           // smallest batch that takes k_forward (default: half the CUs)
-  FwdStatic* d_fwd = nullptr;   // device copy of the network description k_forward reads
   bool use_top = true;          // fuse the top of the network (last Linear edge, last ReLU layer, property node) into k_top
   bool top_ok = false;          // ... which the bound network allows (set by gnnb_bind_network)
   Packs packs;
@@ -2437,18 +2163,12 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   if (const char* e = getenv("GNNB_NO_GATHER")) h->use_gather = !(e[0] == '1');
   if (const char* e = getenv("GNNB_NO_TOP")) h->use_top = !(e[0] == '1');
-  if (const char* e = getenv("GNNB_MEGA")) h->use_mega = e[0] == '1';
-  h->mega_min_b = h->n_cu / 2;
-  if (const char* e = getenv("GNNB_MEGA_MIN_B")) h->mega_min_b = atoi(e);
-  HIPCHK(hipFuncSetAttribute((const void*)k_forward, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS_FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_top, hipFuncAttributeMaxDynamicSharedMemorySize, TOP_LDS_FLOATS * 4));
   *out = h;
   return GNNB_OK;
 }
 
 static void free_network(gnnb_t* h) {
-  if (h->d_fwd) { (void)hipFree(h->d_fwd); h->d_fwd = nullptr; }
-  h->mega_ok = false;
   for (auto& d : h->dev) {
     if (d.w_fwd) (void)hipFree(d.w_fwd);
     if (d.w_bwd) (void)hipFree(d.w_bwd);
@@ -2483,8 +2203,6 @@ extern "C" int gnnb_destroy(gnnb_t* h) {
 }
 
 static bool conv_channels_ok(int c) { return c == 3 || c == 8 || c == 16 || c == 32; }
-
-static int build_fwd_static(gnnb_t* h);
 
 extern "C" int gnnb_bind_network(gnnb_t* h, const gnnb_layer_desc* L, int n, int c0, int h0, int w0) {
   if (!h || !L || n < 2) return fail(GNNB_E_INVALID, "gnnb_bind_network: bad arguments");
@@ -2628,7 +2346,7 @@ extern "C" int gnnb_bind_network(gnnb_t* h, const gnnb_layer_desc* L, int n, int
       }
     }
   h->bound = true;
-  return build_fwd_static(h);
+  return GNNB_OK;
 }
 
 // tile maps of the node-MLP kernels: the forward update of layer k walks the tiles of its incoming conv gather,
@@ -2651,55 +2369,6 @@ static DGather to_dg(const DevGather& d, const float* zero) {
 }
 static size_t gather_lds_bytes(const DevGather& d, size_t pack_floats) {
   return (pack_floats + (size_t)d.g.tm.NCG * d.g.K2 * 64) * 4 + (size_t)(2 * d.g.K2 + KOFF_PAD) * 12 + (size_t)((d.g.tm.TPS + 3) & ~3) * 4;
-}
-
-// The network description k_forward reads (device memory), when the network is covered: every edge below the last is a
-// conv with MFMA gather tables in both directions, the last is the small Linear edge k_top handles, and every phase's
-// tables fit the 160 KB of LDS next to its weights.
-static int build_fwd_static(gnnb_t* h) {
-  const int L = (int)h->N.size() - 2;
-  h->mega_ok = false;
-  if (!h->top_ok || !h->use_gather || L < 2 || L > MAXL) return GNNB_OK;
-  for (int k = 1; k < L; ++k)
-    if (h->edges[k].kind != 0 || !h->gf[k].ok || !h->gb[k].ok) return GNNB_OK;
-  FwdStatic fs{};
-  fs.L = L; fs.T = h->T; fs.R = h->R;
-  for (int k = 0; k <= L + 1; ++k) fs.N[k] = h->N[k];
-  for (int k = 2; k <= L + 1; ++k) fs.roff[k] = fs.roff[k - 1] + h->N[k - 1];
-  for (int k = 1; k < L; ++k) {
-    fs.gf[k] = GatherDesc{to_dtm(h->gf[k].g.tm), to_dg(h->gf[k], h->d_zero)};
-    fs.gb[k - 1] = GatherDesc{to_dtm(h->gb[k].g.tm), to_dg(h->gb[k], h->d_zero)};
-    const size_t pack = k == 1 ? (size_t)(PackUpdInp::FLOATS + PackPreInp::FLOATS) : (size_t)PackUpd::FLOATS;   // gb[1] feeds the input update
-    if (gather_lds_bytes(h->gf[k], PackUpd::FLOATS) > (size_t)FWD_PERSIST * 4 || gather_lds_bytes(h->gb[k], pack) > (size_t)FWD_PERSIST * 4)
-      return GNNB_OK;
-  }
-  int q = 0, woff = 0;
-  auto push = [&](int kind, const Edge& e, const float* wt, int ld, int src, int dst, int fwd, int normalise) {
-    LiveSumJob& j = fs.job[q];
-    j.kind = kind; j.w = wt; j.lf = nullptr; j.out = nullptr; j.Ndst = h->N[dst]; j.Nsrc = h->N[src]; j.ld = ld; j.normalise = normalise;
-    j.c_in = e.c_in; j.h_in = e.h_in; j.w_in = e.w_in; j.c_out = e.c_out; j.h_out = e.h_out; j.w_out = e.w_out;
-    j.kh = e.kh; j.kw = e.kw; j.stride = e.stride; j.pad = e.pad;
-    const long nw = (long)e.c_in * e.c_out * e.kh * e.kw;
-    j.wlds = (e.kind == 0 && nw <= LIVESUM_MAXW) ? (int)nw : 0;
-    fs.job_src[q] = src; fs.job_dst[q] = dst; fs.job_fwd[q] = fwd; fs.job_woff[q] = woff;
-    woff += (j.wlds + 3) & ~3;
-    ++q;
-  };
-  for (int k = 1; k <= L; ++k) {
-    const Edge& e = h->edges[k];
-    push(e.kind == 0 ? 0 : 1, e, e.kind == 0 ? h->dev[k].w_fwd : h->dev[k].w_bwd, h->dev[k].ld_bwd, k - 1, k, 1, 0);
-  }
-  for (int k = 0; k < L; ++k) {
-    const Edge& e = h->edges[k + 1];
-    push(e.kind == 0 ? 2 : 3, e, h->dev[k + 1].w_bwd, h->dev[k + 1].ld_bwd, k + 1, k, 0, k >= 1 ? 1 : 0);
-  }
-  fs.njobs = q; fs.w_floats = woff;
-  if ((size_t)64 + ((h->R + 3) & ~3) + woff > (size_t)FWD_PERSIST) return GNNB_OK;      // live flags + conv weights of the bias-sum phase
-  for (int i = 0; i < N_PACKS; ++i) fs.pack[i] = h->d_pack[i];
-  HIPCHK(hipMalloc((void**)&h->d_fwd, sizeof(FwdStatic)));
-  HIPCHK(hipMemcpy(h->d_fwd, &fs, sizeof(FwdStatic), hipMemcpyHostToDevice));
-  h->mega_ok = true;
-  return GNNB_OK;
 }
 
 extern "C" int gnnb_graph_info(const gnnb_t* h, int* n_graph, int* sizes, int* n_relu_total) {
@@ -2939,54 +2608,6 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   const int total_halfpasses = 2 * h->T;
   const int limit = h->halfpass_limit > 0 ? std::min(h->halfpass_limit, total_halfpasses) : total_halfpasses;
   const bool debug_full = h->halfpass_limit > 0;   // with a limit set nothing is restricted or skipped as dead
-
-  // ---- batches that fill the chip: the whole forward in one launch, one workgroup per subproblem (k_forward) ----
-  if (h->use_mega && h->mega_ok && h->use_top && h->embed_fuse && !debug_full && B >= h->mega_min_b) {
-    FwdArgs fa{};
-    fa.S = h->d_fwd;
-    fa.cls.L = L; fa.cls.mask = in->mask; fa.cls.scores = scores; fa.cls.cnt = nullptr; fa.cls.R = h->R;
-    fa.pre.pack_f = h->d_pack[PK_PRE_FWD]; fa.pre.pack_b = h->d_pack[PK_PRE_BWD]; fa.pre.L = L; fa.pre.do_bwd = 1; fa.pre.cnt = nullptr;
-    fa.sc.pack = h->d_pack[PK_SCORE_B]; fa.sc.scores = scores; fa.sc.L = L; fa.sc.R = h->R; fa.sc.cnt = nullptr;
-    fa.am = ArgmaxArgs{scores, decisions, B, h->R, L, {0}};
-    for (int k = 1; k <= L; ++k) {
-      const int i = k - 1, q = h->relu_q[k];
-      fa.cls.lb[i] = in->lb[k]; fa.cls.ub[i] = in->ub[k]; fa.cls.mu[i] = mu(k);
-      fa.cls.live[i] = ilist(w.live[k]); fa.cls.amb[i] = ilist(w.amb[k]); fa.cls.score[i] = ilist(w.score[k]);
-      fa.cls.livef[i] = nullptr;
-      fa.cls.G[i] = (long)B * h->N[k]; fa.cls.N[i] = h->N[k]; fa.cls.off[i] = roff[k];
-      fa.pre.lb[i] = in->lb[k]; fa.pre.ub[i] = in->ub[k]; fa.pre.dual[i] = in->dual[k - 1];
-      fa.pre.z_pre[i] = in->primal[q - 1]; fa.pre.z_post[i] = in->primal[q]; fa.pre.bias[i] = h->dev[k].bias;
-      fa.pre.Pf[i] = ws + w.Pf[k]; fa.pre.Pb[i] = ws + w.Pb[k]; fa.pre.list[i] = nullptr;
-      fa.pre.N[i] = h->N[k]; fa.pre.hw[i] = h->hw[k];
-      fa.sc.mu[i] = mu(k); fa.sc.list[i] = nullptr; fa.sc.N[i] = h->N[k]; fa.sc.off[i] = roff[k];
-      fa.sc.lb[i] = in->lb[k]; fa.sc.ub[i] = in->ub[k];
-      fa.am.cum[k - 1] = roff[k] + h->N[k];
-      fa.sf[k] = ws + w.sf[k];
-    }
-    for (int k = 0; k < L; ++k) fa.sb[k] = ws + w.sb[k];
-    {
-      const Edge& e = h->edges[L];
-      const DevEdge& de = h->dev[L];
-      TopArgs& ta = fa.top;
-      ta.df = DenseLArgs{de.w_fwd, mu(L - 1), nullptr, B, e.n_in, e.n_out, de.ld_fwd, de.mt_fwd, de.kpad_fwd};
-      ta.db = DenseLArgs{de.w_bwd, nullptr, nb, B, e.n_out, e.n_in, de.ld_bwd, de.mt_bwd, de.kpad_bwd};
-      ta.pack_f = h->d_pack[PK_UPD_FWD_F]; ta.pack_b = h->d_pack[PK_UPD_BWD]; ta.pack_p = h->d_pack[PK_PROP];
-      ta.Pf = ws + w.Pf[L]; ta.Pb = ws + w.Pb[L]; ta.sf = ws + w.sf[L];
-      ta.lb = in->lb[L]; ta.ub = in->ub[L];
-      ta.prop_w = in->prop_w; ta.prop_b = in->prop_b; ta.lbK = in->lb[K]; ta.ubK = in->ub[K]; ta.z_out = in->primal[in->n_primal - 1];
-      ta.mu_prop = mu(K); ta.mu = mu(L); ta.status = status; ta.N = h->N[L];
-    }
-    fa.es = EmbedSrc{in->lb[0], in->x_lp, in->ub[0], h->d_pack[PK_EMBED]};
-    fa.lb0 = in->lb[0]; fa.ub0 = in->ub[0];
-    fa.mu0 = mu(0); fa.muK = mu(K); fa.nb = nb; fa.status = status;
-    fa.B = B; fa.restrict_last = h->restrict_last ? 1 : 0;
-    const int grid = std::min(B, h->n_cu);
-    lz.run(PC_FORWARD, [&] { hipLaunchKernelGGL(k_forward, dim3(grid), dim3(FWD_THREADS), FWD_LDS_FLOATS * 4, st, fa); });
-    for (int k = 1; k <= L; ++k) h->proj[k] = L_BC4_1;
-    h->proj[0] = h->T > 1 ? L_INP_B2_2 : -1;       // (T == 1: the embedding is computed inside the first gather, mu[0] holds no rows)
-    h->proj[K] = -1;
-    return lz.rc;
-  }
 
   const bool embed_in_gather = h->embed_fuse && !debug_full && h->gf[1].ok;
   // ---- once per forward: classification lists, input embedding, embedding-independent feature chains ----
