@@ -679,10 +679,13 @@ struct DGather {
   const int* ttab;       // [TPS]: cg | by << 8 | bx << 20
   const float* zero;     // 64 zero floats
   int K2, ncg_k2, Hs, Ws, Ns, ystep, ybase, xstep, xbase, WY, WX, normalise, kh, kw, stride, pad;
+  int lanes;             // dst nodes per tile: 32 (32x32x2 MFMA, 2 window slots per k-step) or 16 (16x16x4, 4 slots per k-step)
 };
 
 #define GATHER_CH 8   // k-steps per prefetch chunk
 #define KOFF_PAD (2 * GATHER_CH)   // always-masked koff entries behind the table (one chunk is loaded past the end)
+// window slots in the koff / kvo tables, padding included (gnnb_pack.h fill_gather_tables)
+__host__ __device__ inline int gather_slots(int K2, int lanes) { return lanes == 32 ? 2 * K2 + KOFF_PAD : 4 * K2 + 2 * KOFF_PAD; }
 
 // Source rows are read with buffer loads: the descriptor covers exactly this sample's source layer (wave-uniform base
 // in SGPRs), the per-lane part is a 32-bit byte offset, and a masked window node / the k padding simply gets an
@@ -834,6 +837,130 @@ __device__ __forceinline__ void gather_tile_embed(Frag& X, const float* cm, cons
   if (K2 & GATHER_CH) mma(cur, s0);
 }
 
+// ---- 16-node tiles on v_mfma_f32_16x16x4_f32 (forward conv edges: a third less window per node than 32-node tiles) ----
+// lane l = (i = l & 15, g = l >> 4).  k-step s covers window slots 4s .. 4s+3; lane (i, g) loads channels 4i .. 4i+3 of slot 4s+g
+// (one b128; the 16 lanes of a group read one whole 256-B row) and feeds channel 4i+t to the MFMA of M-tile t; the B operand
+// is the tap weight of (slot 4s+g, dst node i).  D of tile t: lane (j, g'), register r = channel 16g' + 4r + t of dst node j,
+// so a lane ends up with 16 consecutive channels of its node.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+#define GATHER_CH16 4   // k-steps per prefetch chunk (16 window slots, as in the 32-lane variant)
+
+template <bool INTERIOR>
+__device__ __forceinline__ void gather_tile16(f32x4 (&acc)[4], const float* cm, const int2* ko, const unsigned* kvo, int K2,
+                                              __amdgpu_buffer_rsrc_t rsrc, int wy0, int wx0, int Hs, int Ws, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int origin = wy0 * Ws + wx0;
+  const unsigned lane_off = 16u * (unsigned)i;
+  const unsigned soff = (unsigned)origin * 256u;
+  f32x4 cur[GATHER_CH16], nxt[GATHER_CH16];
+  auto load = [&](f32x4 (&dst)[GATHER_CH16], int s0) {
+#pragma unroll
+    for (int u = 0; u < GATHER_CH16; ++u) {
+      if (INTERIOR) {
+        const unsigned vo = kvo[4 * (s0 + u) + g] + lane_off;
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, soff, 0);
+        dst[u] = f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+      } else {
+        const unsigned long long ev = reinterpret_cast<const unsigned long long*>(ko)[4 * (s0 + u) + g];
+        const int ex = (int)(unsigned)ev, ey = (int)(unsigned)(ev >> 32);
+        const int wy = wy0 + (ey & 0xffff), wx = wx0 + (ey >> 16);
+        unsigned o = (unsigned)(origin + ex) * 256u + lane_off;
+        o = ((unsigned)wy < (unsigned)Hs && (unsigned)wx < (unsigned)Ws) ? o : BUF_OOB;
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, 0, 0);
+        dst[u] = f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+      }
+    }
+  };
+  auto mma = [&](const f32x4 (&v)[GATHER_CH16], int s0) {
+#pragma unroll
+    for (int u = 0; u < GATHER_CH16; ++u) {
+      const float b = cm[(s0 + u) * 64 + lane];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = mfma16(v[u][t], b, acc[t]);
+    }
+  };
+  load(cur, 0);
+  const int npairs = K2 / (2 * GATHER_CH16);
+  int s0 = 0;
+  for (int pr = 0; pr < npairs; ++pr, s0 += 2 * GATHER_CH16) {
+    load(nxt, s0 + GATHER_CH16);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(cur, s0);
+    __builtin_amdgcn_sched_barrier(0);
+    load(cur, s0 + 2 * GATHER_CH16);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(nxt, s0 + GATHER_CH16);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (K2 & GATHER_CH16) mma(cur, s0);
+}
+
+// the embedding variant (round 0, first edge): the four channels of a slot are computed from its three input scalars
+template <bool INTERIOR>
+__device__ __forceinline__ void gather_tile16_embed(f32x4 (&acc)[4], const float* cm, const int2* ko, const unsigned* kvo, int K2,
+                                                    __amdgpu_buffer_rsrc_t rl, __amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t ru,
+                                                    const float (&w)[4][3], const float (&bias)[4], int wy0, int wx0, int Hs, int Ws, int lane) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int origin = wy0 * Ws + wx0;
+  const unsigned soff = (unsigned)origin * 4u;
+  struct Chunk { float l[GATHER_CH16], x[GATHER_CH16], u[GATHER_CH16]; unsigned o[GATHER_CH16]; };
+  Chunk cur, nxt;
+  auto load = [&](Chunk& c, int s0) {
+#pragma unroll
+    for (int q = 0; q < GATHER_CH16; ++q) {
+      unsigned o;
+      if (INTERIOR) {
+        o = kvo[4 * (s0 + q) + g] >> 6;                 // byte offset of the window node in a float array
+        c.l[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rl, o, soff, 0));
+        c.x[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, o, soff, 0));
+        c.u[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, o, soff, 0));
+      } else {
+        const unsigned long long ev = reinterpret_cast<const unsigned long long*>(ko)[4 * (s0 + q) + g];
+        const int ex = (int)(unsigned)ev, ey = (int)(unsigned)(ev >> 32);
+        const int wy = wy0 + (ey & 0xffff), wx = wx0 + (ey >> 16);
+        o = (unsigned)(origin + ex) * 4u;
+        o = ((unsigned)wy < (unsigned)Hs && (unsigned)wx < (unsigned)Ws) ? o : BUF_OOB;
+        c.l[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rl, o, 0, 0));
+        c.x[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, 0));
+        c.u[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, o, 0, 0));
+      }
+      c.o[q] = o;
+    }
+  };
+  auto mma = [&](const Chunk& c, int s0) {
+#pragma unroll
+    for (int q = 0; q < GATHER_CH16; ++q) {
+      const float b = cm[(s0 + q) * 64 + lane];
+      const bool v = INTERIOR || c.o[q] != BUF_OOB;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float e = relu_nan(fmaf(c.u[q], w[t][2], fmaf(c.x[q], w[t][1], fmaf(c.l[q], w[t][0], bias[t]))));
+        e = v ? e : 0.0f;
+        acc[t] = mfma16(e, b, acc[t]);
+      }
+    }
+  };
+  load(cur, 0);
+  const int npairs = K2 / (2 * GATHER_CH16);
+  int s0 = 0;
+  for (int pr = 0; pr < npairs; ++pr, s0 += 2 * GATHER_CH16) {
+    load(nxt, s0 + GATHER_CH16);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(cur, s0);
+    __builtin_amdgcn_sched_barrier(0);
+    load(cur, s0 + 2 * GATHER_CH16);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(nxt, s0 + GATHER_CH16);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (K2 & GATHER_CH16) mma(cur, s0);
+}
+
 // number of kernel taps that touch dst position t along one axis (the reference's `freq`, graph_conv.py:306-311)
 __device__ __forceinline__ int tap_count(int t, int w0, int WN, int Hs, int k, int stride, int pad) {
   int n = 0;
@@ -847,7 +974,7 @@ __device__ __forceinline__ int tap_count(int t, int w0, int WN, int Hs, int k, i
 
 __device__ __forceinline__ void stage_gather(float* lds_cm, int2* lds_ko, int* lds_tt, unsigned* lds_kvo, const DGather& g, int TPS) {
   copy_to_lds(lds_cm, g.cmat, g.ncg_k2 * 64);
-  for (int i = threadIdx.x; i < 2 * g.K2 + KOFF_PAD; i += blockDim.x) {
+  for (int i = threadIdx.x; i < gather_slots(g.K2, g.lanes); i += blockDim.x) {
     const int2 e = g.koff[i];
     lds_ko[i] = e;
     lds_kvo[i] = (e.y & 0xffff) == 0x7fff ? 0u : (unsigned)e.x * 256u;      // byte offset of window node i from the window origin
@@ -946,13 +1073,48 @@ __device__ __forceinline__ void gather_process_tile(const GArgs& a, const TileCt
   if (need) frag_store_rows_gathered(X, a.nb, gc, h);
 }
 
+// one 16-node tile of phase A (forward edges only: no tap-count division)
+template <bool EMBED>
+__device__ __forceinline__ void gather_process_tile16(const GArgs& a, const TileCtx& tc, int sample, const float* lds_cm, const int2* lds_ko,
+                                                      const unsigned* lds_kvo, const float (&ew)[4][3], const float (&eb)[4], int lane) {
+  const int gq = lane >> 4;
+  const long gc = tc.sample * a.tm.N + tc.n;
+  bool need;
+  if (a.need_scored) need = tc.valid && a.mask[tc.sample * a.R + a.off + tc.n] != 0.0f;
+  else need = tc.valid && node_is_live(a.lb[gc], a.ub[gc]);
+  if (!__any(need)) return;
+  const int wy0 = tc.by * a.g.ystep + a.g.ybase, wx0 = tc.bx * a.g.xstep + a.g.xbase;
+  const int uy = __builtin_amdgcn_readfirstlane(wy0), ux = __builtin_amdgcn_readfirstlane(wx0);
+  const bool interior = uy >= 0 && ux >= 0 && uy + a.g.WY <= a.g.Hs && ux + a.g.WX <= a.g.Ws;
+  const float* cmt = lds_cm + tc.cg * a.g.K2 * 64;
+  f32x4 acc[4];
+  if (EMBED) {
+    const long sb = (long)sample * a.g.Ns;
+    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(a.es.lb + sb), 0, a.g.Ns * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.es.x + sb), 0, a.g.Ns * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)(a.es.ub + sb), 0, a.g.Ns * 4, 0x00020000);
+    if (interior) gather_tile16_embed<true>(acc, cmt, lds_ko, lds_kvo, a.g.K2, rl, rx, ru, ew, eb, uy, ux, a.g.Hs, a.g.Ws, lane);
+    else gather_tile16_embed<false>(acc, cmt, lds_ko, lds_kvo, a.g.K2, rl, rx, ru, ew, eb, uy, ux, a.g.Hs, a.g.Ws, lane);
+  } else {
+    const float* sbase = a.mu_src + (long)sample * a.g.Ns * 64;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)sbase, 0, a.g.Ns * 256, 0x00020000);
+    if (interior) gather_tile16<true>(acc, cmt, lds_ko, lds_kvo, a.g.K2, rsrc, uy, ux, a.g.Hs, a.g.Ws, lane);
+    else gather_tile16<false>(acc, cmt, lds_ko, lds_kvo, a.g.K2, rsrc, uy, ux, a.g.Hs, a.g.Ws, lane);
+  }
+  if (need) {                                  // lane (j, g'): channels 16g' + 4r + t of its node
+    f32x4* p = reinterpret_cast<f32x4*>(a.nb + gc * 64 + 16 * gq);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[r] = f32x4{acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+  }
+}
+
 // LDS image of a gather's tables: tap matrix, window offsets (two forms), tile table
 struct GatherLds { float* cm; int2* ko; int* tt; unsigned* kvo; };
 __device__ __forceinline__ GatherLds gather_lds(float* base, const DGather& g, int TPS) {
   GatherLds l;
   l.cm = base;
   l.ko = reinterpret_cast<int2*>(l.cm + g.ncg_k2 * 64);
-  l.tt = reinterpret_cast<int*>(l.ko + 2 * g.K2 + KOFF_PAD);
+  l.tt = reinterpret_cast<int*>(l.ko + gather_slots(g.K2, g.lanes));
   l.kvo = reinterpret_cast<unsigned*>(l.tt + ((TPS + 3) & ~3));
   return l;
 }
@@ -977,6 +1139,36 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_gather(GArgs a) {
     while (t >= a.tm.TPS) { t -= a.tm.TPS; ++sample; }
     const TileCtx tc = block_decode(a.tm, gl.tt, sample, t, j);
     gather_process_tile<EMBED>(a, tc, sample, gl.cm, gl.ko, gl.kvo, el, lane);
+  }
+}
+
+// the 16-node-tile form of k_gather (forward conv edges)
+template <bool EMBED>
+__global__ __launch_bounds__(WG_MLP, 2) void k_gather16(GArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const GatherLds gl = gather_lds(lds, a.g, a.tm.TPS);
+  stage_gather(gl.cm, gl.ko, gl.tt, gl.kvo, a.g, a.tm.TPS);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, j = lane & 15, wave = threadIdx.x >> 6;
+  float ew[4][3] = {}, eb[4] = {};               // EMBED: inp_f rows of this lane's channels 4i .. 4i+3
+  if (EMBED) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      eb[c] = a.es.wb[192 + 4 * j + c];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) ew[c][q] = a.es.wb[(4 * j + c) * 3 + q];
+    }
+  }
+  long t0, t1;
+  tile_range(a.ntiles, WAVES_MLP, t0, t1);
+  long tile = t0 + wave;
+  if (tile >= t1) return;
+  int sample = __builtin_amdgcn_readfirstlane((int)(tile / a.tm.TPS));
+  int t = __builtin_amdgcn_readfirstlane((int)(tile - (long)sample * a.tm.TPS));
+  for (; tile < t1; tile += WAVES_MLP, t += WAVES_MLP) {
+    while (t >= a.tm.TPS) { t -= a.tm.TPS; ++sample; }
+    const TileCtx tc = block_decode(a.tm, gl.tt, sample, t, j);
+    gather_process_tile16<EMBED>(a, tc, sample, gl.cm, gl.ko, gl.kvo, ew, eb, lane);
   }
 }
 
@@ -2083,6 +2275,7 @@ struct gnnb_handle {
   int gather_occ = 2;           // workgroups per CU for k_gather (its LDS footprint is only the tap matrix)
   bool dense_lds = true;        // Linear edges: one workgroup per sample with the source rows in LDS (false: per-tile kernel)
   bool restrict_last = true;    // last backward step of layer 1 only for the scored nodes (nothing else reads it)
+  bool gather16 = true;         // forward conv edges: 16-node tiles on the 16x16x4 MFMA when their window is smaller
   bool embed_fuse = true;       // round 0: the first forward gather computes the input embedding itself (no k_embed, no mu[0] rows)
   bool use_top = true;          // fuse the top of the network (last Linear edge, last ReLU layer, property node) into k_top
   bool top_ok = false;          // ... which the bound network allows (set by gnnb_bind_network)
@@ -2156,6 +2349,9 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   HIPCHK(hipFuncSetAttribute((const void*)k_score, hipFuncAttributeMaxDynamicSharedMemorySize, PackScore::FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_gather<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_gather<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  if (const char* e = getenv("GNNB_NO_GATHER16")) h->gather16 = !(e[0] == '1');
   if (const char* e = getenv("GNNB_NO_EMBED_FUSE")) h->embed_fuse = !(e[0] == '1');
   HIPCHK(hipFuncSetAttribute((const void*)k_livesum, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   if (const char* e = getenv("GNNB_NO_RESTRICT")) h->restrict_last = !(e[0] == '1');
@@ -2325,7 +2521,7 @@ extern "C" int gnnb_bind_network(gnnb_t* h, const gnnb_layer_desc* L, int n, int
       for (int dir = 0; dir < 2; ++dir) {
         GatherHost gh;
         // the input layer's transposed gather is fused with its feature chain and update (132 MFMAs per tile)
-        if (!build_gather(h->edges[k], dir, dir == 1 && k > 1, gh, (dir == 1 && k == 1) ? 132 : 0)) continue;
+        if (!build_gather(h->edges[k], dir, dir == 1 && k > 1, gh, (dir == 1 && k == 1) ? 132 : 0, h->gather16)) continue;
         DevGather& d = dir == 0 ? h->gf[k] : h->gb[k];
         d.g = gh.g;
         if (int rc = upload(&d.cmat, gh.cmat.data(), gh.cmat.size())) return rc;
@@ -2365,10 +2561,10 @@ static DTileMap to_dtm(const TileMap& t) {
 static DGather to_dg(const DevGather& d, const float* zero) {
   const GatherGeom& g = d.g;
   return DGather{d.cmat, reinterpret_cast<const int2*>(d.koff), d.ttab, zero, g.K2, g.tm.NCG * g.K2, g.Hs, g.Ws, g.Ns, g.ystep, g.ybase,
-                 g.xstep, g.xbase, g.WY, g.WX, g.normalise, g.kh, g.kw, g.stride, g.pad};
+                 g.xstep, g.xbase, g.WY, g.WX, g.normalise, g.kh, g.kw, g.stride, g.pad, g.lanes};
 }
 static size_t gather_lds_bytes(const DevGather& d, size_t pack_floats) {
-  return (pack_floats + (size_t)d.g.tm.NCG * d.g.K2 * 64) * 4 + (size_t)(2 * d.g.K2 + KOFF_PAD) * 12 + (size_t)((d.g.tm.TPS + 3) & ~3) * 4;
+  return (pack_floats + (size_t)d.g.tm.NCG * d.g.K2 * 64) * 4 + (size_t)gather_slots(d.g.K2, d.g.lanes) * 12 + (size_t)((d.g.tm.TPS + 3) & ~3) * 4;
 }
 
 extern "C" int gnnb_graph_info(const gnnb_t* h, int* n_graph, int* sizes, int* n_relu_total) {
@@ -2399,9 +2595,9 @@ extern "C" int gnnb_describe(const gnnb_t* h, char* buf, size_t cap) {
     if (d && d->ok) {
       const GatherGeom& g = d->g;
       snprintf(t, sizeof t,
-               "{\"update\": \"%s\", \"layer\": %d, \"kernel\": \"%s\", \"nodes\": %d, \"tiles_per_sample\": %d, "
+               "{\"update\": \"%s\", \"layer\": %d, \"kernel\": \"%s\", \"nodes\": %d, \"tiles_per_sample\": %d, \"tile_nodes\": %d, "
                "\"tile\": [%d, %d, %d], \"align\": [%d, %d], \"window\": [%d, %d], \"gather_ksteps\": %d, \"n_src\": %d, \"edge_nnz\": %ld}",
-               what, k, k == 0 ? "k_gather_input_update" : "k_gather+k_node_update", h->N[k], g.tm.TPS, g.tm.CT, g.tm.PY, g.tm.PX,
+               what, k, k == 0 ? "k_gather_input_update" : "k_gather+k_node_update", h->N[k], g.tm.TPS, g.lanes, g.tm.CT, g.tm.PY, g.tm.PX,
                g.tm.ay, g.tm.ax, g.WY, g.WX, g.K2, n_src, ez);
     } else {
       snprintf(t, sizeof t, "{\"update\": \"%s\", \"layer\": %d, \"kernel\": \"%s\", \"nodes\": %d, \"n_src\": %d, \"edge_nnz\": %ld}",
@@ -2715,7 +2911,10 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     long grid = (nt + WAVES_MLP - 1) / WAVES_MLP;
     if (grid > (long)h->n_cu * h->gather_occ) grid = (long)h->n_cu * h->gather_occ;
     lz.run(PC_GATHER, [&] {
-      if (embed_src) hipLaunchKernelGGL(k_gather<true>, dim3((unsigned)grid), dim3(WG_MLP), lds, st, a);
+      if (d.g.lanes == 16) {
+        if (embed_src) hipLaunchKernelGGL(k_gather16<true>, dim3((unsigned)grid), dim3(WG_MLP), lds, st, a);
+        else hipLaunchKernelGGL(k_gather16<false>, dim3((unsigned)grid), dim3(WG_MLP), lds, st, a);
+      } else if (embed_src) hipLaunchKernelGGL(k_gather<true>, dim3((unsigned)grid), dim3(WG_MLP), lds, st, a);
       else hipLaunchKernelGGL(k_gather<false>, dim3((unsigned)grid), dim3(WG_MLP), lds, st, a);
     });
   };

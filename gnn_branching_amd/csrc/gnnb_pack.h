@@ -379,7 +379,10 @@ struct TileMap {        // lane j of tile t <-> node of the dst layer
 
 struct GatherGeom {     // everything the kernel needs besides the tables
   TileMap tm;
-  int K2 = 0;           // k-steps (padded to a multiple of 8)
+  int lanes = 32;       // dst nodes per tile: 32 (v_mfma_f32_32x32x2, 2 window slots per k-step) or 16 (16x16x4, 4 slots per
+                        // k-step).  A k-step costs 128 MFMA cycles either way, so the cost of a tile is its window size;
+                        // the 16-node tiles of a forward conv edge see a third less window per node.
+  int K2 = 0;           // k-steps (padded to a multiple of 8 for 32 lanes, of 4 for 16 lanes)
   int Hs = 0, Ws = 0, Ns = 0;                 // src layer
   int ystep = 0, ybase = 0, xstep = 0, xbase = 0;   // window origin: wy0 = by*ystep + ybase
   int WY = 0, WX = 0;
@@ -388,22 +391,23 @@ struct GatherGeom {     // everything the kernel needs besides the tables
 
 struct GatherHost {
   GatherGeom g;
-  std::vector<float> cmat;       // [NCG][K2][64]
-  std::vector<int32_t> koff;     // [2*K2][2]: {row offset relative to the window origin, wy | wx << 16}
-  long mfma_per_sample = 0;
+  std::vector<float> cmat;       // [NCG][K2][64]: column of slot k, dst lane j: (k / spk) * 64 + (k % spk) * lanes + j, spk = 64 / lanes
+  std::vector<int32_t> koff;     // [spk*K2 + pad][2]: {row offset relative to the window origin, wy | wx << 16}
+  long mfma_per_sample = 0;      // in units of one 32x32x2 MFMA (64 cycles): 2 per k-step
 };
 
 inline int floor_div(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 inline int ceil_div(int a, int b) { return -floor_div(-a, b); }
 
 // dir 0: forward (src = conv input, dst = conv output); dir 1: transposed (src = conv output, dst = conv input)
-inline bool build_gather_candidate(const Edge& e, int dir, int CT, int PY, int PX, int ay, int ax, GatherHost& out) {
+inline bool build_gather_candidate(const Edge& e, int dir, int CT, int PY, int PX, int ay, int ax, GatherHost& out, int lanes = 32) {
   const int s = e.stride, p = e.pad;
   const int Cd = dir == 0 ? e.c_out : e.c_in, Hd = dir == 0 ? e.h_out : e.h_in, Wd = dir == 0 ? e.w_out : e.w_in;
   const int Cs = dir == 0 ? e.c_in : e.c_out, Hs = dir == 0 ? e.h_in : e.h_out, Ws = dir == 0 ? e.w_in : e.w_out;
-  if (CT * PY * PX > 32 || Cd % CT) return false;
+  if (CT * PY * PX > lanes || Cd % CT) return false;
   if (dir == 1 && (PY % s || PX % s)) return false;
   GatherGeom& g = out.g;
+  g.lanes = lanes;
   g.tm.mode = 1; g.tm.N = Cd * Hd * Wd; g.tm.C = Cd; g.tm.H = Hd; g.tm.W = Wd;
   g.tm.CT = CT; g.tm.PY = PY; g.tm.PX = PX; g.tm.ay = ay; g.tm.ax = ax;
   g.tm.NBY = ceil_div(Hd - ay, PY); g.tm.NBX = ceil_div(Wd - ax, PX); g.tm.NCG = Cd / CT;
@@ -418,7 +422,7 @@ inline bool build_gather_candidate(const Edge& e, int dir, int CT, int PY, int P
   }
   if (g.WY < 1 || g.WX < 1 || g.WY > 255 || g.WX > 255) return false;
   const int K = Cs * g.WY * g.WX;
-  g.K2 = ((K + 15) / 16) * 8;
+  g.K2 = lanes == 32 ? ((K + 15) / 16) * 8 : ((K + 15) / 16) * 4;
   g.normalise = 0; g.kh = e.kh; g.kw = e.kw; g.stride = s; g.pad = p;
   out.mfma_per_sample = (long)g.tm.TPS * g.K2 * 2;
   return true;
@@ -428,7 +432,8 @@ inline void fill_gather_tables(const Edge& e, int dir, GatherHost& out) {
   const GatherGeom& g = out.g;
   const int s = e.stride, p = e.pad;
   const int Cs = dir == 0 ? e.c_in : e.c_out;
-  const int K = Cs * g.WY * g.WX, Kpad = 2 * g.K2 + 16;     // 16 always-masked entries behind the table (kernel prefetch)
+  const int spk = 64 / g.lanes;                             // window slots per k-step
+  const int K = Cs * g.WY * g.WX, Kpad = spk * g.K2 + 16 * (spk / 2);   // always-masked entries behind the table (kernel prefetch: one chunk)
   out.koff.assign((size_t)Kpad * 2, 0);
   for (int k = 0; k < Kpad; ++k) {
     if (k < K) {
@@ -455,31 +460,33 @@ inline void fill_gather_tables(const Edge& e, int dir, GatherHost& out) {
         }
         if (ky < 0 || ky >= e.kh || kx < 0 || kx >= e.kw) continue;
         const float w = e.w[(((size_t)co * e.c_in + ci) * e.kh + ky) * e.kw + kx];
-        const int sidx = k >> 1, h = k & 1;
-        out.cmat[((size_t)cg * g.K2 + sidx) * 64 + h * 32 + j] = w;
+        const int sidx = k / spk, h = k % spk;
+        out.cmat[((size_t)cg * g.K2 + sidx) * 64 + h * g.lanes + j] = w;
       }
     }
 }
 
 // pick the tile shape with the fewest MFMAs per sample
 // `tile_mfma`: MFMAs of whatever runs per tile after the gather in the same kernel (0 for a stand-alone gather)
-inline bool build_gather(const Edge& e, int dir, bool normalise, GatherHost& best, int tile_mfma = 0) {
+// `allow16`: also consider 16-node tiles (stand-alone forward gathers: k_gather has a 16x16x4 variant for those)
+inline bool build_gather(const Edge& e, int dir, bool normalise, GatherHost& best, int tile_mfma = 0, bool allow16 = false) {
   const int Cd = dir == 0 ? e.c_out : e.c_in;
   bool found = false;
   long best_cost = 0;
-  for (int CT = 1; CT <= 32 && CT <= Cd; ++CT) {
-    if (Cd % CT) continue;
-    for (int PY = 1; PY <= 8; PY *= 2)
-      for (int PX = 1; PX <= 8; PX *= 2)
-        for (int ay = 0; ay > -PY; --ay)
-          for (int ax = 0; ax > -PX; --ax) {
-            GatherHost c;
-            if (!build_gather_candidate(e, dir, CT, PY, PX, ay, ax, c)) continue;
-            if ((size_t)c.g.tm.NCG * c.g.K2 * 64 * 4 > 40 * 1024) continue;   // tap matrix must fit beside the MLP weights in LDS
-            const long cost = c.mfma_per_sample + (long)c.g.tm.TPS * tile_mfma;
-            if (!found || cost < best_cost) { best = c; best_cost = cost; found = true; }
-          }
-  }
+  for (int lanes = 32; lanes >= (allow16 && dir == 0 && tile_mfma == 0 ? 16 : 32); lanes /= 2)
+    for (int CT = 1; CT <= lanes && CT <= Cd; ++CT) {
+      if (Cd % CT) continue;
+      for (int PY = 1; PY <= 8; PY *= 2)
+        for (int PX = 1; PX <= 8; PX *= 2)
+          for (int ay = 0; ay > -PY; --ay)
+            for (int ax = 0; ax > -PX; --ax) {
+              GatherHost c;
+              if (!build_gather_candidate(e, dir, CT, PY, PX, ay, ax, c, lanes)) continue;
+              if ((size_t)c.g.tm.NCG * c.g.K2 * 64 * 4 > 40 * 1024) continue;   // tap matrix must fit beside the MLP weights in LDS
+              const long cost = c.mfma_per_sample + (long)c.g.tm.TPS * tile_mfma;
+              if (!found || cost < best_cost) { best = c; best_cost = cost; found = true; }
+            }
+    }
   if (!found) return false;
   best.g.normalise = normalise ? 1 : 0;
   fill_gather_tables(e, dir, best);

@@ -242,22 +242,22 @@ def test_prop_pack_is_transposed(packs):
 
 # ---- MFMA gather tables (conv / conv-transpose message passing as dense local blocks) ----
 GEOM = ["N", "C", "H", "W", "CT", "PY", "PX", "ay", "ax", "NBY", "NBX", "NCG", "TPS", "K2", "Hs", "Ws", "Ns",
-        "ystep", "ybase", "xstep", "xbase", "WY", "WX", "normalise", "n_cmat", "n_koff"]
+        "ystep", "ybase", "xstep", "xbase", "WY", "WX", "normalise", "n_cmat", "n_koff", "lanes"]
 
 
-def build_gather(packlib, w, h_in, w_in, stride, pad, direction, normalise):
+def build_gather(packlib, w, h_in, w_in, stride, pad, direction, normalise, allow16=0):
     c_out, c_in, kh, kw = w.shape
     packlib.gnnb_pt_gather.restype = C.c_long
-    packlib.gnnb_pt_gather.argtypes = [C.c_void_p] + [C.c_int] * 10 + [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    packlib.gnnb_pt_gather.argtypes = [C.c_void_p] + [C.c_int] * 11 + [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     w = np.ascontiguousarray(w, np.float32)
-    geom = np.zeros(26, np.int32)
-    cost = packlib.gnnb_pt_gather(w.ctypes.data, c_in, h_in, w_in, c_out, kh, kw, stride, pad, direction, normalise,
+    geom = np.zeros(27, np.int32)
+    cost = packlib.gnnb_pt_gather(w.ctypes.data, c_in, h_in, w_in, c_out, kh, kw, stride, pad, direction, normalise, allow16,
                                   geom.ctypes.data, None, 0, None, 0)
     assert cost > 0
     g = dict(zip(GEOM, geom.tolist()))
     cmat = np.zeros(g["n_cmat"], np.float32)
     koff = np.zeros(g["n_koff"], np.int32)
-    packlib.gnnb_pt_gather(w.ctypes.data, c_in, h_in, w_in, c_out, kh, kw, stride, pad, direction, normalise,
+    packlib.gnnb_pt_gather(w.ctypes.data, c_in, h_in, w_in, c_out, kh, kw, stride, pad, direction, normalise, allow16,
                            geom.ctypes.data, cmat.ctypes.data, cmat.size, koff.ctypes.data, koff.size)
     return g, cmat.reshape(g["NCG"], g["K2"], 64), koff.reshape(-1, 2), cost
 
@@ -273,15 +273,17 @@ def emulate_gather(g, cmat, koff, mu_src):
         y0, x0 = by * g["PY"] + g["ay"], bx * g["PX"] + g["ax"]
         wy0, wx0 = by * g["ystep"] + g["ybase"], bx * g["xstep"] + g["xbase"]
         origin = wy0 * g["Ws"] + wx0
-        acc = np.zeros((32, p))
-        assert len(koff) == 2 * g["K2"] + 16 and all(p & 0xffff == 0x7fff for _, p in koff[2 * g["K2"]:])
-        for k in range(2 * g["K2"]):
+        lanes = g["lanes"]
+        spk = 64 // lanes                      # window slots per k-step: 2 (32x32x2 MFMA) or 4 (16x16x4)
+        acc = np.zeros((lanes, p))
+        assert len(koff) == spk * g["K2"] + 8 * spk and all(p & 0xffff == 0x7fff for _, p in koff[spk * g["K2"]:])
+        for k in range(spk * g["K2"]):
             off, packed = koff[k]
             wy, wx = wy0 + (packed & 0xffff), wx0 + (packed >> 16)
             if not (0 <= wy < g["Hs"] and 0 <= wx < g["Ws"]):
                 continue
             row = mu_src[origin + off]
-            acc += np.outer(cmat[cg, k >> 1, (k & 1) * 32:(k & 1) * 32 + 32], row)
+            acc += np.outer(cmat[cg, k // spk, (k % spk) * lanes:(k % spk) * lanes + lanes], row)
         for j in range(g["CT"] * g["PY"] * g["PX"]):
             cl, rem = divmod(j, g["PY"] * g["PX"])
             py, px = divmod(rem, g["PX"])
@@ -301,14 +303,17 @@ CONVS = [  # (c_in, c_out, k, stride, pad, h_in)  -- every conv of cifar_{base,w
 
 
 @pytest.mark.parametrize("cfg", CONVS)
-@pytest.mark.parametrize("direction", [0, 1])
-def test_gather_tables_match_torch_conv(packlib, cfg, direction):
+@pytest.mark.parametrize("direction,allow16", [(0, 0), (1, 0), (0, 1)])
+def test_gather_tables_match_torch_conv(packlib, cfg, direction, allow16):
     import torch
     import torch.nn.functional as F
     c_in, c_out, k, s, pad, h_in = cfg
     rng = np.random.RandomState(c_in * 100 + c_out + direction)
     w = rng.standard_normal((c_out, c_in, k, k)).astype(np.float32)
-    g, cmat, koff, cost = build_gather(packlib, w, h_in, h_in, s, pad, direction, normalise=direction)
+    g, cmat, koff, cost = build_gather(packlib, w, h_in, h_in, s, pad, direction, normalise=direction, allow16=allow16)
+    assert g["lanes"] in ((16, 32) if allow16 else (32,))
+    if allow16:                                      # never worse than the 32-node tiling, usually a third cheaper
+        assert cost <= build_gather(packlib, w, h_in, h_in, s, pad, direction, normalise=direction)[3]
     h_out = (h_in + 2 * pad - k) // s + 1
     p = 4
     if direction == 0:
@@ -325,7 +330,7 @@ def test_gather_tables_match_torch_conv(packlib, cfg, direction):
     np.testing.assert_allclose(got, want, atol=1e-5)
     dense = cost * 2 * 32 * 32 * 2 / 2          # MACs issued per sample (each MFMA: 32x32x2)
     useful = w.size * (h_out * h_out)           # MACs of the sparse map per channel
-    print(f"conv {cfg} dir {direction}: tile {g['CT']}x{g['PY']}x{g['PX']} align ({g['ay']},{g['ax']}) window {g['WY']}x{g['WX']} "
+    print(f"conv {cfg} dir {direction} lanes {g['lanes']}: tile {g['CT']}x{g['PY']}x{g['PX']} align ({g['ay']},{g['ax']}) window {g['WY']}x{g['WX']} "
           f"K2={g['K2']} tiles/sample={g['TPS']} mfma/sample={cost} density={useful / (dense / 64 * 32):.2f}")
 
 
