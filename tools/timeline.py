@@ -10,8 +10,8 @@ for f in files:
         for r in csv.DictReader(fh):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0]))
 rows.sort()
-# the last forward starts at the last k_classify
-idx = max(i for i, r in enumerate(rows) if "k_classify" in r[2])
+# the last forward starts at the last k_setup
+idx = max(i for i, r in enumerate(rows) if "k_setup" in r[2] or "k_classify" in r[2])
 step = rows[idx:]
 t0 = step[0][0]
 prev_end = t0
