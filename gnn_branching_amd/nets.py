@@ -36,6 +36,24 @@ _ARCH = {
 }
 NET_NAMES = tuple(_ARCH)
 INPUT_SHAPE = (3, 32, 32)
+_EXTRA_WEIGHTS = {}
+
+
+def register_arch(name, spec, seed=0):
+    """Register another architecture (same spec tuples as above) with seeded random weights: the scorer is not tied to
+    the three CIFAR networks (the reference dispatches on layer types, graph_conv.py:110-192), and the tests exercise
+    networks that take the engine's other kernels (first layer Linear, 3x3 stride-1 convolutions, ...)."""
+    rng = np.random.RandomState(seed)
+    layers = [_make(s) for s in spec]
+    weights = {}
+    for i, l in enumerate(layers):
+        if isinstance(l, (nn.Conv2d, nn.Linear)):
+            fan_in = int(np.prod(l.weight.shape[1:]))
+            weights[f"{i}.weight"] = (rng.standard_normal(tuple(l.weight.shape)) / np.sqrt(fan_in)).astype(np.float32)
+            weights[f"{i}.bias"] = (0.1 * rng.standard_normal(tuple(l.bias.shape))).astype(np.float32)
+    _ARCH[name] = list(spec)
+    _EXTRA_WEIGHTS[name] = weights
+    return name
 
 
 def _make(spec):
@@ -57,7 +75,7 @@ def build_net(name, weights=None):
     if name not in _ARCH:
         raise NotImplementedError(name)
     if weights is None:
-        weights = np.load(os.path.join(ASSETS, name + ".npz"))
+        weights = _EXTRA_WEIGHTS[name] if name in _EXTRA_WEIGHTS else np.load(os.path.join(ASSETS, name + ".npz"))
     layers = [_make(s) for s in _ARCH[name]]
     with torch.no_grad():
         for i, l in enumerate(layers):
