@@ -95,9 +95,9 @@ def plan_flops(plan, B, stats, restrict_last=True):
                 add(issued, agg, MFMA_FLOP * B * tiles(u["nodes"]) * ((u["n_src"] + 1) // 2) * 2)
     for k, st in stats.items():
         add(alg, "k_pre_fwd", 2.0 * (7 * 64 + 2 * 64 * 64) * st["amb"])
-        add(issued, "k_pre_fwd", MFMA_FLOP * tiles(st["amb"]) * 136)
+        add(issued, "k_pre_fwd", MFMA_FLOP * tiles(st["amb"]) * 72)
         add(alg, "k_pre_bwd", 2.0 * (7 * 64 + 3 * 64 * 64 + 192 * 64 + 64 * 64) * st["amb"])
-        add(issued, "k_pre_bwd", MFMA_FLOP * tiles(st["amb"]) * 456)
+        add(issued, "k_pre_bwd", MFMA_FLOP * tiles(st["amb"]) * 392)
         add(alg, "k_score", 2.0 * (64 * 64 + 64) * st["scored"])
         add(issued, "k_score", MFMA_FLOP * tiles(st["scored"]) * 64)
     return alg, issued, agg_bytes

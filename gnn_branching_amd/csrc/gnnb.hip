@@ -421,7 +421,7 @@ struct PreAllArgs {       // hoisted feature chains of every ReLU layer, forward
 };
 
 // tile space: (do_bwd) the backward tiles of all layers, ceil(c_k/32) each, then the forward tiles of all layers: a
-// backward tile is 456 MFMAs, a forward tile 136, and there are only a few tiles per wave, so the strided dealing below
+// backward tile is 392 MFMAs, a forward tile 72, and there are only a few tiles per wave, so the strided dealing below
 // hands every wave its share of the long ones first
 //   forward  P'_f[g] = fc4[:, :64] . fc1_1(relu(fc1(feat7))) + bcb_f                           graph_conv.py:153-161,176-177
 //   backward P'_b[g] = bc4[:, :64] . bc2_1(relu(bc2([s, -d2 s, d1 s]))) + bcb_b,
@@ -452,12 +452,9 @@ __device__ __forceinline__ void pre_tile(const PreAllArgs& a, const float* lds, 
       frag_bias(H, lds + PackPreFwd::B1, h);
       gemm_small<4>(lds + PackPreFwd::W1, lane, H, x);
       frag_relu(H);
-      Frag S;
-      frag_bias(S, lds + PackPreFwd::B2, h);
-      gemm_w64<32>(lds + PackPreFwd::W2, lane, S, [&](int s) { return FRAG_AT(H, s); });
-      Frag Pf;
-      frag_bias(Pf, lds + PackPreFwd::B3, h);
-      gemm_w64<32>(lds + PackPreFwd::W3, lane, Pf, [&](int s) { return FRAG_AT(S, s); });
+      Frag Pf;                                   // fc1_1 and the first half of fc4 are one folded 64x64 map
+      frag_bias(Pf, lds + PackPreFwd::B2, h);
+      gemm_w64<32>(lds + PackPreFwd::W2, lane, Pf, [&](int s) { return FRAG_AT(H, s); });
       if (valid) frag_store_rows(Pf, a.Pf[k], gc, h);
     } else {
       // feat7' = [l, u, beta, -d2+d1, z_post, z_pre, c]
@@ -485,12 +482,9 @@ __device__ __forceinline__ void pre_tile(const PreAllArgs& a, const float* lds, 
         return s < 32 ? v : (s < 64 ? v * nd2 : v * d1);
       });
       frag_relu(H4);
-      Frag X;
-      frag_bias(X, lds_b + PackPreBwd::B5, h);
-      gemm_w64<32>(lds_b + PackPreBwd::W5, lane, X, [&](int s) { return FRAG_AT(H4, s); });
-      Frag Pb;
-      frag_bias(Pb, lds_b + PackPreBwd::B6, h);
-      gemm_w64<32>(lds_b + PackPreBwd::W6, lane, Pb, [&](int s) { return FRAG_AT(X, s); });
+      Frag Pb;                                   // bc2_1 and the first half of bc4 are one folded 64x64 map
+      frag_bias(Pb, lds_b + PackPreBwd::B5, h);
+      gemm_w64<32>(lds_b + PackPreBwd::W5, lane, Pb, [&](int s) { return FRAG_AT(H4, s); });
       if (valid) frag_store_rows(Pb, a.Pb[k], gc, h);
     }
   }

@@ -118,8 +118,9 @@ inline void pack_transposed(float* dst, const float* W, int out, int in) {
 // k_embed: E0 = relu(inp_f([l0, x, u0])); mu0 = inp_f_1(E0) is deferred       (graph_conv.py:90-95)
 // (VALU kernel: plain row-major inp_f.weight (64 x 3) and bias)
 struct PackEmbed { enum { W = 0, B = W + 192, FLOATS = B + 64 }; };
-// k_pre_fwd: P = fc4[:, :64] (fc1_1(relu(fc1 feat7)) * amb) + fc4.bias    (:153-161, :176-177)
-struct PackPreFwd { enum { W1 = 0, B1 = W1 + 512, W2 = B1 + 64, B2 = W2 + 4096, W3 = B2 + 64, B3 = W3 + 4096, FLOATS = B3 + 64 }; };
+// k_pre, forward chain: P' = fc4[:, :64] (fc1_1(relu(fc1 feat7)) * amb) + bcb    (:153-161, :176-177)
+// fc1_1 feeds fc4 linearly, so W2 = fc4[:, :64].fc1_1.W (one GEMM instead of two), B2 = fc4[:, :64].fc1_1.b + bcb
+struct PackPreFwd { enum { W1 = 0, B1 = W1 + 512, W2 = B1 + 64, B2 = W2 + 4096, FLOATS = B2 + 64 }; };
 // k_node_update (forward: fc3, fc3_2, fc4[:, 64:], fc4_2; backward: bc3, bc3_1, bc4[:, 64:], bc4_1)
 // Folded form (exact algebra): e = Wb.h + bb enters the next layer linearly, so
 //   relu(W4.[relax, e] + b4) = relu(P' + Wcb.h),  Wcb = W4[:, 64:].Wb,  P' = W4[:, :64].relax + b4 + W4[:, 64:].bb
@@ -134,9 +135,10 @@ struct PackUpd { enum { WA = 0, WAS = WA + 8192, BA = WAS + 4096, WCB = BA + 64,
                         VAW = BCBROW + 64, FLOATS = VAW + 128 }; };
 // k_pre_bwd: P = bc4[:, :64] (bc2_1(relu(bc2([s, -d2 s, d1 s]))) * amb) + bc4.bias,
 //            s = bc1_2(relu(bc1_1(relu(bc1 feat7'))))                      (:273-293, :344-345)
+// likewise W5 = bc4[:, :64].bc2_1.W, B5 = bc4[:, :64].bc2_1.b + bcb
 struct PackPreBwd {
   enum { W1 = 0, B1 = W1 + 512, W2 = B1 + 64, B2 = W2 + 4096, W3 = B2 + 64, B3 = W3 + 4096, W4 = B3 + 64,
-         B4 = W4 + 12288, W5 = B4 + 64, B5 = W5 + 4096, W6 = B5 + 64, B6 = W6 + 4096, FLOATS = B6 + 64 };
+         B4 = W4 + 12288, W5 = B4 + 64, B5 = W5 + 4096, FLOATS = B5 + 64 };
 };
 // k_pre_inp: Q = inp_b2[:, :64] inp_b_1(relu(inp_b([l0,u0]))) + inp_b2.bias   (:380-384)
 // folded: Q = (inp_b2[:, :64].inp_b_1.W) relu(inp_b([l0,u0])) + (inp_b2[:, :64].inp_b_1.b + inp_b2.b)
@@ -189,10 +191,6 @@ inline void build_packs(const float* blob, Packs& pk) {
   pk.pre_fwd.assign(PackPreFwd::FLOATS, 0.f);
   pack_wsmall(&pk.pre_fwd[PackPreFwd::W1], W(L_FC1), 7, 4);
   pack_vec64(&pk.pre_fwd[PackPreFwd::B1], Bv(L_FC1));
-  pack_w64(&pk.pre_fwd[PackPreFwd::W2], W(L_FC1_1), 64, 0, 1);
-  pack_vec64(&pk.pre_fwd[PackPreFwd::B2], Bv(L_FC1_1));
-  pack_w64(&pk.pre_fwd[PackPreFwd::W3], W(L_FC4), 128, 0, 1);
-  pack_vec64(&pk.pre_fwd[PackPreFwd::B3], Bv(L_FC4));
 
   // folded bias of the update chain: bcb = b_c + W_c[:, 64:].b_b  (also added to the P' the feature chains cache)
   auto bcb_of = [&](int b, int c, float* out) { matvec64(out, W(c), 128, 64, Bv(b), Bv(c)); };
@@ -246,10 +244,14 @@ inline void build_packs(const float* blob, Packs& pk) {
   upd(pk.upd_fwd_f, L_FC3, L_FC3_2, L_FC4, L_FC4_2, false, L_FC4_2);        // layers >= 2: from the forward update below
   upd(pk.upd_bwd, L_BC3, L_BC3_1, L_BC4, L_BC4_1, false);                   // top layer: final aggregate from the property node
   upd(pk.upd_bwd_b, L_BC3, L_BC3_1, L_BC4, L_BC4_1, false, L_BC4_1);        // below: from the backward update above
-  {   // the feature chains cache P' = W4[:, :64].relax + bcb
-    float bcb[64];
+  {   // the feature chains cache P' = W4[:, :64].relax + bcb, relax = fc1_1(.) folded in
+    float bcb[64], b2[64];
+    std::vector<float> w2(64 * 64);
     bcb_of(L_FC3_2, L_FC4, bcb);
-    pack_vec64(&pk.pre_fwd[PackPreFwd::B3], bcb);
+    matmul64(w2.data(), W(L_FC4), 128, 0, W(L_FC1_1));
+    matvec64(b2, W(L_FC4), 128, 0, Bv(L_FC1_1), bcb);
+    pack_w64(&pk.pre_fwd[PackPreFwd::W2], w2.data(), 64, 0, 1);
+    pack_vec64(&pk.pre_fwd[PackPreFwd::B2], b2);
   }
 
   pk.pre_bwd.assign(PackPreBwd::FLOATS, 0.f);
@@ -261,13 +263,14 @@ inline void build_packs(const float* blob, Packs& pk) {
   pack_vec64(&pk.pre_bwd[PackPreBwd::B3], Bv(L_BC1_2));
   pack_w64(&pk.pre_bwd[PackPreBwd::W4], W(L_BC2), 192, 0, 3);
   pack_vec64(&pk.pre_bwd[PackPreBwd::B4], Bv(L_BC2));
-  pack_w64(&pk.pre_bwd[PackPreBwd::W5], W(L_BC2_1), 64, 0, 1);
-  pack_vec64(&pk.pre_bwd[PackPreBwd::B5], Bv(L_BC2_1));
-  pack_w64(&pk.pre_bwd[PackPreBwd::W6], W(L_BC4), 128, 0, 1);
   {
-    float bcb[64];
+    float bcb[64], b5[64];
+    std::vector<float> w5(64 * 64);
     bcb_of(L_BC3_1, L_BC4, bcb);
-    pack_vec64(&pk.pre_bwd[PackPreBwd::B6], bcb);
+    matmul64(w5.data(), W(L_BC4), 128, 0, W(L_BC2_1));
+    matvec64(b5, W(L_BC4), 128, 0, Bv(L_BC2_1), bcb);
+    pack_w64(&pk.pre_bwd[PackPreBwd::W5], w5.data(), 64, 0, 1);
+    pack_vec64(&pk.pre_bwd[PackPreBwd::B5], b5);
   }
 
   pk.pre_inp.assign(PackPreInp::FLOATS, 0.f);

@@ -173,13 +173,30 @@ def test_input_update_pack(packs):
     np.testing.assert_allclose(rows_from_frag(np.maximum(Hf, 0)), want, atol=2e-5)
 
 
+def test_pre_fwd_chain(packs):
+    """k_pre, forward: fc1 on the 7 scalar features, then fc1_1 folded into fc4[:, :64] (one 64x64 map), bias = folded bcb."""
+    sd, pk = packs
+    rng = np.random.RandomState(12)
+    f7 = rng.standard_normal((32, 7))
+    p = pk["pre_fwd"]
+    assert p.size == 512 + 64 + 4096 + 64
+    f8 = np.concatenate([f7, np.zeros((32, 1))], 1)
+    H1 = frag_bias(p[512:576]); gemm_small(p[0:], 4, H1, [f8[J, 2 * s + H] for s in range(4)]); H1 = np.maximum(H1, 0)
+    Pf = frag_bias(p[4672:4736]); gemm_w64(p[576:], 32, Pf, lambda s: H1[:, s])
+    relax = lin(sd, E + "fc1_1", np.maximum(lin(sd, E + "fc1", f7), 0))
+    w4, b4 = np.asarray(sd[E + "fc4.weight"], np.float64), np.asarray(sd[E + "fc4.bias"], np.float64)
+    bcb = b4 + w4[:, 64:] @ np.asarray(sd[E + "fc3_2.bias"], np.float64)
+    np.testing.assert_allclose(rows_from_frag(Pf), relax @ w4[:, :64].T + bcb, atol=1e-5)
+
+
 def test_pre_bwd_chain(packs):
     """k_pre_bwd: bc1 (7 scalar features, zero-padded k-steps) .. bc2 on [s, -d2 s, d1 s] .. bc4[:, :64]."""
     sd, pk = packs
     rng = np.random.RandomState(2)
     f7 = rng.standard_normal((32, 7)); d1 = rng.uniform(0, 1, 32); d2 = rng.uniform(0, 1, 32)
     p = pk["pre_bwd"]
-    W1, B1, W2, B2, W3, B3, W4, B4, W5, B5, W6, B6 = 0, 512, 576, 4672, 4736, 8832, 8896, 21184, 21248, 25344, 25408, 29504
+    W1, B1, W2, B2, W3, B3, W4, B4, W5, B5 = 0, 512, 576, 4672, 4736, 8832, 8896, 21184, 21248, 25344
+    assert p.size == 25408
     f8 = np.concatenate([f7, np.zeros((32, 1))], 1)
     x = [f8[J, 2 * s + H] for s in range(4)]
     H1 = frag_bias(p[B1:B1 + 64]); gemm_small(p[W1:], 4, H1, x); H1 = np.maximum(H1, 0)
@@ -188,8 +205,7 @@ def test_pre_bwd_chain(packs):
     H4 = frag_bias(p[B4:B4 + 64])
     gemm_w64(p[W4:], 96, H4, lambda s: S[:, s & 31] * (1.0 if s < 32 else (-d2[J] if s < 64 else d1[J])))
     H4 = np.maximum(H4, 0)
-    X = frag_bias(p[B5:B5 + 64]); gemm_w64(p[W5:], 32, X, lambda s: H4[:, s])
-    Pb = frag_bias(p[B6:B6 + 64]); gemm_w64(p[W6:], 32, Pb, lambda s: X[:, s])
+    Pb = frag_bias(p[B5:B5 + 64]); gemm_w64(p[W5:], 32, Pb, lambda s: H4[:, s])     # bc2_1 folded into bc4[:, :64]
     got = rows_from_frag(Pb)
     s_ = lin(sd, E + "bc1_2", np.maximum(lin(sd, E + "bc1_1", np.maximum(lin(sd, E + "bc1", f7), 0)), 0))
     relax = lin(sd, E + "bc2_1", np.maximum(lin(sd, E + "bc2", np.concatenate([s_, s_ * -d2[:, None], s_ * d1[:, None]], 1)), 0))
