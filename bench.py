@@ -228,7 +228,11 @@ def main():
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_path) and args.net == "cifar_base_kw" and B == 256:
-            traffic = json.load(open(pmc_path)).get(dom, {}).get("hbm_bytes_per_launch")
+            # a profile class may cover several kernel templates (k_gather, k_gather16): launch-weighted mean
+            pmc = json.load(open(pmc_path))
+            rows = [v for k, v in pmc.items() if (k == dom or (k.startswith(dom) and k[len(dom):].isdigit())) and "hbm_bytes_per_launch" in v]
+            n = sum(v.get("launches_sampled", 1) for v in rows)
+            traffic = round(sum(v["hbm_bytes_per_launch"] * v.get("launches_sampled", 1) for v in rows) / n) if n else None
         ach_tf = alg.get(dom, 0.0) / dom_s / 1e12 if dom_s > 0 else 0.0
         iss_tf = issued.get(dom, 0.0) / dom_s / 1e12 if dom_s > 0 else 0.0
         launches = kern[dom]["launches"] // args.steps
