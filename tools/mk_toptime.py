@@ -2,12 +2,12 @@
 import subprocess
 src = open('/root/repo/gnn_branching_amd/csrc/gnnb.hip').read()
 src = src.replace('"../../include/gnnb.h"', '"/root/repo/include/gnnb.h"').replace('"gnnb_pack.h"', '"/root/repo/gnn_branching_amd/csrc/gnnb_pack.h"')
-a = src.index('__global__ __launch_bounds__(512, 1) void k_top(TopArgs a) {')
-b = src.index('// ------------------------------------------------------------------------------------------\n// k_livesum')
+a = src.index('__device__ __forceinline__ void top_sample(')
+b = src.index('__global__ __launch_bounds__(512, 1) void k_top(TopArgs a) {')
 body = src[a:b]
 marks = ['  // ---- F1: rows of C', '  // per-lane node of the update phases', '  // ---- F2: forward node update', '  // ---- F3: property node',
          '  // ---- B1: backward node update', '  // ---- B2: aggregate rows']
-body = body.replace('  const int b = blockIdx.x, N = a.N;', '  const int b = blockIdx.x, N = a.N;\n  long long tt[8]; int ti = 0;\n  tt[ti++] = wall_clock64();')
+body = body.replace('  const int N = a.N;', '  const int N = a.N;\n  long long tt[8]; int ti = 0;\n  tt[ti++] = wall_clock64();')
 for m in marks:
     assert m in body, m
     body = body.replace(m, '  __syncthreads(); tt[ti++] = wall_clock64();\n' + m)
