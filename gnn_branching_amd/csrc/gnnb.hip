@@ -1,22 +1,22 @@
 // gnnb.hip -- MI355X (gfx950 / CDNA4) GNN branching-score forward pass: HIP kernels + C-ABI.
 //
 // What runs here is the reference's graphnet/graph_conv.py (EmbedLayerUpdate.forward :77-388,
-// ComputeFinalScore.forward :442-470) and the argmax of graphnet/graph_score.py :41-47, for a
-// batch of B subproblems, re-designed for CDNA4:
+// ComputeFinalScore.forward :442-470), the argmax of graphnet/graph_score.py :41-47 and the BaBSR heuristic of
+// plnn/kw_score_conv.py :41-113, for a batch of B subproblems, re-designed for CDNA4 (DESIGN.md sections 3-5):
 //
 //   * embeddings mu[k] live in HBM as (B, N_k, 64) fp32, one 256-B row per node;
-//   * every node MLP is a chain of exact-fp32 MFMAs (v_mfma_f32_32x32x2_f32) run TRANSPOSED:
-//     weights are the A operand (staged once per workgroup in LDS, pre-permuted on the host, see
-//     gnnb_pack.h), the 32 nodes of a tile sit on the lanes, and the accumulators of one layer
-//     are the B operands of the next -- no LDS round trip between layers;
-//   * node-feature-only sub-chains (fc1*, bc1*/bc2*, inp_b*) do not depend on the embeddings, so
-//     they are evaluated ONCE per forward (not once per round) and folded through the first half
-//     of the following 128->64 layer into a cached 64-vector per node ("P");
-//   * edge aggregation (the message passing): conv / conv-transpose gathers run on the VALU with
-//     lane = embedding channel (coalesced 256-B row loads, wave-uniform weights in SGPRs), dense
-//     Linear edges run on the MFMA;
-//   * provably dead work of the reference is not executed: the `ratio` chain (:214-216,228,243,356)
-//     and the last round's input-layer update (:360-385), whose result nothing reads.
+//   * every node MLP is a chain of exact-fp32 MFMAs (v_mfma_f32_32x32x2_f32) run TRANSPOSED: weights are the A operand
+//     (staged once per workgroup in LDS, pre-permuted on the host, gnnb_pack.h), the 32 nodes of a tile sit on the lanes,
+//     and the accumulators of one layer are the B operands of the next -- no LDS round trip between layers;
+//   * node-feature-only sub-chains do not depend on the embeddings: evaluated ONCE per forward (k_pre) and folded
+//     into a cached 64-vector per ambiguous node; linear layers that meet are pre-multiplied on the host; every producer's
+//     last Linear is deferred into its consumers ("deferred projection", gnnb_pack.h);
+//   * node classes (live / ambiguous / scored) are compacted once per forward (k_classify) and the node MLPs run over
+//     the lists only;
+//   * conv / conv-transpose message passing is a dense local block per tile on the MFMA (k_gather, k_gather16,
+//     k_gather_input_update), Linear edges and everything above the last conv layer run per sample out of LDS (k_top);
+//   * provably dead work of the reference is not executed: the `ratio` chain (:214-216,228,243,356) and the last
+//     round's input-layer update (:360-385), whose result nothing reads.
 //
 // gfx950 only.  No HIP call at load time.
 #include <hip/hip_runtime.h>
