@@ -2422,8 +2422,6 @@ extern "C" int gnnb_bind_network(gnnb_t* h, const gnnb_layer_desc* L, int n, int
         return fail(GNNB_E_INVALID, "layer %d: conv geometry leaves a remainder (conv_transpose2d of the reference would need output_padding)", q);
       e.h_out = (H + 2 * d.pad - d.kh) / d.stride + 1;
       e.w_out = (W + 2 * d.pad - d.kw) / d.stride + 1;
-      if (!conv_channels_ok(e.c_in) || !conv_channels_ok(e.c_out))
-        return fail(GNNB_E_INVALID, "layer %d: conv channel counts %d->%d not in {3,8,16,32}", q, e.c_in, e.c_out);
       e.n_in = C * H * W;
       e.n_out = e.c_out * e.h_out * e.w_out;
       e.w.assign(d.weight, d.weight + (size_t)e.c_out * e.c_in * e.kh * e.kw);
@@ -2535,6 +2533,14 @@ extern "C" int gnnb_bind_network(gnnb_t* h, const gnnb_layer_desc* L, int n, int
         d.ok = true;
       }
     }
+  // an edge without MFMA gather tables falls back to the VALU gathers, which are compiled for a few channel counts only
+  for (int k = 1; k <= Lr; ++k) {
+    const Edge& e = h->edges[k];
+    if (e.kind != 0) continue;
+    if ((!h->gf[k].ok && !conv_channels_ok(e.c_out)) || (!h->gb[k].ok && !conv_channels_ok(e.c_in)))
+      return fail(GNNB_E_INVALID, "conv edge %d (%d -> %d channels): no MFMA gather tables and the fallback kernels only cover channel counts "
+                  "{3, 8, 16, 32}", k, e.c_in, e.c_out);
+  }
   h->bound = true;
   return GNNB_OK;
 }

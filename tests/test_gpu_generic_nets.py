@@ -20,6 +20,9 @@ ARCHS = {
                   ("relu",), ("linear", 48, 10)],
     # last ReLU layer with 200 nodes: too wide for k_top, separate dense / update / property kernels
     "toy_widehead": [("conv", 3, 8, 4, 2, 1), ("relu",), ("flatten",), ("linear", 8 * 16 * 16, 200), ("relu",), ("linear", 200, 10)],
+    # channel counts the VALU fallback kernels are not compiled for (12, 6): MFMA gather tables only
+    "toy_oddch": [("conv", 3, 12, 3, 1, 1), ("relu",), ("conv", 12, 6, 4, 2, 1), ("relu",), ("flatten",), ("linear", 6 * 16 * 16, 32),
+                  ("relu",), ("linear", 32, 10)],
     # a single ReLU layer (L = 1)
     "toy_single": [("conv", 3, 8, 4, 2, 1), ("relu",), ("flatten",), ("linear", 8 * 16 * 16, 10)],
 }
