@@ -318,9 +318,30 @@ def cpu_baseline(sd, net, cpu_batch):
             if time.perf_counter() - t0 > 10.0 or reps >= 20:
                 break
         dt = time.perf_counter() - t0
-    return {"value": round(n_amb * reps / dt, 1), "unit": "scores/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{reps} forwards of {cpu_batch} {net} subproblems (seed 1234), oracle/gnn_oracle.py, {dt:.1f}s",
-            "subproblems_per_s": round(cpu_batch * reps / dt, 2)}
+    out = {"value": round(n_amb * reps / dt, 1), "unit": "scores/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{reps} forwards of {cpu_batch} {net} subproblems (seed 1234), oracle/gnn_oracle.py, {dt:.1f}s",
+           "subproblems_per_s": round(cpu_batch * reps / dt, 2)}
+    # the reference's own deployment is ONE core per BaB process (scripts/bab_mip.sh:3-5 pins with taskset) and one
+    # subproblem per call; SURVEY 8(d) asks for that figure next to the all-cores one
+    nthreads = torch.get_num_threads()
+    try:
+        torch.set_num_threads(1)
+        one = batch.slice(0, 1)
+        n1 = int(one.masks.sum().item())
+        with torch.no_grad():
+            gnn_oracle.oracle_forward(state, *one.forward_args())
+            reps1, t0 = 0, time.perf_counter()
+            while True:
+                gnn_oracle.oracle_forward(state, *one.forward_args())
+                reps1 += 1
+                if time.perf_counter() - t0 > 5.0 or reps1 >= 20:
+                    break
+            dt1 = time.perf_counter() - t0
+        out["one_core_batch1"] = {"value": round(n1 * reps1 / dt1, 1), "unit": "scores/s", "cores": 1,
+                                  "sample": f"{reps1} forwards of 1 subproblem, {dt1:.1f}s", "ms_per_decision": round(1e3 * dt1 / reps1, 1)}
+    finally:
+        torch.set_num_threads(nthreads)
+    return out
 
 
 if __name__ == "__main__":

@@ -14,16 +14,20 @@ tile = base[a:b]
 def variant(name):
     t = tile
     s = base
-    if name in ('none', 'noflag', 'nonorm', 'noload'):
+    if name in ('none', 'noflag', 'nonorm', 'noload', 'nostage', 'notiles'):
         t = t.replace('        const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, vo, soff, 0);\n        dst[u] = make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));',
                       '        dst[u] = make_float2(__uint_as_float(vo), 1.0f);')
         t = t.replace('        dst[u] = buf_load2(rsrc, o);', '        dst[u] = make_float2(__uint_as_float(o), 1.0f);')
-    if name in ('none', 'noflag', 'nonorm', 'nomfma'):
+    if name in ('none', 'noflag', 'nonorm', 'nomfma', 'nostage', 'notiles'):
         t = t.replace('      X.t[0] = mfma32(v[u].x, b, X.t[0]);\n      X.t[1] = mfma32(v[u].y, b, X.t[1]);',
                       '      X.t[0][u] += v[u].x * b;\n      X.t[1][u] += v[u].y * b;')
     s = s[:a] + t + s[b:]
-    if name in ('none', 'noflag', 'nonorm'):
+    if name in ('none', 'noflag', 'nonorm', 'nostage', 'notiles'):
         s = s.replace('    if (need) frag_store_rows_gathered(X, a.nb, gc, h);\n  }\n}', '    if (need && X.t[0][0] == 123.456f) frag_store_rows_gathered(X, a.nb, gc, h);\n  }\n}')
+    if name == 'nostage':
+        s = s.replace('  stage_gather(gl.cm, gl.ko, gl.tt, gl.kvo, a.g, a.tm.TPS);\n  __syncthreads();\n  const int lane = threadIdx.x & 63, j = lane & 31, wave = threadIdx.x >> 6;\n  const EmbedLane el', '  const int lane = threadIdx.x & 63, j = lane & 31, wave = threadIdx.x >> 6;\n  const EmbedLane el', 1)
+    if name == 'notiles':
+        s = s.replace('  long tile = t0 + wave;\n  if (tile >= t1) return;\n  // tile, sample and t are wave-uniform by construction; make them provably so (scalar registers, scalar base address)\n  int sample = __builtin_amdgcn_readfirstlane((int)(tile / a.tm.TPS));\n  int t = __builtin_amdgcn_readfirstlane((int)(tile - (long)sample * a.tm.TPS));\n  for (; tile < t1; tile += WAVES_MLP, t += WAVES_MLP) {\n    while (t >= a.tm.TPS) { t -= a.tm.TPS; ++sample; }\n    const TileCtx tc = block_decode(a.tm, gl.tt, sample, t, j);\n    gather_process_tile<EMBED>', '  long tile = t0 + wave;\n  if (tile >= t1 || a.ntiles > 0) return;\n  int sample = __builtin_amdgcn_readfirstlane((int)(tile / a.tm.TPS));\n  int t = __builtin_amdgcn_readfirstlane((int)(tile - (long)sample * a.tm.TPS));\n  for (; tile < t1; tile += WAVES_MLP, t += WAVES_MLP) {\n    while (t >= a.tm.TPS) { t -= a.tm.TPS; ++sample; }\n    const TileCtx tc = block_decode(a.tm, gl.tt, sample, t, j);\n    gather_process_tile<EMBED>', 1)
     if name == 'noflag':
         s = s.replace('    else need = tc.valid && node_is_live(a.lb[gc], a.ub[gc]);', '    else need = tc.valid;')
     if name == 'nonorm':
