@@ -1,0 +1,285 @@
+"""Input producer without Gurobi: the LP relaxation of a BaB subproblem on scipy's HiGHS.
+
+The reference builds its subproblems with Gurobi (plnn/conv_kwinter_gen.py build_the_model :179-555 and
+update_the_model :558-795): intermediate bounds, the triangle relaxation of every undecided ReLU as three constraints
+(``v >= 0``, ``v >= pre``, ``v <= slope * pre + bias``, :419-421 / :456-458), minimise the folded property output, then
+read the primal point, the per-layer primal values and the constraint duals ``Pi`` (:535-552) -- exactly the arguments
+``GraphChoice.decision`` takes.  Gurobi is not available here, so this module restates that producer on
+``scipy.optimize.linprog(method="highs")``:
+
+* intermediate bounds: interval arithmetic through the fixed layers (the reference intersects them with Wong-Kolter
+  bounds, dual_network_linear_approximation.py:205-451, which are tighter; interval bounds are valid, only looser),
+  honouring the split mask (a node forced passing gets ``pre >= 0``, forced blocking ``pre <= 0``);
+* the LP: one variable block per network layer, affine layers as equalities with their scipy.sparse matrix, decided
+  ReLUs as equalities / fixed bounds, undecided ones as the two inequality rows (``v >= 0`` is the variable bound);
+* duals in Gurobi's sign convention: ``Pi(v >= pre) = -marginal(pre - v <= 0)``, ``Pi(v <= slope pre + bias) =
+  marginal(v - slope pre <= bias)``; the column of ``v >= 0`` stays 0 (graph_conv.py reads columns 1 and 2 only).
+
+Parity with the reference's Gurobi numbers cannot be pinned here (no Gurobi to compare with; LP duals are not unique
+anyway): ``tests/test_lp_producer.py`` checks what can be checked without it -- soundness of the bound, primal
+feasibility, complementary slackness of the reported duals, monotonicity under branching.
+Host-side CPU code, like the reference's; the GPU only scores.
+"""
+from dataclasses import dataclass
+from typing import List
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+from scipy.optimize import linprog
+from torch import nn
+from torch.nn import functional as F
+
+from .plnn.modules import Flatten
+
+
+def _is_flatten(layer):
+    return isinstance(layer, Flatten) or type(layer).__name__ == "Flatten"
+
+
+def conv_matrix(layer, in_shape):
+    """scipy.sparse CSR matrix of a Conv2d on a (C, H, W) input, C-order flattened both sides."""
+    c_in, h_in, w_in = in_shape
+    w = layer.weight.detach().double().numpy()
+    c_out, _, kh, kw = w.shape
+    sy, sx = layer.stride
+    py, px = layer.padding
+    h_out = (h_in + 2 * py - kh) // sy + 1
+    w_out = (w_in + 2 * px - kw) // sx + 1
+    co, oy, ox, ci, ky, kx = np.meshgrid(np.arange(c_out), np.arange(h_out), np.arange(w_out), np.arange(c_in), np.arange(kh),
+                                         np.arange(kw), indexing="ij")
+    iy, ix = oy * sy - py + ky, ox * sx - px + kx
+    ok = (iy >= 0) & (iy < h_in) & (ix >= 0) & (ix < w_in)
+    rows = ((co * h_out + oy) * w_out + ox)[ok]
+    cols = ((ci * h_in + iy) * w_in + ix)[ok]
+    vals = w[co[ok], ci[ok], ky[ok], kx[ok]]
+    n_out, n_in = c_out * h_out * w_out, c_in * h_in * w_in
+    return sp.csr_matrix((vals, (rows, cols)), shape=(n_out, n_in)), (c_out, h_out, w_out)
+
+
+@dataclass
+class Subproblem:
+    """What one LP solve yields: the arguments of ``GraphChoice.decision`` plus the bounds of the domain."""
+    lb: float                        # LP optimum: lower bound on the property output over the domain
+    ub: float                        # network output at the LP's input point: upper bound on the minimum
+    ub_point: torch.Tensor           # (1, C, H, W)
+    lower_all: List[torch.Tensor]    # per network layer (input first), layer-shaped
+    upper_all: List[torch.Tensor]
+    dual_vars: List[torch.Tensor]    # per ReLU layer (N, 3)
+    primals: List[list]              # per network layer after the input
+    mask: List[torch.Tensor]         # per ReLU layer, {-1, 0, 1}
+
+    def graph_bounds(self, pre_relu_indices, n_layers):
+        idx = [0] + list(pre_relu_indices) + [n_layers]
+        return [self.lower_all[i].unsqueeze(0) for i in idx], [self.upper_all[i].unsqueeze(0) for i in idx]
+
+
+class LayerGraphLP:
+    """LP relaxation of ``layers`` (net.layers with the folded Linear(., 1) property layer last) over an input box."""
+
+    def __init__(self, layers, input_lb, input_ub):
+        self.layers = list(layers)
+        self.input_lb, self.input_ub = input_lb.detach().double(), input_ub.detach().double()
+        self.shapes = [tuple(input_lb.shape)]
+        self.mats = []                       # per layer: ("affine", A, b) / ("relu",) / ("flatten",)
+        shape = tuple(input_lb.shape)
+        for l in self.layers:
+            if type(l) is nn.Conv2d:
+                A, shape = conv_matrix(l, shape)
+                b = np.repeat(l.bias.detach().double().numpy(), shape[1] * shape[2])
+                self.mats.append(("affine", A, b))
+            elif type(l) is nn.Linear:
+                A = sp.csr_matrix(l.weight.detach().double().numpy())
+                shape = (l.out_features,)
+                self.mats.append(("affine", A, l.bias.detach().double().numpy()))
+            elif type(l) is nn.ReLU:
+                self.mats.append(("relu",))
+            elif _is_flatten(l):
+                shape = (int(np.prod(shape)),)
+                self.mats.append(("flatten",))
+            else:
+                raise NotImplementedError(type(l))
+            self.shapes.append(shape)
+        if self.shapes[-1] != (1,):
+            raise ValueError("the last layer must be the folded property layer Linear(., 1)")
+        self.pre_relu_indices = [i for i, l in enumerate(self.layers) if type(l) is nn.ReLU]   # bounds-list index of the pre-activation
+        self.offsets = np.cumsum([0] + [int(np.prod(s)) for s in self.shapes])
+
+    # ---- intermediate bounds ----------------------------------------------------------------
+    def interval_bounds(self, mask):
+        """Interval arithmetic through the layers, honouring the split mask (list per ReLU layer, {-1, 0, 1})."""
+        lbs, ubs = [self.input_lb.clone()], [self.input_ub.clone()]
+        r = 0
+        for l in self.layers:
+            lo, up = lbs[-1], ubs[-1]
+            if type(l) is nn.Conv2d:
+                wp, wn = l.weight.double().clamp(min=0), l.weight.double().clamp(max=0)
+                nl = F.conv2d(lo[None], wp, l.bias.double(), l.stride, l.padding) + F.conv2d(up[None], wn, None, l.stride, l.padding)
+                nu = F.conv2d(up[None], wp, l.bias.double(), l.stride, l.padding) + F.conv2d(lo[None], wn, None, l.stride, l.padding)
+                nl, nu = nl[0], nu[0]
+            elif type(l) is nn.Linear:
+                wp, wn = l.weight.double().clamp(min=0), l.weight.double().clamp(max=0)
+                nl = wp @ lo + wn @ up + l.bias.double()
+                nu = wp @ up + wn @ lo + l.bias.double()
+            elif type(l) is nn.ReLU:
+                m = mask[r].reshape(lo.shape)
+                # a split tightens the PRE-activation bounds of the node (update_the_model, conv_kwinter_gen.py:573-585)
+                lo = torch.where(m == 1, lo.clamp(min=0), lo)
+                up = torch.where(m == 0, up.clamp(max=0), up)
+                lbs[-1], ubs[-1] = lo, up
+                nl, nu = lo.clamp(min=0), up.clamp(min=0)
+                r += 1
+            else:
+                nl, nu = lo.reshape(-1), up.reshape(-1)
+            lbs.append(nl)
+            ubs.append(nu)
+        return lbs, ubs
+
+    # ---- the LP -----------------------------------------------------------------------------
+    def solve(self, mask):
+        """Bounds + LP for the domain described by ``mask``; returns a Subproblem, or None when the domain is infeasible."""
+        mask = [m.clone() for m in mask]
+        lbs, ubs = self.interval_bounds(mask)
+        for lo, up in zip(lbs, ubs):
+            if bool((lo > up + 1e-9).any()):
+                return None
+        off = self.offsets
+        nvar = int(off[-1])
+        lo_v = np.concatenate([t.reshape(-1).numpy() for t in lbs])
+        up_v = np.concatenate([t.reshape(-1).numpy() for t in ubs])
+        eq_rows, eq_rhs, ub_rows, ub_rhs = [], [], [], []
+        amb_index = []                      # per ReLU layer: node ids of the undecided nodes, in constraint order
+        r = 0
+        for li, kind in enumerate(self.mats):
+            src, dst = slice(off[li], off[li + 1]), slice(off[li + 1], off[li + 2])
+            n_dst = dst.stop - dst.start
+            eye = sp.identity(n_dst, format="csr")
+
+            def row(block_src, block_dst, nrows):
+                left = sp.csr_matrix((nrows, src.start))
+                mid = sp.csr_matrix((nrows, dst.start - src.stop))
+                right = sp.csr_matrix((nrows, nvar - dst.stop))
+                return sp.hstack([left, block_src, mid, block_dst, right], format="csr")
+            if kind[0] == "affine":
+                _, A, b = kind
+                eq_rows.append(row(-A, eye, n_dst))
+                eq_rhs.append(b)
+            elif kind[0] == "flatten":
+                eq_rows.append(row(-eye, eye, n_dst))
+                eq_rhs.append(np.zeros(n_dst))
+            else:
+                pre_lo, pre_up = lo_v[src], up_v[src]
+                m = mask[r].reshape(-1).numpy().copy()
+                # bounds decide what the split mask left open (build_the_model :404-421)
+                m[(m == -1) & (pre_lo >= 0)] = 1
+                m[(m == -1) & (pre_up <= 0)] = 0
+                mask[r] = torch.from_numpy(m).to(mask[r].dtype)
+                passing, blocked, amb = np.nonzero(m == 1)[0], np.nonzero(m == 0)[0], np.nonzero(m == -1)[0]
+                if len(passing):
+                    S = sp.csr_matrix((np.ones(len(passing)), (np.arange(len(passing)), passing)), shape=(len(passing), n_dst))
+                    eq_rows.append(row(-S, S, len(passing)))
+                    eq_rhs.append(np.zeros(len(passing)))
+                post_up = np.maximum(pre_up, 0.0)
+                post_up[blocked] = 0.0
+                up_v[dst.start:dst.stop] = post_up
+                lo_v[dst.start:dst.stop] = 0.0
+                if len(amb):
+                    S = sp.csr_matrix((np.ones(len(amb)), (np.arange(len(amb)), amb)), shape=(len(amb), n_dst))
+                    slope = pre_up[amb] / (pre_up[amb] - pre_lo[amb])
+                    bias = -pre_lo[amb] * slope
+                    ub_rows.append(row(S, -S, len(amb)))                                   # pre - v <= 0
+                    ub_rhs.append(np.zeros(len(amb)))
+                    ub_rows.append(row(-sp.diags(slope) @ S, S, len(amb)))                 # v - slope pre <= bias
+                    ub_rhs.append(bias)
+                amb_index.append(amb)
+                r += 1
+        c = np.zeros(nvar)
+        c[-1] = 1.0
+        res = linprog(c, A_ub=sp.vstack(ub_rows, format="csr") if ub_rows else None, b_ub=np.concatenate(ub_rhs) if ub_rhs else None,
+                      A_eq=sp.vstack(eq_rows, format="csr"), b_eq=np.concatenate(eq_rhs), bounds=np.stack([lo_v, up_v], 1), method="highs")
+        if res.status == 2:
+            return None                      # infeasible domain
+        if res.status != 0:
+            raise RuntimeError(f"HiGHS: {res.message}")
+        z = res.x
+        marg = res.ineqlin.marginals if ub_rows else np.zeros(0)
+        duals, pos = [], 0
+        for ridx, amb in enumerate(amb_index):
+            n = int(np.prod(self.shapes[self.pre_relu_indices[ridx] + 1]))
+            d = np.zeros((n, 3))
+            if len(amb):
+                d[amb, 1] = -marg[pos:pos + len(amb)]                 # Pi of  v >= pre
+                d[amb, 2] = marg[pos + len(amb):pos + 2 * len(amb)]   # Pi of  v <= slope pre + bias
+                pos += 2 * len(amb)
+            duals.append(torch.from_numpy(d).float())
+        x0 = torch.from_numpy(z[off[0]:off[1]].copy()).float().reshape(self.shapes[0])
+        with torch.no_grad():
+            act = x0[None]
+            for l in self.layers:
+                act = l(act)
+        primals = [z[off[i + 1]:off[i + 2]].tolist() for i in range(len(self.layers))]
+        lower_all = [t.float() for t in lbs]
+        upper_all = [t.float() for t in ubs]
+        lower_all[-1] = torch.tensor([float(res.fun)])
+        return Subproblem(float(res.fun), float(act.reshape(-1)[0]), x0[None], lower_all, upper_all, duals, primals, mask)
+
+
+def branch_and_bound(lp, scorer, layers, eps=1e-4, max_nodes=200, decision_bound=None, log=print):
+    """The BaB loop of plnn/relu_conv_gnnkwthreshold.py:120-262 in its plain form: pick the domain with the lowest bound,
+    split the ReLU the scorer names, bound both children, keep those that can still improve the answer.
+
+    ``scorer(sub, layers_dict) -> [layer, idx]`` (gnn_scorer / babsr_scorer below).  ``decision_bound``: stop as soon as the
+    sign of (minimum - decision_bound) is known (the reference verifies with decision_bound = 0, :257-262); None: minimise
+    to ``eps``.  Returns (global_lb, global_ub, visited LP solves)."""
+    fixed = {"fixed_layers": list(layers[:-1]), "prop_layers": [layers[-1]]}
+    root_mask = [torch.full((int(np.prod(lp.shapes[i + 1])),), -1, dtype=torch.long) for i in lp.pre_relu_indices]
+    root = lp.solve(root_mask)
+    if root is None:
+        raise RuntimeError("infeasible root domain")
+    global_lb, global_ub, domains, visited = root.lb, root.ub, [root], 0
+    while domains and global_ub - global_lb > eps and visited < max_nodes:
+        if decision_bound is not None and (global_lb >= decision_bound or global_ub < decision_bound):
+            break
+        domains.sort(key=lambda d: d.lb)
+        dom = domains.pop(0)
+        if not any(bool((m == -1).any()) for m in dom.mask):
+            global_lb = min([d.lb for d in domains] + [global_ub])      # fully decided: its LP is exact
+            continue
+        decision = scorer(dom, fixed)
+        children = []
+        for choice in (0, 1):
+            m = [t.clone() for t in dom.mask]
+            m[decision[0]][decision[1]] = choice
+            child = lp.solve(m)
+            visited += 1
+            if child is None:
+                continue
+            global_ub = min(global_ub, child.ub)
+            children.append(child)
+        log(f"branch {visited} decision {decision} parent lb {dom.lb:.5f} children lb {[round(c.lb, 5) for c in children]}")
+        for c in children:
+            if c.lb < global_ub - eps and (decision_bound is None or c.lb < decision_bound):
+                domains.append(c)
+        global_lb = min([d.lb for d in domains], default=global_ub - eps)
+    return global_lb, global_ub, visited
+
+
+# ---- scorers for branch_and_bound -------------------------------------------------------------
+def gnn_scorer(choice, lp):
+    """The GNN decision on a Subproblem (``choice``: graph_score.GraphChoice or bab_caller.BatchedGraphChoice)."""
+    def score(sub, layers):
+        lbg, ubg = sub.graph_bounds(lp.pre_relu_indices, len(lp.layers))
+        return choice.decision(lbg, ubg, sub.dual_vars, sub.ub_point, sub.primals, layers, sub.mask)
+    return score
+
+
+def babsr_scorer(lp):
+    """The BaBSR heuristic on a Subproblem (plnn/kw_score_conv.choose_node_conv; relu_conv_gnnkwthreshold.py:157)."""
+    from .plnn.kw_score_conv import choose_node_conv
+    state = {"icp": 0}
+
+    def score(sub, layers):
+        order = list(range(len(lp.pre_relu_indices)))
+        decision, state["icp"] = choose_node_conv(sub.lower_all, sub.upper_all, sub.mask, lp.layers, lp.pre_relu_indices, state["icp"], order, -1)
+        return decision
+    return score
