@@ -195,8 +195,11 @@ class LayerGraphLP:
                 r += 1
         c = np.zeros(nvar)
         c[-1] = 1.0
-        res = linprog(c, A_ub=sp.vstack(ub_rows, format="csr") if ub_rows else None, b_ub=np.concatenate(ub_rhs) if ub_rhs else None,
-                      A_eq=sp.vstack(eq_rows, format="csr"), b_eq=np.concatenate(eq_rhs), bounds=np.stack([lo_v, up_v], 1), method="highs")
+        args = dict(A_ub=sp.vstack(ub_rows, format="csr") if ub_rows else None, b_ub=np.concatenate(ub_rhs) if ub_rhs else None,
+                    A_eq=sp.vstack(eq_rows, format="csr"), b_eq=np.concatenate(eq_rhs), bounds=np.stack([lo_v, up_v], 1), method="highs")
+        res = linprog(c, **args)
+        if res.status not in (0, 2):         # HiGHS' presolve sometimes ends without a model status on an infeasible child
+            res = linprog(c, options={"presolve": False}, **args)
         if res.status == 2:
             return None                      # infeasible domain
         if res.status != 0:
