@@ -240,13 +240,15 @@ def branch_and_bound(lp, scorer, layers, eps=1e-4, max_nodes=200, decision_bound
     if root is None:
         raise RuntimeError("infeasible root domain")
     global_lb, global_ub, domains, visited = root.lb, root.ub, [root], 0
+    closed_lb = float("inf")                # lowest bound among the leaves that were closed (proved >= decision_bound or optimal)
     while domains and global_ub - global_lb > eps and visited < max_nodes:
         if decision_bound is not None and (global_lb >= decision_bound or global_ub < decision_bound):
             break
         domains.sort(key=lambda d: d.lb)
         dom = domains.pop(0)
         if not any(bool((m == -1).any()) for m in dom.mask):
-            global_lb = min([d.lb for d in domains] + [global_ub])      # fully decided: its LP is exact
+            closed_lb = min(closed_lb, dom.lb)                          # fully decided: its LP is exact
+            global_lb = min([d.lb for d in domains] + [closed_lb])
             continue
         decision = scorer(dom, fixed)
         children = []
@@ -263,7 +265,9 @@ def branch_and_bound(lp, scorer, layers, eps=1e-4, max_nodes=200, decision_bound
         for c in children:
             if c.lb < global_ub - eps and (decision_bound is None or c.lb < decision_bound):
                 domains.append(c)
-        global_lb = min([d.lb for d in domains], default=global_ub - eps)
+            else:
+                closed_lb = min(closed_lb, c.lb)
+        global_lb = min([d.lb for d in domains] + [closed_lb, global_ub])
     return global_lb, global_ub, visited
 
 
