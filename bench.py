@@ -302,41 +302,43 @@ def main():
 
 
 def cpu_baseline(sd, net, cpu_batch):
-    """The CPU oracle (a torch-CPU port with the reference's op sequence) on a bounded sample of the
-    same workload, all host threads torch uses by default, default denormal handling."""
+    """The CPU oracle (a torch-CPU port with the reference's op sequence) on a bounded sample of the same workload.
+    The small per-layer ops of this path do not scale with threads (128 threads are SLOWER than 16), so a few thread
+    counts are tried for ~4 s each and the best is the baseline; the reference's own deployment point -- one core, one
+    subproblem per call (scripts/bab_mip.sh:3-5 pins with taskset) -- is reported next to it, as SURVEY 8(d) asks."""
     from gnn_branching_amd import synth
     from oracle import gnn_oracle
     state = {k: v.numpy() for k, v in sd.items()}
     batch = synth.make_batch(net, cpu_batch, seed=1234)
     n_amb = int(batch.masks.sum().item())
-    with torch.no_grad():
-        gnn_oracle.oracle_forward(state, *batch.forward_args())      # warm-up
-        reps, t0 = 0, time.perf_counter()
-        while True:
-            gnn_oracle.oracle_forward(state, *batch.forward_args())
-            reps += 1
-            if time.perf_counter() - t0 > 10.0 or reps >= 20:
-                break
-        dt = time.perf_counter() - t0
-    out = {"value": round(n_amb * reps / dt, 1), "unit": "scores/s", "cores": torch.get_num_threads(), "kind": "port",
-           "sample": f"{reps} forwards of {cpu_batch} {net} subproblems (seed 1234), oracle/gnn_oracle.py, {dt:.1f}s",
-           "subproblems_per_s": round(cpu_batch * reps / dt, 2)}
-    # the reference's own deployment is ONE core per BaB process (scripts/bab_mip.sh:3-5 pins with taskset) and one
-    # subproblem per call; SURVEY 8(d) asks for that figure next to the all-cores one
     nthreads = torch.get_num_threads()
+
+    def timed(b, budget_s, max_reps=20):
+        with torch.no_grad():
+            gnn_oracle.oracle_forward(state, *b.forward_args())      # warm-up
+            reps, t0 = 0, time.perf_counter()
+            while True:
+                gnn_oracle.oracle_forward(state, *b.forward_args())
+                reps += 1
+                if time.perf_counter() - t0 > budget_s or reps >= max_reps:
+                    break
+            return reps, time.perf_counter() - t0
     try:
+        tried = {}
+        for nt in sorted({nthreads, min(nthreads, 16), 1}, reverse=True):
+            torch.set_num_threads(nt)
+            reps, dt = timed(batch, 4.0)
+            tried[nt] = (n_amb * reps / dt, reps, dt)
+        best = max(tried, key=lambda k: tried[k][0])
+        rate, reps, dt = tried[best]
+        out = {"value": round(rate, 1), "unit": "scores/s", "cores": best, "kind": "port",
+               "sample": f"{reps} forwards of {cpu_batch} {net} subproblems (seed 1234), oracle/gnn_oracle.py, {dt:.1f}s, best of "
+                         f"{len(tried)} thread counts", "subproblems_per_s": round(cpu_batch * reps / dt, 2),
+               "by_threads": {str(k): round(v[0], 1) for k, v in tried.items()}}
         torch.set_num_threads(1)
         one = batch.slice(0, 1)
         n1 = int(one.masks.sum().item())
-        with torch.no_grad():
-            gnn_oracle.oracle_forward(state, *one.forward_args())
-            reps1, t0 = 0, time.perf_counter()
-            while True:
-                gnn_oracle.oracle_forward(state, *one.forward_args())
-                reps1 += 1
-                if time.perf_counter() - t0 > 5.0 or reps1 >= 20:
-                    break
-            dt1 = time.perf_counter() - t0
+        reps1, dt1 = timed(one, 4.0)
         out["one_core_batch1"] = {"value": round(n1 * reps1 / dt1, 1), "unit": "scores/s", "cores": 1,
                                   "sample": f"{reps1} forwards of 1 subproblem, {dt1:.1f}s", "ms_per_decision": round(1e3 * dt1 / reps1, 1)}
     finally:
