@@ -2189,7 +2189,7 @@ __device__ __forceinline__ void argmax_sample(const ArgmaxArgs& a, int b, float*
   si[threadIdx.x] = bi;
   __syncthreads();
   for (int st = NT / 2; st > 0; st >>= 1) {
-    if (threadIdx.x < st) {
+    if ((int)threadIdx.x < st) {
       const float v = sv[threadIdx.x + st];
       const int i = si[threadIdx.x + st];
       if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && i < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = i; }
@@ -2545,10 +2545,8 @@ extern "C" int gnnb_bind_network(gnnb_t* h, const gnnb_layer_desc* L, int n, int
   return GNNB_OK;
 }
 
-// tile maps of the node-MLP kernels: the forward update of layer k walks the tiles of its incoming conv gather,
-// the backward update those of the transposed gather from layer k+1; everything else is flat.
+// tile map of the input layer's update: the tiles of the transposed gather of edge 1 when it exists, else flat
 static TileMap flat_map(int N) { TileMap t; t.mode = 0; t.N = N; return t; }
-static TileMap fwd_map(const gnnb_t* h, int k) { return h->gf[k].ok ? h->gf[k].g.tm : flat_map(h->N[k]); }
 static TileMap bwd_map(const gnnb_t* h, int k) {
   const int L = (int)h->N.size() - 2;
   return (k + 1 <= L && h->gb[k + 1].ok) ? h->gb[k + 1].g.tm : flat_map(h->N[k]);
