@@ -267,9 +267,12 @@ __device__ __forceinline__ void tile_range(long ntiles, int waves, long& begin, 
   int wg = blockIdx.x;
   const int nwg = gridDim.x;
   if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
-  const long per = ((ntiles + (long)nwg * waves - 1) / ((long)nwg * waves)) * waves;
-  begin = (long)wg * per;
-  end = begin + per < ntiles ? begin + per : ntiles;
+  // chunks differ by at most one tile (rounding every chunk up to whole rounds of `waves` tiles left up to a sixth of the
+  // workgroups without work on the 81-tiles-per-sample edge)
+  (void)waves;
+  const long base = ntiles / nwg, rem = ntiles - base * nwg;
+  begin = (long)wg * base + (wg < rem ? wg : rem);
+  end = begin + base + (wg < rem ? 1 : 0);
 }
 
 #define WG_MLP 512       // 8 waves: 2 per SIMD share one LDS copy of the weights
