@@ -23,6 +23,9 @@ ARCHS = {
     # channel counts the VALU fallback kernels are not compiled for (12, 6): MFMA gather tables only
     "toy_oddch": [("conv", 3, 12, 3, 1, 1), ("relu",), ("conv", 12, 6, 4, 2, 1), ("relu",), ("flatten",), ("linear", 6 * 16 * 16, 32),
                   ("relu",), ("linear", 32, 10)],
+    # kernel sizes / strides without a compile-time stencil in the bias-sum pass: 5x5 stride 1 pad 2, 2x2 stride 2 pad 0
+    "toy_k5": [("conv", 3, 8, 5, 1, 2), ("relu",), ("conv", 8, 8, 2, 2, 0), ("relu",), ("flatten",), ("linear", 8 * 16 * 16, 40),
+               ("relu",), ("linear", 40, 10)],
     # a single ReLU layer (L = 1)
     "toy_single": [("conv", 3, 8, 4, 2, 1), ("relu",), ("flatten",), ("linear", 8 * 16 * 16, 10)],
 }
