@@ -66,11 +66,11 @@ def plan_flops(plan, B, stats, restrict_last=True):
             reps, nodes = T - 1, u["nodes"] * B
             if u["kernel"] == "k_gather_input_update":
                 add(alg, u["kernel"], reps * 2.0 * (2 * 64 * 64 * nodes + nnz * 64))
-                add(issued, u["kernel"], reps * MFMA_FLOP * u["tiles_per_sample"] * B * (2 * u["gather_ksteps"] + 132))   # inp_b2_2 is deferred
+                add(issued, u["kernel"], reps * MFMA_FLOP * u["tiles_per_sample"] * B * (2 * u["gather_ksteps"] + 68))   # inp_b2_2 deferred, inp_b2[:, 64:] applied on the producer side
             else:
                 agg, upd = u["kernel"].split("+")
                 add(alg, upd, reps * 2.0 * 2 * 64 * 64 * nodes)
-                add(issued, upd, reps * MFMA_FLOP * tiles(nodes) * 64)
+                add(issued, upd, reps * MFMA_FLOP * tiles(nodes) * 66)
                 add(alg, agg, reps * 2.0 * nnz * 64)
             continue
         agg, upd = u["kernel"].split("+")

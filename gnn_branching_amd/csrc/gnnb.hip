@@ -336,6 +336,7 @@ struct ClassifyArgs {    // every ReLU layer of the network in one launch
   int L;
   const float* lb[MAXL]; const float* ub[MAXL];
   float* mu[MAXL];                 // (B*N_k, 64) rows of layer k
+  float* mu2;                      // second row buffer of layer 1 (F1, PackPostInp) whose dead rows must read as zero too, or null
   int* live[MAXL]; int* amb[MAXL]; int* score[MAXL];
   float* livef[MAXL];              // (B*N_k) 1.0 / 0.0: [r0 != 0], read by k_livesum
   long G[MAXL];
@@ -392,11 +393,13 @@ __global__ __launch_bounds__(CLS_THREADS) void k_classify(ClassifyArgs a) {
     if (flag[c]) lists[c][wbase[c][wave] + __popcll(bal[c] & ((1ull << lane) - 1ull))] = (int)gc;
   unsigned long long dead = __ballot(valid && !live);
   float* mu = a.mu[k];
+  float* mu2 = k == 0 ? a.mu2 : nullptr;
   while (dead) {                       // the whole wave zeroes one dead row per iteration (coalesced 256 B)
     const int l = __ffsll((long long)dead) - 1;
     dead &= dead - 1;
     const long row = g - lane + l;
     mu[row * 64 + lane] = 0.0f;
+    if (mu2) mu2[row * 64 + lane] = 0.0f;
   }
 }
 
@@ -548,6 +551,10 @@ struct UpdArgs {
   const int *list0, *cnt0;  // nodes with r0 == r1 and no relaxation term (live, not ambiguous): short chain
   const int *list1, *cnt1;  // general nodes (ambiguous; or the scored nodes for the last backward step of layer 1)
   const float* sarr;        // DEFERRED: s[g] = sum over the edge of live_src (k_livesum), the bias term of the source rows' projection
+  // POST (layer 1, backward, an input-layer update follows): the consumer's 64x64 map inp_b2[:, 64:].bc4_1.W is applied here,
+  // on the ~3x fewer producer nodes: F = WP.E goes to `post` (rows by node id), and `mu` may be null (nothing else reads E)
+  float* post;
+  const float* wp;          // PackPostInp block (WPN or WPG), staged behind the update pack
 };
 
 // folded node update (gnnb_pack.h PackUpd):  E_g = relu(P'_g + Wcb.h) [r0 != 0],  h = relu(Wa.[r0 nb_g, r1 nb_g] + ba);
@@ -559,7 +566,7 @@ struct UpdArgs {
 // forward:  fc3, fc3_2, fc4, fc4_2   graph_conv.py:169-181        backward: bc3, bc3_1, bc4, bc4_1   :331-349
 // The tile loop of the node update: tiles `tile`, `tile + stride`, ... of the lists in `a` (c0 / c1 entries); the weight
 // pack is staged into `lds` here (the first fetch overlaps it).
-template <bool DEFERRED>
+template <bool DEFERRED, bool POST = false>
 __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, int c0, int c1, long tile, long stride, int lane) {
   const int h = lane >> 5, j = lane & 31;
   const long n0 = (c0 + 31) / 32, ntiles = n0 + (c1 + 31) / 32;
@@ -580,6 +587,8 @@ __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, i
     frag_load_rows(x_, a.nb, g_, h);
   };
   if (tile < ntiles) fetch(tile, gc, valid, lb, ub, sw, X);
+  constexpr bool post = POST;
+  if (post) copy_to_lds(lds + PackUpd::FLOATS, a.wp, 4096);
   stage_pack(lds, a.pack, PackUpd::FLOATS);
   if (tile >= ntiles) return;
   for (;;) {
@@ -615,7 +624,13 @@ __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, i
     frag_scale(H2, r.live);
     if (valid) {
       if (frag_has_nan(H2)) atomicOr(a.status, 1);      // a NaN here is a NaN in mu = Wd.E + bd (:184-186, :339-341)
-      frag_store_rows(H2, a.mu, gc, h);
+      if (a.mu) frag_store_rows(H2, a.mu, gc, h);
+    }
+    if (post) {
+#pragma unroll
+      for (int R = 0; R < 32; ++R) FRAG_AT(H, R) = 0.0f;
+      gemm_w64<32>(lds + PackUpd::FLOATS, lane, H, [&](int s) { return FRAG_AT(H2, s); });
+      if (valid) frag_store_rows(H, a.post, gc, h);
     }
     if (!has_next) break;
     tile = next; gc = gc_n; valid = valid_n; lb = lb_n; ub = ub_n; sw = sw_n;
@@ -624,7 +639,7 @@ __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, i
   }
 }
 
-template <int WAVES, bool DEFERRED>
+template <int WAVES, bool DEFERRED, bool POST = false>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_node_update(UpdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -635,7 +650,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_node_update(UpdArgs a
   static_assert(WAVES % 4 == 0, "tile dealing assumes whole waves per SIMD");
   const long stride = (long)gridDim.x * 4 * (WAVES / 4);
   const long tile = (long)(wave >> 2) * gridDim.x * 4 + (long)blockIdx.x * 4 + (wave & 3);
-  node_update_loop<DEFERRED>(a, lds, *a.cnt0, *a.cnt1, tile, stride, lane);
+  node_update_loop<DEFERRED, POST>(a, lds, *a.cnt0, *a.cnt1, tile, stride, lane);
 }
 
 struct UpdInpArgs { const float* pack; const float* nb; const float* Q; const float* sarr; float* mu; long G, ntiles; };
@@ -657,7 +672,8 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_input_update(UpdInpArgs a) {
       const float x[1] = {h ? 0.0f : a.sarr[gc]};
       gemm_small<1>(lds + PackUpdInp::VC, lane, H, x);
     }
-    gemm_w64<32>(lds + PackUpdInp::WC, lane, H, [&](int s) { return FRAG_AT(X, s); });
+#pragma unroll
+    for (int R = 0; R < 32; ++R) FRAG_AT(H, R) += FRAG_AT(X, R);      // the aggregate already went through inp_b2[:, 64:].bc4_1.W (PackPostInp)
     frag_relu(H);
     if (valid) frag_store_rows(H, a.mu, g, h);
   }
@@ -1201,7 +1217,10 @@ __device__ __forceinline__ void input_update_tile(const GIArgs& a, const TileCtx
     const float xs[1] = {h ? 0.0f : a.sarr[gc]};
     gemm_small<1>(lds_upd + PackUpdInp::VC, lane, H, xs);
   }
-  gemm_w64<32>(lds_upd + PackUpdInp::WC, lane, H, [&](int s) { return FRAG_AT(X, s); });
+  // the aggregate already went through inp_b2[:, 64:].bc4_1.W on the producer side, with its rows permuted to this
+  // fragment layout (PackPostInp::WPG): register for register
+#pragma unroll
+  for (int R = 0; R < 32; ++R) FRAG_AT(H, R) += FRAG_AT(X, R);
   frag_relu(H);
   if (tc.valid) frag_store_rows(H, a.mu, gc, h);
 }
@@ -2220,7 +2239,7 @@ __global__ __launch_bounds__(256) void k_argmax(ArgmaxArgs a) {
 
 #define N_PACKS 14   // == PK_COUNT
 enum { PK_EMBED, PK_PRE_FWD, PK_PRE_BWD, PK_PRE_INP, PK_PROP, PK_UPD_FWD_E, PK_UPD_FWD_I, PK_UPD_FWD_F, PK_UPD_BWD, PK_UPD_BWD_B,
-       PK_UPD_INP, PK_UPD_INP_G, PK_SCORE_B, PK_SCORE_F, PK_COUNT };
+       PK_UPD_INP, PK_POST_INP, PK_SCORE_B, PK_SCORE_F, PK_COUNT };
 static_assert(PK_COUNT == N_PACKS, "pack table");
 
 // ------------------------------------------------------------------------------------------
@@ -2332,7 +2351,7 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   build_packs(w_blob, h->packs);
   const std::vector<float>* pv[N_PACKS] = {&h->packs.embed, &h->packs.pre_fwd, &h->packs.pre_bwd, &h->packs.pre_inp, &h->packs.prop,
                                            &h->packs.upd_fwd_e, &h->packs.upd_fwd_i, &h->packs.upd_fwd_f, &h->packs.upd_bwd,
-                                           &h->packs.upd_bwd_b, &h->packs.upd_inp, &h->packs.upd_inp_g, &h->packs.score_b,
+                                           &h->packs.upd_bwd_b, &h->packs.upd_inp, &h->packs.post_inp, &h->packs.score_b,
                                            &h->packs.score_f};
   for (int i = 0; i < N_PACKS; ++i)
     if (int rc = upload(&h->d_pack[i], pv[i]->data(), pv[i]->size())) return rc;
@@ -2341,10 +2360,14 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   // > 64 KiB of dynamic LDS needs the attribute
   HIPCHK(hipFuncSetAttribute((const void*)k_pre, hipFuncAttributeMaxDynamicSharedMemorySize, (PackPreFwd::FLOATS + PackPreBwd::FLOATS) * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_pre_inp, hipFuncAttributeMaxDynamicSharedMemorySize, PackPreInp::FLOATS * 4));
-  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpd::FLOATS * 4));
-  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpd::FLOATS * 4));
-  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpd::FLOATS * 4));
-  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpd::FLOATS * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpd::FLOATS + 4096) * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpd::FLOATS + 4096) * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpd::FLOATS + 4096) * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpd::FLOATS + 4096) * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpd::FLOATS + 4096) * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpd::FLOATS + 4096) * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpd::FLOATS + 4096) * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpd::FLOATS + 4096) * 4));
   if (const char* e = getenv("GNNB_NU_WAVES")) h->nu_waves = atoi(e) == 8 ? 8 : 12;
   if (const char* e = getenv("GNNB_GATHER_OCC")) h->gather_occ = atoi(e) < 1 ? 1 : atoi(e);
   HIPCHK(hipFuncSetAttribute((const void*)k_input_update, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpdInp::FLOATS * 4));
@@ -2639,6 +2662,7 @@ struct WsLayout {
   std::vector<size_t> mu, Pf, Pb, live, amb, score;
   std::vector<size_t> lf;       // live flags (B, N_k) as floats
   std::vector<size_t> sf, sb;   // k_livesum outputs: sf[k] (B, N_k) over edge k, sb[k] (B, N_k) over edge k+1 transposed
+  size_t F1 = 0;                // rows of layer 1 after the producer-side map of the input update (PackPostInp)
   size_t cnt = 0, nb = 0, Q = 0, total = 0;
 };
 static size_t align64(size_t nfloats) { return (nfloats + 63) & ~(size_t)63; }
@@ -2664,6 +2688,7 @@ static WsLayout ws_layout(const gnnb_t* h, int B) {
   for (int k = 1; k < K; ++k) { w.lf[k] = off; off += align64((size_t)B * h->N[k]); }
   for (int k = 1; k < K; ++k) { w.sf[k] = off; off += align64((size_t)B * h->N[k]); }
   for (int k = 0; k < K - 1; ++k) { w.sb[k] = off; off += align64((size_t)B * h->N[k]); }
+  w.F1 = off; off += align64((size_t)B * h->N[1] * 64);
   w.Q = off; off += (size_t)map_tiles(bwd_map(h, 0), B) * 2048;
   w.total = off;
   return w;
@@ -2818,6 +2843,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   {
     ClassifyArgs a{};
     a.L = L; a.mask = in->mask; a.scores = scores; a.cnt = cnt + 4; a.R = h->R;
+    a.mu2 = (limit >= 2 && (h->T > 1 || debug_full)) ? ws + w.F1 : nullptr;      // only read when an input-layer update runs
     int blk = 0;
     for (int k = 1; k <= L; ++k) {
       const int i = k - 1;
@@ -2958,9 +2984,11 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   // phase A: nb <- A_{k+1}^T mu[k+1]  (k+1 <= L), conv case divided by the tap count when `normalise`
   auto agg_bwd = [&](int k, int normalise, bool scored) {
     const Edge& e = h->edges[k + 1];
+    // the input layer (k = 0) aggregates the rows of layer 1 that already went through its 64x64 map (F1, PackPostInp)
+    const float* srcb = k == 0 ? ws + w.F1 : mu(k + 1);
     if (k >= 1 && h->gb[k + 1].ok) { gather(h->gb[k + 1], k, mu(k + 1), scored, false); return; }
     if (e.kind == 0) {
-      ConvArgs a = conv_args(e, mu(k + 1), nb, h->dev[k + 1].w_bwd, normalise);
+      ConvArgs a = conv_args(e, srcb, nb, h->dev[k + 1].w_bwd, normalise);
       lz.run(PC_CONVT_BWD, [&] {
         switch (e.c_in) {
           case 3: launch_convT<3>(a, st); break;
@@ -2972,11 +3000,11 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     } else {
       const DevEdge& de = h->dev[k + 1];
       if (h->dense_lds && per_sample && de.kpad_bwd <= 128) {    // one workgroup per sample, the whole source layer in LDS
-        DenseLArgs a{de.w_bwd, mu(k + 1), nb, B, e.n_out, e.n_in, de.ld_bwd, de.mt_bwd, de.kpad_bwd};
+        DenseLArgs a{de.w_bwd, srcb, nb, B, e.n_out, e.n_in, de.ld_bwd, de.mt_bwd, de.kpad_bwd};
         lz.run(PC_DENSE_AGG, [&] { hipLaunchKernelGGL(k_dense_bwd_lds, dim3(B), dim3(512), 0, st, a); });
         return;
       }
-      DenseArgs a{de.w_bwd, mu(k + 1), nb, h->d_zero, B, e.n_out, e.n_in, de.ld_bwd, de.mt_bwd, de.ksq_bwd};
+      DenseArgs a{de.w_bwd, srcb, nb, h->d_zero, B, e.n_out, e.n_in, de.ld_bwd, de.mt_bwd, de.ksq_bwd};
       const long tiles = (long)B * a.MT;
       lz.run(PC_DENSE_AGG, [&] {
         if (a.K >= 512) hipLaunchKernelGGL(k_dense_agg<true>, dim3((unsigned)tiles), dim3(256), 0, st, a);
@@ -2985,7 +3013,9 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     }
   };
   // phase B: node MLP over a compacted list of nodes
-  auto node_update = [&](int k, bool fwd, bool scored) {
+  // post_input: this is the backward update of layer 1 and an input-layer update follows -- the kernel also applies the input
+  // update's 64x64 map to its rows (PackPostInp) and writes them to F1; only inspection runs still need the plain rows
+  auto node_update = [&](int k, bool fwd, bool scored, bool post_input = false) {
     const long nt = ((long)B * h->N[k] + 31) / 32;
     // the aggregate in `nb` was built from rows whose last Linear is deferred (gnnb_pack.h), except the one k_prop writes
     const int src_proj = fwd ? h->proj[k - 1] : (k < L ? h->proj[k + 1] : -1);
@@ -3000,16 +3030,24 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     }
     const bool deferred = sarr != nullptr;
     // normal: list0 = live non-ambiguous nodes (short chain), list1 = ambiguous nodes; restricted: the scored nodes, general chain
-    UpdArgs a{h->d_pack[pack], in->lb[k], in->ub[k], nb, ws + (fwd ? w.Pf[k] : w.Pb[k]), mu(k), status,
-              ilist(w.live[k]), cnt + 4 * k + (scored ? 3 : 0), ilist(scored ? w.score[k] : w.amb[k]), cnt + 4 * k + (scored ? 2 : 1), sarr};
+    UpdArgs a{h->d_pack[pack], in->lb[k], in->ub[k], nb, ws + (fwd ? w.Pf[k] : w.Pb[k]), (post_input && !debug_full) ? nullptr : mu(k), status,
+              ilist(w.live[k]), cnt + 4 * k + (scored ? 3 : 0), ilist(scored ? w.score[k] : w.amb[k]), cnt + 4 * k + (scored ? 2 : 1), sarr,
+              post_input ? ws + w.F1 : nullptr, h->d_pack[PK_POST_INP] + (h->gb[1].ok ? PackPostInp::WPG : PackPostInp::WPN)};
+    const size_t ldsb = (size_t)(PackUpd::FLOATS + (post_input ? 4096 : 0)) * 4;
     const int wv = h->nu_waves;  // waves per workgroup (one workgroup per CU shares the LDS weights)
     long grid = (nt + wv - 1) / wv;
     if (grid > h->n_cu) grid = h->n_cu;
     lz.run(PC_NODE_UPDATE, [&] {
-      if (wv == 12 && deferred) hipLaunchKernelGGL((k_node_update<12, true>), dim3((unsigned)grid), dim3(768), PackUpd::FLOATS * 4, st, a);
-      else if (wv == 12) hipLaunchKernelGGL((k_node_update<12, false>), dim3((unsigned)grid), dim3(768), PackUpd::FLOATS * 4, st, a);
-      else if (deferred) hipLaunchKernelGGL((k_node_update<8, true>), dim3((unsigned)grid), dim3(512), PackUpd::FLOATS * 4, st, a);
-      else hipLaunchKernelGGL((k_node_update<8, false>), dim3((unsigned)grid), dim3(512), PackUpd::FLOATS * 4, st, a);
+      const dim3 g((unsigned)grid), b12(768), b8(512);
+      if (post_input) {
+        if (wv == 12 && deferred) hipLaunchKernelGGL((k_node_update<12, true, true>), g, b12, ldsb, st, a);
+        else if (wv == 12) hipLaunchKernelGGL((k_node_update<12, false, true>), g, b12, ldsb, st, a);
+        else if (deferred) hipLaunchKernelGGL((k_node_update<8, true, true>), g, b8, ldsb, st, a);
+        else hipLaunchKernelGGL((k_node_update<8, false, true>), g, b8, ldsb, st, a);
+      } else if (wv == 12 && deferred) hipLaunchKernelGGL((k_node_update<12, true>), g, b12, ldsb, st, a);
+      else if (wv == 12) hipLaunchKernelGGL((k_node_update<12, false>), g, b12, ldsb, st, a);
+      else if (deferred) hipLaunchKernelGGL((k_node_update<8, true>), g, b8, ldsb, st, a);
+      else hipLaunchKernelGGL((k_node_update<8, false>), g, b8, ldsb, st, a);
     });
     h->proj[k] = fwd ? L_FC4_2 : L_BC4_1;
   };
@@ -3018,7 +3056,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     if (h->gb[1].ok) {
       const DevGather& d = h->gb[1];
       const long nt = map_tiles(d.g.tm, B);
-      GIArgs a{h->d_pack[PK_PRE_INP], h->d_pack[PK_UPD_INP_G], in->lb[0], in->ub[0], mu(1), ws + w.sb[0], mu(0), nt, to_dtm(d.g.tm), to_dg(d, h->d_zero)};
+      GIArgs a{h->d_pack[PK_PRE_INP], h->d_pack[PK_UPD_INP], in->lb[0], in->ub[0], ws + w.F1, ws + w.sb[0], mu(0), nt, to_dtm(d.g.tm), to_dg(d, h->d_zero)};
       const size_t lds = gather_lds_bytes(d, PackUpdInp::FLOATS + PackPreInp::FLOATS);
       lz.run(PC_GATHER_INPUT, [&] { hipLaunchKernelGGL(k_gather_input_update, dim3(mlp_grid(h, nt)), dim3(WG_MLP), lds, st, a); });
       return;
@@ -3057,7 +3095,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       for (int k = L - 1; k >= 1; --k) {
         const bool scored = h->restrict_last && t == h->T - 1 && k == 1;
         if (k < L - 1) agg_bwd(k, 1, scored);
-        node_update(k, false, scored);
+        node_update(k, false, scored, k == 1 && t < h->T - 1);
       }
       if (t < h->T - 1) update_input();
       done += 2;
@@ -3081,7 +3119,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       // after the last backward step mu[1] is only read by the score head, i.e. at the scored nodes
       const bool scored = h->restrict_last && !debug_full && t == h->T - 1 && k == 1;
       if (k < L) agg_bwd(k, 1, scored);          // (k == L: k_prop already wrote the aggregate from the property node)
-      node_update(k, false, scored);
+      node_update(k, false, scored, k == 1 && (t < h->T - 1 || debug_full));
     }
     // input layer (:360-385): its last-round result is never read, so it only runs when another round follows
     if (t < h->T - 1 || debug_full) update_input();

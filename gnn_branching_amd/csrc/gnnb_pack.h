@@ -144,8 +144,15 @@ struct PackPreBwd {
 // folded: Q = (inp_b2[:, :64].inp_b_1.W) relu(inp_b([l0,u0])) + (inp_b2[:, :64].inp_b_1.b + inp_b2.b)
 struct PackPreInp { enum { W1 = 0, B1 = W1 + 128, W2 = B1 + 64, B2 = W2 + 4096, FLOATS = B2 + 64 }; };
 // k_input_update: E0 = relu(Q + inp_b2[:, 64:] nb); mu0 = inp_b2_2(E0) is deferred   (:383-385)
-// WC = inp_b2[:, 64:].bc4_1.W (the rows of mu_1 it aggregates have bc4_1 deferred), VC = [inp_b2[:, 64:].bc4_1.b, 0] small k-step
-struct PackUpdInp { enum { WC = 0, VC = WC + 4096, FLOATS = VC + 128 }; };
+// The 64x64 map inp_b2[:, 64:].bc4_1.W that the aggregate of layer 1 has to go through commutes with the aggregation, and
+// layer 1 has ~1100 live producer nodes per sample against 3072 consumer nodes here: it is applied on the PRODUCER side
+// (PackPostInp, the last backward update of layer 1 before an input update) and the input kernels just add the aggregate.
+// VC = [inp_b2[:, 64:].bc4_1.b, 0] small k-step (bias term of the deferred bc4_1, times the bias-sum scalar)
+struct PackUpdInp { enum { VC = 0, FLOATS = VC + 128 }; };
+// WPN: inp_b2[:, 64:].bc4_1.W in pack_w64 order, rows natural (the flat input update reads the aggregate row-major);
+// WPG: the same with output rows permuted so that, after the MFMA gather, register R of lane half h (gather channel
+//      gather_feature(R, h)) holds feature frag_feature(R, h) -- the fragment layout of the chain it is added to.
+struct PackPostInp { enum { WPN = 0, WPG = WPN + 4096, FLOATS = WPG + 4096 }; };
 // k_score: fscore(relu(fnode(mu)))                                           (:448-449)
 // W1 = fnode.Wp, V1 = [fnode.bp, 0] small k-step fed with live (the scored rows have their last Linear Wp deferred)
 struct PackScore { enum { W1 = 0, B1 = W1 + 4096, WS = B1 + 64, BS = WS + 64, V1 = BS + 4, FLOATS = V1 + 128 }; };
@@ -177,7 +184,7 @@ struct Packs {
   // node updates by the projection deferred in the rows they aggregate:
   std::vector<float> upd_fwd_e, upd_fwd_i, upd_fwd_f;   // forward: inp_f_1 (layer 1, round 0) / inp_b2_2 (layer 1, later) / fc4_2
   std::vector<float> upd_bwd, upd_bwd_b;                // backward: none (top layer: aggregate from the property node) / bc4_1
-  std::vector<float> upd_inp, upd_inp_g;                // input layer (bc4_1 folded); _g: first layer permuted for a gathered fragment
+  std::vector<float> upd_inp, post_inp;                 // input layer: bias small k-step; the producer-side map (PackPostInp)
   std::vector<float> score_b, score_f;                  // score head on rows with bc4_1 / fc4_2 deferred
 };
 
@@ -286,20 +293,19 @@ inline void build_packs(const float* blob, Packs& pk) {
   }
 
   pk.upd_inp.assign(PackUpdInp::FLOATS, 0.f);
-  std::vector<float> wc(64 * 64);
+  pk.post_inp.assign(PackPostInp::FLOATS, 0.f);
   {
-    float vc[128];
+    std::vector<float> wc(64 * 64), wcg(64 * 64);
+    float vc[128], t[64];
     matmul64(wc.data(), W(L_INP_B2), 128, 64, W(L_BC4_1));
-    float t[64];
     matvec64(t, W(L_INP_B2), 128, 64, Bv(L_BC4_1), nullptr);
     for (int i = 0; i < 64; ++i) { vc[2 * i] = t[i]; vc[2 * i + 1] = 0.f; }
-    pack_w64(&pk.upd_inp[PackUpdInp::WC], wc.data(), 64, 0, 1);
     pack_wsmall(&pk.upd_inp[PackUpdInp::VC], vc, 2, 1);
+    pack_w64(&pk.post_inp[PackPostInp::WPN], wc.data(), 64, 0, 1);
+    for (int h = 0; h < 2; ++h)
+      for (int R = 0; R < 32; ++R) std::memcpy(&wcg[(size_t)gather_feature(R, h) * 64], &wc[(size_t)frag_feature(R, h) * 64], 64 * sizeof(float));
+    pack_w64(&pk.post_inp[PackPostInp::WPG], wcg.data(), 64, 0, 1);
   }
-
-  // variant whose first layer reads the fragment produced by the MFMA gather (gather_feature map)
-  pk.upd_inp_g = pk.upd_inp;
-  pack_w64_gather(&pk.upd_inp_g[PackUpdInp::WC], wc.data(), 64, 0, 1);
 
   auto score = [&](std::vector<float>& v, int proj) {
     v.assign(PackScore::FLOATS, 0.f);

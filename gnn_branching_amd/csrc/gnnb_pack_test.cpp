@@ -5,12 +5,12 @@
 extern "C" {
 size_t gnnb_pt_blob_floats() { return gnnb::blob_floats(); }
 // which: 0 embed, 1 pre_fwd, 2 pre_bwd, 3 pre_inp, 4 prop, 5 upd_fwd_e, 6 upd_fwd_i, 7 upd_fwd_f, 8 upd_bwd, 9 upd_bwd_b,
-// 10 upd_inp, 11 upd_inp_g, 12 score_b, 13 score_f
+// 10 upd_inp, 11 post_inp, 12 score_b, 13 score_f
 size_t gnnb_pt_pack(const float* blob, int which, float* out, size_t cap) {
   gnnb::Packs pk;
   gnnb::build_packs(blob, pk);
   const std::vector<float>* v[14] = {&pk.embed, &pk.pre_fwd, &pk.pre_bwd, &pk.pre_inp, &pk.prop, &pk.upd_fwd_e, &pk.upd_fwd_i,
-                                     &pk.upd_fwd_f, &pk.upd_bwd, &pk.upd_bwd_b, &pk.upd_inp, &pk.upd_inp_g, &pk.score_b, &pk.score_f};
+                                     &pk.upd_fwd_f, &pk.upd_bwd, &pk.upd_bwd_b, &pk.upd_inp, &pk.post_inp, &pk.score_b, &pk.score_f};
   if (which < 0 || which > 13) return 0;
   if (out && cap >= v[which]->size()) std::memcpy(out, v[which]->data(), v[which]->size() * sizeof(float));
   return v[which]->size();

@@ -33,7 +33,7 @@ def packs(packlib):
     assert blob.size == packlib.gnnb_pt_blob_floats() == 117825
     out = {}
     for which, name in enumerate(["embed", "pre_fwd", "pre_bwd", "pre_inp", "prop", "upd_fwd_e", "upd_fwd_i", "upd_fwd_f", "upd_bwd",
-                                  "upd_bwd_b", "upd_inp", "upd_inp_g", "score_b", "score_f"]):
+                                  "upd_bwd_b", "upd_inp", "post_inp", "score_b", "score_f"]):
         n = packlib.gnnb_pt_pack(blob.ctypes.data, which, None, 0)
         buf = np.zeros(n, np.float32)
         assert packlib.gnnb_pt_pack(blob.ctypes.data, which, buf.ctypes.data, n) == n
@@ -155,22 +155,39 @@ def test_node_update_chain(packs, pack, chain, proj):
     np.testing.assert_allclose(tail(Hf, frag_bias(p[BCB:BCB + 64])), reference(nb, r0, r0, np.zeros_like(relax)), atol=2e-5)
 
 
-def test_input_update_pack(packs):
-    """E_0 = relu(Q + inp_b2[:, 64:].nb) with nb = bc4_1.W.G + s.bc4_1.b folded (PackUpdInp WC, VC)."""
+def test_input_update_packs(packs):
+    """E_0 = relu(Q + inp_b2[:, 64:].nb) with nb = bc4_1.W.G + s.bc4_1.b.  The 64x64 map is applied on the producer side
+    (PackPostInp: rows F = (inp_b2[:, 64:].bc4_1.W).E of layer 1), the input kernels add the aggregate of F and the bias
+    small k-step (PackUpdInp VC)."""
     sd, pk = packs
     rng = np.random.RandomState(11)
-    G = rng.standard_normal((32, 64)); Q = rng.standard_normal((32, 64)); sw = rng.standard_normal(32)
+    Erows = rng.standard_normal((32, 64)); Q = rng.standard_normal((32, 64)); sw = rng.standard_normal(32)
     wp, bp = np.asarray(sd[E + "bc4_1.weight"], np.float64), np.asarray(sd[E + "bc4_1.bias"], np.float64)
-    nb = G @ wp.T + sw[:, None] * bp[None, :]
     w2 = np.asarray(sd[E + "inp_b2.weight"], np.float64)
-    want = np.maximum(Q + nb @ w2[:, 64:].T, 0)
-    p = pk["upd_inp"]
-    assert p.size == 4096 + 128
+    wc = w2[:, 64:] @ wp
+    # producer side, natural row order: the flat input update adds the row-major aggregate
+    p = pk["post_inp"]
+    assert p.size == 8192
+    X = frag_from_rows(Erows)
+    F = np.zeros((64, 32)); gemm_w64(p[0:], 32, F, lambda s: X[:, s])
+    np.testing.assert_allclose(rows_from_frag(F), Erows @ wc.T, atol=2e-5)
+    # producer side, gather-permuted rows: stored channel gather_feature(R, h) holds feature frag_feature(R, h)
+    Fg = np.zeros((64, 32)); gemm_w64(p[4096:], 32, Fg, lambda s: X[:, s])
+    stored = rows_from_frag(Fg)                          # what the producer writes, row-major
+    want = Erows @ wc.T
+    for hh in range(2):
+        for R in range(32):
+            it, r = R >> 4, R & 15
+            g = 2 * ((r & 3) + 8 * (r >> 2) + 4 * hh) + it
+            np.testing.assert_allclose(stored[:, g], want[:, feat(R, hh)], atol=2e-5)
+    # consumer side: with every node's row equal to its own aggregate (identity edge), H = Q + VC.s + F
+    pu = pk["upd_inp"]
+    assert pu.size == 128
     Hf = frag_from_rows(Q)
-    gemm_small(p[4096:], 1, Hf, [np.where(H == 0, sw[J], 0.0)])
-    X = frag_from_rows(G)
-    gemm_w64(p[0:], 32, Hf, lambda s: X[:, s])
-    np.testing.assert_allclose(rows_from_frag(np.maximum(Hf, 0)), want, atol=2e-5)
+    gemm_small(pu[0:], 1, Hf, [np.where(H == 0, sw[J], 0.0)])
+    Hf += frag_from_rows(want)
+    nb = Erows @ wp.T + sw[:, None] * bp[None, :]
+    np.testing.assert_allclose(rows_from_frag(np.maximum(Hf, 0)), np.maximum(Q + nb @ w2[:, 64:].T, 0), atol=2e-5)
 
 
 def test_pre_fwd_chain(packs):
@@ -348,21 +365,3 @@ def test_gather_tables_match_torch_conv(packlib, cfg, direction, allow16):
     useful = w.size * (h_out * h_out)           # MACs of the sparse map per channel
     print(f"conv {cfg} dir {direction} lanes {g['lanes']}: tile {g['CT']}x{g['PY']}x{g['PX']} align ({g['ay']},{g['ax']}) window {g['WY']}x{g['WX']} "
           f"K2={g['K2']} tiles/sample={g['TPS']} mfma/sample={cost} density={useful / (dense / 64 * 32):.2f}")
-
-
-def test_gather_fragment_feeds_first_layer(packs):
-    """The MFMA gather leaves channel 2*row+it in register (it, r); pack_w64_gather must absorb that map."""
-    sd, pk = packs
-    rng = np.random.RandomState(5)
-    nb = rng.standard_normal((32, 64))                       # (dst node j, channel)
-    r0 = rng.uniform(0, 1, 32); r1 = 1 - r0
-    # fragment as the gather produces it: D_it[row i][col j] = nb[j][2i + it]
-    X = np.zeros((64, 32))
-    for it in range(2):
-        for r in range(16):
-            X[:, 16 * it + r] = nb[J, 2 * ((r & 3) + 8 * (r >> 2) + 4 * H) + it]
-    p = pk["upd_inp_g"]
-    Hf = np.zeros((64, 32))
-    gemm_w64(p[0:], 32, Hf, lambda s: X[:, s])
-    want = nb @ (np.asarray(sd[E + "inp_b2.weight"], np.float64)[:, 64:] @ np.asarray(sd[E + "bc4_1.weight"], np.float64)).T
-    np.testing.assert_allclose(rows_from_frag(Hf), want, atol=2e-5)
