@@ -2837,13 +2837,17 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   const int limit = h->halfpass_limit > 0 ? std::min(h->halfpass_limit, total_halfpasses) : total_halfpasses;
   const bool debug_full = h->halfpass_limit > 0;   // with a limit set nothing is restricted or skipped as dead
   const bool per_sample = B >= h->per_sample_min_b;   // batch large enough for the one-workgroup-per-sample kernels
+  // The rows of layer 1 the input-layer update aggregates went through its 64x64 map on the producer side (PackPostInp).
+  // Outside inspection runs nothing else reads the plain rows of that half-pass, so the mapped rows simply take their place
+  // in mu[1] (whose dead rows k_classify already zeroed); inspection runs keep both, the mapped ones in F1.
+  float* const rows1_for_input = debug_full ? ws + w.F1 : mu(1);
 
   const bool embed_in_gather = h->embed_fuse && !debug_full && h->gf[1].ok;
   // ---- once per forward: classification lists, input embedding, embedding-independent feature chains ----
   {
     ClassifyArgs a{};
     a.L = L; a.mask = in->mask; a.scores = scores; a.cnt = cnt + 4; a.R = h->R;
-    a.mu2 = (limit >= 2 && (h->T > 1 || debug_full)) ? ws + w.F1 : nullptr;      // only read when an input-layer update runs
+    a.mu2 = debug_full ? ws + w.F1 : nullptr;      // inspection runs keep the plain rows in mu[1] and the mapped ones in F1
     int blk = 0;
     for (int k = 1; k <= L; ++k) {
       const int i = k - 1;
@@ -2984,8 +2988,8 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   // phase A: nb <- A_{k+1}^T mu[k+1]  (k+1 <= L), conv case divided by the tap count when `normalise`
   auto agg_bwd = [&](int k, int normalise, bool scored) {
     const Edge& e = h->edges[k + 1];
-    // the input layer (k = 0) aggregates the rows of layer 1 that already went through its 64x64 map (F1, PackPostInp)
-    const float* srcb = k == 0 ? ws + w.F1 : mu(k + 1);
+    // the input layer (k = 0) aggregates the rows of layer 1 that already went through its 64x64 map (PackPostInp)
+    const float* srcb = k == 0 ? rows1_for_input : mu(k + 1);
     if (k >= 1 && h->gb[k + 1].ok) { gather(h->gb[k + 1], k, mu(k + 1), scored, false); return; }
     if (e.kind == 0) {
       ConvArgs a = conv_args(e, srcb, nb, h->dev[k + 1].w_bwd, normalise);
@@ -3032,7 +3036,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     // normal: list0 = live non-ambiguous nodes (short chain), list1 = ambiguous nodes; restricted: the scored nodes, general chain
     UpdArgs a{h->d_pack[pack], in->lb[k], in->ub[k], nb, ws + (fwd ? w.Pf[k] : w.Pb[k]), (post_input && !debug_full) ? nullptr : mu(k), status,
               ilist(w.live[k]), cnt + 4 * k + (scored ? 3 : 0), ilist(scored ? w.score[k] : w.amb[k]), cnt + 4 * k + (scored ? 2 : 1), sarr,
-              post_input ? ws + w.F1 : nullptr, h->d_pack[PK_POST_INP] + (h->gb[1].ok ? PackPostInp::WPG : PackPostInp::WPN)};
+              post_input ? rows1_for_input : nullptr, h->d_pack[PK_POST_INP] + (h->gb[1].ok ? PackPostInp::WPG : PackPostInp::WPN)};
     const size_t ldsb = (size_t)(PackUpd::FLOATS + (post_input ? 4096 : 0)) * 4;
     const int wv = h->nu_waves;  // waves per workgroup (one workgroup per CU shares the LDS weights)
     long grid = (nt + wv - 1) / wv;
@@ -3056,7 +3060,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     if (h->gb[1].ok) {
       const DevGather& d = h->gb[1];
       const long nt = map_tiles(d.g.tm, B);
-      GIArgs a{h->d_pack[PK_PRE_INP], h->d_pack[PK_UPD_INP], in->lb[0], in->ub[0], ws + w.F1, ws + w.sb[0], mu(0), nt, to_dtm(d.g.tm), to_dg(d, h->d_zero)};
+      GIArgs a{h->d_pack[PK_PRE_INP], h->d_pack[PK_UPD_INP], in->lb[0], in->ub[0], rows1_for_input, ws + w.sb[0], mu(0), nt, to_dtm(d.g.tm), to_dg(d, h->d_zero)};
       const size_t lds = gather_lds_bytes(d, PackUpdInp::FLOATS + PackPreInp::FLOATS);
       lz.run(PC_GATHER_INPUT, [&] { hipLaunchKernelGGL(k_gather_input_update, dim3(mlp_grid(h, nt)), dim3(WG_MLP), lds, st, a); });
       return;
