@@ -1156,8 +1156,9 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_gather(GArgs a) {
 }
 
 // the 16-node-tile form of k_gather (forward conv edges)
+// (4 waves per SIMD: the embedding variant sits right at 128 VGPRs, and at 130 it loses a quarter of its waves and 10 %)
 template <bool EMBED>
-__global__ __launch_bounds__(WG_MLP, 2) void k_gather16(GArgs a) {
+__global__ __launch_bounds__(WG_MLP, 4) void k_gather16(GArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const GatherLds gl = gather_lds(lds, a.g, a.tm.TPS);
   stage_gather(gl.cm, gl.ko, gl.tt, gl.kvo, a.g, a.tm.TPS);
