@@ -81,6 +81,8 @@ def plan_flops(plan, B, stats, restrict_last=True):
             # message passing of this half-pass: every source row read once, every updated row written once
             add(agg_bytes, agg, 4.0 * 64 * (B * u["n_src"] + n_upd))
             # folded chains, last layer deferred: 128 (+2) MFMAs per tile of live non-ambiguous nodes, 192 (+2) per tile of general nodes
+            if u["update"] == "bwd" and k == 1 and t < T - 1 and upd == "k_node_update":
+                add(issued, upd, MFMA_FLOP * tiles(stats[k]["live"]) * 64)      # the input update's 64x64 map, applied on the producer side
             if upd == "k_top":                   # one workgroup per sample: every node of the layer through the general chain
                 add(issued, upd, MFMA_FLOP * B * tiles(u["nodes"]) * 194)
             elif restricted:
