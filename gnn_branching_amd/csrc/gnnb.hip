@@ -1173,14 +1173,19 @@ __global__ __launch_bounds__(WG_MLP, 4) void k_gather16(GArgs a) {
       for (int q = 0; q < 3; ++q) ew[c][q] = a.es.wb[(4 * j + c) * 3 + q];
     }
   }
-  long t0, t1;
-  tile_range(a.ntiles, WAVES_MLP, t0, t1);
-  long tile = t0 + wave;
-  if (tile >= t1) return;
-  int sample = __builtin_amdgcn_readfirstlane((int)(tile / a.tm.TPS));
-  int t = __builtin_amdgcn_readfirstlane((int)(tile - (long)sample * a.tm.TPS));
-  for (; tile < t1; tile += WAVES_MLP, t += WAVES_MLP) {
-    while (t >= a.tm.TPS) { t -= a.tm.TPS; ++sample; }
+  // Rounds of 8 tiles (one per wave) are dealt ROUND-ROBIN over the workgroups, in the XCD-grouped order of tile_range:
+  // at any moment the 64 workgroups of an XCD then work on 8 neighbouring rounds each side by side, i.e. on 8-16 samples
+  // whose source rows (~4 MB) stay in that XCD's L2 -- with one contiguous chunk per workgroup they covered 32 samples,
+  // 16 MB, and every window row was fetched from HBM 1.7 times.
+  int wg = blockIdx.x;
+  const int nwg = gridDim.x;
+  if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
+  const long nrounds = (a.ntiles + WAVES_MLP - 1) / WAVES_MLP;
+  for (long r = wg; r < nrounds; r += nwg) {
+    const long tile = r * WAVES_MLP + wave;
+    if (tile >= a.ntiles) break;
+    const int sample = __builtin_amdgcn_readfirstlane((int)(tile / a.tm.TPS));
+    const int t = __builtin_amdgcn_readfirstlane((int)(tile - (long)sample * a.tm.TPS));
     const TileCtx tc = block_decode(a.tm, gl.tt, sample, t, j);
     gather_process_tile16<EMBED>(a, tc, sample, gl.cm, gl.ko, gl.kvo, ew, eb, lane);
   }
