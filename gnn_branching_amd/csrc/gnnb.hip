@@ -1497,14 +1497,18 @@ struct DenseLArgs {
 // forward edge (long K) of sample b: 8 waves = 4 row tiles x 2 K-halves; X streams through LDS in double-buffered chunks
 // of 2 x 32 rows (one slab per K-half), the two halves are summed through LDS in a fixed order.  Requires MT <= 4 and 512
 // threads.  `scratch`: DENSE_FWD_LDS_FLOATS floats of LDS; store(row, channel pair index j, value pair).
+// klist (LDS) != nullptr: only the K_eff source rows klist[0..K_eff) are walked (the caller dropped the all-zero rows of dead
+// nodes); klist must be padded with a.Kpad (a zero row of At) up to round_up(K_eff, 64) + 32 entries.
 template <class Store>
-__device__ __forceinline__ void dense_fwd_sample(const DenseLArgs& a, int b, float* scratch, Store store) {
+__device__ __forceinline__ void dense_fwd_sample(const DenseLArgs& a, int b, float* scratch, Store store, const int* klist = nullptr,
+                                                 int K_eff = 0) {
   float (*xs)[2][32][64] = reinterpret_cast<float (*)[2][32][64]>(scratch);                 // [buffer][K-half][row][channel]  32 KB
   float (*red)[32][64] = reinterpret_cast<float (*)[32][64]>(scratch + 2 * 2 * 32 * 64);    // 32 KB
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int mt = wave & 3, kh = wave >> 2;
-  const int khalf = a.Kpad / 2;                  // rows per K-half, a multiple of 32
+  const int Kw = klist ? K_eff : a.K;            // source rows walked
+  const int khalf = (klist ? (K_eff + 63) / 64 * 64 : a.Kpad) / 2;      // rows per K-half, a multiple of 32
   const int nchunks = khalf / 32;
   const float* Xb = a.X + (long)b * a.K * 64;
   // cooperative stage of chunk c: 2 slabs x 32 rows x 256 B = 16 KB, 512 threads x 2 x 16 B.  The global loads are issued
@@ -1517,9 +1521,10 @@ __device__ __forceinline__ void dense_fwd_sample(const DenseLArgs& a, int b, flo
       const int e = threadIdx.x + 512 * r;        // 16-B piece index, 0..1023
       const int slab = e >> 9, row = (e >> 4) & 31, piece = e & 15;
       const int k = slab * khalf + c * 32 + row;
-      const f32x4* src = reinterpret_cast<const f32x4*>(Xb + (long)(k < a.K ? k : 0) * 64 + piece * 4);
+      const int krow = k < Kw ? (klist ? klist[k] : k) : 0;
+      const f32x4* src = reinterpret_cast<const f32x4*>(Xb + (long)krow * 64 + piece * 4);
       const f32x4 v = *src;
-      sv[r] = k < a.K ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      sv[r] = k < Kw ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   auto lstore = [&](int buf) {
@@ -1530,14 +1535,15 @@ __device__ __forceinline__ void dense_fwd_sample(const DenseLArgs& a, int b, flo
       *reinterpret_cast<f32x4*>(&xs[buf][slab][row][piece * 4]) = sv[r];
     }
   };
-  const float* At = a.At + (long)(kh * khalf) * a.ldA + (mt < a.MT ? mt : 0) * 32 + j;   // waves beyond MT idle on tile 0
+  const float* At = a.At + (klist ? 0 : (long)(kh * khalf) * a.ldA) + (mt < a.MT ? mt : 0) * 32 + j;   // waves beyond MT idle on tile 0
+  const int* kl = klist ? klist + kh * khalf : nullptr;
   f32x16 acc0, acc1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
   float av[16], nav[16];
   auto loadA = [&](float (&A)[16], int c) {
 #pragma unroll
-    for (int u = 0; u < 16; ++u) A[u] = At[(long)(c * 32 + 2 * u + h) * a.ldA];
+    for (int u = 0; u < 16; ++u) A[u] = At[(long)(kl ? kl[c * 32 + 2 * u + h] : c * 32 + 2 * u + h) * a.ldA];
   };
   auto mma = [&](const float (&A)[16], int buf) {
 #pragma unroll
@@ -1752,6 +1758,7 @@ struct TopArgs {
   const float *Pf, *Pb;     // cached P' rows of layer L (by node id), forward / backward
   const float* sf;          // bias-sum scalars of the forward edge (B, N)
   const float *lb, *ub;     // bounds of layer L, flat (B*N)
+  const float *lbm, *ubm;   // bounds of layer L-1, flat (B*K): its dead rows (all zero) are skipped by the forward edge
   const float *prop_w, *prop_b, *lbK, *ubK, *z_out;
   float* mu_prop;           // (B, 64)
   float* mu;                // (B, N, 64) rows of layer L (backward-produced)
@@ -1793,12 +1800,37 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int N = a.N;
   for (int i = tid; i < DENSE_BWD_ROWS * 16; i += 512) reinterpret_cast<f32x4*>(Cr)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  copy_to_lds(Bp, a.pack_p, PackProp::FLOATS);
+  // live source rows of layer L-1 (the dead ones are all zero: ~45 % of the forward edge's k-steps), compacted in node order
+  // into the region PackProp takes afterwards
+  int* klist = reinterpret_cast<int*>(Bp);
+  int K_eff = 0;
+  const bool compact = a.df.K + 96 <= PackProp::FLOATS;
+  if (compact) {
+    int* wc = reinterpret_cast<int*>(part);              // per-wave counts
+    const int K = a.df.K;
+    for (int n0 = 0; n0 < K; n0 += 512) {
+      const int n = n0 + tid;
+      const long gm = (long)b * K + (n < K ? n : 0);
+      const bool live = n < K && node_is_live(a.lbm[gm], a.ubm[gm]);
+      const unsigned long long bal = __ballot(live);
+      if (lane == 0) wc[wave] = __popcll(bal);
+      __syncthreads();
+      int before = 0, total = 0;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) { before += w8 < wave ? wc[w8] : 0; total += wc[w8]; }
+      if (live) klist[K_eff + before + __popcll(bal & ((1ull << lane) - 1ull))] = n;
+      K_eff += total;
+      __syncthreads();
+    }
+    for (int i = K_eff + tid; i < (K_eff + 63) / 64 * 64 + 32; i += 512) klist[i] = a.df.Kpad;     // a zero row of At
+  }
   __syncthreads();
 
   // ---- F1: rows of C <- W_L . mu_{L-1}
-  dense_fwd_sample(a.df, b, A, [&](int row, int jj, float2 v) { *reinterpret_cast<float2*>(Cr + row * 64 + 2 * jj) = v; });
+  dense_fwd_sample(a.df, b, A, [&](int row, int jj, float2 v) { *reinterpret_cast<float2*>(Cr + row * 64 + 2 * jj) = v; },
+                   compact ? klist : nullptr, K_eff);
   __syncthreads();
+  copy_to_lds(Bp, a.pack_p, PackProp::FLOATS);            // (read from F3 on, behind two more barriers)
 
   // per-lane node of the update phases (waves 0..3: one tile of 32 nodes each)
   const int n = wave * 32 + j;
@@ -3088,6 +3120,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     a.pack_f = h->d_pack[PK_UPD_FWD_F]; a.pack_b = h->d_pack[PK_UPD_BWD]; a.pack_p = h->d_pack[PK_PROP];
     a.Pf = ws + w.Pf[L]; a.Pb = ws + w.Pb[L]; a.sf = ws + w.sf[L];
     a.lb = in->lb[L]; a.ub = in->ub[L];
+    a.lbm = in->lb[L - 1]; a.ubm = in->ub[L - 1];
     a.prop_w = in->prop_w; a.prop_b = in->prop_b; a.lbK = in->lb[K]; a.ubK = in->ub[K]; a.z_out = in->primal[in->n_primal - 1];
     a.mu_prop = mu(K); a.mu = mu(L); a.status = status; a.N = h->N[L];
     lz.run(PC_TOP, [&] { hipLaunchKernelGGL(k_top, dim3(B), dim3(512), TOP_LDS_FLOATS * 4, st, a); });
