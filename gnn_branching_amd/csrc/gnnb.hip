@@ -621,7 +621,10 @@ __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, i
     frag_relu(H);
     gemm_w64<32>(lds + PackUpd::WCB, lane, H2, [&](int s) { return FRAG_AT(H, s); });
     frag_relu(H2);
-    frag_scale(H2, r.live);
+    if (r.live == 0.0f) {                      // a dead node's row is zero whatever its (possibly never written) aggregate held
+#pragma unroll
+      for (int R = 0; R < 32; ++R) FRAG_AT(H2, R) = 0.0f;
+    }
     if (valid) {
       if (frag_has_nan(H2)) atomicOr(a.status, 1);      // a NaN here is a NaN in mu = Wd.E + bd (:184-186, :339-341)
       if (a.mu) frag_store_rows(H2, a.mu, gc, h);
@@ -1599,14 +1602,20 @@ __global__ __launch_bounds__(512, 2) void k_dense_fwd_lds(DenseLArgs a) {
 
 // transposed edge (short K <= 128) of one sample whose source rows sit in LDS (`xs`: DENSE_BWD_ROWS x 64, rows >= K zero);
 // 8 waves walk the MT row tiles.
+// Optional compaction (lists in LDS): `rlist` / n_rows -- only these output rows are computed (the live nodes of the layer
+// below; the others are never read); `klist` / K_eff -- only these source rows are walked (the live nodes of this layer; the
+// rows of dead ones are zero), padded with a.Kpad (a zero row of At and of xs) up to round_up(K_eff, 16) + 32 entries.
 template <class Store>
-__device__ __forceinline__ void dense_bwd_sample(const DenseLArgs& a, const float* xs_raw, Store store) {
+__device__ __forceinline__ void dense_bwd_sample(const DenseLArgs& a, const float* xs_raw, Store store, const int* rlist = nullptr,
+                                                 int n_rows = 0, const int* klist = nullptr, int K_eff = 0) {
   const float (*xs)[64] = reinterpret_cast<const float (*)[64]>(xs_raw);
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nch = a.Kpad / 16;                       // chunks of 8 k-steps
-  for (int mt = wave; mt < a.MT; mt += 8) {
-    const float* At = a.At + mt * 32 + j;
+  const int nch = (klist ? (K_eff + 15) / 16 * 16 : a.Kpad) / 16;      // chunks of 8 k-steps
+  const int M = rlist ? n_rows : a.M, MT = rlist ? (n_rows + 31) / 32 : a.MT;
+  for (int mt = wave; mt < MT; mt += 8) {
+    const int arow = rlist ? rlist[mt * 32 + j < M ? mt * 32 + j : 0] : mt * 32 + j;
+    const float* At = a.At + arow;
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
@@ -1615,12 +1624,12 @@ __device__ __forceinline__ void dense_bwd_sample(const DenseLArgs& a, const floa
     float a0[DL_CH], a1[DL_CH], a2[DL_CH];
     auto loadA = [&](float (&A)[DL_CH], int c) {
 #pragma unroll
-      for (int u = 0; u < DL_CH; ++u) A[u] = At[(long)(c * 16 + 2 * u + h) * a.ldA];
+      for (int u = 0; u < DL_CH; ++u) A[u] = At[(long)(klist ? klist[c * 16 + 2 * u + h] : c * 16 + 2 * u + h) * a.ldA];
     };
     auto mma = [&](const float (&A)[DL_CH], int c) {
 #pragma unroll
       for (int u = 0; u < DL_CH; ++u) {
-        const float2 bv = *reinterpret_cast<const float2*>(&xs[c * 16 + 2 * u + h][2 * j]);
+        const float2 bv = *reinterpret_cast<const float2*>(&xs[klist ? klist[c * 16 + 2 * u + h] : c * 16 + 2 * u + h][2 * j]);
         acc0 = mfma32(A[u], bv.x, acc0);
         acc1 = mfma32(A[u], bv.y, acc1);
       }
@@ -1646,7 +1655,7 @@ __device__ __forceinline__ void dense_bwd_sample(const DenseLArgs& a, const floa
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (row < a.M) store(row, j, make_float2(acc0[r], acc1[r]));
+      if (row < M) store(rlist ? rlist[row] : row, j, make_float2(acc0[r], acc1[r]));
     }
   }
 }
@@ -1766,7 +1775,10 @@ struct TopArgs {
   int N;
 };
 #define TOP_A_FLOATS (PackUpd::FLOATS > DENSE_FWD_LDS_FLOATS ? PackUpd::FLOATS : DENSE_FWD_LDS_FLOATS)
-#define TOP_LDS_FLOATS (TOP_A_FLOATS + PackProp::FLOATS + DENSE_BWD_ROWS * 64 + 8 * 64 + 128 + 64 + 64)
+#define TOP_FIXED_FLOATS (TOP_A_FLOATS + PackProp::FLOATS + DENSE_BWD_ROWS * 64 + 8 * 64 + 128 + 64 + 64)
+#define TOP_LDS_FLOATS 40960                   // all 160 KB: what the fixed regions leave holds the live-row lists
+#define TOP_K2_INTS (128 + 48)                  // live rows of layer L, padded for the chunks read ahead
+#define TOP_LIST_INTS (TOP_LDS_FLOATS - TOP_FIXED_FLOATS - TOP_K2_INTS)
 
 __device__ __forceinline__ void copy_to_lds_part(float* lds, const float* src, int nfloats, int tid, int nthr) {
   const f32x4* g = reinterpret_cast<const f32x4*>(src);
@@ -1802,9 +1814,14 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
   for (int i = tid; i < DENSE_BWD_ROWS * 16; i += 512) reinterpret_cast<f32x4*>(Cr)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   // live source rows of layer L-1 (the dead ones are all zero: ~45 % of the forward edge's k-steps), compacted in node order
   // into the region PackProp takes afterwards
-  int* klist = reinterpret_cast<int*>(Bp);
+  // The list goes behind the fixed regions when it fits there (then the transposed edge B2 also uses it, to compute only the
+  // live rows of layer L-1), else into the region PackProp takes after F1.
+  int* k2list = reinterpret_cast<int*>(spart + 8);        // live rows of layer L (B2)
+  int* tail = k2list + TOP_K2_INTS;
+  const bool keep = a.df.K + 96 <= TOP_LIST_INTS;
+  int* klist = keep ? tail : reinterpret_cast<int*>(Bp);
   int K_eff = 0;
-  const bool compact = a.df.K + 96 <= PackProp::FLOATS;
+  const bool compact = keep || a.df.K + 96 <= PackProp::FLOATS;
   if (compact) {
     int* wc = reinterpret_cast<int*>(part);              // per-wave counts
     const int K = a.df.K;
@@ -1953,9 +1970,25 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
   }
   __syncthreads();
 
-  // ---- B2: aggregate rows of layer L-1 <- W_L^T . rows of C
+  // ---- B2: aggregate rows of layer L-1 <- W_L^T . rows of C: only the live rows of layer L-1 (nothing reads the others), only
+  // the live (non-zero) rows of layer L
+  int K2 = 0;
+  if (keep) {
+    int* wc = reinterpret_cast<int*>(part);
+    const unsigned long long bal = __ballot(upd_wave && valid && r.live != 0.0f && (lane < 32));
+    if (lane == 0) wc[wave] = __popcll(bal);
+    __syncthreads();
+    int before = 0;
+#pragma unroll
+    for (int w8 = 0; w8 < 8; ++w8) { before += w8 < wave ? wc[w8] : 0; K2 += wc[w8]; }
+    if (upd_wave && valid && r.live != 0.0f && lane < 32) k2list[before + __popcll(bal & ((1ull << lane) - 1ull))] = n;
+    for (int i = K2 + tid; i < TOP_K2_INTS; i += 512) k2list[i] = a.db.Kpad;   // zero row of At and of C
+    __syncthreads();
+  }
   float* out = a.db.out + (long)b * a.db.M * 64;
-  dense_bwd_sample(a.db, Cr, [&](int row, int jj, float2 v) { *reinterpret_cast<float2*>(out + (long)row * 64 + 2 * jj) = v; });
+  auto put = [&](int row, int jj, float2 v) { *reinterpret_cast<float2*>(out + (long)row * 64 + 2 * jj) = v; };
+  if (keep) dense_bwd_sample(a.db, Cr, put, klist, K_eff, k2list, K2);
+  else dense_bwd_sample(a.db, Cr, put);
 }
 
 __global__ __launch_bounds__(512, 1) void k_top(TopArgs a) {
