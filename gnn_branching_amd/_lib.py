@@ -44,6 +44,12 @@ SYMBOLS = [
                              C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("gnnb_mu_projection", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     ("gnnb_destroy", C.c_int, [C.c_void_p]),
+    ("gnnb_get_weights", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("gnnb_set_weights", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("gnnb_online_create", C.c_int, [C.c_void_p, C.c_float, C.c_float]),
+    ("gnnb_online_step", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_int, C.c_void_p]),
+    ("gnnb_online_grad", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     ("gnnb_last_error", C.c_char_p, []),
     ("gnnb_abi_version", C.c_int, []),
     ("gnnb_describe", C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),

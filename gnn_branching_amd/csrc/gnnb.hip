@@ -31,6 +31,7 @@
 
 #include "../../include/gnnb.h"
 #include "gnnb_pack.h"
+#include "gnnb_train.h"
 
 using namespace gnnb;
 
@@ -2529,6 +2530,8 @@ struct gnnb_handle {
                                 // the break-even).  Off by default: the two paths round differently, and with one path for
                                 // every batch size a sample's scores do not depend on what it is batched or sharded with.
   Packs packs;
+  std::vector<float> blob;      // the GNN parameters as handed to gnnb_create / gnnb_set_weights / left by gnnb_online_step
+  gnnb_train::Trainer* trainer = nullptr;     // online learning (gnnb_online_create)
   float* d_pack[N_PACKS] = {nullptr};
   float* d_zero = nullptr;      // 64 zero floats: where masked gather loads point
   std::vector<int> proj;        // per graph layer: which Linear (LayerId) the rows of mu[k] still have to go through after
@@ -2558,6 +2561,25 @@ static int upload(float** d, const float* h, size_t n) {
   return 0;
 }
 
+// (re)build the operand packs of the scorer from a parameter blob and put them on the device
+static int load_weights(gnnb_t* h, const float* w_blob, hipStream_t st) {
+  h->blob.assign(w_blob, w_blob + blob_floats());
+  build_packs(h->blob.data(), h->packs);
+  const std::vector<float>* pv[N_PACKS] = {&h->packs.embed, &h->packs.pre_fwd, &h->packs.pre_bwd, &h->packs.pre_inp, &h->packs.prop,
+                                           &h->packs.upd_fwd_e, &h->packs.upd_fwd_i, &h->packs.upd_fwd_f, &h->packs.upd_bwd,
+                                           &h->packs.upd_bwd_b, &h->packs.upd_inp, &h->packs.post_inp, &h->packs.score_b,
+                                           &h->packs.score_f};
+  for (int i = 0; i < N_PACKS; ++i) {
+    if (!h->d_pack[i]) {
+      if (int rc = upload(&h->d_pack[i], pv[i]->data(), pv[i]->size())) return rc;
+    } else {
+      HIPCHK(hipMemcpyAsync(h->d_pack[i], pv[i]->data(), pv[i]->size() * sizeof(float), hipMemcpyHostToDevice, st));
+    }
+  }
+  HIPCHK(hipStreamSynchronize(st));       // the host vectors are reused by the next call
+  return 0;
+}
+
 extern "C" int gnnb_abi_version(void) { return GNNB_ABI_VERSION; }
 extern "C" const char* gnnb_last_error(void) { return g_err.c_str(); }
 
@@ -2576,13 +2598,7 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, h->device));
   h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  build_packs(w_blob, h->packs);
-  const std::vector<float>* pv[N_PACKS] = {&h->packs.embed, &h->packs.pre_fwd, &h->packs.pre_bwd, &h->packs.pre_inp, &h->packs.prop,
-                                           &h->packs.upd_fwd_e, &h->packs.upd_fwd_i, &h->packs.upd_fwd_f, &h->packs.upd_bwd,
-                                           &h->packs.upd_bwd_b, &h->packs.upd_inp, &h->packs.post_inp, &h->packs.score_b,
-                                           &h->packs.score_f};
-  for (int i = 0; i < N_PACKS; ++i)
-    if (int rc = upload(&h->d_pack[i], pv[i]->data(), pv[i]->size())) return rc;
+  if (int rc = load_weights(h, w_blob, nullptr)) return rc;
   HIPCHK(hipMalloc((void**)&h->d_zero, 256 * sizeof(float)));
   HIPCHK(hipMemset(h->d_zero, 0, 256 * sizeof(float)));
   // > 64 KiB of dynamic LDS needs the attribute
@@ -2622,7 +2638,25 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   return GNNB_OK;
 }
 
+static void free_trainer(gnnb_t* h) {
+  gnnb_train::Trainer* t = h->trainer;
+  if (!t) return;
+  for (float* p : {t->d_w, t->d_g, t->d_m, t->d_v, t->d_scores, t->d_ds, t->d_loss, t->d_imp})
+    if (p) (void)hipFree(p);
+  if (t->d_kw) (void)hipFree(t->d_kw);
+  for (float* p : t->edge_w)
+    if (p) (void)hipFree(p);
+  t->arena.release();
+  delete t;
+  h->trainer = nullptr;
+}
+
 static void free_network(gnnb_t* h) {
+  if (h->trainer) {                       // the edge weights of the trainer belong to the network that goes away
+    for (float* p : h->trainer->edge_w)
+      if (p) (void)hipFree(p);
+    h->trainer->edge_w.clear();
+  }
   for (auto& d : h->dev) {
     if (d.w_fwd) (void)hipFree(d.w_fwd);
     if (d.w_bwd) (void)hipFree(d.w_bwd);
@@ -2650,6 +2684,7 @@ extern "C" int gnnb_destroy(gnnb_t* h) {
   for (int i = 0; i < N_PACKS; ++i)
     if (h->d_pack[i]) (void)hipFree(h->d_pack[i]);
   if (h->d_zero) (void)hipFree(h->d_zero);
+  free_trainer(h);
   for (auto& ev : h->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
   for (auto& ev : h->pool) (void)hipEventDestroy(ev);
   delete h;
@@ -3425,5 +3460,242 @@ extern "C" int gnnb_babsr(gnnb_t* h, const float* const* lb, const float* const*
   hipLaunchKernelGGL(k_babsr, dim3(B), dim3(256), (size_t)2 * maxN * sizeof(float), (hipStream_t)stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(GNNB_E_HIP, "launch of k_babsr failed: %s", hipGetErrorString(e));
+  return GNNB_OK;
+}
+
+
+// ================================================================================================================
+// Online learning (reference graphnet/graph_score_online.py:9-23, :62-77)
+// ================================================================================================================
+extern "C" int gnnb_get_weights(const gnnb_t* h, float* w_blob, size_t n_floats) {
+  if (!h || !w_blob) return fail(GNNB_E_INVALID, "gnnb_get_weights: null argument");
+  if (n_floats != blob_floats()) return fail(GNNB_E_INVALID, "gnnb_get_weights: %zu floats, expected %zu", n_floats, blob_floats());
+  memcpy(w_blob, h->blob.data(), n_floats * sizeof(float));
+  return GNNB_OK;
+}
+
+extern "C" int gnnb_set_weights(gnnb_t* h, const float* w_blob, size_t n_floats) {
+  if (!h || !w_blob) return fail(GNNB_E_INVALID, "gnnb_set_weights: null argument");
+  if (n_floats != blob_floats()) return fail(GNNB_E_INVALID, "gnnb_set_weights: %zu floats, expected %zu", n_floats, blob_floats());
+  HIPCHK(hipDeviceSynchronize());          // no forward may still be reading the packs
+  if (int rc = load_weights(h, w_blob, nullptr)) return rc;
+  if (h->trainer) HIPCHK(hipMemcpy(h->trainer->d_w, w_blob, n_floats * sizeof(float), hipMemcpyHostToDevice));
+  return GNNB_OK;
+}
+
+// torch.optim.Adam(model.parameters(), lr, weight_decay) of graph_score_online.py:15; the moments start at zero
+extern "C" int gnnb_online_create(gnnb_t* h, float lr, float weight_decay) {
+  if (!h) return fail(GNNB_E_INVALID, "gnnb_online_create: null handle");
+  free_trainer(h);
+  gnnb_train::Trainer* t = new gnnb_train::Trainer();
+  h->trainer = t;
+  t->lr = lr; t->wd = weight_decay;
+  const size_t n = blob_floats();
+  for (float** p : {&t->d_w, &t->d_g, &t->d_m, &t->d_v}) {
+    HIPCHK(hipMalloc((void**)p, n * sizeof(float)));
+    HIPCHK(hipMemset(*p, 0, n * sizeof(float)));
+  }
+  HIPCHK(hipMemcpy(t->d_w, h->blob.data(), n * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(hipFuncSetAttribute((const void*)gnnb_train::k_tlin_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  return GNNB_OK;
+}
+
+extern "C" int gnnb_online_grad(const gnnb_t* h, float* grad, size_t n_floats) {
+  if (!h || !grad || !h->trainer) return fail(GNNB_E_STATE, "gnnb_online_grad: no trainer (gnnb_online_create)");
+  if (n_floats != blob_floats()) return fail(GNNB_E_INVALID, "gnnb_online_grad: %zu floats, expected %zu", n_floats, blob_floats());
+  HIPCHK(hipMemcpy(grad, h->trainer->d_g, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+  return GNNB_OK;
+}
+
+// One GraphChoice.online_learning step (graph_score_online.py:62-77) for B subproblems (the reference: B = 1):
+//   loss = sum_b ( max_j scores_b[j] - scores_b[kw_b] + improvement_b );  backward;  Adam step;  scorer packs rebuilt.
+// in: the batch exactly as for gnnb_forward.  kw_index (HOST, B): the KW decision as a flat index into the R ReLU nodes
+// (trans_len[lay-1] + idx, :63-67), which must be an undecided node of the mask.  improvement (HOST, B).  loss (HOST, B,
+// may be NULL).  scores_padded (DEVICE (B, R), may be NULL): the scores of the training-form forward BEFORE the update.
+// apply = 0: gradient only (gnnb_online_grad), the parameters and the Adam state stay as they are.
+extern "C" int gnnb_online_step(gnnb_t* h, const gnnb_batch* in, int B, const int32_t* kw_index, const float* improvement,
+                                float* loss, float* scores_padded, int apply, void* stream) {
+  using namespace gnnb_train;
+  if (!h || !in || !kw_index || !improvement) return fail(GNNB_E_INVALID, "gnnb_online_step: null argument");
+  if (!h->bound) return fail(GNNB_E_STATE, "gnnb_online_step: call gnnb_bind_network first");
+  if (!h->trainer) return fail(GNNB_E_STATE, "gnnb_online_step: call gnnb_online_create first");
+  const int K = (int)h->N.size() - 1, L = K - 1, R = h->R, T = h->T;
+  if (B < 1 || in->n_graph != K + 1 || in->n_relu != L || in->n_primal < h->n_fixed)
+    return fail(GNNB_E_INVALID, "gnnb_online_step: batch does not match the bound network");
+  for (int b = 0; b < B; ++b)
+    if (kw_index[b] < 0 || kw_index[b] >= R) return fail(GNNB_E_INVALID, "gnnb_online_step: kw_index[%d] = %d outside [0, %d)", b, kw_index[b], R);
+  Trainer& t = *h->trainer;
+  hipStream_t st = (hipStream_t)stream;
+  t.st = st;
+  t.tape.clear();
+  if (t.arena.reset(st)) return fail(GNNB_E_HIP, "gnnb_online_step: arena reset failed");
+  if (t.edge_w.empty()) {                                  // torch-layout copies of the verified network's weights
+    t.edge_w.assign(h->edges.size(), nullptr);
+    for (int k = 1; k <= L; ++k)
+      if (int rc = upload(&t.edge_w[k], h->edges[k].w.data(), h->edges[k].w.size())) return rc;
+  }
+  if (t.cap_B < B) {
+    for (float** p : {&t.d_scores, &t.d_ds, &t.d_loss, &t.d_imp}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    if (t.d_kw) (void)hipFree(t.d_kw);
+    HIPCHK(hipMalloc((void**)&t.d_scores, (size_t)B * R * 4));
+    HIPCHK(hipMalloc((void**)&t.d_ds, (size_t)B * R * 4));
+    HIPCHK(hipMalloc((void**)&t.d_loss, (size_t)B * 4));
+    HIPCHK(hipMalloc((void**)&t.d_imp, (size_t)B * 4));
+    HIPCHK(hipMalloc((void**)&t.d_kw, (size_t)B * 4));
+    t.cap_B = B;
+  }
+  HIPCHK(hipMemcpyAsync(t.d_kw, kw_index, (size_t)B * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(t.d_imp, improvement, (size_t)B * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(t.d_ds, 0, (size_t)B * R * 4, st));
+  HIPCHK(hipMemsetAsync(t.d_g, 0, blob_floats() * 4, st));
+
+  // ---- per-node constants ----
+  struct LC { float *r0, *r1, *amb, *live, *nd2, *d1, *ff, *fb; };
+  std::vector<LC> lc(L + 1);
+  for (int k = 1; k <= L; ++k) {
+    const long n = (long)B * h->N[k];
+    LC& c = lc[k];
+    for (float** p : {&c.r0, &c.r1, &c.amb, &c.live, &c.nd2, &c.d1}) *p = t.arena.alloc(n);
+    c.ff = t.arena.alloc(7 * n);
+    c.fb = t.arena.alloc(7 * n);
+    if (t.arena.err) return fail(GNNB_E_NOMEM, "gnnb_online_step: out of device memory");
+    const int q = h->relu_q[k];
+    TPrepArgs a{in->lb[k], in->ub[k], in->dual[k - 1], in->primal[q - 1], in->primal[q], h->dev[k].bias, h->N[k], h->hw[k], n,
+                c.r0, c.r1, c.amb, c.live, c.nd2, c.d1, c.ff, c.fb};
+    hipLaunchKernelGGL(k_tprep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+  }
+  auto cols = [&](std::initializer_list<const float*> cs, long n) {
+    TColsArgs a{};
+    int w = 0;
+    for (const float* c : cs) a.c[w++] = c;
+    a.w = w; a.n = n; a.dst = t.arena.alloc((size_t)n * w);
+    hipLaunchKernelGGL(k_tcols, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    return (const float*)a.dst;
+  };
+  const long n0 = (long)B * h->N[0];
+  const float* inp3 = cols({in->lb[0], in->x_lp, in->ub[0]}, n0);                       // graph_conv.py:90-93
+  const float* inp2 = cols({in->lb[0], in->ub[0]}, n0);                                 // :380-381
+  const float* featp = cols({in->lb[K], in->ub[K], in->primal[in->n_primal - 1], in->prop_b}, B);     // :202-205
+
+  auto edge = [&](int k, int dir, int norm, const TT& src) {       // nb = A_k src (dir 0) or A_k^T src (dir 1, / tap count if norm)
+    const Edge& e = h->edges[k];
+    TT y = t.rows((long)B * (dir == 0 ? h->N[k] : h->N[k - 1]));
+    if (e.kind == 0) {
+      TConv a{src.v, y.v, t.edge_w[k], B, e.c_in, e.h_in, e.w_in, e.c_out, e.h_out, e.w_out, e.kh, e.kw, e.stride, e.pad, dir, norm, 0};
+      hipLaunchKernelGGL(k_tconv, dim3((unsigned)((y.n + 3) / 4)), dim3(256), 0, st, a);
+      TConv b = a;
+      b.src = y.g; b.dst = src.g; b.dir = 1 - dir; b.acc = 1;
+      const long nsrc = src.n;
+      t.tape.push_back([b, nsrc, st]() { hipLaunchKernelGGL(k_tconv, dim3((unsigned)((nsrc + 3) / 4)), dim3(256), 0, st, b); });
+    } else {
+      TDense a{t.edge_w[k], 0, src.v, y.v, B, e.n_out, e.n_in, dir, 0};
+      hipLaunchKernelGGL(k_tdense, dim3((unsigned)((y.n + 3) / 4)), dim3(256), 0, st, a);
+      TDense b = a;
+      b.src = y.g; b.dst = src.g; b.dir = 1 - dir; b.acc = 1;
+      const long nsrc = src.n;
+      t.tape.push_back([b, nsrc, st]() { hipLaunchKernelGGL(k_tdense, dim3((unsigned)((nsrc + 3) / 4)), dim3(256), 0, st, b); });
+    }
+    return y;
+  };
+  auto prop_edge = [&](int dir, const TT& src) {                   // the property layer: one (1, N_L) matrix per sample
+    TT y = t.rows(dir == 0 ? (long)B : (long)B * h->N[L]);
+    TDense a{in->prop_w, (long)h->N[L], src.v, y.v, B, 1, h->N[L], dir, 0};
+    hipLaunchKernelGGL(k_tdense, dim3((unsigned)((y.n + 3) / 4)), dim3(256), 0, st, a);
+    TDense b = a;
+    b.src = y.g; b.dst = src.g; b.dir = 1 - dir; b.acc = 1;
+    const long nsrc = src.n;
+    t.tape.push_back([b, nsrc, st]() { hipLaunchKernelGGL(k_tdense, dim3((unsigned)((nsrc + 3) / 4)), dim3(256), 0, st, b); });
+    return y;
+  };
+  auto S = [](const TT& x, const float* s = nullptr) { return Trainer::seg(x, s); };
+
+  // ---- the forward of graph_conv.py:77-388, every Linear on the tape ----
+  std::vector<TT> mu(K + 1);
+  for (int r = 0; r < T; ++r) {
+    if (r == 0) {
+      TT a = t.lin(L_INP_F, {}, inp3, n0, true, nullptr);
+      mu[0] = t.lin(L_INP_F_1, {S(a)}, nullptr, n0, false, nullptr);                     // :94
+    }
+    for (int k = 1; k <= L; ++k) {                                                       // :107-192
+      const LC& c = lc[k];
+      const long n = (long)B * h->N[k];
+      TT nb = edge(k, 0, 0, mu[k - 1]);
+      TT a = t.lin(L_FC1, {}, c.ff, n, true, nullptr);
+      TT relax = t.lin(L_FC1_1, {S(a)}, nullptr, n, false, c.amb);                       // :160-161
+      TT e1 = t.lin(L_FC3, {S(nb, c.r0), S(nb, c.r1)}, nullptr, n, true, nullptr);      // :169-170
+      TT e = t.lin(L_FC3_2, {S(e1)}, nullptr, n, false, nullptr);
+      TT d = t.lin(L_FC4, {S(relax), S(e)}, nullptr, n, true, nullptr);                 // :176-177
+      mu[k] = t.lin(L_FC4_2, {S(d)}, nullptr, n, false, c.live);                         // :178
+    }
+    {                                                                                    // :194-210
+      TT nb = prop_edge(0, mu[L]);
+      TT hh = t.lin(L_OUT1, {}, featp, B, true, nullptr);
+      TT o = t.lin(L_OUT2, {S(hh), S(nb)}, nullptr, B, true, nullptr);
+      mu[K] = t.lin(L_OUT3, {S(o)}, nullptr, B, false, nullptr);
+    }
+    for (int k = L; k >= 1; --k) {                                                       // :222-350
+      const LC& c = lc[k];
+      const long n = (long)B * h->N[k];
+      TT a1 = t.lin(L_BC1, {}, c.fb, n, true, nullptr);
+      TT a2 = t.lin(L_BC1_1, {S(a1)}, nullptr, n, true, nullptr);
+      TT s = t.lin(L_BC1_2, {S(a2)}, nullptr, n, false, nullptr);                        // :285
+      TT b1 = t.lin(L_BC2, {S(s), S(s, c.nd2), S(s, c.d1)}, nullptr, n, true, nullptr);  // :287-291
+      TT relax = t.lin(L_BC2_1, {S(b1)}, nullptr, n, false, c.amb);                      // :293
+      TT nb = k == L ? prop_edge(1, mu[K]) : edge(k + 1, 1, h->edges[k + 1].kind == 0 ? 1 : 0, mu[k + 1]);   // :299-326
+      TT e1 = t.lin(L_BC3, {S(nb, c.r0), S(nb, c.r1)}, nullptr, n, true, nullptr);      // :331-336
+      TT e = t.lin(L_BC3_1, {S(e1)}, nullptr, n, false, nullptr);
+      TT d = t.lin(L_BC4, {S(relax), S(e)}, nullptr, n, true, nullptr);                 // :344-345
+      mu[k] = t.lin(L_BC4_1, {S(d)}, nullptr, n, false, c.live);                         // :347
+    }
+    if (r + 1 < T) {                                                                     // :360-385 (the last round's input rows feed nothing)
+      TT nb = edge(1, 1, 0, mu[1]);
+      TT a = t.lin(L_INP_B, {}, inp2, n0, true, nullptr);
+      TT relax = t.lin(L_INP_B_1, {S(a)}, nullptr, n0, false, nullptr);
+      TT c2 = t.lin(L_INP_B2, {S(relax), S(nb)}, nullptr, n0, true, nullptr);
+      mu[0] = t.lin(L_INP_B2_2, {S(c2)}, nullptr, n0, false, nullptr);
+    }
+  }
+  // ---- scores (:442-450) and the loss ----
+  int off = 0;
+  for (int k = 1; k <= L; ++k) {
+    const long n = (long)B * h->N[k];
+    TT hk = t.lin(L_FNODE, {S(mu[k])}, nullptr, n, true, nullptr);
+    TScore a{hk.v, hk.g, t.d_w + weight_offset(L_FSCORE), t.d_w + bias_offset(L_FSCORE), in->mask, t.d_scores, t.d_ds, h->N[k], R, off, n,
+             t.d_g + weight_offset(L_FSCORE), t.d_g + bias_offset(L_FSCORE)};
+    hipLaunchKernelGGL(k_tscore_fwd, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, a);
+    t.tape.push_back([a, n, st]() {
+      hipLaunchKernelGGL(k_tscore_bwd, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(k_tscore_bwd_w, dim3(1), dim3(64), 0, st, a);
+    });
+    off += h->N[k];
+  }
+  if (t.arena.err) return fail(GNNB_E_NOMEM, "gnnb_online_step: out of device memory");
+  if (scores_padded) HIPCHK(hipMemcpyAsync(scores_padded, t.d_scores, (size_t)B * R * 4, hipMemcpyDeviceToDevice, st));
+  TLoss la{t.d_scores, t.d_ds, t.d_kw, t.d_imp, t.d_loss, R};
+  hipLaunchKernelGGL(k_tloss, dim3(B), dim3(256), 0, st, la);
+  // ---- backward: the tape in reverse ----
+  for (auto it = t.tape.rbegin(); it != t.tape.rend(); ++it) (*it)();
+  t.tape.clear();
+  if (t.arena.err) return fail(GNNB_E_NOMEM, "gnnb_online_step: out of device memory");
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(GNNB_E_HIP, "gnnb_online_step: a launch failed: %s", hipGetErrorString(e));
+  if (loss) {
+    t.h_loss.resize(B);
+    HIPCHK(hipMemcpyAsync(t.h_loss.data(), t.d_loss, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  }
+  if (apply) {
+    t.step += 1;
+    const double b1 = 0.9, b2 = 0.999;
+    const double bc1 = 1.0 - std::pow(b1, t.step), bc2 = 1.0 - std::pow(b2, t.step);
+    TAdam a{t.d_w, t.d_g, t.d_m, t.d_v, (int)blob_floats(), (float)(t.lr / bc1), t.wd, (float)b1, (float)b2, 1e-8f, (float)std::sqrt(bc2)};
+    hipLaunchKernelGGL(k_tadam, dim3((unsigned)((blob_floats() + 255) / 256)), dim3(256), 0, st, a);
+    std::vector<float> nw(blob_floats());
+    HIPCHK(hipMemcpyAsync(nw.data(), t.d_w, nw.size() * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (int rc = load_weights(h, nw.data(), st)) return rc;      // the scorer's folded packs follow the new parameters
+  } else {
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  if (loss) memcpy(loss, t.h_loss.data(), (size_t)B * 4);
   return GNNB_OK;
 }

@@ -186,7 +186,8 @@ class ScorerEngine:
             self._ws[(B, slot)] = ws
         return ws
 
-    def forward(self, lower_bounds_all, upper_bounds_all, dual_vars, primals, primal_inputs, layers, masks):
+    def _marshal(self, lower_bounds_all, upper_bounds_all, dual_vars, primals, primal_inputs, layers, masks):
+        """Bind the network, move the arguments of GraphNet.forward to the device and validate their sizes."""
         fixed = layers["fixed_layers"]
         self.bind(fixed, tuple(lower_bounds_all[0].shape[1:]))
         B = int(lower_bounds_all[0].shape[0])
@@ -214,7 +215,11 @@ class ScorerEngine:
         self._check_primals(fixed, prim, B)
         pw, pb = self._prop(layers["prop_layers"])
         self._last_bounds = list(zip(lbs, ubs))           # for mu() (inspection)
+        return B, lbs, ubs, duals, prim, x_lp, mask, pw, pb
 
+    def forward(self, lower_bounds_all, upper_bounds_all, dual_vars, primals, primal_inputs, layers, masks):
+        B, lbs, ubs, duals, prim, x_lp, mask, pw, pb = self._marshal(lower_bounds_all, upper_bounds_all, dual_vars, primals,
+                                                                     primal_inputs, layers, masks)
         scores = torch.empty(B, self.R, dtype=torch.float32, device=self.device)
         dec = torch.empty(B, 2, dtype=torch.int32, device=self.device)
         nchunk = self.n_streams if (self.n_streams > 1 and B >= self.n_streams * self.min_chunk) else 1
@@ -254,6 +259,58 @@ class ScorerEngine:
                     # stream and it now waits for the side streams, the caching allocator cannot recycle them early
                     cur.wait_stream(self._streams[c])
         return ForwardResult(scores, dec, status, mask2)
+
+    # ---- online learning --------------------------------------------------------
+    def get_weights(self):
+        """The GNN parameters as a flat float32 array in checkpoint order (see state_blob)."""
+        out = np.empty(GNN_BLOB_FLOATS, dtype=np.float32)
+        _lib.check(self.lib.gnnb_get_weights(self.h, out.ctypes.data_as(C.c_void_p), out.size), "gnnb_get_weights")
+        return out
+
+    def set_weights(self, blob):
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.gnnb_set_weights(self.h, blob.ctypes.data_as(C.c_void_p), blob.size), "gnnb_set_weights")
+        self._blob = blob
+
+    def online_create(self, lr=1e-4, wd=1e-4):
+        """torch.optim.Adam(model.parameters(), lr=lr, weight_decay=wd) of graph_score_online.py:15."""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.gnnb_online_create(self.h, lr, wd), "gnnb_online_create")
+        self._online = True
+
+    def online_step(self, args, kw_index, improvement, apply=True, want_scores=False):
+        """graph_score_online.py:62-77 for the batch ``args`` (the argument tuple of GraphNet.forward): kw_index (B) flat
+        indices into the R ReLU nodes, improvement (B).  Returns (loss (B) numpy, scores (B, R) device tensor or None)."""
+        if not getattr(self, "_online", False):
+            raise RuntimeError("online_step: call online_create first")
+        B, lbs, ubs, duals, prim, x_lp, mask, pw, pb = self._marshal(*args)
+        kw = np.ascontiguousarray(kw_index, dtype=np.int32).reshape(-1)
+        imp = np.ascontiguousarray(improvement, dtype=np.float32).reshape(-1)
+        if kw.size != B or imp.size != B:
+            raise ValueError(f"online_step: {kw.size} KW decisions / {imp.size} improvements for a batch of {B}")
+        mask_host = mask.view(B, self.R).cpu()
+        for b in range(B):
+            if not (0 <= kw[b] < self.R) or mask_host[b, kw[b]] == 0:
+                raise IndexError(f"online_step: KW decision {int(kw[b])} of subproblem {b} is not an undecided ReLU of its mask")
+        loss = np.empty(B, dtype=np.float32)
+        scores = torch.empty(B, self.R, dtype=torch.float32, device=self.device) if want_scores else None
+        tabs = [(C.c_void_p * len(g))(*[t.data_ptr() for t in g]) for g in (lbs, ubs, duals, prim)]
+        batch = _lib.Batch(tabs[0], tabs[1], tabs[2], tabs[3], x_lp.data_ptr(), pw.data_ptr(), pb.data_ptr(), mask.data_ptr(),
+                           len(lbs), len(duals), len(prim))
+        with torch.cuda.device(self.device):
+            st = torch.cuda.current_stream().cuda_stream
+            rc = self.lib.gnnb_online_step(self.h, C.byref(batch), B, kw.ctypes.data_as(C.c_void_p), imp.ctypes.data_as(C.c_void_p),
+                                           loss.ctypes.data_as(C.c_void_p), scores.data_ptr() if want_scores else None,
+                                           1 if apply else 0, C.c_void_p(st))
+        _lib.check(rc, "gnnb_online_step")
+        return loss, scores
+
+    def online_grad(self):
+        """d loss / d parameters of the last online_step, flat float32 array in checkpoint order."""
+        out = np.empty(GNN_BLOB_FLOATS, dtype=np.float32)
+        _lib.check(self.lib.gnnb_online_grad(self.h, out.ctypes.data_as(C.c_void_p), out.size), "gnnb_online_grad")
+        return out
 
     # ---- BaBSR fallback scorer (SURVEY 8(f) N3) -------------------------------------------------
     def babsr(self, lower_bounds_all, upper_bounds_all, layers, masks):

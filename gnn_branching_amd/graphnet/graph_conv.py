@@ -8,6 +8,8 @@ layers, reference graph_conv.py:26-74) and ``ComputeFinalScore.{fnode,fscore}``
 the HIP kernels through the C-ABI; nothing is evaluated with torch ops, and there
 is no CPU fallback.
 """
+import numpy as np
+import torch
 from torch import nn
 
 from ..engine import ScorerEngine
@@ -74,6 +76,18 @@ class GraphNet(nn.Module):
             self._engine = ScorerEngine(self.state_dict(), T=self.T, p=self.p)
             self._engine_key = key
         return self._engine
+
+    def load_blob(self, blob):
+        """Copy a flat parameter array (checkpoint order, engine.get_weights()) into the module WITHOUT invalidating the
+        engine that already holds exactly these parameters (after an online-learning step on the device)."""
+        off = 0
+        with torch.no_grad():
+            for q in self.state_dict().values():
+                n = q.numel()
+                q.copy_(torch.from_numpy(np.asarray(blob[off:off + n], dtype=np.float32)).reshape(q.shape))
+                off += n
+        if self._engine is not None:
+            self._engine_key = tuple((q.data_ptr(), q._version) for q in self.parameters())
 
     def forward_device(self, lower_bounds_all, upper_bounds_all, dual_vars, primals, primal_inputs, layers, masks):
         """Batched forward; returns the device-resident ForwardResult (padded scores, decisions,

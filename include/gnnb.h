@@ -101,6 +101,31 @@ int gnnb_babsr(gnnb_t* h, const float* const* lb, const float* const* ub, int n_
 
 int gnnb_destroy(gnnb_t* h);
 
+/* ---- online learning (reference graphnet/graph_score_online.py) ----
+ * gnnb_get_weights / gnnb_set_weights: the 117 825 GNN parameters in gnnb_create's blob order (HOST) -- the
+ * state_dict()/load_state_dict() of the model GraphChoice holds (graph_score_online.py:11-14).  set_weights rebuilds the
+ * scorer's operand packs (device-synchronising). */
+int gnnb_get_weights(const gnnb_t* h, float* w_blob, size_t n_floats);
+int gnnb_set_weights(gnnb_t* h, const float* w_blob, size_t n_floats);
+
+/* torch.optim.Adam(model.parameters(), lr=lr, weight_decay=wd) of graph_score_online.py:15 (betas 0.9/0.999, eps 1e-8,
+ * moments start at zero).  Calling it again resets the optimizer state. */
+int gnnb_online_create(gnnb_t* h, float lr, float weight_decay);
+
+/* GraphChoice.online_learning (graph_score_online.py:62-77) for B subproblems (the reference: B = 1; B > 1 sums the B
+ * losses):  loss_b = max_j scores_b[j] - scores_b[kw_b] + improvement_b;  backward through GraphNet.forward;  one Adam step;
+ * the scorer (gnnb_forward) uses the new parameters from the next call on.
+ * in: the batch as for gnnb_forward (device pointers).  kw_index: HOST (B), the KW decision as a flat index into the R ReLU
+ * nodes (trans_len[lay-1] + idx, :63-67) -- must be an undecided node of the mask.  improvement: HOST (B).  loss: HOST (B)
+ * or NULL.  scores_padded: DEVICE (B, R) or NULL, the scores of the training-form forward before the update.  apply = 0:
+ * compute the gradient only (read it with gnnb_online_grad), parameters and optimizer state untouched.
+ * Synchronises `stream` before returning. */
+int gnnb_online_step(gnnb_t* h, const gnnb_batch* in, int B, const int32_t* kw_index, const float* improvement,
+                     float* loss, float* scores_padded, int apply, void* stream);
+
+/* d loss / d parameters of the last gnnb_online_step (before weight decay), HOST, blob order. */
+int gnnb_online_grad(const gnnb_t* h, float* grad, size_t n_floats);
+
 const char* gnnb_last_error(void);
 int gnnb_abi_version(void);
 
