@@ -2644,6 +2644,7 @@ static void free_trainer(gnnb_t* h) {
   for (float* p : {t->d_w, t->d_g, t->d_m, t->d_v, t->d_scores, t->d_ds, t->d_loss, t->d_imp})
     if (p) (void)hipFree(p);
   if (t->d_kw) (void)hipFree(t->d_kw);
+  if (t->d_sel) (void)hipFree(t->d_sel);
   for (float* p : t->edge_w)
     if (p) (void)hipFree(p);
   t->arena.release();
@@ -3537,6 +3538,8 @@ extern "C" int gnnb_online_step(gnnb_t* h, const gnnb_batch* in, int B, const in
   if (t.cap_B < B) {
     for (float** p : {&t.d_scores, &t.d_ds, &t.d_loss, &t.d_imp}) { if (*p) (void)hipFree(*p); *p = nullptr; }
     if (t.d_kw) (void)hipFree(t.d_kw);
+    if (t.d_sel) (void)hipFree(t.d_sel);
+    HIPCHK(hipMalloc((void**)&t.d_sel, (size_t)B * 8));
     HIPCHK(hipMalloc((void**)&t.d_scores, (size_t)B * R * 4));
     HIPCHK(hipMalloc((void**)&t.d_ds, (size_t)B * R * 4));
     HIPCHK(hipMalloc((void**)&t.d_loss, (size_t)B * 4));
@@ -3589,22 +3592,22 @@ extern "C" int gnnb_online_step(gnnb_t* h, const gnnb_batch* in, int B, const in
       t.tape.push_back([b, nsrc, st]() { hipLaunchKernelGGL(k_tconv, dim3((unsigned)((nsrc + 3) / 4)), dim3(256), 0, st, b); });
     } else {
       TDense a{t.edge_w[k], 0, src.v, y.v, B, e.n_out, e.n_in, dir, 0};
-      hipLaunchKernelGGL(k_tdense, dim3((unsigned)((y.n + 3) / 4)), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(k_tdense, dim3((unsigned)y.n), dim3(256), 0, st, a);
       TDense b = a;
       b.src = y.g; b.dst = src.g; b.dir = 1 - dir; b.acc = 1;
       const long nsrc = src.n;
-      t.tape.push_back([b, nsrc, st]() { hipLaunchKernelGGL(k_tdense, dim3((unsigned)((nsrc + 3) / 4)), dim3(256), 0, st, b); });
+      t.tape.push_back([b, nsrc, st]() { hipLaunchKernelGGL(k_tdense, dim3((unsigned)nsrc), dim3(256), 0, st, b); });
     }
     return y;
   };
   auto prop_edge = [&](int dir, const TT& src) {                   // the property layer: one (1, N_L) matrix per sample
     TT y = t.rows(dir == 0 ? (long)B : (long)B * h->N[L]);
     TDense a{in->prop_w, (long)h->N[L], src.v, y.v, B, 1, h->N[L], dir, 0};
-    hipLaunchKernelGGL(k_tdense, dim3((unsigned)((y.n + 3) / 4)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_tdense, dim3((unsigned)y.n), dim3(256), 0, st, a);
     TDense b = a;
     b.src = y.g; b.dst = src.g; b.dir = 1 - dir; b.acc = 1;
     const long nsrc = src.n;
-    t.tape.push_back([b, nsrc, st]() { hipLaunchKernelGGL(k_tdense, dim3((unsigned)((nsrc + 3) / 4)), dim3(256), 0, st, b); });
+    t.tape.push_back([b, nsrc, st]() { hipLaunchKernelGGL(k_tdense, dim3((unsigned)nsrc), dim3(256), 0, st, b); });
     return y;
   };
   auto S = [](const TT& x, const float* s = nullptr) { return Trainer::seg(x, s); };
@@ -3661,7 +3664,7 @@ extern "C" int gnnb_online_step(gnnb_t* h, const gnnb_batch* in, int B, const in
     const long n = (long)B * h->N[k];
     TT hk = t.lin(L_FNODE, {S(mu[k])}, nullptr, n, true, nullptr);
     TScore a{hk.v, hk.g, t.d_w + weight_offset(L_FSCORE), t.d_w + bias_offset(L_FSCORE), in->mask, t.d_scores, t.d_ds, h->N[k], R, off, n,
-             t.d_g + weight_offset(L_FSCORE), t.d_g + bias_offset(L_FSCORE)};
+             t.d_g + weight_offset(L_FSCORE), t.d_g + bias_offset(L_FSCORE), t.d_sel, B};
     hipLaunchKernelGGL(k_tscore_fwd, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, a);
     t.tape.push_back([a, n, st]() {
       hipLaunchKernelGGL(k_tscore_bwd, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, a);
@@ -3671,7 +3674,7 @@ extern "C" int gnnb_online_step(gnnb_t* h, const gnnb_batch* in, int B, const in
   }
   if (t.arena.err) return fail(GNNB_E_NOMEM, "gnnb_online_step: out of device memory");
   if (scores_padded) HIPCHK(hipMemcpyAsync(scores_padded, t.d_scores, (size_t)B * R * 4, hipMemcpyDeviceToDevice, st));
-  TLoss la{t.d_scores, t.d_ds, t.d_kw, t.d_imp, t.d_loss, R};
+  TLoss la{t.d_scores, t.d_ds, t.d_kw, t.d_imp, t.d_loss, R, t.d_sel};
   hipLaunchKernelGGL(k_tloss, dim3(B), dim3(256), 0, st, la);
   // ---- backward: the tape in reverse ----
   for (auto it = t.tape.rbegin(); it != t.tape.rend(); ++it) (*it)();

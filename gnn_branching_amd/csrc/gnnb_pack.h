@@ -163,12 +163,16 @@ struct PackProp { enum { W1T = 0, B1 = W1T + 4 * 64, W2T = B1 + 64, B2 = W2T + 1
 
 // C (64 x 64) = A (64 x 64, row stride lda, columns [acol0, acol0+64)) . B (64 x 64 row-major), accumulated in double
 inline void matmul64(float* C, const float* A, int lda, int acol0, const float* B) {
-  for (int i = 0; i < 64; ++i)
-    for (int j = 0; j < 64; ++j) {
-      double acc = 0.0;
-      for (int k = 0; k < 64; ++k) acc += (double)A[(size_t)i * lda + acol0 + k] * (double)B[(size_t)k * 64 + j];
-      C[(size_t)i * 64 + j] = (float)acc;
+  for (int i = 0; i < 64; ++i) {          // k outer, j inner: the same sums in the same order, but contiguous and vectorisable
+    double acc[64];                       // (this runs after every online-learning step, gnnb_online_step)
+    for (int j = 0; j < 64; ++j) acc[j] = 0.0;
+    for (int k = 0; k < 64; ++k) {
+      const double a = (double)A[(size_t)i * lda + acol0 + k];
+      const float* Bk = B + (size_t)k * 64;
+      for (int j = 0; j < 64; ++j) acc[j] += a * (double)Bk[j];
     }
+    for (int j = 0; j < 64; ++j) C[(size_t)i * 64 + j] = (float)acc[j];
+  }
 }
 // y (64) = A[:, acol0:acol0+64] . x (64) + y0 (64)
 inline void matvec64(float* y, const float* A, int lda, int acol0, const float* x, const float* y0) {
@@ -217,12 +221,15 @@ inline void build_packs(const float* blob, Packs& pk) {
           s1 += (double)W(a)[i * 128 + 64 + k] * (double)Bv(proj)[k];
         }
         vaw[2 * i] = (float)s0; vaw[2 * i + 1] = (float)s1;
-        for (int half = 0; half < 2; ++half)
-          for (int j = 0; j < 64; ++j) {
-            double acc = 0.0;
-            for (int k = 0; k < 64; ++k) acc += (double)W(a)[i * 128 + 64 * half + k] * (double)W(proj)[k * 64 + j];
-            t[i * 128 + 64 * half + j] = acc;
+        for (int half = 0; half < 2; ++half) {
+          double* acc = &t[i * 128 + 64 * half];
+          for (int j = 0; j < 64; ++j) acc[j] = 0.0;
+          for (int k = 0; k < 64; ++k) {
+            const double wa_ik = (double)W(a)[i * 128 + 64 * half + k];
+            const float* Pk = W(proj) + k * 64;
+            for (int j = 0; j < 64; ++j) acc[j] += wa_ik * (double)Pk[j];
           }
+        }
         for (int j = 0; j < 64; ++j) was[i * 64 + j] = (float)(t[i * 128 + j] + t[i * 128 + 64 + j]);
       }
       for (size_t q = 0; q < t.size(); ++q) wa[q] = (float)t[q];

@@ -102,10 +102,10 @@ __device__ __forceinline__ TSeg tl_seg(const TLin& a, int j) { return j == 0 ? a
 
 __global__ __launch_bounds__(256) void k_tlin_fwd(TLin a) {
   extern __shared__ float tl_lds[];
-  float* Wt = tl_lds;                    // [K][64]
-  float* Xs = tl_lds + a.K * 64;         // [TL_ROWS][K]
-  const int K = a.K, tid = threadIdx.x;
-  for (int i = tid; i < 64 * K; i += 256) { const int c = i / K, k = i - c * K; Wt[k * 64 + c] = a.W[i]; }
+  const int K = a.K, KP = a.K | 1, tid = threadIdx.x;
+  float* Ws = tl_lds;                    // [64][KP]: row-major like the checkpoint, odd row stride (lane c reads bank c + k)
+  float* Xs = tl_lds + 64 * KP;          // [TL_ROWS][K]
+  for (int i = tid; i < 64 * K; i += 256) { const int c = i / K, k = i - c * K; Ws[c * KP + k] = a.W[i]; }
   const long row0 = (long)blockIdx.x * TL_ROWS;
   for (int i = tid; i < TL_ROWS * K; i += 256) {
     const int r = i / K, k = i - r * K;
@@ -127,8 +127,9 @@ __global__ __launch_bounds__(256) void k_tlin_fwd(TLin a) {
 #pragma unroll
   for (int r = 0; r < 8; ++r) acc[r] = bias;
   const float* xr = Xs + rq * 8 * K;
+  const float* wr = Ws + c * KP;
   for (int k = 0; k < K; ++k) {
-    const float w = Wt[k * 64 + c];
+    const float w = wr[k];
 #pragma unroll
     for (int r = 0; r < 8; ++r) acc[r] = fmaf(xr[r * K + k], w, acc[r]);
   }
@@ -185,8 +186,8 @@ __global__ __launch_bounds__(256) void k_tlin_bwd_x(TLin a) {
 // partial weight gradients of one chunk of rows: part[chunk][c][col] = sum_r dym[r][c] * (s x)[r][col], col K = bias
 // blockIdx.y = segment (or 0 for a feature block)
 __global__ __launch_bounds__(256) void k_tlin_bwd_w(TLin a) {
-  __shared__ float Ds[TL_CHUNK * 64];
-  __shared__ float Xs[TL_CHUNK * 64];
+  __shared__ __attribute__((aligned(16))) float Ds[TL_CHUNK * 64];
+  __shared__ __attribute__((aligned(16))) float Xs[TL_CHUNK * 64];
   const int j = blockIdx.y, tid = threadIdx.x;
   const int KW = a.nseg ? 64 : a.kf;
   const long row0 = (long)blockIdx.x * TL_CHUNK;
@@ -207,6 +208,27 @@ __global__ __launch_bounds__(256) void k_tlin_bwd_w(TLin a) {
   }
   __syncthreads();
   float* part = a.part + (long)blockIdx.x * 64 * (a.K + 1);
+  if (a.nseg) {                    // 64 x 64 outputs: a 4 x 4 block per thread, two b128 LDS reads per row
+    const int c0 = (tid >> 4) * 4, k0 = (tid & 15) * 4;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[i][q] = 0.0f;
+    for (int r = 0; r < TL_CHUNK; ++r) {
+      const float4 d = *reinterpret_cast<const float4*>(&Ds[r * 64 + c0]);
+      const float4 x = *reinterpret_cast<const float4*>(&Xs[r * 64 + k0]);
+      const float dv[4] = {d.x, d.y, d.z, d.w}, xv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[i][q] = fmaf(dv[i], xv[q], acc[i][q]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) part[(c0 + i) * (a.K + 1) + 64 * j + k0 + q] = acc[i][q];
+  } else
   for (int o = tid; o < 64 * KW; o += 256) {
     const int c = o / KW, k = o - c * KW;
     float s = 0.0f;
@@ -302,17 +324,22 @@ struct TDense {
   int dir;    // 0: dst (B, n_out, 64) = A src (B, n_in, 64);  1: dst (B, n_in, 64) = A^T src (B, n_out, 64)
   int acc;
 };
+// one workgroup per destination row: its 4 waves take every 4th source row, partial sums added in wave order
 __global__ __launch_bounds__(256) void k_tdense(TDense a) {
-  const int lane = threadIdx.x & 63;
-  const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long wv = blockIdx.x;
   const int nd = a.dir == 0 ? a.n_out : a.n_in, ns = a.dir == 0 ? a.n_in : a.n_out;
-  if (wv >= (long)a.B * nd) return;
   const int i = (int)(wv % nd), b = (int)(wv / nd);
   const float* A = a.A + (long)b * a.a_bstride;
   const float* src = a.src + (long)b * ns * 64 + lane;
   float acc = 0.0f;
-  if (a.dir == 0) for (int k = 0; k < ns; ++k) acc = fmaf(A[(long)i * a.n_in + k], src[(long)k * 64], acc);
-  else for (int k = 0; k < ns; ++k) acc = fmaf(A[(long)k * a.n_in + i], src[(long)k * 64], acc);
+  if (a.dir == 0) for (int k = wave; k < ns; k += 4) acc = fmaf(A[(long)i * a.n_in + k], src[(long)k * 64], acc);
+  else for (int k = wave; k < ns; k += 4) acc = fmaf(A[(long)k * a.n_in + i], src[(long)k * 64], acc);
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave) return;
+  acc = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
   if (a.acc) a.dst[wv * 64 + lane] += acc;
   else a.dst[wv * 64 + lane] = acc;
 }
@@ -325,6 +352,7 @@ struct TScore {
   float* scores; float* ds;        // (B, R)
   int N, R, off; long n;
   float* gw; float* gb;
+  const int* sel; int B;           // (B, 2): the two nodes of every sample the loss reads (argmax, KW), flat ReLU indices
 };
 __global__ __launch_bounds__(256) void k_tscore_fwd(TScore a) {
   const int lane = threadIdx.x & 63;
@@ -342,19 +370,25 @@ __global__ __launch_bounds__(256) void k_tscore_bwd(TScore a) {        // gh = d
   const float d = a.ds[(row / a.N) * a.R + a.off + row % a.N];
   a.gh[row * 64 + lane] += d * a.w[lane];
 }
-__global__ __launch_bounds__(64) void k_tscore_bwd_w(TScore a) {      // one wave, rows in order: deterministic
+// d loss / d fscore: ds is +1 at the argmax and -1 at the KW node of every sample and zero elsewhere -- one wave walks those
+// 2 B nodes in order (deterministic) and takes the ones that belong to this layer
+__global__ __launch_bounds__(64) void k_tscore_bwd_w(TScore a) {
   const int lane = threadIdx.x;
   float gw = 0.0f, gb = 0.0f;
-  for (long row = 0; row < a.n; ++row) {
-    const float d = a.ds[(row / a.N) * a.R + a.off + row % a.N];
-    if (d != 0.0f) { gw = fmaf(d, a.h[row * 64 + lane], gw); gb += d; }
-  }
+  for (int b = 0; b < a.B; ++b)
+    for (int q = 0; q < 2; ++q) {
+      const int f = a.sel[2 * b + q] - a.off;
+      if (f < 0 || f >= a.N) continue;
+      const float d = q == 0 ? 1.0f : -1.0f;
+      gw = fmaf(d, a.h[((long)b * a.N + f) * 64 + lane], gw);
+      gb += d;
+    }
   a.gw[lane] += gw;
   if (lane == 0) a.gb[0] += gb;
 }
 
 // loss_b = max_j s_b[j] - s_b[kw_b] + improvement_b (graph_score_online.py:73); ds = d loss / d scores
-struct TLoss { const float* scores; float* ds; const int* kw; const float* imp; float* loss; int R; };
+struct TLoss { const float* scores; float* ds; const int* kw; const float* imp; float* loss; int R; int* sel; };
 __global__ __launch_bounds__(256) void k_tloss(TLoss a) {
   __shared__ float sv[256];
   __shared__ int si[256];
@@ -376,6 +410,7 @@ __global__ __launch_bounds__(256) void k_tloss(TLoss a) {
     a.loss[b] = sv[0] - s[kw] + a.imp[b];
     a.ds[(long)b * a.R + am] += 1.0f;
     a.ds[(long)b * a.R + kw] -= 1.0f;
+    a.sel[2 * b] = am; a.sel[2 * b + 1] = kw;
   }
 }
 
@@ -401,7 +436,7 @@ struct Trainer {
   std::vector<float*> edge_w;            // torch-layout weights of the bound network's edges, device
   std::vector<std::function<void()>> tape;
   hipStream_t st = nullptr;
-  float *d_scores = nullptr, *d_ds = nullptr, *d_loss = nullptr, *d_imp = nullptr; int* d_kw = nullptr;
+  float *d_scores = nullptr, *d_ds = nullptr, *d_loss = nullptr, *d_imp = nullptr; int *d_kw = nullptr, *d_sel = nullptr;
   int cap_B = 0;
   std::vector<float> h_loss;
 
@@ -417,7 +452,7 @@ struct Trainer {
     for (int j = 0; j < a.nseg; ++j) a.seg[j] = segs[j];
     a.feat = feat; a.omask = omask; a.relu = relu ? 1 : 0; a.y = y.v; a.gy = y.g; a.n = n;
     const unsigned nblk = (unsigned)((n + TL_ROWS - 1) / TL_ROWS);
-    const size_t lds = ((size_t)a.K * 64 + (size_t)TL_ROWS * a.K) * 4;
+    const size_t lds = ((size_t)(a.K | 1) * 64 + (size_t)TL_ROWS * a.K) * 4;
     hipLaunchKernelGGL(k_tlin_fwd, dim3(nblk), dim3(256), lds, st, a);
     tape.push_back([this, a, nblk]() mutable {
       a.nchunks = (int)((a.n + TL_CHUNK - 1) / TL_CHUNK);

@@ -8,7 +8,7 @@ from gnn_branching_amd.engine import ScorerEngine
 from tests.common import shipped_state
 
 net = sys.argv[1] if len(sys.argv) > 1 else "cifar_base_kw"
-for B in (1, 8):
+for B in [int(v) for v in os.environ.get("ONLINE_B", "1,8").split(",")]:
     batch = synth.make_batch(net, B, seed=1234)
     eng = ScorerEngine(shipped_state())
     eng.online_create()
