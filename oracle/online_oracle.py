@@ -17,7 +17,8 @@ from .gnn_oracle import oracle_forward
 
 
 class OnlineOracle:
-    def __init__(self, state, lr=1e-4, wd=1e-4):
+    def __init__(self, state, lr=1e-4, wd=1e-4, T=2):
+        self.T = T
         self.params = OrderedDict((k, torch.nn.Parameter(torch.as_tensor(np.asarray(v)).float().clone())) for k, v in state.items())
         self.opt = torch.optim.Adam(list(self.params.values()), lr=lr, weight_decay=wd)       # graph_score_online.py:15
 
@@ -31,7 +32,7 @@ class OnlineOracle:
         """forward_args: the argument tuple of GraphNet.forward for B subproblems; kw_flat (B) flat ReLU indices;
         improvement (B).  Returns (loss per subproblem, ragged scores)."""
         lbs, ubs, duals, prim, x_lp, layers, masks = forward_args
-        scores = oracle_forward(self.params, lbs, ubs, duals, prim, x_lp, layers, masks)
+        scores = oracle_forward(self.params, lbs, ubs, duals, prim, x_lp, layers, masks, T=self.T)
         losses = []
         for b, s in enumerate(scores):
             gnn_score, _ = torch.max(s, 0)                                                    # :41

@@ -156,3 +156,29 @@ def test_online_graph_choice_surface():
         g.del_score()
     with pytest.raises(RuntimeError):
         g.online_learning([0, 0], 0.1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,T", [("toy_mlp", 2), ("toy_conv3", 2), ("toy_oddch", 2), ("toy_single", 2), ("toy_k5", 3), ("cifar_deep_kw", 1)])
+def test_hip_step_on_other_networks(name, T):
+    """Linear first layer (dense edges and their adjoints everywhere), 3x3 stride-1 / 5x5 / 2x2 convolutions, odd channel
+    counts, a single ReLU layer, T = 1 and 3: gradient, loss and Adam step against the autograd oracle."""
+    from gnn_branching_amd import nets, synth
+    from gnn_branching_amd.engine import ScorerEngine
+    from oracle.online_oracle import OnlineOracle
+    from tests.test_gpu_generic_nets import ARCHS
+    for i, (n, spec) in enumerate(ARCHS.items()):
+        nets.register_arch(n, spec, seed=100 + i)
+    batch = synth.make_batch(name, 2, seed=11, props=[(3, 5), (1, 7)])
+    state = state_of("random")
+    kws = [int(batch.masks[b].nonzero().view(-1)[-2]) for b in range(2)]
+    imps = [0.3, 0.01]
+    o = OnlineOracle(state, T=T)
+    loss_o, _ = o.step(batch.forward_args(), kws, imps)
+    eng = ScorerEngine(state, T=T)
+    eng.online_create()
+    loss, _ = eng.online_step(batch.forward_args(), kws, imps)
+    np.testing.assert_allclose(loss, loss_o, rtol=1e-4, atol=1e-5)
+    grad_close(eng.online_grad(), o.grad_blob())
+    w0 = np.concatenate([np.asarray(v).reshape(-1) for v in state.values()])
+    params_close(eng.get_weights(), o.blob(), o.grad_blob(), w0, 0)
