@@ -2648,6 +2648,8 @@ static void free_trainer(gnnb_t* h) {
   for (float* p : t->edge_w)
     if (p) (void)hipFree(p);
   t->arena.release();
+  for (hipEvent_t e : t->events) (void)hipEventDestroy(e);
+  if (t->side) (void)hipStreamDestroy(t->side);
   delete t;
   h->trainer = nullptr;
 }
@@ -3498,6 +3500,8 @@ extern "C" int gnnb_online_create(gnnb_t* h, float lr, float weight_decay) {
   }
   HIPCHK(hipMemcpy(t->d_w, h->blob.data(), n * sizeof(float), hipMemcpyHostToDevice));
   HIPCHK(hipFuncSetAttribute((const void*)gnnb_train::k_tlin_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  if (!(getenv("GNNB_ONLINE_ONE_STREAM") && getenv("GNNB_ONLINE_ONE_STREAM")[0] == '1'))
+    HIPCHK(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
   return GNNB_OK;
 }
 
@@ -3528,6 +3532,7 @@ extern "C" int gnnb_online_step(gnnb_t* h, const gnnb_batch* in, int B, const in
   Trainer& t = *h->trainer;
   hipStream_t st = (hipStream_t)stream;
   t.st = st;
+  t.ev_next = 0;
   t.tape.clear();
   if (t.arena.reset(st)) return fail(GNNB_E_HIP, "gnnb_online_step: arena reset failed");
   if (t.edge_w.empty()) {                                  // torch-layout copies of the verified network's weights
@@ -3553,7 +3558,7 @@ extern "C" int gnnb_online_step(gnnb_t* h, const gnnb_batch* in, int B, const in
   HIPCHK(hipMemsetAsync(t.d_g, 0, blob_floats() * 4, st));
 
   // ---- per-node constants ----
-  struct LC { float *r0, *r1, *amb, *live, *nd2, *d1, *ff, *fb; };
+  struct LC { float *r0, *r1, *amb, *live, *nd2, *d1, *ff, *fb; Trainer::List ambl, livel; };
   std::vector<LC> lc(L + 1);
   for (int k = 1; k <= L; ++k) {
     const long n = (long)B * h->N[k];
@@ -3566,6 +3571,13 @@ extern "C" int gnnb_online_step(gnnb_t* h, const gnnb_batch* in, int B, const in
     TPrepArgs a{in->lb[k], in->ub[k], in->dual[k - 1], in->primal[q - 1], in->primal[q], h->dev[k].bias, h->N[k], h->hw[k], n,
                 c.r0, c.r1, c.amb, c.live, c.nd2, c.d1, c.ff, c.fb};
     hipLaunchKernelGGL(k_tprep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    // node lists: the relaxation chains run over the ambiguous nodes, the update chains over the live ones
+    int* buf = reinterpret_cast<int*>(t.arena.alloc(2 * n + 2));
+    if (!buf) return fail(GNNB_E_NOMEM, "gnnb_online_step: out of device memory");
+    c.ambl = Trainer::List{buf, buf + 2 * n, n};
+    c.livel = Trainer::List{buf + n, buf + 2 * n + 1, n};
+    hipLaunchKernelGGL(k_tcompact, dim3(1), dim3(256), 0, st, TCompact{c.amb, buf, buf + 2 * n, n});
+    hipLaunchKernelGGL(k_tcompact, dim3(1), dim3(256), 0, st, TCompact{c.live, buf + n, buf + 2 * n + 1, n});
   }
   auto cols = [&](std::initializer_list<const float*> cs, long n) {
     TColsArgs a{};
@@ -3611,6 +3623,23 @@ extern "C" int gnnb_online_step(gnnb_t* h, const gnnb_batch* in, int B, const in
     return y;
   };
   auto S = [](const TT& x, const float* s = nullptr) { return Trainer::seg(x, s); };
+  auto SF = [](const TT& x, const float* s = nullptr) { return Trainer::seg(x, s, true); };     // a segment addressed by node
+
+  // ---- relaxation terms (graph_conv.py:153-161, :273-293): functions of the node features only, so the same in every round
+  // -- computed once (the reference recomputes them per round; their gradient contributions from all rounds add up in
+  // relax.g before the chain is walked back once) and only for the ambiguous nodes (`* amb` zeroes every other row)
+  std::vector<TT> relax_f(L + 1), relax_b(L + 1);
+  for (int k = 1; k <= L; ++k) {
+    const LC& c = lc[k];
+    const long n = (long)B * h->N[k];
+    TT a = t.lin(L_FC1, {}, c.ff, n, true, nullptr, &c.ambl);
+    relax_f[k] = t.lin(L_FC1_1, {S(a)}, nullptr, n, false, c.amb, &c.ambl, true);      // :160-161
+    TT a1 = t.lin(L_BC1, {}, c.fb, n, true, nullptr, &c.ambl);
+    TT a2 = t.lin(L_BC1_1, {S(a1)}, nullptr, n, true, nullptr, &c.ambl);
+    TT sb = t.lin(L_BC1_2, {S(a2)}, nullptr, n, false, nullptr, &c.ambl);              // :285
+    TT b1 = t.lin(L_BC2, {S(sb), S(sb, c.nd2), S(sb, c.d1)}, nullptr, n, true, nullptr, &c.ambl);    // :287-291
+    relax_b[k] = t.lin(L_BC2_1, {S(b1)}, nullptr, n, false, c.amb, &c.ambl, true);     // :293
+  }
 
   // ---- the forward of graph_conv.py:77-388, every Linear on the tape ----
   std::vector<TT> mu(K + 1);
@@ -3623,12 +3652,11 @@ extern "C" int gnnb_online_step(gnnb_t* h, const gnnb_batch* in, int B, const in
       const LC& c = lc[k];
       const long n = (long)B * h->N[k];
       TT nb = edge(k, 0, 0, mu[k - 1]);
-      TT a = t.lin(L_FC1, {}, c.ff, n, true, nullptr);
-      TT relax = t.lin(L_FC1_1, {S(a)}, nullptr, n, false, c.amb);                       // :160-161
-      TT e1 = t.lin(L_FC3, {S(nb, c.r0), S(nb, c.r1)}, nullptr, n, true, nullptr);      // :169-170
-      TT e = t.lin(L_FC3_2, {S(e1)}, nullptr, n, false, nullptr);
-      TT d = t.lin(L_FC4, {S(relax), S(e)}, nullptr, n, true, nullptr);                 // :176-177
-      mu[k] = t.lin(L_FC4_2, {S(d)}, nullptr, n, false, c.live);                         // :178
+      // the update chain over the live nodes only (`* live` zeroes the rows of the others, :178)
+      TT e1 = t.lin(L_FC3, {SF(nb, c.r0), SF(nb, c.r1)}, nullptr, n, true, nullptr, &c.livel);      // :169-170
+      TT e = t.lin(L_FC3_2, {S(e1)}, nullptr, n, false, nullptr, &c.livel);
+      TT d = t.lin(L_FC4, {SF(relax_f[k]), S(e)}, nullptr, n, true, nullptr, &c.livel);             // :176-177
+      mu[k] = t.lin(L_FC4_2, {S(d)}, nullptr, n, false, c.live, &c.livel, true);                     // :178
     }
     {                                                                                    // :194-210
       TT nb = prop_edge(0, mu[L]);
@@ -3639,16 +3667,11 @@ extern "C" int gnnb_online_step(gnnb_t* h, const gnnb_batch* in, int B, const in
     for (int k = L; k >= 1; --k) {                                                       // :222-350
       const LC& c = lc[k];
       const long n = (long)B * h->N[k];
-      TT a1 = t.lin(L_BC1, {}, c.fb, n, true, nullptr);
-      TT a2 = t.lin(L_BC1_1, {S(a1)}, nullptr, n, true, nullptr);
-      TT s = t.lin(L_BC1_2, {S(a2)}, nullptr, n, false, nullptr);                        // :285
-      TT b1 = t.lin(L_BC2, {S(s), S(s, c.nd2), S(s, c.d1)}, nullptr, n, true, nullptr);  // :287-291
-      TT relax = t.lin(L_BC2_1, {S(b1)}, nullptr, n, false, c.amb);                      // :293
       TT nb = k == L ? prop_edge(1, mu[K]) : edge(k + 1, 1, h->edges[k + 1].kind == 0 ? 1 : 0, mu[k + 1]);   // :299-326
-      TT e1 = t.lin(L_BC3, {S(nb, c.r0), S(nb, c.r1)}, nullptr, n, true, nullptr);      // :331-336
-      TT e = t.lin(L_BC3_1, {S(e1)}, nullptr, n, false, nullptr);
-      TT d = t.lin(L_BC4, {S(relax), S(e)}, nullptr, n, true, nullptr);                 // :344-345
-      mu[k] = t.lin(L_BC4_1, {S(d)}, nullptr, n, false, c.live);                         // :347
+      TT e1 = t.lin(L_BC3, {SF(nb, c.r0), SF(nb, c.r1)}, nullptr, n, true, nullptr, &c.livel);      // :331-336
+      TT e = t.lin(L_BC3_1, {S(e1)}, nullptr, n, false, nullptr, &c.livel);
+      TT d = t.lin(L_BC4, {SF(relax_b[k]), S(e)}, nullptr, n, true, nullptr, &c.livel);             // :344-345
+      mu[k] = t.lin(L_BC4_1, {S(d)}, nullptr, n, false, c.live, &c.livel, true);                     // :347
     }
     if (r + 1 < T) {                                                                     // :360-385 (the last round's input rows feed nothing)
       TT nb = edge(1, 1, 0, mu[1]);
@@ -3679,6 +3702,7 @@ extern "C" int gnnb_online_step(gnnb_t* h, const gnnb_batch* in, int B, const in
   // ---- backward: the tape in reverse ----
   for (auto it = t.tape.rbegin(); it != t.tape.rend(); ++it) (*it)();
   t.tape.clear();
+  if (t.join()) return fail(GNNB_E_HIP, "gnnb_online_step: joining the weight-gradient stream failed");
   if (t.arena.err) return fail(GNNB_E_NOMEM, "gnnb_online_step: out of device memory");
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(GNNB_E_HIP, "gnnb_online_step: a launch failed: %s", hipGetErrorString(e));

@@ -84,14 +84,19 @@ __global__ void k_tcols(TColsArgs a) {
 // ---- one Linear of the GNN:  y = omask * act(b + sum_seg W[:, 64 seg : 64 seg + 64] (s_seg * x_seg))  ----
 // inputs: up to three 64-wide row segments (a torch.cat along dim 1; each optionally scaled per row by a constant), or
 // one (n, kf) block of scalar node features.  act = relu or identity; omask = a per-row constant (amb / live) or null.
-struct TSeg { const float* x; const float* s; float* gx; };
+// Compact form (ridx != null): the op runs over the first *n_dev entries of a node list only -- the ambiguous nodes for the
+// relaxation chains, the live nodes for the update chains; every other row of its output is (and stays) zero, exactly what
+// the `* amb` / `* live` masks of the reference produce.  Row i of a compact tensor belongs to node ridx[i]; features,
+// per-row constants, and the segments / outputs flagged `full` are addressed by node.
+struct TSeg { const float* x; const float* s; float* gx; int full; };
 struct TLin {
   const float* W; const float* b; float* gW; float* gb;    // W (64, K) row-major as in the checkpoint
   int K, nseg, kf;
   TSeg seg[3];
   const float* feat;
   const float* omask; int relu;
-  float* y; const float* gy; long n;
+  float* y; const float* gy; long n;      // n: rows (compact form: capacity of the list)
+  const int* ridx; const int* n_dev; int out_full;
   float* part; int nchunks;
   int jbase;      // k_tlin_bwd_x: first segment of this launch
 };
@@ -99,24 +104,40 @@ struct TLin {
 #define TL_CHUNK 64
 
 __device__ __forceinline__ TSeg tl_seg(const TLin& a, int j) { return j == 0 ? a.seg[0] : j == 1 ? a.seg[1] : a.seg[2]; }
+__device__ __forceinline__ long tl_rows(const TLin& a) {
+  if (!a.n_dev) return a.n;
+  const long m = *a.n_dev;
+  return m < a.n ? m : a.n;
+}
+// node of each local row (or -1 past the end) into LDS
+__device__ __forceinline__ void tl_stage_rows(const TLin& a, long row0, long n, int* Rs, int rows) {
+  for (int r = threadIdx.x; r < rows; r += blockDim.x) {
+    const long i = row0 + r;
+    Rs[r] = i < n ? (a.ridx ? a.ridx[i] : (int)i) : -1;
+  }
+}
 
 __global__ __launch_bounds__(256) void k_tlin_fwd(TLin a) {
   extern __shared__ float tl_lds[];
+  __shared__ int Rs[TL_ROWS];
+  const long n = tl_rows(a), row0 = (long)blockIdx.x * TL_ROWS;
+  if (row0 >= n) return;
   const int K = a.K, KP = a.K | 1, tid = threadIdx.x;
   float* Ws = tl_lds;                    // [64][KP]: row-major like the checkpoint, odd row stride (lane c reads bank c + k)
   float* Xs = tl_lds + 64 * KP;          // [TL_ROWS][K]
+  tl_stage_rows(a, row0, n, Rs, TL_ROWS);
   for (int i = tid; i < 64 * K; i += 256) { const int c = i / K, k = i - c * K; Ws[c * KP + k] = a.W[i]; }
-  const long row0 = (long)blockIdx.x * TL_ROWS;
+  __syncthreads();
   for (int i = tid; i < TL_ROWS * K; i += 256) {
     const int r = i / K, k = i - r * K;
-    const long row = row0 + r;
+    const int node = Rs[r];
     float v = 0.0f;
-    if (row < a.n) {
+    if (node >= 0) {
       if (a.nseg) {
         const TSeg sg = tl_seg(a, k >> 6);
-        v = sg.x[row * 64 + (k & 63)];
-        if (sg.s) v *= sg.s[row];
-      } else v = a.feat[row * a.kf + k];
+        v = sg.x[(sg.full ? (long)node : row0 + r) * 64 + (k & 63)];
+        if (sg.s) v *= sg.s[node];
+      } else v = a.feat[(long)node * a.kf + k];
     }
     Xs[i] = v;
   }
@@ -135,19 +156,19 @@ __global__ __launch_bounds__(256) void k_tlin_fwd(TLin a) {
   }
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
-    const long row = row0 + rq * 8 + r;
-    if (row >= a.n) continue;
+    const int node = Rs[rq * 8 + r];
+    if (node < 0) continue;
     float v = a.relu ? fmaxf(acc[r], 0.0f) : acc[r];
-    if (a.omask) v *= a.omask[row];
-    a.y[row * 64 + c] = v;
+    if (a.omask) v *= a.omask[node];
+    a.y[(a.out_full ? (long)node : row0 + rq * 8 + r) * 64 + c] = v;
   }
 }
 
-// gradient that reaches the pre-activation: dym = gy * relu'(y) * omask
-__device__ __forceinline__ float tl_dym(const TLin& a, long row, int c) {
-  float d = a.gy[row * 64 + c];
-  if (a.relu && !(a.y[row * 64 + c] > 0.0f)) d = 0.0f;
-  if (a.omask) d *= a.omask[row];
+// gradient that reaches the pre-activation: dym = gy * relu'(y) * omask   (orow: row of y / gy, node: its node)
+__device__ __forceinline__ float tl_dym(const TLin& a, long orow, int node, int c) {
+  float d = a.gy[orow * 64 + c];
+  if (a.relu && !(a.y[orow * 64 + c] > 0.0f)) d = 0.0f;
+  if (a.omask) d *= a.omask[node];
   return d;
 }
 
@@ -155,14 +176,18 @@ __device__ __forceinline__ float tl_dym(const TLin& a, long row, int c) {
 __global__ __launch_bounds__(256) void k_tlin_bwd_x(TLin a) {
   __shared__ float Ws[64 * 64];          // [c][k]
   __shared__ float Ds[TL_ROWS * 64];     // [r][c]
+  __shared__ int Rs[TL_ROWS];
+  const long n = tl_rows(a), row0 = (long)blockIdx.x * TL_ROWS;
+  if (row0 >= n) return;
   const int j = blockIdx.y + a.jbase, tid = threadIdx.x;
   const TSeg sg = tl_seg(a, j);
   if (!sg.gx) return;
+  tl_stage_rows(a, row0, n, Rs, TL_ROWS);
   for (int i = tid; i < 4096; i += 256) Ws[i] = a.W[(i >> 6) * a.K + 64 * j + (i & 63)];
-  const long row0 = (long)blockIdx.x * TL_ROWS;
+  __syncthreads();
   for (int i = tid; i < TL_ROWS * 64; i += 256) {
-    const long row = row0 + (i >> 6);
-    Ds[i] = row < a.n ? tl_dym(a, row, i & 63) : 0.0f;
+    const int r = i >> 6, node = Rs[r];
+    Ds[i] = node >= 0 ? tl_dym(a, a.out_full ? (long)node : row0 + r, node, i & 63) : 0.0f;
   }
   __syncthreads();
   const int k = tid & 63, rq = tid >> 6;
@@ -176,10 +201,10 @@ __global__ __launch_bounds__(256) void k_tlin_bwd_x(TLin a) {
   }
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
-    const long row = row0 + rq * 8 + r;
-    if (row >= a.n) continue;
-    const float s = sg.s ? sg.s[row] : 1.0f;
-    sg.gx[row * 64 + k] += s * acc[r];
+    const int node = Rs[rq * 8 + r];
+    if (node < 0) continue;
+    const float s = sg.s ? sg.s[node] : 1.0f;
+    sg.gx[(sg.full ? (long)node : row0 + rq * 8 + r) * 64 + k] += s * acc[r];
   }
 }
 
@@ -188,21 +213,25 @@ __global__ __launch_bounds__(256) void k_tlin_bwd_x(TLin a) {
 __global__ __launch_bounds__(256) void k_tlin_bwd_w(TLin a) {
   __shared__ __attribute__((aligned(16))) float Ds[TL_CHUNK * 64];
   __shared__ __attribute__((aligned(16))) float Xs[TL_CHUNK * 64];
+  __shared__ int Rs[TL_CHUNK];
+  const long n = tl_rows(a), row0 = (long)blockIdx.x * TL_CHUNK;
+  if (row0 >= n) return;
   const int j = blockIdx.y, tid = threadIdx.x;
   const int KW = a.nseg ? 64 : a.kf;
-  const long row0 = (long)blockIdx.x * TL_CHUNK;
   const TSeg sg = tl_seg(a, j);
+  tl_stage_rows(a, row0, n, Rs, TL_CHUNK);
+  __syncthreads();
   for (int i = tid; i < TL_CHUNK * 64; i += 256) {
-    const long row = row0 + (i >> 6);
-    Ds[i] = row < a.n ? tl_dym(a, row, i & 63) : 0.0f;
+    const int r = i >> 6, node = Rs[r];
+    Ds[i] = node >= 0 ? tl_dym(a, a.out_full ? (long)node : row0 + r, node, i & 63) : 0.0f;
   }
   for (int i = tid; i < TL_CHUNK * KW; i += 256) {
     const int r = i / KW, k = i - r * KW;
-    const long row = row0 + r;
+    const int node = Rs[r];
     float v = 0.0f;
-    if (row < a.n) {
-      if (a.nseg) { v = sg.x[row * 64 + k]; if (sg.s) v *= sg.s[row]; }
-      else v = a.feat[row * a.kf + k];
+    if (node >= 0) {
+      if (a.nseg) { v = sg.x[(sg.full ? (long)node : row0 + r) * 64 + k]; if (sg.s) v *= sg.s[node]; }
+      else v = a.feat[(long)node * a.kf + k];
     }
     Xs[i] = v;
   }
@@ -245,11 +274,36 @@ __global__ __launch_bounds__(256) void k_tlin_bwd_w(TLin a) {
 __global__ void k_tlin_reduce(TLin a) {
   const int o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= 64 * (a.K + 1)) return;
+  const int nch = (int)((tl_rows(a) + TL_CHUNK - 1) / TL_CHUNK);
   float s = 0.0f;
-  for (int ch = 0; ch < a.nchunks; ++ch) s += a.part[(long)ch * 64 * (a.K + 1) + o];
+  for (int ch = 0; ch < nch; ++ch) s += a.part[(long)ch * 64 * (a.K + 1) + o];
   const int c = o / (a.K + 1), col = o - c * (a.K + 1);
   if (col < a.K) a.gW[c * a.K + col] += s;
   else a.gb[c] += s;
+}
+
+// ordered list of the rows with a non-zero flag, and their number: one workgroup
+struct TCompact { const float* flag; int* idx; int* cnt; long n; };
+__global__ __launch_bounds__(256) void k_tcompact(TCompact a) {
+  __shared__ int wsum[4];
+  __shared__ int base;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (long start = 0; start < a.n; start += 256) {
+    const long i = start + tid;
+    const bool f = i < a.n && a.flag[i] != 0.0f;
+    const unsigned long long bal = __ballot(f);
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int off = base + __popcll(bal & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (f) a.idx[off] = (int)i;
+    __syncthreads();
+    if (tid == 0) base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+  if (tid == 0) *a.cnt = base;
 }
 
 // ---- edges of the layer graph (graph_conv.py:110-137, :299-326, :361-376) and their adjoints ----
@@ -436,30 +490,64 @@ struct Trainer {
   std::vector<float*> edge_w;            // torch-layout weights of the bound network's edges, device
   std::vector<std::function<void()>> tape;
   hipStream_t st = nullptr;
+  // weight-gradient kernels never feed the rest of the backward pass: they run on a side stream, ordered behind the point of
+  // the main stream where their gy is final (same order among themselves as on one stream, so the sums stay reproducible)
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> events;
+  size_t ev_next = 0;
+  hipStream_t fork() {
+    if (!side) return st;
+    if (ev_next == events.size()) {
+      hipEvent_t e;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return st;
+      events.push_back(e);
+    }
+    hipEvent_t e = events[ev_next++];
+    if (hipEventRecord(e, st) != hipSuccess || hipStreamWaitEvent(side, e, 0) != hipSuccess) return st;
+    return side;
+  }
+  int join() {                     // the main stream continues behind everything on the side stream
+    if (!side) return 0;
+    if (ev_next == events.size()) {
+      hipEvent_t e;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return 1;
+      events.push_back(e);
+    }
+    hipEvent_t e = events[ev_next++];
+    return hipEventRecord(e, side) != hipSuccess || hipStreamWaitEvent(st, e, 0) != hipSuccess;
+  }
   float *d_scores = nullptr, *d_ds = nullptr, *d_loss = nullptr, *d_imp = nullptr; int *d_kw = nullptr, *d_sel = nullptr;
   int cap_B = 0;
   std::vector<float> h_loss;
 
   TT rows(long n) { TT t; t.n = n; t.v = arena.alloc((size_t)n * 64); t.g = arena.alloc((size_t)n * 64); return t; }
 
-  // y = omask * act(W x + b); records the adjoint
-  TT lin(int layer, std::vector<TSeg> segs, const float* feat, long n, bool relu, const float* omask) {
-    TT y = rows(n);
+  // a node list: idx (cap) ordered node ids, *cnt their number
+  struct List { const int* idx = nullptr; const int* cnt = nullptr; long cap = 0; };
+
+  // y = omask * act(W x + b); records the adjoint.  list: compact form over that node list (rows of `y` = list entries,
+  // or nodes when out_full); n: rows of the plain form / nodes of the layer.
+  TT lin(int layer, std::vector<TSeg> segs, const float* feat, long n, bool relu, const float* omask, const List* list = nullptr,
+         bool out_full = false) {
+    TT y = rows(list && !out_full ? list->cap : n);
     TLin a{};
     a.W = d_w + weight_offset(layer); a.b = d_w + bias_offset(layer);
     a.gW = d_g + weight_offset(layer); a.gb = d_g + bias_offset(layer);
     a.K = kLin[layer].in; a.nseg = (int)segs.size(); a.kf = feat ? a.K : 0;
     for (int j = 0; j < a.nseg; ++j) a.seg[j] = segs[j];
-    a.feat = feat; a.omask = omask; a.relu = relu ? 1 : 0; a.y = y.v; a.gy = y.g; a.n = n;
-    const unsigned nblk = (unsigned)((n + TL_ROWS - 1) / TL_ROWS);
+    a.feat = feat; a.omask = omask; a.relu = relu ? 1 : 0; a.y = y.v; a.gy = y.g;
+    a.n = list ? list->cap : n;
+    if (list) { a.ridx = list->idx; a.n_dev = list->cnt; a.out_full = out_full ? 1 : 0; }
+    const unsigned nblk = (unsigned)((a.n + TL_ROWS - 1) / TL_ROWS);
     const size_t lds = ((size_t)(a.K | 1) * 64 + (size_t)TL_ROWS * a.K) * 4;
     hipLaunchKernelGGL(k_tlin_fwd, dim3(nblk), dim3(256), lds, st, a);
     tape.push_back([this, a, nblk]() mutable {
       a.nchunks = (int)((a.n + TL_CHUNK - 1) / TL_CHUNK);
       a.part = arena.alloc((size_t)a.nchunks * 64 * (a.K + 1));
       if (!a.part) return;
-      hipLaunchKernelGGL(k_tlin_bwd_w, dim3((unsigned)a.nchunks, a.nseg ? a.nseg : 1), dim3(256), 0, st, a);
-      hipLaunchKernelGGL(k_tlin_reduce, dim3((64 * (a.K + 1) + 255) / 256), dim3(256), 0, st, a);
+      hipStream_t ws = fork();
+      hipLaunchKernelGGL(k_tlin_bwd_w, dim3((unsigned)a.nchunks, a.nseg ? a.nseg : 1), dim3(256), 0, ws, a);
+      hipLaunchKernelGGL(k_tlin_reduce, dim3((64 * (a.K + 1) + 255) / 256), dim3(256), 0, ws, a);
       bool any = false, alias = false;
       for (int j = 0; j < a.nseg; ++j) {
         any = any || a.seg[j].gx;
@@ -472,7 +560,7 @@ struct Trainer {
     });
     return y;
   }
-  static TSeg seg(const TT& t, const float* s = nullptr) { return TSeg{t.v, s, t.g}; }
+  static TSeg seg(const TT& t, const float* s = nullptr, bool full = false) { return TSeg{t.v, s, t.g, full ? 1 : 0}; }
 };
 
 }  // namespace gnnb_train
