@@ -116,6 +116,21 @@ def resolve_branching(gnn_decision, gnn_improvement_value, kw_decision, kw_impro
     return gnn_decision, False
 
 
+def resolve_online(gnn_decision, gnn_improvement_value, kw_decision, kw_improvement_value, wrong_pts_dc, online_threshold=5):
+    """The online-learning variant of the same choice (plnn/relu_conv_online.py:183-207): the KW decision is kept when it
+    improves MORE than the GNN's; the GNN's decision is then counted as a wrong point in ``wrong_pts_dc`` (mutated, key
+    'lay-idx'), and once that count reaches ``online_threshold`` the caller runs
+    ``graph.online_learning(kw_decision, improve)`` with improve = 1 if the KW point is better by more than 0.1, else 0.
+    Returns (decision, used_kw, learn, improve); kw_decision None / kw_improvement -1 when the KW branch was not bounded."""
+    if kw_decision is None or not gnn_improvement_value < kw_improvement_value:
+        return gnn_decision, False, False, 0
+    key = f'{gnn_decision[0]}-{gnn_decision[1]}'
+    wrong_pts_dc[key] = wrong_pts_dc.get(key, 0) + 1
+    learn = wrong_pts_dc[key] >= online_threshold
+    improve = 1 if kw_improvement_value - gnn_improvement_value > 0.1 else 0
+    return kw_decision, True, learn, improve
+
+
 def gnn_improvement(dom_lb, dom_lb1, lower_bound):
     """relu_conv_gnnkwthreshold.py:151."""
     return (min(dom_lb, 0) + min(dom_lb1, 0) - 2 * lower_bound) / (-2 * lower_bound)

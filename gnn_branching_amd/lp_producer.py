@@ -271,6 +271,81 @@ def branch_and_bound(lp, scorer, layers, eps=1e-4, max_nodes=200, decision_bound
     return global_lb, global_ub, visited
 
 
+def branch_and_bound_online(lp, graph, layers, eps=1e-4, max_nodes=200, decision_bound=None, branching_threshold=0.2,
+                            online_threshold=5, sparsest_layer=0, log=print):
+    """The BaB loop of plnn/relu_conv_online.py:126-276: branch on the GNN's decision; when its improvement of the bound
+    is below ``branching_threshold`` also bound the KW (BaBSR) decision's children and keep the better pair; a GNN decision
+    that lost ``online_threshold`` times triggers ``graph.online_learning(kw_decision, improve)`` (:196-205).
+
+    ``graph``: graphnet.graph_score_online.GraphChoice.  Returns (global_lb, global_ub, visited LP solves, online steps)."""
+    from .bab_caller import gnn_improvement, resolve_online, trace_line
+    from .plnn.kw_score_conv import choose_node_conv
+    fixed = {"fixed_layers": list(layers[:-1]), "prop_layers": [layers[-1]]}
+    n_relu = len(lp.pre_relu_indices)
+    root_mask = [torch.full((int(np.prod(lp.shapes[i + 1])),), -1, dtype=torch.long) for i in lp.pre_relu_indices]
+    root = lp.solve(root_mask)
+    if root is None:
+        raise RuntimeError("infeasible root domain")
+    random_order = [l for l in range(n_relu) if l != sparsest_layer]
+    random_order = ([sparsest_layer] if 0 <= sparsest_layer < n_relu else []) + random_order      # :104-109
+    global_lb, global_ub, domains, visited, icp, steps = root.lb, root.ub, [root], 0, 0, 0
+    wrong_pts_dc, closed_lb = {}, float("inf")
+
+    def bound_children(dom, decision):
+        out = []
+        for choice in (0, 1):
+            m = [t.clone() for t in dom.mask]
+            m[decision[0]][decision[1]] = choice
+            out.append(lp.solve(m))
+        return out
+
+    def child_lb(c):                          # an infeasible child cannot contain a counter-example
+        return float("inf") if c is None else c.lb
+
+    while domains and global_ub - global_lb > eps and visited < max_nodes:
+        if decision_bound is not None and (global_lb >= decision_bound or global_ub < decision_bound):
+            break
+        domains.sort(key=lambda d: d.lb)
+        dom = domains.pop(0)
+        if not any(bool((m == -1).any()) for m in dom.mask):
+            closed_lb = min(closed_lb, dom.lb)
+            global_lb = min([d.lb for d in domains] + [closed_lb])
+            continue
+        lbg, ubg = dom.graph_bounds(lp.pre_relu_indices, len(lp.layers))
+        gnn_decision = graph.decision(lbg, ubg, dom.dual_vars, dom.ub_point, dom.primals, fixed, dom.mask)       # :146
+        children = bound_children(dom, gnn_decision)
+        visited += 2
+        gnn_imp = gnn_improvement(child_lb(children[0]), child_lb(children[1]), dom.lb) if dom.lb < 0 else 1.0     # :156
+        kw_decision, kw_imp, kw_children = None, -1, None
+        if gnn_imp < branching_threshold:                                                                         # :158-166
+            kw_decision, icp = choose_node_conv(dom.lower_all, dom.upper_all, dom.mask, lp.layers, lp.pre_relu_indices, icp,
+                                                random_order, sparsest_layer)
+            kw_children = bound_children(dom, kw_decision)
+            visited += 2
+            kw_imp = gnn_improvement(child_lb(kw_children[0]), child_lb(kw_children[1]), dom.lb)
+        decision, used_kw, learn, improve = resolve_online(gnn_decision, gnn_imp, kw_decision, kw_imp, wrong_pts_dc, online_threshold)
+        if used_kw:
+            children = kw_children
+        if learn:
+            graph.online_learning(kw_decision, improve)                                                           # :205
+            steps += 1
+        graph.del_score()                                                                                         # :209
+        log(trace_line(visited, decision, gnn_imp, gnn_decision, kw_imp, kw_decision).rstrip())
+        for c in children:
+            if c is None:
+                continue
+            global_ub = min(global_ub, c.ub)
+        for c in children:
+            if c is None:
+                continue
+            if c.lb < global_ub - eps and (decision_bound is None or c.lb < decision_bound):
+                domains.append(c)
+            else:
+                closed_lb = min(closed_lb, c.lb)
+        global_lb = min([d.lb for d in domains] + [closed_lb, global_ub])
+    return global_lb, global_ub, visited, steps
+
+
 # ---- scorers for branch_and_bound -------------------------------------------------------------
 def gnn_scorer(choice, lp):
     """The GNN decision on a Subproblem (``choice``: graph_score.GraphChoice or bab_caller.BatchedGraphChoice)."""

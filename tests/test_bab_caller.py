@@ -84,3 +84,22 @@ def test_batched_kw_decisions_equal_reference_decisions(case):
         dec, counters = choice.kw_decision_many(subs, batch.layers, [int(cnt)] * len(subs), list(range(L)), int(sp), float(thr))
         want = [gb[f"dec_{b}_{si}"].tolist() for b in range(len(subs))]
         assert [d + [c] for d, c in zip(dec, counters)] == want, si
+
+
+def test_resolve_online_rule():
+    """plnn/relu_conv_online.py:183-207."""
+    wrong = {}
+    # KW not bounded (GNN improvement above the branching threshold): GNN decision, nothing recorded
+    assert bab_caller.resolve_online([2, 5], 0.30, None, -1, wrong, 2) == ([2, 5], False, False, 0)
+    # KW not better: GNN decision
+    assert bab_caller.resolve_online([2, 5], 0.10, [1, 7], 0.10, wrong, 2) == ([2, 5], False, False, 0)
+    assert wrong == {}
+    # KW better by a little: kept, counted, below the threshold -> no learning yet
+    assert bab_caller.resolve_online([2, 5], 0.10, [1, 7], 0.15, wrong, 2) == ([1, 7], True, False, 0)
+    assert wrong == {"2-5": 1}
+    # second loss of the same GNN point, better by more than 0.1 -> learn with improve = 1
+    assert bab_caller.resolve_online([2, 5], 0.10, [0, 3], 0.25, wrong, 2) == ([0, 3], True, True, 1)
+    assert wrong == {"2-5": 2}
+    # another GNN point starts its own count
+    assert bab_caller.resolve_online([1, 1], 0.00, [0, 3], 0.05, wrong, 2) == ([0, 3], True, False, 0)
+    assert wrong == {"2-5": 2, "1-1": 1}

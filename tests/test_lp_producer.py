@@ -113,3 +113,27 @@ def test_bab_with_the_gpu_scorers(problem):
         glb, gub, visited = lp_producer.branch_and_bound(lp, scorer, layers, max_nodes=12, log=lines.append)
         assert visited >= 2 and glb >= sub.lb - 1e-7 and gub <= sub.ub + 1e-7
         assert any("decision" in l for l in lines)
+
+
+@pytest.mark.gpu
+def test_online_bab_learns_on_the_device(problem):
+    """The loop of plnn/relu_conv_online.py: GNN decision, KW decision when the GNN's improves too little, online learning
+    once a GNN decision lost `online_threshold` times -- with the threshold at 1 and the branching threshold above any
+    improvement, every lost comparison is a device-side Adam step; the model must change and the bound must still tighten."""
+    import os
+    from gnn_branching_amd.graphnet.graph_score_online import GraphChoice
+    layers, x, eps, lp, mask, sub = problem
+    ckpt = os.path.join(os.path.dirname(__file__), "..", "models", "cifar_trained_gnn", "best_snapshot_None_0_val_acc_0.826_loss_val_0.1036_epoch_57.pt")
+    graph = GraphChoice(sub.mask, ckpt)
+    graph.verbose = False
+    before = np.concatenate([v.numpy().reshape(-1) for v in graph.model.state_dict().values()])
+    lines = []
+    glb, gub, visited, steps = lp_producer.branch_and_bound_online(lp, graph, layers, max_nodes=24, branching_threshold=2.0,
+                                                                   online_threshold=1, sparsest_layer=0, log=lines.append)
+    assert visited >= 4 and glb >= sub.lb - 1e-7 and gub <= sub.ub + 1e-7
+    assert all(l.startswith("branch ") and " kw: improvement " in l for l in lines)
+    after = np.concatenate([v.numpy().reshape(-1) for v in graph.model.state_dict().values()])
+    # branches that ended on the KW decision (it may also coincide with the GNN's): threshold 1 makes every KW win a step
+    kw_lines = sum(1 for l in lines if l.split(" decision ")[1].split(" gnn:")[0] == l.rsplit(" decision ", 1)[1])
+    assert 1 <= steps <= kw_lines
+    assert np.abs(after - before).max() > 0 and np.abs(after - before).max() <= 1.05e-4 * steps + 1e-7
