@@ -90,6 +90,48 @@ __device__ __forceinline__ void gemm_small(const float* wl, int lane, Frag& acc,
   }
 }
 
+// ---- the 64x64 block on v_mfma_f32_32x32x16_bf16 with both operands in three bf16 pieces (gnnb_pack.h pack_w64_bf3):
+// acc += W.x with the six products w1x1 + w1x2 + w2x1 + w1x3 + w2x2 + w3x1, smallest first.  48 MFMAs of 32 cycles per
+// 64 inputs instead of 64 of 64 cycles; the price is the VALU work of splitting the activations (cvt_pk + subtract per piece).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{a, b}, bf16x2v)); }
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+
+template <int NFRAG, class GetB>
+__device__ __forceinline__ void gemm_w64_bf3(const float* wl, int lane, Frag& acc, GetB getB) {
+  const u32x4* w = reinterpret_cast<const u32x4*>(wl) + lane;
+#pragma unroll
+  for (int fk = 0; fk < 4 * NFRAG; ++fk) {         // fragment fk / 4, k-step fk % 4: registers 8 (fk % 4) .. + 7
+    u32x4 p1, p2, p3;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float a = getB(8 * fk + 2 * q), b = getB(8 * fk + 2 * q + 1);
+      const unsigned u1 = pk_bf16(a, b);
+      const float ra = a - __uint_as_float(u1 << 16), rb = b - __uint_as_float(u1 & 0xffff0000u);
+      const unsigned u2 = pk_bf16(ra, rb);
+      const float sa = ra - __uint_as_float(u2 << 16), sb = rb - __uint_as_float(u2 & 0xffff0000u);
+      p1[q] = u1; p2[q] = u2; p3[q] = pk_bf16(sa, sb);
+    }
+    const bf16x8 x1 = __builtin_bit_cast(bf16x8, p1), x2 = __builtin_bit_cast(bf16x8, p2), x3 = __builtin_bit_cast(bf16x8, p3);
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+      const bf16x8 w1 = __builtin_bit_cast(bf16x8, w[((fk * 2 + ot) * 3 + 0) * 64]);
+      const bf16x8 w2 = __builtin_bit_cast(bf16x8, w[((fk * 2 + ot) * 3 + 1) * 64]);
+      const bf16x8 w3 = __builtin_bit_cast(bf16x8, w[((fk * 2 + ot) * 3 + 2) * 64]);
+      acc.t[ot] = mfma_bf16(w3, x1, acc.t[ot]);
+      acc.t[ot] = mfma_bf16(w2, x2, acc.t[ot]);
+      acc.t[ot] = mfma_bf16(w1, x3, acc.t[ot]);
+      acc.t[ot] = mfma_bf16(w2, x1, acc.t[ot]);
+      acc.t[ot] = mfma_bf16(w1, x2, acc.t[ot]);
+      acc.t[ot] = mfma_bf16(w1, x1, acc.t[ot]);
+    }
+    __builtin_amdgcn_sched_barrier(0);      // one k-step's pieces and weight fragments at a time (else hipcc hoists them all and spills)
+  }
+}
+
 __device__ __forceinline__ void frag_bias(Frag& a, const float* bl, int h) {
   const f32x4* b4 = reinterpret_cast<const f32x4*>(bl + h * 32);
 #pragma unroll
@@ -567,10 +609,16 @@ struct UpdArgs {
 // forward:  fc3, fc3_2, fc4, fc4_2   graph_conv.py:169-181        backward: bc3, bc3_1, bc4, bc4_1   :331-349
 // The tile loop of the node update: tiles `tile`, `tile + stride`, ... of the lists in `a` (c0 / c1 entries); the weight
 // pack is staged into `lds` here (the first fetch overlaps it).
-template <bool DEFERRED, bool POST = false>
+// BF3: the 64x64 blocks of the short chain (WAS, WCB) and of POST run on the bf16 matrix rate with three-piece operands
+// (gemm_w64_bf3; LDS image PackUpdL3); the general chain's 128-wide first layer stays on the fp32 MFMA (6-11 % of the tiles).
+template <bool DEFERRED, bool POST = false, bool BF3 = false>
 __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, int c0, int c1, long tile, long stride, int lane) {
+  constexpr int O_WA = BF3 ? (int)PackUpdL3::WA : (int)PackUpd::WA, O_BA = BF3 ? (int)PackUpdL3::BA : (int)PackUpd::BA;
+  constexpr int O_BCB = BF3 ? (int)PackUpdL3::BCB : (int)PackUpd::BCB, O_VAW = BF3 ? (int)PackUpdL3::VAW : (int)PackUpd::VAW;
+  constexpr int O_END = BF3 ? (int)PackUpdL3::FLOATS : (int)PackUpd::FLOATS;
   const int h = lane >> 5, j = lane & 31;
-  const long n0 = (c0 + 31) / 32, ntiles = n0 + (c1 + 31) / 32;
+  // the general tiles (1.5-3x the work of a short-chain tile) come FIRST in the tile order, so they are never a SIMD's tail
+  const long n1 = (c1 + 31) / 32, n0 = (c0 + 31) / 32, ntiles = n0 + n1;
   const float* bias_row = a.pack + PackUpd::BCBROW;
   long gc = 0, gc_n = 0;
   bool valid = false, valid_n = false;
@@ -578,8 +626,8 @@ __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, i
   Frag X, Xn;
   constexpr bool deferred = DEFERRED;            // the aggregate is built from rows with a deferred projection (gnnb_pack.h)
   auto fetch = [&](long tl, long& g_, bool& v_, float& l_, float& u_, float& s_, Frag& x_) {
-    const bool k0 = tl < n0;
-    const long idx = (k0 ? tl : tl - n0) * 32 + j;
+    const bool k0 = tl >= n1;
+    const long idx = (k0 ? tl - n1 : tl) * 32 + j;
     v_ = idx < (k0 ? c0 : c1);
     g_ = (k0 ? a.list0 : a.list1)[v_ ? idx : 0];
     l_ = a.lb[g_];
@@ -589,25 +637,31 @@ __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, i
   };
   if (tile < ntiles) fetch(tile, gc, valid, lb, ub, sw, X);
   constexpr bool post = POST;
-  if (post) copy_to_lds(lds + PackUpd::FLOATS, a.wp, 4096);
-  stage_pack(lds, a.pack, PackUpd::FLOATS);
+  if (post) copy_to_lds(lds + O_END, a.wp, BF3 ? 6144 : 4096);
+  if (BF3) {
+    copy_to_lds(lds + PackUpdL3::WA, a.pack + PackUpd::WA, 8192);
+    copy_to_lds(lds + PackUpdL3::BA, a.pack + PackUpd::BA, 64);
+    copy_to_lds(lds + PackUpdL3::BCB, a.pack + PackUpd::BCB, 64 + 64 + 128);          // BCB, BCBROW, VAW
+    stage_pack(lds + PackUpdL3::WAS3, a.pack + PackUpd::WAS3, 2 * 6144);               // WAS3, WCB3
+  } else stage_pack(lds, a.pack, PackUpd::FLOATS);
   if (tile >= ntiles) return;
   for (;;) {
     const Ratio r = compute_ratio(lb, ub);
-    const bool kind0 = tile < n0;              // wave-uniform
+    const bool kind0 = tile >= n1;             // wave-uniform
     const long next = tile + stride;
     const bool has_next = next < ntiles;
     Frag H, H2;
-    frag_bias(H, lds + PackUpd::BA, h);
+    frag_bias(H, lds + O_BA, h);
     if (kind0) {
       if (has_next) fetch(next, gc_n, valid_n, lb_n, ub_n, sw_n, Xn);
       const float r0 = r.r0;
       if (deferred) {                        // + s.(r0 Wa0.bp + r1 Wa1.bp), r0 == r1: one small k-step
         const float x[1] = {r0 * sw};
-        gemm_small<1>(lds + PackUpd::VAW, lane, H, x);
+        gemm_small<1>(lds + O_VAW, lane, H, x);
       }
-      gemm_w64<32>(lds + PackUpd::WAS, lane, H, [&](int s) { return FRAG_AT(X, s) * r0; });
-      frag_bias(H2, lds + PackUpd::BCB, h);
+      if (BF3) gemm_w64_bf3<1>(lds + PackUpdL3::WAS3, lane, H, [&](int s) { return FRAG_AT(X, s) * r0; });
+      else gemm_w64<32>(lds + PackUpd::WAS, lane, H, [&](int s) { return FRAG_AT(X, s) * r0; });
+      frag_bias(H2, lds + O_BCB, h);
     } else {
       // nodes without a relaxation term (amb = 0) read the bias row instead of their (never written) P' row
       frag_load_rowptr(H2, r.amb != 0.0f ? a.P + gc * 64 : bias_row, h);
@@ -615,12 +669,13 @@ __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, i
       const float r0 = r.r0, r1 = r.r1;
       if (deferred) {
         const float x[1] = {(h ? r1 : r0) * sw};
-        gemm_small<1>(lds + PackUpd::VAW, lane, H, x);
+        gemm_small<1>(lds + O_VAW, lane, H, x);
       }
-      gemm_w64<64>(lds + PackUpd::WA, lane, H, [&](int s) { return FRAG_AT(X, s & 31) * (s < 32 ? r0 : r1); });
+      gemm_w64<64>(lds + O_WA, lane, H, [&](int s) { return FRAG_AT(X, s & 31) * (s < 32 ? r0 : r1); });
     }
     frag_relu(H);
-    gemm_w64<32>(lds + PackUpd::WCB, lane, H2, [&](int s) { return FRAG_AT(H, s); });
+    if (BF3) gemm_w64_bf3<1>(lds + PackUpdL3::WCB3, lane, H2, [&](int s) { return FRAG_AT(H, s); });
+    else gemm_w64<32>(lds + PackUpd::WCB, lane, H2, [&](int s) { return FRAG_AT(H, s); });
     frag_relu(H2);
     if (r.live == 0.0f) {                      // a dead node's row is zero whatever its (possibly never written) aggregate held
 #pragma unroll
@@ -633,7 +688,8 @@ __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, i
     if (post) {
 #pragma unroll
       for (int R = 0; R < 32; ++R) FRAG_AT(H, R) = 0.0f;
-      gemm_w64<32>(lds + PackUpd::FLOATS, lane, H, [&](int s) { return FRAG_AT(H2, s); });
+      if (BF3) gemm_w64_bf3<1>(lds + O_END, lane, H, [&](int s) { return FRAG_AT(H2, s); });
+      else gemm_w64<32>(lds + O_END, lane, H, [&](int s) { return FRAG_AT(H2, s); });
       if (valid) frag_store_rows(H, a.post, gc, h);
     }
     if (!has_next) break;
@@ -643,7 +699,7 @@ __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, i
   }
 }
 
-template <int WAVES, bool DEFERRED, bool POST = false>
+template <int WAVES, bool DEFERRED, bool POST = false, bool BF3 = false>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_node_update(UpdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -654,7 +710,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_node_update(UpdArgs a
   static_assert(WAVES % 4 == 0, "tile dealing assumes whole waves per SIMD");
   const long stride = (long)gridDim.x * 4 * (WAVES / 4);
   const long tile = (long)(wave >> 2) * gridDim.x * 4 + (long)blockIdx.x * 4 + (wave & 3);
-  node_update_loop<DEFERRED, POST>(a, lds, *a.cnt0, *a.cnt1, tile, stride, lane);
+  node_update_loop<DEFERRED, POST, BF3>(a, lds, *a.cnt0, *a.cnt1, tile, stride, lane);
 }
 
 struct UpdInpArgs { const float* pack; const float* nb; const float* Q; const float* sarr; float* mu; long G, ntiles; };
@@ -2518,6 +2574,7 @@ struct gnnb_handle {
   int gather_occ = 2;           // workgroups per CU for k_gather (its LDS footprint is only the tap matrix)
   bool dense_lds = true;        // Linear edges: one workgroup per sample with the source rows in LDS (false: per-tile kernel)
   bool restrict_last = true;    // last backward step of layer 1 only for the scored nodes (nothing else reads it)
+  bool bf3 = true;              // node update: 64x64 blocks on the bf16 matrix rate with three-piece operands (fp32 accuracy)
   int gather_sparse = 7;        // gathers behind a ReLU layer walk only the live rows of their window: bit 0 = 16-node forward
                                 // gathers, bit 1 = 32-node gathers, bit 2 = the input-layer gather
   bool gather16 = true;         // forward conv edges: 16-node tiles on the 16x16x4 MFMA when their window is smaller
@@ -2612,6 +2669,11 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   HIPCHK(hipFuncSetAttribute((const void*)k_node_update<8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpd::FLOATS + 4096) * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpd::FLOATS + 4096) * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpd::FLOATS + 4096) * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpdL3::FLOATS + 6144) * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpdL3::FLOATS + 6144) * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpdL3::FLOATS + 6144) * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpdL3::FLOATS + 6144) * 4));
+  if (const char* e = getenv("GNNB_BF3")) h->bf3 = e[0] == '1';
   if (const char* e = getenv("GNNB_NU_WAVES")) h->nu_waves = atoi(e) == 8 ? 8 : 12;
   if (const char* e = getenv("GNNB_GATHER_OCC")) h->gather_occ = atoi(e) < 1 ? 1 : atoi(e);
   HIPCHK(hipFuncSetAttribute((const void*)k_input_update, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpdInp::FLOATS * 4));
@@ -3315,14 +3377,21 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     // normal: list0 = live non-ambiguous nodes (short chain), list1 = ambiguous nodes; restricted: the scored nodes, general chain
     UpdArgs a{h->d_pack[pack], in->lb[k], in->ub[k], nb, ws + (fwd ? w.Pf[k] : w.Pb[k]), (post_input && !debug_full) ? nullptr : mu(k), status,
               ilist(w.live[k]), cnt + 4 * k + (scored ? 3 : 0), ilist(scored ? w.score[k] : w.amb[k]), cnt + 4 * k + (scored ? 2 : 1), sarr,
-              post_input ? rows1_for_input : nullptr, h->d_pack[PK_POST_INP] + (h->gb[1].ok ? PackPostInp::WPG : PackPostInp::WPN)};
-    const size_t ldsb = (size_t)(PackUpd::FLOATS + (post_input ? 4096 : 0)) * 4;
+              post_input ? rows1_for_input : nullptr, nullptr};
     const int wv = h->nu_waves;  // waves per workgroup (one workgroup per CU shares the LDS weights)
+    const bool bf3 = h->bf3 && wv == 12;
+    a.wp = h->d_pack[PK_POST_INP] + (bf3 ? (h->gb[1].ok ? PackPostInp::WPG3 : PackPostInp::WPN3) : (h->gb[1].ok ? PackPostInp::WPG : PackPostInp::WPN));
+    const size_t ldsb = bf3 ? (size_t)(PackUpdL3::FLOATS + (post_input ? 6144 : 0)) * 4 : (size_t)(PackUpd::FLOATS + (post_input ? 4096 : 0)) * 4;
     long grid = (nt + wv - 1) / wv;
     if (grid > h->n_cu) grid = h->n_cu;
     lz.run(PC_NODE_UPDATE, [&] {
       const dim3 g((unsigned)grid), b12(768), b8(512);
-      if (post_input) {
+      if (bf3) {
+        if (post_input && deferred) hipLaunchKernelGGL((k_node_update<12, true, true, true>), g, b12, ldsb, st, a);
+        else if (post_input) hipLaunchKernelGGL((k_node_update<12, false, true, true>), g, b12, ldsb, st, a);
+        else if (deferred) hipLaunchKernelGGL((k_node_update<12, true, false, true>), g, b12, ldsb, st, a);
+        else hipLaunchKernelGGL((k_node_update<12, false, false, true>), g, b12, ldsb, st, a);
+      } else if (post_input) {
         if (wv == 12 && deferred) hipLaunchKernelGGL((k_node_update<12, true, true>), g, b12, ldsb, st, a);
         else if (wv == 12) hipLaunchKernelGGL((k_node_update<12, false, true>), g, b12, ldsb, st, a);
         else if (deferred) hipLaunchKernelGGL((k_node_update<8, true, true>), g, b8, ldsb, st, a);

@@ -68,6 +68,42 @@ inline void pack_w64(float* dst, const float* W, int ldw, int col0, int nfrag) {
 }
 inline size_t w64_floats(int nfrag) { return (size_t)4096 * nfrag; }
 
+// ---- the same block for v_mfma_f32_32x32x16_bf16 with every weight split into three bf16 pieces, w = w1 + w2 + w3 (round
+// to nearest each time: 24 mantissa bits together).  The kernel splits the activations the same way and sums the six
+// products of total order <= 4 in the fp32 accumulator -- fp32 accuracy (tools/micro/bf16x3_chain.hip: same error against
+// fp64 as the fp32 MFMA) at a quarter of the matrix-pipe time.  k-step ks of input fragment f covers fragment registers
+// 8 ks .. 8 ks + 7, i.e. features 64 f + frag_feature(8 ks + j, h): entry ((f*4 + ks)*2 + ot)*3 + piece holds, for lane
+// (r, h), the 8 bf16 of W[32 ot + r][col0 + 64 f + frag_feature(8 ks + j, h)], j = 0..7 (16 bytes: one ds_read_b128).
+inline unsigned short bf16_rne(float f) {
+  unsigned u;
+  std::memcpy(&u, &f, 4);
+  if ((u & 0x7f800000u) == 0x7f800000u) return (unsigned short)((u >> 16) | ((u & 0xffffu) ? 0x40u : 0u));   // inf / nan
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+inline float bf16_f32(unsigned short b) {
+  const unsigned u = (unsigned)b << 16;
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+inline size_t w64_bf3_floats(int nfrag) { return (size_t)6144 * nfrag; }
+inline void pack_w64_bf3(float* dst, const float* W, int ldw, int col0, int nfrag) {
+  unsigned short* d = reinterpret_cast<unsigned short*>(dst);
+  for (int f = 0; f < nfrag; ++f)
+    for (int ks = 0; ks < 4; ++ks)
+      for (int ot = 0; ot < 2; ++ot)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            float w = W[(size_t)(32 * ot + (lane & 31)) * ldw + col0 + 64 * f + frag_feature(8 * ks + j, lane >> 5)];
+            for (int p = 0; p < 3; ++p) {
+              const unsigned short b = bf16_rne(w);
+              d[((((size_t)(f * 4 + ks) * 2 + ot) * 3 + p) * 64 + lane) * 8 + j] = b;
+              w -= bf16_f32(b);
+            }
+          }
+}
+
 // First layers on scalar node features (K = 2,3,4,7): natural order, k-step s holds input feature
 // 2*s + h (zero-padded to 2*ksteps); float index = (s*2 + it)*64 + lane  (ds_read_b32).
 inline void pack_wsmall(float* dst, const float* W, int K, int ksteps) {
@@ -132,7 +168,13 @@ struct PackPreFwd { enum { W1 = 0, B1 = W1 + 512, W2 = B1 + 64, B2 = W2 + 4096, 
 //         the SOURCE rows: H += VAW.[r0 s, r1 s] costs 2 MFMAs and no registers (zero when the aggregate is final)
 // The last layer (fc4_2 / bc4_1) is not here: it is deferred into whoever consumes the rows this kernel writes.
 struct PackUpd { enum { WA = 0, WAS = WA + 8192, BA = WAS + 4096, WCB = BA + 64, BCB = WCB + 4096, BCBROW = BCB + 64,
-                        VAW = BCBROW + 64, FLOATS = VAW + 128 }; };
+                        VAW = BCBROW + 64, FLOATS = VAW + 128,
+                        // bf16 x 3 forms of WAS and WCB (pack_w64_bf3) behind the fp32 image
+                        WAS3 = FLOATS, WCB3 = WAS3 + 6144, FLOATS3 = WCB3 + 6144 }; };
+// LDS image of the bf16 x 3 node update: WAS / WCB in three bf16 pieces; the general chain's 128-wide WA stays fp32 (its
+// tiles are 6-11 % of the work; as bf16 x 3 it costs 16 KB more staging and register spills, measured slower)
+struct PackUpdL3 { enum { WA = 0, BA = WA + 8192, BCB = BA + 64, BCBROW = BCB + 64, VAW = BCBROW + 64, WAS3 = VAW + 128,
+                          WCB3 = WAS3 + 6144, FLOATS = WCB3 + 6144 }; };
 // k_pre_bwd: P = bc4[:, :64] (bc2_1(relu(bc2([s, -d2 s, d1 s]))) * amb) + bc4.bias,
 //            s = bc1_2(relu(bc1_1(relu(bc1 feat7'))))                      (:273-293, :344-345)
 // likewise W5 = bc4[:, :64].bc2_1.W, B5 = bc4[:, :64].bc2_1.b + bcb
@@ -152,7 +194,7 @@ struct PackUpdInp { enum { VC = 0, FLOATS = VC + 128 }; };
 // WPN: inp_b2[:, 64:].bc4_1.W in pack_w64 order, rows natural (the flat input update reads the aggregate row-major);
 // WPG: the same with output rows permuted so that, after the MFMA gather, register R of lane half h (gather channel
 //      gather_feature(R, h)) holds feature frag_feature(R, h) -- the fragment layout of the chain it is added to.
-struct PackPostInp { enum { WPN = 0, WPG = WPN + 4096, FLOATS = WPG + 4096 }; };
+struct PackPostInp { enum { WPN = 0, WPG = WPN + 4096, WPN3 = WPG + 4096, WPG3 = WPN3 + 6144, FLOATS = WPG3 + 6144 }; };   // ..3: bf16 x 3
 // k_score: fscore(relu(fnode(mu)))                                           (:448-449)
 // W1 = fnode.Wp, V1 = [fnode.bp, 0] small k-step fed with live (the scored rows have their last Linear Wp deferred)
 struct PackScore { enum { W1 = 0, B1 = W1 + 4096, WS = B1 + 64, BS = WS + 64, V1 = BS + 4, FLOATS = V1 + 128 }; };
@@ -207,7 +249,7 @@ inline void build_packs(const float* blob, Packs& pk) {
   auto bcb_of = [&](int b, int c, float* out) { matvec64(out, W(c), 128, 64, Bv(b), Bv(c)); };
   // proj >= 0: the aggregate this update reads is built from rows whose projection Linear `proj` is deferred
   auto upd = [&](std::vector<float>& v, int a, int b, int c, int d, bool gathered_input, int proj = -1) {
-    v.assign(PackUpd::FLOATS, 0.f);
+    v.assign(PackUpd::FLOATS3, 0.f);
     std::vector<float> was(64 * 64), wcb(64 * 64), wa(64 * 128);
     float bcb[64];
     std::memcpy(wa.data(), W(a), sizeof(float) * 64 * 128);
@@ -249,6 +291,8 @@ inline void build_packs(const float* blob, Packs& pk) {
     }
     pack_vec64(&v[PackUpd::BA], Bv(a));
     pack_w64(&v[PackUpd::WCB], wcb.data(), 64, 0, 1);
+    if (!gathered_input) pack_w64_bf3(&v[PackUpd::WAS3], was.data(), 64, 0, 1);
+    pack_w64_bf3(&v[PackUpd::WCB3], wcb.data(), 64, 0, 1);
     pack_vec64(&v[PackUpd::BCB], bcb);
     (void)d;   // the last layer is folded into the consumers of the rows
     std::memcpy(&v[PackUpd::BCBROW], bcb, 64 * sizeof(float));
@@ -312,6 +356,8 @@ inline void build_packs(const float* blob, Packs& pk) {
     for (int h = 0; h < 2; ++h)
       for (int R = 0; R < 32; ++R) std::memcpy(&wcg[(size_t)gather_feature(R, h) * 64], &wc[(size_t)frag_feature(R, h) * 64], 64 * sizeof(float));
     pack_w64(&pk.post_inp[PackPostInp::WPG], wcg.data(), 64, 0, 1);
+    pack_w64_bf3(&pk.post_inp[PackPostInp::WPN3], wc.data(), 64, 0, 1);
+    pack_w64_bf3(&pk.post_inp[PackPostInp::WPG3], wcg.data(), 64, 0, 1);
   }
 
   auto score = [&](std::vector<float>& v, int proj) {

@@ -85,6 +85,37 @@ def gemm_w64(wl, ksteps, acc, getB):
             mfma(a, getB(s), acc[:, 16 * it:16 * it + 16])
 
 
+def bf16_pieces(x):
+    """x (float32) -> three bf16-valued float32 arrays, round to nearest even each time (the kernel's v_cvt_pk_bf16_f32 + subtract)."""
+    out, r = [], np.asarray(x, np.float32).copy()
+    for _ in range(3):
+        u = r.view(np.uint32).astype(np.uint64)
+        b = (((u + 0x7fff + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32)
+        out.append(b)
+        r = (r - b).astype(np.float32)
+    return out
+
+
+def gemm_w64_bf3(wl, nfrag, acc, getB):
+    """numpy model of gemm_w64_bf3 (gnnb.hip): v_mfma_f32_32x32x16_bf16 operand maps, operands in three bf16 pieces, the six
+    products of total order <= 4.  wl: the pack as float32 (reinterpreted as 8 bf16 per lane and entry)."""
+    w16 = np.ascontiguousarray(wl[:6144 * nfrag]).view(np.uint16).reshape(nfrag * 4, 2, 3, 64, 8)
+    wf = (w16.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    for fk in range(4 * nfrag):
+        xs = [np.stack([pc for pc in bf16_pieces(np.stack([getB(8 * fk + j) for j in range(8)], 1).astype(np.float32))][i], 0)
+              for i in range(3)]                                  # xs[piece][lane, j]
+        for ot in range(2):
+            D = np.zeros((32, 32))
+            for pw, px in ((2, 0), (1, 1), (0, 2), (1, 0), (0, 1), (0, 0)):
+                A = np.zeros((32, 16)); Bm = np.zeros((16, 32))
+                for j in range(8):
+                    A[J, 8 * H + j] = wf[fk, ot, pw, LANES, j]
+                    Bm[8 * H + j, J] = xs[px][LANES, j]
+                D += A @ Bm
+            for r in range(16):
+                acc[:, 16 * ot + r] += D[(r & 3) + 8 * (r >> 2) + 4 * H, J]
+
+
 def gemm_small(wl, ksteps, acc, x):
     for s in range(ksteps):
         for it in range(2):
@@ -98,7 +129,8 @@ def lin(sd, name, x):
 E = "EmbedUpdates.update."
 
 
-UPD = dict(WA=0, WAS=8192, BA=12288, WCB=12352, BCB=16448, BCBROW=16512, VAW=16576, FLOATS=16704)
+UPD = dict(WA=0, WAS=8192, BA=12288, WCB=12352, BCB=16448, BCBROW=16512, VAW=16576, WAS3=16704, WCB3=16704 + 6144,
+           FLOATS=16704 + 2 * 6144)
 
 
 @pytest.mark.parametrize("pack,chain,proj", [
@@ -153,6 +185,14 @@ def test_node_update_chain(packs, pack, chain, proj):
     gemm_small(p[VAW:], 1, Hf, [r0[J] * sw[J]])
     gemm_w64(p[WAS:], 32, Hf, lambda s: X[:, s] * r0[J])
     np.testing.assert_allclose(tail(Hf, frag_bias(p[BCB:BCB + 64])), reference(nb, r0, r0, np.zeros_like(relax)), atol=2e-5)
+    # the short chain on the bf16 matrix rate (three-piece operands): WAS3 / WCB3 hold the same matrices
+    Hf = frag_bias(p[BA:BA + 64])
+    gemm_small(p[VAW:], 1, Hf, [r0[J] * sw[J]])
+    gemm_w64_bf3(p[UPD["WAS3"]:], 1, Hf, lambda s: X[:, s] * r0[J])
+    Hf = np.maximum(Hf, 0)
+    H2 = frag_bias(p[BCB:BCB + 64])
+    gemm_w64_bf3(p[UPD["WCB3"]:], 1, H2, lambda s: Hf[:, s])
+    np.testing.assert_allclose(rows_from_frag(np.maximum(H2, 0)), reference(nb, r0, r0, np.zeros_like(relax)), atol=2e-5)
 
 
 def test_input_update_packs(packs):
@@ -167,13 +207,17 @@ def test_input_update_packs(packs):
     wc = w2[:, 64:] @ wp
     # producer side, natural row order: the flat input update adds the row-major aggregate
     p = pk["post_inp"]
-    assert p.size == 8192
+    assert p.size == 8192 + 2 * 6144
     X = frag_from_rows(Erows)
     F = np.zeros((64, 32)); gemm_w64(p[0:], 32, F, lambda s: X[:, s])
     np.testing.assert_allclose(rows_from_frag(F), Erows @ wc.T, atol=2e-5)
+    F3 = np.zeros((64, 32)); gemm_w64_bf3(p[8192:], 1, F3, lambda s: X[:, s])          # bf16 x 3 forms of the same two maps
+    np.testing.assert_allclose(rows_from_frag(F3), Erows @ wc.T, atol=2e-5)
+    Fg3 = np.zeros((64, 32)); gemm_w64_bf3(p[8192 + 6144:], 1, Fg3, lambda s: X[:, s])
     # producer side, gather-permuted rows: stored channel gather_feature(R, h) holds feature frag_feature(R, h)
     Fg = np.zeros((64, 32)); gemm_w64(p[4096:], 32, Fg, lambda s: X[:, s])
     stored = rows_from_frag(Fg)                          # what the producer writes, row-major
+    np.testing.assert_allclose(rows_from_frag(Fg3), stored, atol=2e-5)
     want = Erows @ wc.T
     for hh in range(2):
         for R in range(32):
