@@ -49,9 +49,13 @@ def node_stats(batch):
 
 def plan_flops(plan, B, stats, restrict_last=True):
     """Per kernel class, for ONE forward of batch B: algorithmic flops (MACs the algorithm needs for the nodes that
-    are updated, sparse edge sums 2*nnz*p) and issued MFMA flops (instructions x 4096, incl. tile padding and the
-    zeros of the dense gather blocks)."""
+    are updated, sparse edge sums 2*nnz*p) and issued matrix-pipe work in fp32-MFMA equivalents x 4096 flop (one
+    v_mfma_f32_32x32x2_f32 = 64 pipe cycles = 1; one v_mfma_f32_32x32x16_bf16 of the three-piece blocks = 32 cycles = 0.5;
+    incl. tile padding and the zeros of the dense gather blocks): issued / time / peak = the share of the time the matrix
+    pipe is busy at the 2.4 GHz the peak is quoted at."""
     T = plan["T"]
+    bf3 = bool(plan.get("bf3", 0))
+    W64 = 24 if bf3 else 64           # one 64x64 block: 48 bf16 MFMAs of 32 cycles, or 64 fp32 MFMAs of 64 cycles
     alg, issued, agg_bytes = {}, {}, {}
 
     def add(d, k, v):
@@ -66,7 +70,7 @@ def plan_flops(plan, B, stats, restrict_last=True):
             reps, nodes = T - 1, u["nodes"] * B
             if u["kernel"] == "k_gather_input_update":
                 add(alg, u["kernel"], reps * 2.0 * (2 * 64 * 64 * nodes + nnz * 64))
-                add(issued, u["kernel"], reps * MFMA_FLOP * u["tiles_per_sample"] * B * (2 * u["gather_ksteps"] + 68))   # inp_b2_2 deferred, inp_b2[:, 64:] applied on the producer side
+                add(issued, u["kernel"], reps * MFMA_FLOP * u["tiles_per_sample"] * B * (2 * u["gather_ksteps"] + W64 + 4))   # inp_b2_2 deferred, inp_b2[:, 64:] applied on the producer side
             else:
                 agg, upd = u["kernel"].split("+")
                 add(alg, upd, reps * 2.0 * 2 * 64 * 64 * nodes)
@@ -82,13 +86,13 @@ def plan_flops(plan, B, stats, restrict_last=True):
             add(agg_bytes, agg, 4.0 * 64 * (B * u["n_src"] + n_upd))
             # folded chains, last layer deferred: 128 (+2) MFMAs per tile of live non-ambiguous nodes, 192 (+2) per tile of general nodes
             if u["update"] == "bwd" and k == 1 and t < T - 1 and upd == "k_node_update":
-                add(issued, upd, MFMA_FLOP * tiles(stats[k]["live"]) * 64)      # the input update's 64x64 map, applied on the producer side
+                add(issued, upd, MFMA_FLOP * tiles(stats[k]["live"]) * W64)     # the input update's 64x64 map, applied on the producer side
             if upd == "k_top":                   # one workgroup per sample: every node of the layer through the general chain
                 add(issued, upd, MFMA_FLOP * B * tiles(u["nodes"]) * 194)
             elif restricted:
-                add(issued, upd, MFMA_FLOP * tiles(n_upd) * 194)
+                add(issued, upd, MFMA_FLOP * tiles(n_upd) * (130 + W64))
             else:
-                add(issued, upd, MFMA_FLOP * (tiles(stats[k]["live"] - stats[k]["amb"]) * 130 + tiles(stats[k]["amb"]) * 194))
+                add(issued, upd, MFMA_FLOP * (tiles(stats[k]["live"] - stats[k]["amb"]) * (2 + 2 * W64) + tiles(stats[k]["amb"]) * (130 + W64)))
             frac = n_upd / max(stats[k]["nodes"], 1)
             add(alg, agg, 2.0 * nnz * 64 * frac)
             if agg == "k_gather":
@@ -262,7 +266,8 @@ def main():
             roofline_nu = {"kernel": "k_node_update", "bound": "mfma", "achieved": round(nu_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": round(nu_tf / PEAK_F32_MFMA_TFLOPS, 4),
                            "issued_mfma_tflops": round(nu_iss, 2), "issued_mfma_frac": round(nu_iss / PEAK_F32_MFMA_TFLOPS, 4),
-                           "note": "achieved = the reference's MACs for the updated nodes / time; issued = MFMA instructions after the folds"}
+                           "note": "achieved = the reference's MACs for the updated nodes / time; issued = matrix-pipe time after the folds in "
+                                   "fp32-MFMA equivalents (a 32-cycle bf16 MFMA of the three-piece blocks counts half)"}
         # message passing is fused into the update kernels (the aggregate never reaches HBM): its algorithmic bytes
         # 4*p*(N_src+N_dst) per half-pass over the time of every kernel that performs an update
         mp_names = ("k_gather", "k_gather_input_update", "k_conv_fwd", "k_convT_bwd", "k_dense_agg", "k_prop", "k_top",

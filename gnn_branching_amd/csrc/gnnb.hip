@@ -1410,7 +1410,7 @@ struct GIArgs {
 // mu_0 = inp_b2_2(E_0) is deferred into the next round's forward update of ReLU layer 1 (gnnb_pack.h).
 // graph_conv.py:361-385; the aggregate, the feature chain and the update stay in registers.
 // one tile of the fused input-layer update; lds_upd / lds_pre: PackUpdInp / PackPreInp in LDS
-template <bool SPARSE>
+template <bool SPARSE, bool BF3>
 __device__ __forceinline__ void input_update_tile(const GIArgs& a, const TileCtx& tc, int sample, const float* lds_upd, const float* lds_pre,
                                                   const GatherLds& gl, uint2* tab, int lane) {
   const int h = lane >> 5, j = lane & 31;
@@ -1431,7 +1431,8 @@ __device__ __forceinline__ void input_update_tile(const GIArgs& a, const TileCtx
   frag_relu(H0);
   Frag H;                                  // inp_b_1 and the first half of inp_b2 are folded into one 64x64 map
   frag_bias(H, lds_pre + PackPreInp::B2, h);
-  gemm_w64<32>(lds_pre + PackPreInp::W2, lane, H, [&](int s) { return FRAG_AT(H0, s); });
+  if (BF3) gemm_w64_bf3<1>(lds_pre + PackPreInp::W23, lane, H, [&](int s) { return FRAG_AT(H0, s); });
+  else gemm_w64<32>(lds_pre + PackPreInp::W2, lane, H, [&](int s) { return FRAG_AT(H0, s); });
   {                                          // bias term of the projection deferred in the rows of mu_1
     const float xs[1] = {h ? 0.0f : a.sarr[gc]};
     gemm_small<1>(lds_upd + PackUpdInp::VC, lane, H, xs);
@@ -1444,7 +1445,7 @@ __device__ __forceinline__ void input_update_tile(const GIArgs& a, const TileCtx
   if (tc.valid) frag_store_rows(H, a.mu, gc, h);
 }
 
-template <bool SPARSE>
+template <bool SPARSE, bool BF3>
 __global__ __launch_bounds__(WG_MLP, 2) void k_gather_input_update(GIArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lds_pre = lds + PackUpdInp::FLOATS;
@@ -1464,7 +1465,7 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_gather_input_update(GIArgs a) {
   for (; tile < t1; tile += WAVES_MLP, t += WAVES_MLP) {
     while (t >= a.tm.TPS) { t -= a.tm.TPS; ++sample; }
     const TileCtx tc = block_decode(a.tm, gl.tt, sample, t, j);
-    input_update_tile<SPARSE>(a, tc, sample, lds, lds_pre, gl, tab, lane);
+    input_update_tile<SPARSE, BF3>(a, tc, sample, lds, lds_pre, gl, tab, lane);
   }
 }
 
@@ -2689,8 +2690,10 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   HIPCHK(hipFuncSetAttribute((const void*)k_livesum, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   if (const char* e = getenv("GNNB_NO_RESTRICT")) h->restrict_last = !(e[0] == '1');
   if (const char* e = getenv("GNNB_NO_DENSE_LDS")) h->dense_lds = !(e[0] == '1');
-  HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_gather<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   if (const char* e = getenv("GNNB_NO_GATHER")) h->use_gather = !(e[0] == '1');
   if (const char* e = getenv("GNNB_NO_TOP")) h->use_top = !(e[0] == '1');
@@ -2948,7 +2951,7 @@ extern "C" int gnnb_graph_info(const gnnb_t* h, int* n_graph, int* sizes, int* n
 extern "C" int gnnb_describe(const gnnb_t* h, char* buf, size_t cap) {
   if (!h || !h->bound || !buf || cap < 64) return fail(GNNB_E_INVALID, "gnnb_describe: bad arguments");
   const int L = (int)h->N.size() - 2;
-  std::string o = "{\"T\": " + std::to_string(h->T) + ", \"sizes\": [";
+  std::string o = "{\"T\": " + std::to_string(h->T) + ", \"bf3\": " + std::to_string(h->bf3 && h->nu_waves == 12 ? 1 : 0) + ", \"sizes\": [";
   for (size_t k = 0; k < h->N.size(); ++k) o += (k ? ", " : "") + std::to_string(h->N[k]);
   o += "], \"updates\": [";
   auto nnz = [&](int e) -> long {     // edges of the layer graph between layer e-1 and e (no-padding upper bound)
@@ -3413,8 +3416,10 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
                in->lb[1], in->ub[1]};
       const size_t lds = gather_lds_bytes(d, PackUpdInp::FLOATS + PackPreInp::FLOATS) + (sparse ? sparse_tab_bytes(d) : 0);
       lz.run(PC_GATHER_INPUT, [&] {
-        if (sparse) hipLaunchKernelGGL(k_gather_input_update<true>, dim3(mlp_grid(h, nt)), dim3(WG_MLP), lds, st, a);
-        else hipLaunchKernelGGL(k_gather_input_update<false>, dim3(mlp_grid(h, nt)), dim3(WG_MLP), lds, st, a);
+        if (sparse && h->bf3) hipLaunchKernelGGL((k_gather_input_update<true, true>), dim3(mlp_grid(h, nt)), dim3(WG_MLP), lds, st, a);
+        else if (sparse) hipLaunchKernelGGL((k_gather_input_update<true, false>), dim3(mlp_grid(h, nt)), dim3(WG_MLP), lds, st, a);
+        else if (h->bf3) hipLaunchKernelGGL((k_gather_input_update<false, true>), dim3(mlp_grid(h, nt)), dim3(WG_MLP), lds, st, a);
+        else hipLaunchKernelGGL((k_gather_input_update<false, false>), dim3(mlp_grid(h, nt)), dim3(WG_MLP), lds, st, a);
       });
       return;
     }

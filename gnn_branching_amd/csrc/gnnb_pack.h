@@ -184,7 +184,7 @@ struct PackPreBwd {
 };
 // k_pre_inp: Q = inp_b2[:, :64] inp_b_1(relu(inp_b([l0,u0]))) + inp_b2.bias   (:380-384)
 // folded: Q = (inp_b2[:, :64].inp_b_1.W) relu(inp_b([l0,u0])) + (inp_b2[:, :64].inp_b_1.b + inp_b2.b)
-struct PackPreInp { enum { W1 = 0, B1 = W1 + 128, W2 = B1 + 64, B2 = W2 + 4096, FLOATS = B2 + 64 }; };
+struct PackPreInp { enum { W1 = 0, B1 = W1 + 128, W2 = B1 + 64, B2 = W2 + 4096, W23 = B2 + 64 /* W2 as bf16 x 3 */, FLOATS = W23 + 6144 }; };
 // k_input_update: E0 = relu(Q + inp_b2[:, 64:] nb); mu0 = inp_b2_2(E0) is deferred   (:383-385)
 // The 64x64 map inp_b2[:, 64:].bc4_1.W that the aggregate of layer 1 has to go through commutes with the aggregation, and
 // layer 1 has ~1100 live producer nodes per sample against 3072 consumer nodes here: it is applied on the PRODUCER side
@@ -340,6 +340,7 @@ inline void build_packs(const float* blob, Packs& pk) {
     matmul64(w2.data(), W(L_INP_B2), 128, 0, W(L_INP_B_1));
     matvec64(b2, W(L_INP_B2), 128, 0, Bv(L_INP_B_1), Bv(L_INP_B2));
     pack_w64(&pk.pre_inp[PackPreInp::W2], w2.data(), 64, 0, 1);
+    pack_w64_bf3(&pk.pre_inp[PackPreInp::W23], w2.data(), 64, 0, 1);
     pack_vec64(&pk.pre_inp[PackPreInp::B2], b2);
   }
 
