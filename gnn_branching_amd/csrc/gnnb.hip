@@ -987,6 +987,9 @@ __device__ __forceinline__ void gather_tile_embed(Frag& X, const float* cm, cons
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 #define GATHER_CH16 4   // k-steps per prefetch chunk (16 window slots, as in the 32-lane variant)
+#ifndef EMBED_MFMA
+#define EMBED_MFMA 1    // round 0: the input embedding inside the first gather on the matrix pipe (0: VALU form)
+#endif
 
 template <bool INTERIOR>
 __device__ __forceinline__ void gather_tile16(f32x4 (&acc)[4], const float* cm, const int2* ko, const unsigned* kvo, int K2,
@@ -1287,6 +1290,55 @@ __device__ __forceinline__ void gather_process_tile(const GArgs& a, const TileCt
   if (need) frag_store_rows_gathered(X, a.nb, gc, h);
 }
 
+// The embedding on the matrix pipe: E0 = relu(inp_f [l, x, u] + b) is itself a K = 4 product ([l, x, u, 1] against [W | b]),
+// and the result layout of v_mfma_f32_16x16x4_f32 (lane (i, g), register r = row 4g + r, column i) is the A-operand layout
+// of the tap MFMA (lane (i, g) = channel of row i at the slot of k-index g) if the embedding MFMA's row 4g + r is the window
+// slot that k-step 4 grp + r wants at k-index g, i.e. slot 16 grp + 4 r + g.  So per group of 4 k-steps: one scalar load per
+// lane (lane group 0 / 1 / 2 reads l / x / u of its row's slot, group 3 supplies the 1 of the bias), 4 embedding MFMAs (one
+// per 16-channel tile), 16 v_max, 16 tap MFMAs -- instead of 64 FMAs + 16 v_max + 12 loads per lane.  An out-of-range slot
+// feeds zeros (including its "1"), so its embedding is relu(0) = 0.
+__device__ __forceinline__ void gather_tile16_embed_mfma(f32x4 (&acc)[4], const float* cm, const int2* ko, int K2, __amdgpu_buffer_rsrc_t rl,
+                                                         __amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t ru, const float (&bw)[4],
+                                                         int wy0, int wx0, int Hs, int Ws, int lane) {
+  const int m = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int origin = wy0 * Ws + wx0;
+  const int sl = 4 * (m & 3) + (m >> 2);            // slot of embedding row m inside a group of 16
+  auto load = [&](int grp) -> float {
+    const unsigned long long ev = reinterpret_cast<const unsigned long long*>(ko)[16 * grp + sl];
+    const int ex = (int)(unsigned)ev, ey = (int)(unsigned)(ev >> 32);
+    const int wy = wy0 + (ey & 0xffff), wx = wx0 + (ey >> 16);
+    const bool inb = (unsigned)wy < (unsigned)Hs && (unsigned)wx < (unsigned)Ws;      // (table padding: 0x7fff, never in range)
+    const unsigned o = inb ? (unsigned)(origin + ex) * 4u : BUF_OOB;
+    const float vl = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rl, o, 0, 0));
+    const float vx = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, 0));
+    const float vu = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, o, 0, 0));
+    return kq == 0 ? vl : kq == 1 ? vx : kq == 2 ? vu : (inb ? 1.0f : 0.0f);
+  };
+  const int ngrp = K2 / 4;
+  float ain = load(0);
+  for (int grp = 0; grp < ngrp; ++grp) {
+    const float cur = ain;
+    if (grp + 1 < ngrp) ain = load(grp + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 e[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      e[t] = mfma16(cur, bw[t], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+      for (int r = 0; r < 4; ++r) e[t][r] = relu_nan(e[t][r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float b = cm[(4 * grp + r) * 64 + lane];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = mfma16(e[t][r], b, acc[t]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // one 16-node tile of phase A (forward edges only: no tap-count division)
 template <bool EMBED, bool SPARSE>
 __device__ __forceinline__ void gather_process_tile16(const GArgs& a, const TileCtx& tc, int sample, const float* lds_cm, const int2* lds_ko,
@@ -1307,7 +1359,14 @@ __device__ __forceinline__ void gather_process_tile16(const GArgs& a, const Tile
     const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(a.es.lb + sb), 0, a.g.Ns * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.es.x + sb), 0, a.g.Ns * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)(a.es.ub + sb), 0, a.g.Ns * 4, 0x00020000);
-    if (interior) gather_tile16_embed<true>(acc, cmt, lds_ko, lds_kvo, a.g.K2, rl, rx, ru, ew, eb, uy, ux, a.g.Hs, a.g.Ws, lane);
+    if (EMBED_MFMA) {
+      // B operand of the embedding MFMA of channel tile t: lane (n, k) = inp_f weight k of channel 4n + t, k = 3: its bias
+      const int n = lane & 15, k = lane >> 4;
+      float bw[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) bw[t] = k < 3 ? a.es.wb[(4 * n + t) * 3 + k] : a.es.wb[192 + 4 * n + t];
+      gather_tile16_embed_mfma(acc, cmt, lds_ko, a.g.K2, rl, rx, ru, bw, uy, ux, a.g.Hs, a.g.Ws, lane);
+    } else if (interior) gather_tile16_embed<true>(acc, cmt, lds_ko, lds_kvo, a.g.K2, rl, rx, ru, ew, eb, uy, ux, a.g.Hs, a.g.Ws, lane);
     else gather_tile16_embed<false>(acc, cmt, lds_ko, lds_kvo, a.g.K2, rl, rx, ru, ew, eb, uy, ux, a.g.Hs, a.g.Ws, lane);
   } else {
     const float* sbase = a.mu_src + (long)sample * a.g.Ns * 64;
