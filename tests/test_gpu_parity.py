@@ -186,6 +186,28 @@ def test_separate_top_kernels_path_matches(monkeypatch, case):
     assert res.decisions.cpu().tolist() == g["random_decisions"].tolist()
 
 
+@pytest.mark.parametrize("case", ["cifar_base_kw_B3", "cifar_wide_kw_B2"])
+@pytest.mark.parametrize("fam", ["shipped", "random"])
+def test_bf16x3_blocks_match_the_fp32_mfma(monkeypatch, case, fam):
+    """The 64x64 blocks of the node update and of the input update run on the bf16 matrix rate with three-piece operands
+    (default); GNNB_BF3=0 keeps every block on the exact-fp32 MFMA.  Both must sit inside the parity bar against the
+    reference, agree with each other to fp32 rounding, and take the same decisions."""
+    g, batch = load_golden(case)
+    want = g[f"{fam}_scores"]
+    fin = np.isfinite(want)
+    out = {}
+    for bf3 in ("1", "0"):
+        monkeypatch.setenv("GNNB_BF3", bf3)
+        model = make_model(fam)                      # a new engine: the knob is read by gnnb_create
+        with torch.no_grad():
+            res = model.forward_device(*batch.forward_args()).check()
+        out[bf3] = res.scores.cpu().numpy()
+        assert np.abs(out[bf3][fin] - want[fin]).max() <= SCORE_ATOL
+        assert res.decisions.cpu().tolist() == g[f"{fam}_decisions"].tolist()
+    scale = np.abs(want[fin]).max()
+    assert np.abs(out["1"][fin] - out["0"][fin]).max() <= 2e-6 * max(scale, 1.0)
+
+
 def test_small_batch_latency_path_matches(monkeypatch):
     """GNNB_PER_SAMPLE_MIN_B=96: batches below 96 take the per-tile dense kernel and separate top kernels (18 % lower
     latency at B = 2): same scores within the budget, same decisions."""
