@@ -18,6 +18,10 @@
 //   * provably dead work of the reference is not executed: the `ratio` chain (:214-216,228,243,356) and the last
 //     round's input-layer update (:360-385), whose result nothing reads.
 //
+// One translation unit: gnnb_dev.h (fragments, GEMM blocks, tile maps), gnnb_k_mlp.h (setup + node-MLP kernels),
+// gnnb_k_gather.h (conv-edge message passing + score head), gnnb_k_edges.h (other edges, k_top), gnnb_k_misc.h (k_livesum,
+// k_babsr, k_argmax), gnnb_train.h (online learning) are included below; this file holds the host side and the C-ABI.
+//
 // gfx950 only.  No HIP call at load time.
 #include <hip/hip_runtime.h>
 
@@ -38,2547 +42,11 @@ using namespace gnnb;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// ------------------------------------------------------------------------------------------
-// device helpers
-// ------------------------------------------------------------------------------------------
-struct Frag {
-  f32x16 t[2];  // 64 features x 32 nodes; register R = 16*it + r <-> feature 8*(R>>2) + 4*h + (R&3)
-};
-
-#define FRAG_AT(x, R) ((x).t[(R) >> 4][(R)&15])
-
-__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
-
-// acc += W(64 x 2*KSTEPS, operand order in LDS) * in, where getB(s) yields the B operand of k-step s
-template <int KSTEPS, class GetB>
-__device__ __forceinline__ void gemm_w64(const float* wl, int lane, Frag& acc, GetB getB) {
-  // A operands are prefetched one 4-k-step block ahead; the sched_barrier keeps hipcc from hoisting
-  // every LDS read of the fully unrolled chain to the top (which spills the 256-VGPR budget).
-  const f32x4* w4 = reinterpret_cast<const f32x4*>(wl) + lane;
-  f32x4 a0 = w4[0], a1 = w4[64];
-#pragma unroll
-  for (int s4 = 0; s4 < KSTEPS / 4; ++s4) {
-    f32x4 n0 = a0, n1 = a1;
-    if (s4 + 1 < KSTEPS / 4) {
-      n0 = w4[((s4 + 1) * 2 + 0) * 64];
-      n1 = w4[((s4 + 1) * 2 + 1) * 64];
-    }
-    __builtin_amdgcn_sched_barrier(0);      // reads of the next block issue BEFORE this block's MFMAs, not after them
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float b = getB(s4 * 4 + c);
-      acc.t[0] = mfma32(a0[c], b, acc.t[0]);
-      acc.t[1] = mfma32(a1[c], b, acc.t[1]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    a0 = n0;
-    a1 = n1;
-  }
-}
-
-// first layers on scalar node features: x[s] = input feature 2*s + h of this lane's node
-template <int KSTEPS>
-__device__ __forceinline__ void gemm_small(const float* wl, int lane, Frag& acc, const float (&x)[KSTEPS]) {
-#pragma unroll
-  for (int s = 0; s < KSTEPS; ++s) {
-    const float a0 = wl[(s * 2 + 0) * 64 + lane];
-    const float a1 = wl[(s * 2 + 1) * 64 + lane];
-    acc.t[0] = mfma32(a0, x[s], acc.t[0]);
-    acc.t[1] = mfma32(a1, x[s], acc.t[1]);
-  }
-}
-
-// ---- the 64x64 block on v_mfma_f32_32x32x16_bf16 with both operands in three bf16 pieces (gnnb_pack.h pack_w64_bf3):
-// acc += W.x with the six products w1x1 + w1x2 + w2x1 + w1x3 + w2x2 + w3x1, smallest first.  48 MFMAs of 32 cycles per
-// 64 inputs instead of 64 of 64 cycles; the price is the VALU work of splitting the activations (cvt_pk + subtract per piece).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
-typedef float f32x2v __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ unsigned pk_bf16(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{a, b}, bf16x2v)); }
-__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
-
-template <int NFRAG, class GetB>
-__device__ __forceinline__ void gemm_w64_bf3(const float* wl, int lane, Frag& acc, GetB getB) {
-  const u32x4* w = reinterpret_cast<const u32x4*>(wl) + lane;
-#pragma unroll
-  for (int fk = 0; fk < 4 * NFRAG; ++fk) {         // fragment fk / 4, k-step fk % 4: registers 8 (fk % 4) .. + 7
-    u32x4 p1, p2, p3;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float a = getB(8 * fk + 2 * q), b = getB(8 * fk + 2 * q + 1);
-      const unsigned u1 = pk_bf16(a, b);
-      const float ra = a - __uint_as_float(u1 << 16), rb = b - __uint_as_float(u1 & 0xffff0000u);
-      const unsigned u2 = pk_bf16(ra, rb);
-      const float sa = ra - __uint_as_float(u2 << 16), sb = rb - __uint_as_float(u2 & 0xffff0000u);
-      p1[q] = u1; p2[q] = u2; p3[q] = pk_bf16(sa, sb);
-    }
-    const bf16x8 x1 = __builtin_bit_cast(bf16x8, p1), x2 = __builtin_bit_cast(bf16x8, p2), x3 = __builtin_bit_cast(bf16x8, p3);
-#pragma unroll
-    for (int ot = 0; ot < 2; ++ot) {
-      const bf16x8 w1 = __builtin_bit_cast(bf16x8, w[((fk * 2 + ot) * 3 + 0) * 64]);
-      const bf16x8 w2 = __builtin_bit_cast(bf16x8, w[((fk * 2 + ot) * 3 + 1) * 64]);
-      const bf16x8 w3 = __builtin_bit_cast(bf16x8, w[((fk * 2 + ot) * 3 + 2) * 64]);
-      acc.t[ot] = mfma_bf16(w3, x1, acc.t[ot]);
-      acc.t[ot] = mfma_bf16(w2, x2, acc.t[ot]);
-      acc.t[ot] = mfma_bf16(w1, x3, acc.t[ot]);
-      acc.t[ot] = mfma_bf16(w2, x1, acc.t[ot]);
-      acc.t[ot] = mfma_bf16(w1, x2, acc.t[ot]);
-      acc.t[ot] = mfma_bf16(w1, x1, acc.t[ot]);
-    }
-    __builtin_amdgcn_sched_barrier(0);      // one k-step's pieces and weight fragments at a time (else hipcc hoists them all and spills)
-  }
-}
-
-__device__ __forceinline__ void frag_bias(Frag& a, const float* bl, int h) {
-  const f32x4* b4 = reinterpret_cast<const f32x4*>(bl + h * 32);
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const f32x4 v = b4[q];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) FRAG_AT(a, 4 * q + c) = v[c];
-  }
-}
-
-// torch's relu propagates NaN (fmaxf would swallow it and hide a 0/0 of compute_ratio)
-__device__ __forceinline__ float relu_nan(float x) { return x < 0.0f ? 0.0f : x; }
-
-__device__ __forceinline__ void frag_relu(Frag& a) {
-#pragma unroll
-  for (int R = 0; R < 32; ++R) FRAG_AT(a, R) = relu_nan(FRAG_AT(a, R));
-}
-
-__device__ __forceinline__ void frag_scale(Frag& a, float s) {
-#pragma unroll
-  for (int R = 0; R < 32; ++R) FRAG_AT(a, R) *= s;
-}
-
-// row-major (G, 64) <-> fragment: lane (j, h) owns features [8q+4h, 8q+4h+4) of row `row`, q = 0..7
-__device__ __forceinline__ void frag_load_rows(Frag& x, const float* base, long row, int h) {
-  const f32x4* p = reinterpret_cast<const f32x4*>(base + row * 64 + 4 * h);
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const f32x4 v = p[2 * q];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) FRAG_AT(x, 4 * q + c) = v[c];
-  }
-}
-__device__ __forceinline__ void frag_load_rowptr(Frag& x, const float* rowptr, int h) {
-  const f32x4* p = reinterpret_cast<const f32x4*>(rowptr + 4 * h);
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const f32x4 v = p[2 * q];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) FRAG_AT(x, 4 * q + c) = v[c];
-  }
-}
-__device__ __forceinline__ void frag_store_rows(const Frag& x, float* base, long row, int h) {
-  f32x4* p = reinterpret_cast<f32x4*>(base + row * 64 + 4 * h);
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    f32x4 v;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) v[c] = FRAG_AT(x, 4 * q + c);
-    p[2 * q] = v;
-  }
-}
-// tile-major scratch layout for the cached P vectors: float4 index (tile*8 + q)*64 + lane (1 KiB per wave-instruction)
-__device__ __forceinline__ void frag_load_tiled(Frag& x, const float* base, long tile, int lane) {
-  const f32x4* p = reinterpret_cast<const f32x4*>(base) + tile * 512 + lane;
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const f32x4 v = p[q * 64];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) FRAG_AT(x, 4 * q + c) = v[c];
-  }
-}
-__device__ __forceinline__ void frag_store_tiled(const Frag& x, float* base, long tile, int lane) {
-  f32x4* p = reinterpret_cast<f32x4*>(base) + tile * 512 + lane;
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    f32x4 v;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) v[c] = FRAG_AT(x, 4 * q + c);
-    p[q * 64] = v;
-  }
-}
-
-__device__ __forceinline__ bool frag_has_nan(const Frag& x) {
-  bool bad = false;
-#pragma unroll
-  for (int R = 0; R < 32; ++R) bad |= (FRAG_AT(x, R) != FRAG_AT(x, R));
-  return bad;
-}
-
-// compute_ratio (graph_conv.py:499-514), op for op
-struct Ratio { float r0, r1, beta, amb, live; };
-__device__ __forceinline__ Ratio compute_ratio(float lb, float ub) {
-  Ratio r;
-  const float lower_temp = lb - relu_nan(lb);
-  const float upper_temp = relu_nan(ub);
-  r.r0 = upper_temp / (upper_temp - lower_temp);
-  r.beta = -1.0f * lower_temp * r.r0;
-  r.amb = r.beta > 0.0f ? 1.0f : 0.0f;
-  r.r1 = (1.0f - 2.0f * (r.r0 * r.amb)) * r.amb + r.r0;
-  r.live = (r.r0 != 0.0f) ? 1.0f : 0.0f;   // (ratio_0 != 0), :178 / :347 (NaN != 0 is true)
-  return r;
-}
-
-// global -> LDS copy of a weight pack.  Loads are issued 8 at a time before their LDS stores: a plain copy loop keeps
-// one 16-B load in flight per thread and serialises ~10 L2 round trips per workgroup at the start of every launch.
-__device__ __forceinline__ void copy_to_lds(float* lds, const float* src, int nfloats) {
-  const f32x4* g = reinterpret_cast<const f32x4*>(src);
-  f32x4* l = reinterpret_cast<f32x4*>(lds);
-  const int n4 = nfloats / 4, stride = blockDim.x;
-  for (int i0 = threadIdx.x; i0 < n4; i0 += 8 * stride) {
-    f32x4 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = i0 + u * stride;
-      v[u] = g[i < n4 ? i : i0];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = i0 + u * stride;
-      if (i < n4) l[i] = v[u];
-    }
-  }
-}
-__device__ __forceinline__ void stage_pack(float* lds, const float* pack, int nfloats) {
-  copy_to_lds(lds, pack, nfloats);
-  __syncthreads();
-}
-
-// ---- tile -> node mapping (gnnb_pack.h TileMap) ----
-struct DTileMap { int mode, N, C, H, W, CT, PY, PX, ay, ax, NBY, NBX, NCG, TPS, lpy, lpx; };
-struct TileCtx { long sample; int n, cg, by, bx, y, x; bool valid; };
-
-// lane j of tile `tile`: which node of which sample.  mode 0: 32 consecutive rows of the flat (B*N) layer;
-// mode 1: CT channels x (PY x PX) pixel block of one sample (the blocks an MFMA gather works on).
-__device__ __forceinline__ TileCtx tile_decode(const DTileMap& tm, long tile, int j, long total_rows) {
-  TileCtx c;
-  if (tm.mode == 0) {
-    const long g = tile * 32 + j;
-    c.valid = g < total_rows;
-    const long gc = c.valid ? g : total_rows - 1;
-    c.sample = gc / tm.N;
-    c.n = (int)(gc - c.sample * tm.N);
-    c.cg = c.by = c.bx = c.y = c.x = 0;
-  } else {
-    c.sample = tile / tm.TPS;
-    const int t = (int)(tile - c.sample * tm.TPS);
-    const int nb = tm.NBY * tm.NBX;
-    c.cg = t / nb;
-    const int rem = t - c.cg * nb;
-    c.by = rem / tm.NBX;
-    c.bx = rem - c.by * tm.NBX;
-    const int pp = tm.PY * tm.PX;
-    const int cl = j / pp;
-    const int r2 = j - cl * pp;
-    const int py = r2 / tm.PX, px = r2 - py * tm.PX;
-    c.y = c.by * tm.PY + tm.ay + py;
-    c.x = c.bx * tm.PX + tm.ax + px;
-    c.valid = cl < tm.CT && (unsigned)c.y < (unsigned)tm.H && (unsigned)c.x < (unsigned)tm.W;
-    c.n = c.valid ? ((c.cg * tm.CT + cl) * tm.H + c.y) * tm.W + c.x : 0;
-  }
-  return c;
-}
-
-// block tiles without integer divisions: ttab[t] = cg | by << 8 | bx << 20 for tile t of a sample (built on the host),
-// PY and PX are powers of two.
-__device__ __forceinline__ TileCtx block_decode(const DTileMap& tm, const int* ttab, long sample, int t, int j) {
-  TileCtx c;
-  c.sample = sample;
-  const int e = ttab[t];
-  c.cg = e & 0xff;
-  c.by = (e >> 8) & 0xfff;
-  c.bx = (e >> 20) & 0xfff;
-  const int cl = j >> (tm.lpy + tm.lpx);
-  const int py = (j >> tm.lpx) & (tm.PY - 1), px = j & (tm.PX - 1);
-  c.y = c.by * tm.PY + tm.ay + py;
-  c.x = c.bx * tm.PX + tm.ax + px;
-  c.valid = cl < tm.CT && (unsigned)c.y < (unsigned)tm.H && (unsigned)c.x < (unsigned)tm.W;
-  c.n = c.valid ? ((c.cg * tm.CT + cl) * tm.H + c.y) * tm.W + c.x : 0;
-  return c;
-}
-
-// persistent tile loop: workgroup -> contiguous chunk of tiles, chunks dealt so that the workgroups of one
-// XCD (blockIdx % 8 labels the XCD group) own neighbouring chunks: the samples they gather from stay in that L2.
-__device__ __forceinline__ void tile_range(long ntiles, int waves, long& begin, long& end) {
-  int wg = blockIdx.x;
-  const int nwg = gridDim.x;
-  if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
-  // chunks differ by at most one tile (rounding every chunk up to whole rounds of `waves` tiles left up to a sixth of the
-  // workgroups without work on the 81-tiles-per-sample edge)
-  (void)waves;
-  const long base = ntiles / nwg, rem = ntiles - base * nwg;
-  begin = (long)wg * base + (wg < rem ? wg : rem);
-  end = begin + base + (wg < rem ? 1 : 0);
-}
-
-#define WG_MLP 512       // 8 waves: 2 per SIMD share one LDS copy of the weights
-#define WAVES_MLP 8
-
-// ------------------------------------------------------------------------------------------
-// MFMA node-MLP kernels.  One wave = one tile of 32 consecutive nodes of a (B*N_k) flat layer.
-// ------------------------------------------------------------------------------------------
-struct EmbedArgs { const float* w; const float* b; const float* lb; const float* x; const float* ub; float* mu; long G; };
-
-// E0 = relu(inp_f([l0, x_LP, u0])); mu0 = inp_f_1(E0) is deferred into the forward update of ReLU layer 1
-// (gnnb_pack.h "deferred projection")   graph_conv.py:90-95
-// 3 -> 64 features per node: 192 FMAs against a 256-B row written, i.e. HBM-write-bound VALU work, not an MFMA job.
-// A thread owns 4 consecutive features (its 12 weights + 4 biases stay in registers) and walks nodes; 16 threads
-// write one 256-B row, one wave instruction writes 1 KiB contiguous.
-#define EMBED_UNROLL 4
-__global__ __launch_bounds__(256) void k_embed(EmbedArgs a) {
-  const int q = threadIdx.x & 15;                       // feature quad
-  float w[4][3], bias[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    bias[c] = a.b[4 * q + c];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) w[c][i] = a.w[(4 * q + c) * 3 + i];
-  }
-  const long nodes_per_pass = (long)gridDim.x * 16;      // 16 nodes per workgroup and pass
-  long g = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
-  for (; g < a.G; g += nodes_per_pass * EMBED_UNROLL) {
-    float l[EMBED_UNROLL], x[EMBED_UNROLL], u[EMBED_UNROLL];
-#pragma unroll
-    for (int r = 0; r < EMBED_UNROLL; ++r) {
-      const long gg = g + r * nodes_per_pass;
-      const long gc = gg < a.G ? gg : a.G - 1;
-      l[r] = a.lb[gc]; x[r] = a.x[gc]; u[r] = a.ub[gc];
-    }
-#pragma unroll
-    for (int r = 0; r < EMBED_UNROLL; ++r) {
-      const long gg = g + r * nodes_per_pass;
-      f32x4 o;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        // torch addmm order: bias + sum_k in_k w_k
-        o[c] = relu_nan(fmaf(u[r], w[c][2], fmaf(x[r], w[c][1], fmaf(l[r], w[c][0], bias[c]))));
-      }
-      if (gg < a.G) *reinterpret_cast<f32x4*>(a.mu + gg * 64 + 4 * q) = o;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// classification: what each ReLU node needs this forward (static over the T rounds)
-//   live  = [r0 != 0]  (graph_conv.py:178/:347): only these rows of mu can be non-zero -> node MLP runs on them only
-//   amb   = [beta > 0] (:504): only these have a non-zero relaxation term -> the hoisted feature chains run on them only
-//   score = BaB mask == -1 (:447): only these are scored
-// Each class is compacted into a list of flat node ids (wave-aggregated atomics; the order inside a list does not
-// affect any result: every lane of an MLP tile computes its own column).  Dead rows of mu are zeroed here, once,
-// and scores are preset to -inf.
-// ------------------------------------------------------------------------------------------
-#define MAXL 8            // ReLU layers handled by the merged per-layer kernels (bind rejects deeper networks for them)
-struct ClassifyArgs {    // every ReLU layer of the network in one launch
-  int L;
-  const float* lb[MAXL]; const float* ub[MAXL];
-  float* mu[MAXL];                 // (B*N_k, 64) rows of layer k
-  float* mu2;                      // second row buffer of layer 1 (F1, PackPostInp) whose dead rows must read as zero too, or null
-  int* live[MAXL]; int* amb[MAXL]; int* score[MAXL];
-  float* livef[MAXL];              // (B*N_k) 1.0 / 0.0: [r0 != 0], read by k_livesum
-  long G[MAXL];
-  int N[MAXL], off[MAXL], blk0[MAXL + 1];   // first workgroup of each layer
-  const float* mask;
-  float* scores;                   // (B, R)
-  int* cnt;                        // 4 ints per layer: plain (live, not ambiguous), ambiguous, scored, 0
-  int R;
-};
-
-#define CLS_THREADS 1024
-// one global atomic per list and workgroup (a single counter word only sustains ~90 atomics/us)
-__global__ __launch_bounds__(CLS_THREADS) void k_classify(ClassifyArgs a) {
-  __shared__ int wcnt[3][CLS_THREADS / 64];
-  __shared__ int wbase[3][CLS_THREADS / 64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int k = 0;
-  while (k + 1 < a.L && (int)blockIdx.x >= a.blk0[k + 1]) ++k;
-  const long G = a.G[k];
-  const int N = a.N[k];
-  const long g = (long)(blockIdx.x - a.blk0[k]) * CLS_THREADS + threadIdx.x;
-  const bool valid = g < G;
-  const long gc = valid ? g : G - 1;
-  const Ratio r = compute_ratio(a.lb[k][gc], a.ub[k][gc]);
-  const long b = gc / N;
-  const long sidx = b * a.R + a.off[k] + (gc - b * N);
-  bool flag[3];
-  const bool live = valid && r.live != 0.0f;
-  flag[1] = valid && r.amb != 0.0f;                 // ambiguous (a subset of live)
-  flag[0] = live && !flag[1];                       // live with r0 == r1: the cheap update path
-  flag[2] = valid && a.mask[sidx] != 0.0f;
-  if (valid) {
-    a.scores[sidx] = -INFINITY;
-    a.livef[k][g] = live ? 1.0f : 0.0f;
-  }
-  unsigned long long bal[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    bal[c] = __ballot(flag[c]);
-    if (lane == 0) wcnt[c][wave] = __popcll(bal[c]);
-  }
-  __syncthreads();
-  if (threadIdx.x < 3) {
-    const int c = threadIdx.x;
-    int total = 0;
-    for (int w = 0; w < CLS_THREADS / 64; ++w) { wbase[c][w] = total; total += wcnt[c][w]; }
-    const int base = total ? atomicAdd(a.cnt + 4 * k + c, total) : 0;
-    for (int w = 0; w < CLS_THREADS / 64; ++w) wbase[c][w] += base;
-  }
-  __syncthreads();
-  int* lists[3] = {a.live[k], a.amb[k], a.score[k]};
-#pragma unroll
-  for (int c = 0; c < 3; ++c)
-    if (flag[c]) lists[c][wbase[c][wave] + __popcll(bal[c] & ((1ull << lane) - 1ull))] = (int)gc;
-  unsigned long long dead = __ballot(valid && !live);
-  float* mu = a.mu[k];
-  float* mu2 = k == 0 ? a.mu2 : nullptr;
-  while (dead) {                       // the whole wave zeroes one dead row per iteration (coalesced 256 B)
-    const int l = __ffsll((long long)dead) - 1;
-    dead &= dead - 1;
-    const long row = g - lane + l;
-    mu[row * 64 + lane] = 0.0f;
-    if (mu2) mu2[row * 64 + lane] = 0.0f;
-  }
-}
-
-struct PreArgs {
-  const float* pack;
-  const float *lb, *ub, *dual, *z_pre, *z_post, *bias;   // per-node scalars (flat B*N), bias per channel
-  float* P;                                               // out: tile-major (k_pre_inp) or rows by node id (k_pre_fwd/bwd)
-  long G, ntiles;
-  int N, hw;                                              // nodes per sample; nodes per bias entry (H*W or 1)
-  DTileMap tm;                                            // k_pre_inp: which node sits on which (tile, lane)
-  const int* list;                                        // k_pre_fwd/bwd: ambiguous nodes of the layer
-  const int* cnt;
-};
-
-struct PreAllArgs {       // hoisted feature chains of every ReLU layer, forward and backward, in one launch
-  const float* pack_f;   // PackPreFwd
-  const float* pack_b;   // PackPreBwd
-  int L, do_bwd;
-  const float* lb[MAXL]; const float* ub[MAXL]; const float* dual[MAXL];
-  const float* z_pre[MAXL]; const float* z_post[MAXL]; const float* bias[MAXL];
-  float* Pf[MAXL]; float* Pb[MAXL];            // out: P' rows by node id
-  const int* list[MAXL];                       // ambiguous nodes of layer k
-  const int* cnt;                              // cnt[4k + 1] = number of ambiguous nodes of layer k
-  int N[MAXL], hw[MAXL];
-};
-
-// tile space: (do_bwd) the backward tiles of all layers, ceil(c_k/32) each, then the forward tiles of all layers: a
-// backward tile is 392 MFMAs, a forward tile 72, and there are only a few tiles per wave, so the strided dealing below
-// hands every wave its share of the long ones first
-//   forward  P'_f[g] = fc4[:, :64] . fc1_1(relu(fc1(feat7))) + bcb_f                           graph_conv.py:153-161,176-177
-//   backward P'_b[g] = bc4[:, :64] . bc2_1(relu(bc2([s, -d2 s, d1 s]))) + bcb_b,
-//            s = bc1_2(relu(bc1_1(relu(bc1(feat7')))))                                        graph_conv.py:273-293,344-345
-// for the ambiguous nodes g (everywhere else the relaxation term is multiplied by amb = 0, :161 / :293)
-// one tile (32 ambiguous nodes `list[32 t ..]` of layer k) of the hoisted chains; lds / lds_b: PackPreFwd / PackPreBwd in LDS
-__device__ __forceinline__ void pre_tile(const PreAllArgs& a, const float* lds, const float* lds_b, int k, bool bwd, const int* list, int count,
-                                         long t, int lane) {
-  const int h = lane >> 5, j = lane & 31;
-  {
-    const long idx = t * 32 + j;
-    const bool valid = idx < count;
-    const long gc = list[valid ? idx : 0];
-    const int n = (int)(gc % a.N[k]);
-    const float lb = a.lb[k][gc], ub = a.ub[k][gc];
-    const Ratio r = compute_ratio(lb, ub);
-    const float d1 = a.dual[k][gc * 3 + 1], d2 = a.dual[k][gc * 3 + 2];
-    const float c = a.bias[k][n / a.hw[k]];
-    const float zpre = a.z_pre[k][gc], zpost = a.z_post[k][gc];
-    float x[4];
-    if (!bwd) {
-      // feat7 = [beta, l, u, d1-d2, z_pre, z_post, c]: even features on half 0, odd on half 1
-      x[0] = h ? lb : r.beta;
-      x[1] = h ? (d1 - d2) : ub;
-      x[2] = h ? zpost : zpre;
-      x[3] = h ? 0.0f : c;
-      Frag H;
-      frag_bias(H, lds + PackPreFwd::B1, h);
-      gemm_small<4>(lds + PackPreFwd::W1, lane, H, x);
-      frag_relu(H);
-      Frag Pf;                                   // fc1_1 and the first half of fc4 are one folded 64x64 map
-      frag_bias(Pf, lds + PackPreFwd::B2, h);
-      gemm_w64<32>(lds + PackPreFwd::W2, lane, Pf, [&](int s) { return FRAG_AT(H, s); });
-      if (valid) frag_store_rows(Pf, a.Pf[k], gc, h);
-    } else {
-      // feat7' = [l, u, beta, -d2+d1, z_post, z_pre, c]
-      x[0] = h ? ub : lb;
-      x[1] = h ? (-d2 + d1) : r.beta;
-      x[2] = h ? zpre : zpost;
-      x[3] = h ? 0.0f : c;
-      Frag H1;
-      frag_bias(H1, lds_b + PackPreBwd::B1, h);
-      gemm_small<4>(lds_b + PackPreBwd::W1, lane, H1, x);
-      frag_relu(H1);
-      Frag H2;
-      frag_bias(H2, lds_b + PackPreBwd::B2, h);
-      gemm_w64<32>(lds_b + PackPreBwd::W2, lane, H2, [&](int s) { return FRAG_AT(H1, s); });
-      frag_relu(H2);
-      Frag S;
-      frag_bias(S, lds_b + PackPreBwd::B3, h);
-      gemm_w64<32>(lds_b + PackPreBwd::W3, lane, S, [&](int s) { return FRAG_AT(H2, s); });
-      // bc2 on [s, s*(-d2), s*d1]  (:287-291)
-      const float nd2 = -d2;
-      Frag H4;
-      frag_bias(H4, lds_b + PackPreBwd::B4, h);
-      gemm_w64<96>(lds_b + PackPreBwd::W4, lane, H4, [&](int s) {
-        const float v = FRAG_AT(S, s & 31);
-        return s < 32 ? v : (s < 64 ? v * nd2 : v * d1);
-      });
-      frag_relu(H4);
-      Frag Pb;                                   // bc2_1 and the first half of bc4 are one folded 64x64 map
-      frag_bias(Pb, lds_b + PackPreBwd::B5, h);
-      gemm_w64<32>(lds_b + PackPreBwd::W5, lane, Pb, [&](int s) { return FRAG_AT(H4, s); });
-      if (valid) frag_store_rows(Pb, a.Pb[k], gc, h);
-    }
-  }
-}
-
-__global__ __launch_bounds__(WG_MLP, 2) void k_pre(PreAllArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* lds_b = lds + PackPreFwd::FLOATS;
-  copy_to_lds(lds_b, a.pack_b, PackPreBwd::FLOATS);
-  stage_pack(lds, a.pack_f, PackPreFwd::FLOATS);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  long nhalf = 0;
-  for (int k = 0; k < a.L; ++k) nhalf += (long)((a.cnt[4 * k + 1] + 31) / 32);
-  const long ntiles = nhalf * (a.do_bwd ? 2 : 1);
-  for (long tile = (long)wave * gridDim.x + blockIdx.x; tile < ntiles; tile += (long)gridDim.x * WAVES_MLP) {
-    // which layer / direction (wave-uniform)
-    const bool bwd = a.do_bwd && tile < nhalf;
-    int k = 0, count = 0;
-    long t = (a.do_bwd && !bwd) ? tile - nhalf : tile;
-    for (; k < a.L; ++k) {
-      count = a.cnt[4 * k + 1];
-      const long tk = (count + 31) / 32;
-      if (t < tk) break;
-      t -= tk;
-    }
-    pre_tile(a, lds, lds_b, k, bwd, a.list[k], count, t, lane);
-  }
-}
-
-// Q = inp_b2[:, :64] . inp_b_1(relu(inp_b([l0, u0]))) + inp_b2.bias       graph_conv.py:380-384
-__global__ __launch_bounds__(WG_MLP, 2) void k_pre_inp(PreArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  stage_pack(lds, a.pack, PackPreInp::FLOATS);
-  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
-  for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < a.ntiles; tile += (long)gridDim.x * WAVES_MLP) {
-    const TileCtx tc = tile_decode(a.tm, tile, j, a.G);
-    const long gc = tc.sample * a.N + tc.n;
-    float x[1];
-    x[0] = h ? a.ub[gc] : a.lb[gc];
-    Frag H;
-    frag_bias(H, lds + PackPreInp::B1, h);
-    gemm_small<1>(lds + PackPreInp::W1, lane, H, x);
-    frag_relu(H);
-    Frag Q;                                  // inp_b_1 and the first half of inp_b2 are folded into one 64x64 map
-    frag_bias(Q, lds + PackPreInp::B2, h);
-    gemm_w64<32>(lds + PackPreInp::W2, lane, Q, [&](int s) { return FRAG_AT(H, s); });
-    frag_store_tiled(Q, a.P, tile, lane);
-  }
-}
-
-struct UpdArgs {
-  const float* pack;
-  const float *lb, *ub;     // pre-activation bounds of this layer, flat (B*N)
-  const float* nb;          // aggregated neighbour embeddings, rows by node id (B*N, 64)
-  const float* P;           // cached P' of the ambiguous nodes, rows by node id
-  float* mu;                // out: rows by node id
-  int* status;
-  const int *list0, *cnt0;  // nodes with r0 == r1 and no relaxation term (live, not ambiguous): short chain
-  const int *list1, *cnt1;  // general nodes (ambiguous; or the scored nodes for the last backward step of layer 1)
-  const float* sarr;        // DEFERRED: s[g] = sum over the edge of live_src (k_livesum), the bias term of the source rows' projection
-  // POST (layer 1, backward, an input-layer update follows): the consumer's 64x64 map inp_b2[:, 64:].bc4_1.W is applied here,
-  // on the ~3x fewer producer nodes: F = WP.E goes to `post` (rows by node id), and `mu` may be null (nothing else reads E)
-  float* post;
-  const float* wp;          // PackPostInp block (WPN or WPG), staged behind the update pack
-};
-
-// folded node update (gnnb_pack.h PackUpd):  E_g = relu(P'_g + Wcb.h) [r0 != 0],  h = relu(Wa.[r0 nb_g, r1 nb_g] + ba);
-// the last layer, mu_g = (Wd.E_g + bd) [r0 != 0], is deferred into the consumers of the rows ("deferred projection").
-//   kind 0 tiles (list0): r0 == r1, P' = bcb:  h = relu(WAS.(r0 nb_g) + ba)                      128 MFMAs per 32 nodes
-//   kind 1 tiles (list1): general                                                              192 MFMAs per 32 nodes
-// DEFERRED: nb is an aggregate G of rows whose own last layer Wp is deferred: Wa is pre-multiplied by Wp and the bias
-// term s.(r0 Wa0.bp + r1 Wa1.bp) enters as one small k-step.
-// forward:  fc3, fc3_2, fc4, fc4_2   graph_conv.py:169-181        backward: bc3, bc3_1, bc4, bc4_1   :331-349
-// The tile loop of the node update: tiles `tile`, `tile + stride`, ... of the lists in `a` (c0 / c1 entries); the weight
-// pack is staged into `lds` here (the first fetch overlaps it).
-// BF3: the 64x64 blocks of the short chain (WAS, WCB) and of POST run on the bf16 matrix rate with three-piece operands
-// (gemm_w64_bf3; LDS image PackUpdL3); the general chain's 128-wide first layer stays on the fp32 MFMA (6-11 % of the tiles).
-template <bool DEFERRED, bool POST = false, bool BF3 = false>
-__device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, int c0, int c1, long tile, long stride, int lane) {
-  constexpr int O_WA = BF3 ? (int)PackUpdL3::WA : (int)PackUpd::WA, O_BA = BF3 ? (int)PackUpdL3::BA : (int)PackUpd::BA;
-  constexpr int O_BCB = BF3 ? (int)PackUpdL3::BCB : (int)PackUpd::BCB, O_VAW = BF3 ? (int)PackUpdL3::VAW : (int)PackUpd::VAW;
-  constexpr int O_END = BF3 ? (int)PackUpdL3::FLOATS : (int)PackUpd::FLOATS;
-  const int h = lane >> 5, j = lane & 31;
-  // the general tiles (1.5-3x the work of a short-chain tile) come FIRST in the tile order, so they are never a SIMD's tail
-  const long n1 = (c1 + 31) / 32, n0 = (c0 + 31) / 32, ntiles = n0 + n1;
-  const float* bias_row = a.pack + PackUpd::BCBROW;
-  long gc = 0, gc_n = 0;
-  bool valid = false, valid_n = false;
-  float lb = 0.0f, ub = 0.0f, lb_n = 0.0f, ub_n = 0.0f, sw = 0.0f, sw_n = 0.0f;
-  Frag X, Xn;
-  constexpr bool deferred = DEFERRED;            // the aggregate is built from rows with a deferred projection (gnnb_pack.h)
-  auto fetch = [&](long tl, long& g_, bool& v_, float& l_, float& u_, float& s_, Frag& x_) {
-    const bool k0 = tl >= n1;
-    const long idx = (k0 ? tl - n1 : tl) * 32 + j;
-    v_ = idx < (k0 ? c0 : c1);
-    g_ = (k0 ? a.list0 : a.list1)[v_ ? idx : 0];
-    l_ = a.lb[g_];
-    u_ = a.ub[g_];
-    if (deferred) s_ = a.sarr[g_];
-    frag_load_rows(x_, a.nb, g_, h);
-  };
-  if (tile < ntiles) fetch(tile, gc, valid, lb, ub, sw, X);
-  constexpr bool post = POST;
-  if (post) copy_to_lds(lds + O_END, a.wp, BF3 ? 6144 : 4096);
-  if (BF3) {
-    copy_to_lds(lds + PackUpdL3::WA, a.pack + PackUpd::WA, 8192);
-    copy_to_lds(lds + PackUpdL3::BA, a.pack + PackUpd::BA, 64);
-    copy_to_lds(lds + PackUpdL3::BCB, a.pack + PackUpd::BCB, 64 + 64 + 128);          // BCB, BCBROW, VAW
-    stage_pack(lds + PackUpdL3::WAS3, a.pack + PackUpd::WAS3, 2 * 6144);               // WAS3, WCB3
-  } else stage_pack(lds, a.pack, PackUpd::FLOATS);
-  if (tile >= ntiles) return;
-  for (;;) {
-    const Ratio r = compute_ratio(lb, ub);
-    const bool kind0 = tile >= n1;             // wave-uniform
-    const long next = tile + stride;
-    const bool has_next = next < ntiles;
-    Frag H, H2;
-    frag_bias(H, lds + O_BA, h);
-    if (kind0) {
-      if (has_next) fetch(next, gc_n, valid_n, lb_n, ub_n, sw_n, Xn);
-      const float r0 = r.r0;
-      if (deferred) {                        // + s.(r0 Wa0.bp + r1 Wa1.bp), r0 == r1: one small k-step
-        const float x[1] = {r0 * sw};
-        gemm_small<1>(lds + O_VAW, lane, H, x);
-      }
-      if (BF3) gemm_w64_bf3<1>(lds + PackUpdL3::WAS3, lane, H, [&](int s) { return FRAG_AT(X, s) * r0; });
-      else gemm_w64<32>(lds + PackUpd::WAS, lane, H, [&](int s) { return FRAG_AT(X, s) * r0; });
-      frag_bias(H2, lds + O_BCB, h);
-    } else {
-      // nodes without a relaxation term (amb = 0) read the bias row instead of their (never written) P' row
-      frag_load_rowptr(H2, r.amb != 0.0f ? a.P + gc * 64 : bias_row, h);
-      if (has_next) fetch(next, gc_n, valid_n, lb_n, ub_n, sw_n, Xn);
-      const float r0 = r.r0, r1 = r.r1;
-      if (deferred) {
-        const float x[1] = {(h ? r1 : r0) * sw};
-        gemm_small<1>(lds + O_VAW, lane, H, x);
-      }
-      gemm_w64<64>(lds + O_WA, lane, H, [&](int s) { return FRAG_AT(X, s & 31) * (s < 32 ? r0 : r1); });
-    }
-    frag_relu(H);
-    if (BF3) gemm_w64_bf3<1>(lds + PackUpdL3::WCB3, lane, H2, [&](int s) { return FRAG_AT(H, s); });
-    else gemm_w64<32>(lds + PackUpd::WCB, lane, H2, [&](int s) { return FRAG_AT(H, s); });
-    frag_relu(H2);
-    if (r.live == 0.0f) {                      // a dead node's row is zero whatever its (possibly never written) aggregate held
-#pragma unroll
-      for (int R = 0; R < 32; ++R) FRAG_AT(H2, R) = 0.0f;
-    }
-    if (valid) {
-      if (frag_has_nan(H2)) atomicOr(a.status, 1);      // a NaN here is a NaN in mu = Wd.E + bd (:184-186, :339-341)
-      if (a.mu) frag_store_rows(H2, a.mu, gc, h);
-    }
-    if (post) {
-#pragma unroll
-      for (int R = 0; R < 32; ++R) FRAG_AT(H, R) = 0.0f;
-      if (BF3) gemm_w64_bf3<1>(lds + O_END, lane, H, [&](int s) { return FRAG_AT(H2, s); });
-      else gemm_w64<32>(lds + O_END, lane, H, [&](int s) { return FRAG_AT(H2, s); });
-      if (valid) frag_store_rows(H, a.post, gc, h);
-    }
-    if (!has_next) break;
-    tile = next; gc = gc_n; valid = valid_n; lb = lb_n; ub = ub_n; sw = sw_n;
-#pragma unroll
-    for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = FRAG_AT(Xn, R);
-  }
-}
-
-template <int WAVES, bool DEFERRED, bool POST = false, bool BF3 = false>
-__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_node_update(UpdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // Only a few tiles per wave, so balance matters more than locality (rows stream): tiles are dealt round-robin over
-  // the SIMDs of the whole grid (4 per workgroup), and the two waves that share a SIMD (w, w+4) take alternate rounds,
-  // so every SIMD's MFMA pipe gets floor or ceil of the average.  The inputs of the next tile (list entry -> bounds ->
-  // aggregate row) are fetched while this tile's MFMA chain runs; the first fetch overlaps the weight staging.
-  static_assert(WAVES % 4 == 0, "tile dealing assumes whole waves per SIMD");
-  const long stride = (long)gridDim.x * 4 * (WAVES / 4);
-  const long tile = (long)(wave >> 2) * gridDim.x * 4 + (long)blockIdx.x * 4 + (wave & 3);
-  node_update_loop<DEFERRED, POST, BF3>(a, lds, *a.cnt0, *a.cnt1, tile, stride, lane);
-}
-
-struct UpdInpArgs { const float* pack; const float* nb; const float* Q; const float* sarr; float* mu; long G, ntiles; };
-
-// E_0 = relu(Q + inp_b2[:, 64:] . nb); mu_0 = inp_b2_2(E_0) is deferred (gnnb_pack.h)         graph_conv.py:383-385
-__global__ __launch_bounds__(WG_MLP, 2) void k_input_update(UpdInpArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  stage_pack(lds, a.pack, PackUpdInp::FLOATS);
-  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
-  for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < a.ntiles; tile += (long)gridDim.x * WAVES_MLP) {
-    const long g = tile * 32 + j;
-    const bool valid = g < a.G;
-    const long gc = valid ? g : a.G - 1;
-    Frag X;
-    frag_load_rows(X, a.nb, gc, h);
-    Frag H;
-    frag_load_tiled(H, a.Q, tile, lane);
-    {                                          // bias term of the projection deferred in the rows of mu_1
-      const float x[1] = {h ? 0.0f : a.sarr[gc]};
-      gemm_small<1>(lds + PackUpdInp::VC, lane, H, x);
-    }
-#pragma unroll
-    for (int R = 0; R < 32; ++R) FRAG_AT(H, R) += FRAG_AT(X, R);      // the aggregate already went through inp_b2[:, 64:].bc4_1.W (PackPostInp)
-    frag_relu(H);
-    if (valid) frag_store_rows(H, a.mu, g, h);
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// fused message passing + node update for conv edges: the neighbour aggregate never leaves registers.
-//   nb^T (64 ch x 32 dst) = mu_src^T (64 ch x K window nodes) . Cmat (K x 32 dst)      on the MFMA,
-// A operand = source embedding rows straight from HBM/L2 (one coalesced 256-B row per lane half and k-step:
-// lane i holds channels 2i, 2i+1), B operand = the tap matrix of the tile shape, resident in LDS.
-// Forward edges: graph_conv.py:110-127; transposed edges + tap-count division: :299-318; input layer :361-372.
-// ------------------------------------------------------------------------------------------
-struct DGather {
-  const float* cmat;     // [NCG][K2][64]
-  const int2* koff;      // [2*K2]: {row offset relative to the window origin, wy | wx << 16}
-  const int* ttab;       // [TPS]: cg | by << 8 | bx << 20
-  const float* zero;     // 64 zero floats
-  int K2, ncg_k2, Hs, Ws, Ns, ystep, ybase, xstep, xbase, WY, WX, normalise, kh, kw, stride, pad;
-  int lanes;             // dst nodes per tile: 32 (32x32x2 MFMA, 2 window slots per k-step) or 16 (16x16x4, 4 slots per k-step)
-};
-
-#define GATHER_CH 8   // k-steps per prefetch chunk
-#define KOFF_PAD (2 * GATHER_CH)   // always-masked koff entries behind the table (one chunk is loaded past the end)
-// window slots in the koff / kvo tables, padding included (gnnb_pack.h fill_gather_tables)
-__host__ __device__ inline int gather_slots(int K2, int lanes) { return lanes == 32 ? 2 * K2 + KOFF_PAD : 4 * K2 + 2 * KOFF_PAD; }
-
-// Source rows are read with buffer loads: the descriptor covers exactly this sample's source layer (wave-uniform base
-// in SGPRs), the per-lane part is a 32-bit byte offset, and a masked window node / the k padding simply gets an
-// offset beyond the descriptor's range -- the hardware returns 0 for it without touching memory.  So nothing (no
-// select, no copy) is applied to a loaded value before its MFMA and there is no control flow around the loads, which is
-// what lets hipcc keep the next chunk in flight behind counted vmcnt waits (the koff table carries 16 always-masked
-// entries for the one chunk issued past the end).
-// INTERIOR = the whole window lies inside the source layer (wave-uniform; ~3/4 of the tiles): no bounds arithmetic.
-#define BUF_OOB 0x80000000u
-__device__ __forceinline__ float2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned voff) {
-  const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0);
-  return make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
-}
-
-template <bool INTERIOR>
-__device__ __forceinline__ void gather_tile(Frag& X, const float* cm, const int2* ko, const unsigned* kvo, int K2,
-                                            __amdgpu_buffer_rsrc_t rsrc, int j, int wy0, int wx0, int Hs, int Ws, int lane) {
-  const int h = lane >> 5;
-#pragma unroll
-  for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = 0.0f;
-  const int origin = wy0 * Ws + wx0;
-  const unsigned lane_off = 8u * (unsigned)j;        // channels 2j, 2j+1 of the row
-  const unsigned soff = (unsigned)origin * 256u;     // INTERIOR: wave-uniform window origin goes into the scalar offset
-  float2 cur[GATHER_CH], nxt[GATHER_CH];
-  auto load = [&](float2 (&dst)[GATHER_CH], int s0) {
-#pragma unroll
-    for (int u = 0; u < GATHER_CH; ++u) {
-      if (INTERIOR) {
-        // per k-step: one LDS read of the tile-invariant byte offset + one add; no bounds arithmetic.  k padding
-        // reads row `origin` (in range for an interior tile; its tap-matrix column is zero)
-        const unsigned vo = kvo[2 * (s0 + u) + h] + lane_off;
-        const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, vo, soff, 0);
-        dst[u] = make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
-      } else {
-        // one 64-bit LDS read per entry: with two 32-bit halves hipcc branches around the second one
-        const unsigned long long ev = reinterpret_cast<const unsigned long long*>(ko)[2 * (s0 + u) + h];
-        const int ex = (int)(unsigned)ev, ey = (int)(unsigned)(ev >> 32);
-        const int wy = wy0 + (ey & 0xffff), wx = wx0 + (ey >> 16);
-        unsigned o = (unsigned)(origin + ex) * 256u + lane_off;
-        o = ((unsigned)wy < (unsigned)Hs && (unsigned)wx < (unsigned)Ws) ? o : BUF_OOB;
-        dst[u] = buf_load2(rsrc, o);
-      }
-    }
-  };
-  auto mma = [&](const float2 (&v)[GATHER_CH], int s0) {
-#pragma unroll
-    for (int u = 0; u < GATHER_CH; ++u) {
-      const float b = cm[(s0 + u) * 64 + lane];
-      X.t[0] = mfma32(v[u].x, b, X.t[0]);
-      X.t[1] = mfma32(v[u].y, b, X.t[1]);
-    }
-  };
-  // Two register buffers in ping-pong (a rotating copy would have to wait for the data it copies); the sched_barriers
-  // pin "issue the next chunk's loads, THEN this chunk's MFMAs".
-  load(cur, 0);
-  const int npairs = K2 / (2 * GATHER_CH);
-  int s0 = 0;
-  for (int pr = 0; pr < npairs; ++pr, s0 += 2 * GATHER_CH) {
-    load(nxt, s0 + GATHER_CH);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(cur, s0);
-    __builtin_amdgcn_sched_barrier(0);
-    load(cur, s0 + 2 * GATHER_CH);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(nxt, s0 + GATHER_CH);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (K2 & GATHER_CH) mma(cur, s0);
-}
-
-__device__ __forceinline__ bool node_is_live(float lb, float ub);
-
-// Sparse variant (source = a ReLU layer): the rows of its dead nodes are exactly zero, so the tile first compacts the live,
-// in-range slots of its window into a per-wave LDS table {byte offset of the row, tap-matrix row} and walks only those.
-// `tab`: 2*K2 + 32 entries of this wave; slb / sub: bounds of the source layer of this sample.
-#ifndef GATHER_CHS
-#define GATHER_CHS 4    // k-steps per prefetch chunk of the sparse walk (8 live slots: 3 % faster than 16)
-#endif
-__device__ __forceinline__ void gather_tile_sparse(Frag& X, const float* cm, const int2* ko, uint2* tab, int K2, __amdgpu_buffer_rsrc_t rsrc,
-                                                   const float* slb, const float* sub, int j, int wy0, int wx0, int Hs, int Ws, int lane) {
-  const int h = lane >> 5;
-#pragma unroll
-  for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = 0.0f;
-  const int origin = wy0 * Ws + wx0;
-  int n = 0;
-  for (int base = 0; base < 2 * K2; base += 64) {
-    const int sl = base + lane;
-    const unsigned long long ev = reinterpret_cast<const unsigned long long*>(ko)[sl];
-    const int ex = (int)(unsigned)ev, ey = (int)(unsigned)(ev >> 32);
-    const int wy = wy0 + (ey & 0xffff), wx = wx0 + (ey >> 16);
-    const bool inb = sl < 2 * K2 && (unsigned)wy < (unsigned)Hs && (unsigned)wx < (unsigned)Ws;      // (table padding: 0x7fff, never in range)
-    const int row = inb ? origin + ex : 0;
-    const bool live = inb && node_is_live(slb[row], sub[row]);
-    const unsigned long long bal = __ballot(live);
-    if (live) tab[n + __popcll(bal & ((1ull << lane) - 1ull))] = make_uint2((unsigned)row * 256u, (unsigned)sl * 32u);
-    n += __popcll(bal);
-  }
-  constexpr int CS = 2 * GATHER_CHS;                     // slots per chunk
-  const int npad = (n + CS - 1) / CS * CS;
-  for (int q = n + lane; q < npad + CS; q += 64) tab[q] = make_uint2(BUF_OOB, 0u);       // out-of-range offset: the load returns 0
-  const int K2e = npad / 2;
-  const unsigned lane_off = 8u * (unsigned)j;
-  struct Chunk { float2 v[GATHER_CHS]; unsigned cr[GATHER_CHS]; };
-  Chunk cur, nxt;
-  auto load = [&](Chunk& c, int s0) {
-#pragma unroll
-    for (int u = 0; u < GATHER_CHS; ++u) {
-      const uint2 e = tab[2 * (s0 + u) + h];
-      c.v[u] = buf_load2(rsrc, e.x == BUF_OOB ? BUF_OOB : e.x + lane_off);
-      c.cr[u] = e.y;
-    }
-  };
-  auto mma = [&](const Chunk& c) {
-#pragma unroll
-    for (int u = 0; u < GATHER_CHS; ++u) {
-      const float b = cm[c.cr[u] + j];
-      X.t[0] = mfma32(c.v[u].x, b, X.t[0]);
-      X.t[1] = mfma32(c.v[u].y, b, X.t[1]);
-    }
-  };
-  load(cur, 0);
-  const int npairs = K2e / (2 * GATHER_CHS);
-  int s0 = 0;
-  for (int pr = 0; pr < npairs; ++pr, s0 += 2 * GATHER_CHS) {
-    load(nxt, s0 + GATHER_CHS);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(cur);
-    __builtin_amdgcn_sched_barrier(0);
-    load(cur, s0 + 2 * GATHER_CHS);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(nxt);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (K2e & GATHER_CHS) mma(cur);
-}
-
-// `sbase` = first row of this sample's source layer; must be built from wave-uniform values
-// tab != nullptr: sparse walk (slb / sub = bounds of the source layer of this sample)
-__device__ __forceinline__ void gather_dispatch(Frag& X, const float* cm, const int2* ko, const unsigned* kvo, const DGather& g,
-                                                const float* sbase, int j, int wy0, int wx0, int lane,
-                                                uint2* tab = nullptr, const float* slb = nullptr, const float* sub = nullptr) {
-  const int uy = __builtin_amdgcn_readfirstlane(wy0), ux = __builtin_amdgcn_readfirstlane(wx0);
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)sbase, 0, g.Ns * 256, 0x00020000);
-  if (tab) { gather_tile_sparse(X, cm, ko, tab, g.K2, rsrc, slb, sub, j, uy, ux, g.Hs, g.Ws, lane); return; }
-  if (uy >= 0 && ux >= 0 && uy + g.WY <= g.Hs && ux + g.WX <= g.Ws)
-    gather_tile<true>(X, cm, ko, kvo, g.K2, rsrc, j, uy, ux, g.Hs, g.Ws, lane);
-  else
-    gather_tile<false>(X, cm, ko, kvo, g.K2, rsrc, j, uy, ux, g.Hs, g.Ws, lane);
-}
-
-// Round 0, forward edge into ReLU layer 1: the source rows are the input embedding E0 = relu(inp_f([l0, x, u0]))
-// (graph_conv.py:90-95), 6 FMAs per row and channel pair -- cheaper to recompute per k-step under the MFMAs than to write
-// 201 MB of rows (k_embed) and read them back.  Same structure as gather_tile; the three scalars of a window node come
-// from buffer loads (out-of-range -> masked explicitly, since relu(bias) of a zero input is not zero).
-struct EmbedSrc { const float *lb, *x, *ub; const float* wb; };     // (B, Ns) scalars; inp_f weight (64 x 3) then bias (64)
-
-template <bool INTERIOR>
-__device__ __forceinline__ void gather_tile_embed(Frag& X, const float* cm, const int2* ko, const unsigned* kvo, int K2,
-                                                  __amdgpu_buffer_rsrc_t rl, __amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t ru,
-                                                  const float (&w)[2][3], const float (&bias)[2], int wy0, int wx0, int Hs, int Ws, int lane) {
-  const int h = lane >> 5;
-#pragma unroll
-  for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = 0.0f;
-  const int origin = wy0 * Ws + wx0;
-  const unsigned soff = (unsigned)origin * 4u;
-  struct Chunk { float l[GATHER_CH], x[GATHER_CH], u[GATHER_CH]; unsigned o[GATHER_CH]; };
-  Chunk cur, nxt;
-  auto load = [&](Chunk& c, int s0) {
-#pragma unroll
-    for (int q = 0; q < GATHER_CH; ++q) {
-      unsigned o;
-      if (INTERIOR) {
-        o = kvo[2 * (s0 + q) + h] >> 6;                 // byte offset of the window node in a float array
-        c.l[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rl, o, soff, 0));
-        c.x[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, o, soff, 0));
-        c.u[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, o, soff, 0));
-      } else {
-        const unsigned long long ev = reinterpret_cast<const unsigned long long*>(ko)[2 * (s0 + q) + h];
-        const int ex = (int)(unsigned)ev, ey = (int)(unsigned)(ev >> 32);
-        const int wy = wy0 + (ey & 0xffff), wx = wx0 + (ey >> 16);
-        o = (unsigned)(origin + ex) * 4u;
-        o = ((unsigned)wy < (unsigned)Hs && (unsigned)wx < (unsigned)Ws) ? o : BUF_OOB;
-        c.l[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rl, o, 0, 0));
-        c.x[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, 0));
-        c.u[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, o, 0, 0));
-      }
-      c.o[q] = o;
-    }
-  };
-  auto mma = [&](const Chunk& c, int s0) {
-#pragma unroll
-    for (int q = 0; q < GATHER_CH; ++q) {
-      const float b = cm[(s0 + q) * 64 + lane];
-      float e0 = relu_nan(fmaf(c.u[q], w[0][2], fmaf(c.x[q], w[0][1], fmaf(c.l[q], w[0][0], bias[0]))));
-      float e1 = relu_nan(fmaf(c.u[q], w[1][2], fmaf(c.x[q], w[1][1], fmaf(c.l[q], w[1][0], bias[1]))));
-      if (!INTERIOR) {
-        const bool v = c.o[q] != BUF_OOB;
-        e0 = v ? e0 : 0.0f;
-        e1 = v ? e1 : 0.0f;
-      }
-      X.t[0] = mfma32(e0, b, X.t[0]);
-      X.t[1] = mfma32(e1, b, X.t[1]);
-    }
-  };
-  load(cur, 0);
-  const int npairs = K2 / (2 * GATHER_CH);
-  int s0 = 0;
-  for (int pr = 0; pr < npairs; ++pr, s0 += 2 * GATHER_CH) {
-    load(nxt, s0 + GATHER_CH);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(cur, s0);
-    __builtin_amdgcn_sched_barrier(0);
-    load(cur, s0 + 2 * GATHER_CH);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(nxt, s0 + GATHER_CH);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (K2 & GATHER_CH) mma(cur, s0);
-}
-
-// ---- 16-node tiles on v_mfma_f32_16x16x4_f32 (forward conv edges: a third less window per node than 32-node tiles) ----
-// lane l = (i = l & 15, g = l >> 4).  k-step s covers window slots 4s .. 4s+3; lane (i, g) loads channels 4i .. 4i+3 of slot 4s+g
-// (one b128; the 16 lanes of a group read one whole 256-B row) and feeds channel 4i+t to the MFMA of M-tile t; the B operand
-// is the tap weight of (slot 4s+g, dst node i).  D of tile t: lane (j, g'), register r = channel 16g' + 4r + t of dst node j,
-// so a lane ends up with 16 consecutive channels of its node.
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-#define GATHER_CH16 4   // k-steps per prefetch chunk (16 window slots, as in the 32-lane variant)
-#ifndef EMBED_MFMA
-#define EMBED_MFMA 1    // round 0: the input embedding inside the first gather on the matrix pipe (0: VALU form)
-#endif
-
-template <bool INTERIOR>
-__device__ __forceinline__ void gather_tile16(f32x4 (&acc)[4], const float* cm, const int2* ko, const unsigned* kvo, int K2,
-                                              __amdgpu_buffer_rsrc_t rsrc, int wy0, int wx0, int Hs, int Ws, int lane) {
-  const int g = lane >> 4, i = lane & 15;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int origin = wy0 * Ws + wx0;
-  const unsigned lane_off = 16u * (unsigned)i;
-  const unsigned soff = (unsigned)origin * 256u;
-  f32x4 cur[GATHER_CH16], nxt[GATHER_CH16];
-  auto load = [&](f32x4 (&dst)[GATHER_CH16], int s0) {
-#pragma unroll
-    for (int u = 0; u < GATHER_CH16; ++u) {
-      if (INTERIOR) {
-        const unsigned vo = kvo[4 * (s0 + u) + g] + lane_off;
-        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, soff, 0);
-        dst[u] = f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
-      } else {
-        const unsigned long long ev = reinterpret_cast<const unsigned long long*>(ko)[4 * (s0 + u) + g];
-        const int ex = (int)(unsigned)ev, ey = (int)(unsigned)(ev >> 32);
-        const int wy = wy0 + (ey & 0xffff), wx = wx0 + (ey >> 16);
-        unsigned o = (unsigned)(origin + ex) * 256u + lane_off;
-        o = ((unsigned)wy < (unsigned)Hs && (unsigned)wx < (unsigned)Ws) ? o : BUF_OOB;
-        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, 0, 0);
-        dst[u] = f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
-      }
-    }
-  };
-  auto mma = [&](const f32x4 (&v)[GATHER_CH16], int s0) {
-#pragma unroll
-    for (int u = 0; u < GATHER_CH16; ++u) {
-      const float b = cm[(s0 + u) * 64 + lane];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = mfma16(v[u][t], b, acc[t]);
-    }
-  };
-  load(cur, 0);
-  const int npairs = K2 / (2 * GATHER_CH16);
-  int s0 = 0;
-  for (int pr = 0; pr < npairs; ++pr, s0 += 2 * GATHER_CH16) {
-    load(nxt, s0 + GATHER_CH16);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(cur, s0);
-    __builtin_amdgcn_sched_barrier(0);
-    load(cur, s0 + 2 * GATHER_CH16);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(nxt, s0 + GATHER_CH16);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (K2 & GATHER_CH16) mma(cur, s0);
-}
-
-// Sparse variant: the rows of dead source nodes are exactly zero, so a tile first compacts the live, in-range slots of its
-// window into a per-wave LDS table {byte offset of the row, tap-matrix row} and then walks only those (-35..45 % k-steps
-// behind a ReLU layer).  `tab`: 4*K2 + 32 entries of this wave; slb / sub: bounds of the source layer of this sample.
-#ifndef GATHER_CHS16
-#define GATHER_CHS16 4
-#endif
-__device__ __forceinline__ void gather_tile16_sparse(f32x4 (&acc)[4], const float* cm, const int2* ko, uint2* tab, int K2,
-                                                     __amdgpu_buffer_rsrc_t rsrc, const float* slb, const float* sub, int wy0, int wx0,
-                                                     int Hs, int Ws, int lane) {
-  const int g = lane >> 4, i = lane & 15;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int origin = wy0 * Ws + wx0;
-  int n = 0;
-  for (int base = 0; base < 4 * K2; base += 64) {
-    const int sl = base + lane;
-    const unsigned long long ev = reinterpret_cast<const unsigned long long*>(ko)[sl];
-    const int ex = (int)(unsigned)ev, ey = (int)(unsigned)(ev >> 32);
-    const int wy = wy0 + (ey & 0xffff), wx = wx0 + (ey >> 16);
-    const bool inb = sl < 4 * K2 && (unsigned)wy < (unsigned)Hs && (unsigned)wx < (unsigned)Ws;      // (table padding: 0x7fff, never in range)
-    const int row = inb ? origin + ex : 0;
-    const bool live = inb && node_is_live(slb[row], sub[row]);
-    const unsigned long long bal = __ballot(live);
-    if (live) tab[n + __popcll(bal & ((1ull << lane) - 1ull))] = make_uint2((unsigned)row * 256u, (unsigned)sl * 16u);
-    n += __popcll(bal);
-  }
-  constexpr int CS = 4 * GATHER_CHS16;
-  const int npad = (n + CS - 1) / CS * CS;
-  for (int q = n + lane; q < npad + CS; q += 64) tab[q] = make_uint2(BUF_OOB, 0u);       // out-of-range offset: the load returns 0
-  const int K2e = npad / 4;
-  const unsigned lane_off = 16u * (unsigned)i;
-  struct Chunk { f32x4 v[GATHER_CHS16]; unsigned cr[GATHER_CHS16]; };
-  Chunk cur, nxt;
-  auto load = [&](Chunk& c, int s0) {
-#pragma unroll
-    for (int u = 0; u < GATHER_CHS16; ++u) {
-      const uint2 e = tab[4 * (s0 + u) + g];
-      const unsigned o = e.x == BUF_OOB ? BUF_OOB : e.x + lane_off;
-      const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, 0, 0);
-      c.v[u] = f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
-      c.cr[u] = e.y;
-    }
-  };
-  auto mma = [&](const Chunk& c, int) {
-#pragma unroll
-    for (int u = 0; u < GATHER_CHS16; ++u) {
-      const float b = cm[c.cr[u] + i];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = mfma16(c.v[u][t], b, acc[t]);
-    }
-  };
-  load(cur, 0);
-  const int npairs = K2e / (2 * GATHER_CHS16);
-  int s0 = 0;
-  for (int pr = 0; pr < npairs; ++pr, s0 += 2 * GATHER_CHS16) {
-    load(nxt, s0 + GATHER_CHS16);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(cur, s0);
-    __builtin_amdgcn_sched_barrier(0);
-    load(cur, s0 + 2 * GATHER_CHS16);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(nxt, s0 + GATHER_CHS16);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (K2e & GATHER_CHS16) mma(cur, s0);
-}
-
-// the embedding variant (round 0, first edge): the four channels of a slot are computed from its three input scalars
-template <bool INTERIOR>
-__device__ __forceinline__ void gather_tile16_embed(f32x4 (&acc)[4], const float* cm, const int2* ko, const unsigned* kvo, int K2,
-                                                    __amdgpu_buffer_rsrc_t rl, __amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t ru,
-                                                    const float (&w)[4][3], const float (&bias)[4], int wy0, int wx0, int Hs, int Ws, int lane) {
-  const int g = lane >> 4;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int origin = wy0 * Ws + wx0;
-  const unsigned soff = (unsigned)origin * 4u;
-  struct Chunk { float l[GATHER_CH16], x[GATHER_CH16], u[GATHER_CH16]; unsigned o[GATHER_CH16]; };
-  Chunk cur, nxt;
-  auto load = [&](Chunk& c, int s0) {
-#pragma unroll
-    for (int q = 0; q < GATHER_CH16; ++q) {
-      unsigned o;
-      if (INTERIOR) {
-        o = kvo[4 * (s0 + q) + g] >> 6;                 // byte offset of the window node in a float array
-        c.l[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rl, o, soff, 0));
-        c.x[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, o, soff, 0));
-        c.u[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, o, soff, 0));
-      } else {
-        const unsigned long long ev = reinterpret_cast<const unsigned long long*>(ko)[4 * (s0 + q) + g];
-        const int ex = (int)(unsigned)ev, ey = (int)(unsigned)(ev >> 32);
-        const int wy = wy0 + (ey & 0xffff), wx = wx0 + (ey >> 16);
-        o = (unsigned)(origin + ex) * 4u;
-        o = ((unsigned)wy < (unsigned)Hs && (unsigned)wx < (unsigned)Ws) ? o : BUF_OOB;
-        c.l[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rl, o, 0, 0));
-        c.x[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, 0));
-        c.u[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, o, 0, 0));
-      }
-      c.o[q] = o;
-    }
-  };
-  auto mma = [&](const Chunk& c, int s0) {
-#pragma unroll
-    for (int q = 0; q < GATHER_CH16; ++q) {
-      const float b = cm[(s0 + q) * 64 + lane];
-      const bool v = INTERIOR || c.o[q] != BUF_OOB;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        float e = relu_nan(fmaf(c.u[q], w[t][2], fmaf(c.x[q], w[t][1], fmaf(c.l[q], w[t][0], bias[t]))));
-        e = v ? e : 0.0f;
-        acc[t] = mfma16(e, b, acc[t]);
-      }
-    }
-  };
-  load(cur, 0);
-  const int npairs = K2 / (2 * GATHER_CH16);
-  int s0 = 0;
-  for (int pr = 0; pr < npairs; ++pr, s0 += 2 * GATHER_CH16) {
-    load(nxt, s0 + GATHER_CH16);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(cur, s0);
-    __builtin_amdgcn_sched_barrier(0);
-    load(cur, s0 + 2 * GATHER_CH16);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(nxt, s0 + GATHER_CH16);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (K2 & GATHER_CH16) mma(cur, s0);
-}
-
-// number of kernel taps that touch dst position t along one axis (the reference's `freq`, graph_conv.py:306-311)
-__device__ __forceinline__ int tap_count(int t, int w0, int WN, int Hs, int k, int stride, int pad) {
-  int n = 0;
-  for (int w = 0; w < WN; ++w) {
-    const int o = w0 + w;
-    const int kk = t + pad - o * stride;
-    n += ((unsigned)o < (unsigned)Hs && kk >= 0 && kk < k) ? 1 : 0;
-  }
-  return n;
-}
-
-__device__ __forceinline__ void stage_gather(float* lds_cm, int2* lds_ko, int* lds_tt, unsigned* lds_kvo, const DGather& g, int TPS) {
-  copy_to_lds(lds_cm, g.cmat, g.ncg_k2 * 64);
-  for (int i = threadIdx.x; i < gather_slots(g.K2, g.lanes); i += blockDim.x) {
-    const int2 e = g.koff[i];
-    lds_ko[i] = e;
-    lds_kvo[i] = (e.y & 0xffff) == 0x7fff ? 0u : (unsigned)e.x * 256u;      // byte offset of window node i from the window origin
-  }
-  for (int i = threadIdx.x; i < TPS; i += blockDim.x) lds_tt[i] = g.ttab[i];
-}
-
-// [r0 != 0] without the division: r0 = u+/(u+ - l-) is zero iff u+ == 0 and l- != 0 (0/0 is NaN, and NaN != 0)
-__device__ __forceinline__ bool node_is_live(float lb, float ub) {
-  const float lower_temp = lb - relu_nan(lb);
-  const float upper_temp = relu_nan(ub);
-  return !(upper_temp == 0.0f) || lower_temp == 0.0f;
-}
-
-// rows of the gathered fragment (gather channel map) -> row-major (.., 64): lane (j,h) owns channels [16q+8h, 16q+8h+8)
-__device__ __forceinline__ void frag_store_rows_gathered(const Frag& x, float* base, long row, int h) {
-  f32x4* p = reinterpret_cast<f32x4*>(base + row * 64 + 8 * h);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    f32x4 v0, v1;
-    v0[0] = x.t[0][4 * q + 0]; v0[1] = x.t[1][4 * q + 0]; v0[2] = x.t[0][4 * q + 1]; v0[3] = x.t[1][4 * q + 1];
-    v1[0] = x.t[0][4 * q + 2]; v1[1] = x.t[1][4 * q + 2]; v1[2] = x.t[0][4 * q + 3]; v1[3] = x.t[1][4 * q + 3];
-    p[4 * q] = v0;
-    p[4 * q + 1] = v1;
-  }
-}
-
-struct GArgs {
-  const float *lb, *ub;     // bounds of the dst layer, flat (B*N)
-  const float* mask;        // (B, R) BaB mask, used when `need_scored`
-  const float* mu_src;      // (B, Ns, 64)
-  float* nb;                // out: rows by node id (B*N, 64), written for the lanes that need it
-  long ntiles;
-  int need_scored, R, off;  // 0: every live node needs its aggregate; 1: only the scored nodes (last backward step)
-  DTileMap tm;
-  DGather g;
-  EmbedSrc es;              // EMBED: the source rows are computed from the input scalars (mu_src unused)
-  const float *src_lb, *src_ub;   // SPARSE: bounds of the source layer (B, Ns): the rows of its dead nodes are zero and skipped
-};
-
-// EMBED: inp_f rows of this lane's channels 2j, 2j+1
-struct EmbedLane { float w[2][3], b[2]; };
-template <bool EMBED>
-__device__ __forceinline__ EmbedLane embed_lane(const GArgs& a, int j) {
-  EmbedLane e{};
-  if (EMBED) {
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      e.b[c] = a.es.wb[192 + 2 * j + c];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) e.w[c][i] = a.es.wb[(2 * j + c) * 3 + i];
-    }
-  }
-  return e;
-}
-
-// one tile of phase A: the aggregate rows of the tile's dst nodes that will be updated
-template <bool EMBED, bool SPARSE>
-__device__ __forceinline__ void gather_process_tile(const GArgs& a, const TileCtx& tc, int sample, const float* lds_cm, const int2* lds_ko,
-                                                    const unsigned* lds_kvo, uint2* tab, const EmbedLane& el, int lane) {
-  const int h = lane >> 5, j = lane & 31;
-  const long gc = tc.sample * a.tm.N + tc.n;
-  bool need;
-  if (a.need_scored) need = tc.valid && a.mask[tc.sample * a.R + a.off + tc.n] != 0.0f;
-  else need = tc.valid && node_is_live(a.lb[gc], a.ub[gc]);    // (one load of k_classify's live flag instead: measured 1.7 % slower)
-  if (!__any(need)) return;
-  const int wy0 = tc.by * a.g.ystep + a.g.ybase, wx0 = tc.bx * a.g.xstep + a.g.xbase;
-  Frag X;
-  if (EMBED) {
-    const int uy = __builtin_amdgcn_readfirstlane(wy0), ux = __builtin_amdgcn_readfirstlane(wx0);
-    const long sb = (long)sample * a.g.Ns;
-    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(a.es.lb + sb), 0, a.g.Ns * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.es.x + sb), 0, a.g.Ns * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)(a.es.ub + sb), 0, a.g.Ns * 4, 0x00020000);
-    const float* cmt = lds_cm + tc.cg * a.g.K2 * 64;
-    if (uy >= 0 && ux >= 0 && uy + a.g.WY <= a.g.Hs && ux + a.g.WX <= a.g.Ws)
-      gather_tile_embed<true>(X, cmt, lds_ko, lds_kvo, a.g.K2, rl, rx, ru, el.w, el.b, uy, ux, a.g.Hs, a.g.Ws, lane);
-    else
-      gather_tile_embed<false>(X, cmt, lds_ko, lds_kvo, a.g.K2, rl, rx, ru, el.w, el.b, uy, ux, a.g.Hs, a.g.Ws, lane);
-  } else {
-    if (SPARSE)
-      gather_dispatch(X, lds_cm + tc.cg * a.g.K2 * 64, lds_ko, lds_kvo, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane, tab,
-                      a.src_lb + (long)sample * a.g.Ns, a.src_ub + (long)sample * a.g.Ns);
-    else
-      gather_dispatch(X, lds_cm + tc.cg * a.g.K2 * 64, lds_ko, lds_kvo, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane);
-  }
-  if (a.g.normalise) {
-    const int ny = tap_count(tc.y, wy0, a.g.WY, a.g.Hs, a.g.kh, a.g.stride, a.g.pad);
-    const int nx = tap_count(tc.x, wx0, a.g.WX, a.g.Ws, a.g.kw, a.g.stride, a.g.pad);
-    const int f = tc.valid ? ny * nx : 1;
-    const float freq = (float)f;
-    if (__all((f & (f - 1)) == 0)) {         // power of two: x * (1/f) is exactly x / f
-      const float inv = 1.0f / freq;
-#pragma unroll
-      for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = FRAG_AT(X, R) * inv;
-    } else {
-#pragma unroll
-      for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = FRAG_AT(X, R) / freq;
-    }
-  }
-  if (need) frag_store_rows_gathered(X, a.nb, gc, h);
-}
-
-// The embedding on the matrix pipe: E0 = relu(inp_f [l, x, u] + b) is itself a K = 4 product ([l, x, u, 1] against [W | b]),
-// and the result layout of v_mfma_f32_16x16x4_f32 (lane (i, g), register r = row 4g + r, column i) is the A-operand layout
-// of the tap MFMA (lane (i, g) = channel of row i at the slot of k-index g) if the embedding MFMA's row 4g + r is the window
-// slot that k-step 4 grp + r wants at k-index g, i.e. slot 16 grp + 4 r + g.  So per group of 4 k-steps: one scalar load per
-// lane (lane group 0 / 1 / 2 reads l / x / u of its row's slot, group 3 supplies the 1 of the bias), 4 embedding MFMAs (one
-// per 16-channel tile), 16 v_max, 16 tap MFMAs -- instead of 64 FMAs + 16 v_max + 12 loads per lane.  An out-of-range slot
-// feeds zeros (including its "1"), so its embedding is relu(0) = 0.
-__device__ __forceinline__ void gather_tile16_embed_mfma(f32x4 (&acc)[4], const float* cm, const int2* ko, int K2, __amdgpu_buffer_rsrc_t rl,
-                                                         __amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t ru, const float (&bw)[4],
-                                                         int wy0, int wx0, int Hs, int Ws, int lane) {
-  const int m = lane & 15, kq = lane >> 4;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int origin = wy0 * Ws + wx0;
-  const int sl = 4 * (m & 3) + (m >> 2);            // slot of embedding row m inside a group of 16
-  auto load = [&](int grp) -> float {
-    const unsigned long long ev = reinterpret_cast<const unsigned long long*>(ko)[16 * grp + sl];
-    const int ex = (int)(unsigned)ev, ey = (int)(unsigned)(ev >> 32);
-    const int wy = wy0 + (ey & 0xffff), wx = wx0 + (ey >> 16);
-    const bool inb = (unsigned)wy < (unsigned)Hs && (unsigned)wx < (unsigned)Ws;      // (table padding: 0x7fff, never in range)
-    const unsigned o = inb ? (unsigned)(origin + ex) * 4u : BUF_OOB;
-    const float vl = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rl, o, 0, 0));
-    const float vx = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, 0));
-    const float vu = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, o, 0, 0));
-    return kq == 0 ? vl : kq == 1 ? vx : kq == 2 ? vu : (inb ? 1.0f : 0.0f);
-  };
-  const int ngrp = K2 / 4;
-  float ain = load(0);
-  for (int grp = 0; grp < ngrp; ++grp) {
-    const float cur = ain;
-    if (grp + 1 < ngrp) ain = load(grp + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    f32x4 e[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      e[t] = mfma16(cur, bw[t], f32x4{0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-      for (int r = 0; r < 4; ++r) e[t][r] = relu_nan(e[t][r]);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float b = cm[(4 * grp + r) * 64 + lane];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = mfma16(e[t][r], b, acc[t]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// one 16-node tile of phase A (forward edges only: no tap-count division)
-template <bool EMBED, bool SPARSE>
-__device__ __forceinline__ void gather_process_tile16(const GArgs& a, const TileCtx& tc, int sample, const float* lds_cm, const int2* lds_ko,
-                                                      const unsigned* lds_kvo, uint2* tab, const float (&ew)[4][3], const float (&eb)[4], int lane) {
-  const int gq = lane >> 4;
-  const long gc = tc.sample * a.tm.N + tc.n;
-  bool need;
-  if (a.need_scored) need = tc.valid && a.mask[tc.sample * a.R + a.off + tc.n] != 0.0f;
-  else need = tc.valid && node_is_live(a.lb[gc], a.ub[gc]);
-  if (!__any(need)) return;
-  const int wy0 = tc.by * a.g.ystep + a.g.ybase, wx0 = tc.bx * a.g.xstep + a.g.xbase;
-  const int uy = __builtin_amdgcn_readfirstlane(wy0), ux = __builtin_amdgcn_readfirstlane(wx0);
-  const bool interior = uy >= 0 && ux >= 0 && uy + a.g.WY <= a.g.Hs && ux + a.g.WX <= a.g.Ws;
-  const float* cmt = lds_cm + tc.cg * a.g.K2 * 64;
-  f32x4 acc[4];
-  if (EMBED) {
-    const long sb = (long)sample * a.g.Ns;
-    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(a.es.lb + sb), 0, a.g.Ns * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.es.x + sb), 0, a.g.Ns * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)(a.es.ub + sb), 0, a.g.Ns * 4, 0x00020000);
-    if (EMBED_MFMA) {
-      // B operand of the embedding MFMA of channel tile t: lane (n, k) = inp_f weight k of channel 4n + t, k = 3: its bias
-      const int n = lane & 15, k = lane >> 4;
-      float bw[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) bw[t] = k < 3 ? a.es.wb[(4 * n + t) * 3 + k] : a.es.wb[192 + 4 * n + t];
-      gather_tile16_embed_mfma(acc, cmt, lds_ko, a.g.K2, rl, rx, ru, bw, uy, ux, a.g.Hs, a.g.Ws, lane);
-    } else if (interior) gather_tile16_embed<true>(acc, cmt, lds_ko, lds_kvo, a.g.K2, rl, rx, ru, ew, eb, uy, ux, a.g.Hs, a.g.Ws, lane);
-    else gather_tile16_embed<false>(acc, cmt, lds_ko, lds_kvo, a.g.K2, rl, rx, ru, ew, eb, uy, ux, a.g.Hs, a.g.Ws, lane);
-  } else {
-    const float* sbase = a.mu_src + (long)sample * a.g.Ns * 64;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)sbase, 0, a.g.Ns * 256, 0x00020000);
-    if (SPARSE) {
-      const long sb = (long)sample * a.g.Ns;
-      gather_tile16_sparse(acc, cmt, lds_ko, tab, a.g.K2, rsrc, a.src_lb + sb, a.src_ub + sb, uy, ux, a.g.Hs, a.g.Ws, lane);
-    } else if (interior) gather_tile16<true>(acc, cmt, lds_ko, lds_kvo, a.g.K2, rsrc, uy, ux, a.g.Hs, a.g.Ws, lane);
-    else gather_tile16<false>(acc, cmt, lds_ko, lds_kvo, a.g.K2, rsrc, uy, ux, a.g.Hs, a.g.Ws, lane);
-  }
-  if (need) {                                  // lane (j, g'): channels 16g' + 4r + t of its node
-    f32x4* p = reinterpret_cast<f32x4*>(a.nb + gc * 64 + 16 * gq);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) p[r] = f32x4{acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-  }
-}
-
-// LDS image of a gather's tables: tap matrix, window offsets (two forms), tile table
-struct GatherLds { float* cm; int2* ko; int* tt; unsigned* kvo; };
-__device__ __forceinline__ GatherLds gather_lds(float* base, const DGather& g, int TPS) {
-  GatherLds l;
-  l.cm = base;
-  l.ko = reinterpret_cast<int2*>(l.cm + g.ncg_k2 * 64);
-  l.tt = reinterpret_cast<int*>(l.ko + gather_slots(g.K2, g.lanes));
-  l.kvo = reinterpret_cast<unsigned*>(l.tt + ((TPS + 3) & ~3));
-  return l;
-}
-
-// phase A of a half-pass over a conv edge: nb[g] = sum over the window for the dst nodes that will be updated
-template <bool EMBED, bool SPARSE = false>
-__global__ __launch_bounds__(WG_MLP, 2) void k_gather(GArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const GatherLds gl = gather_lds(lds, a.g, a.tm.TPS);
-  stage_gather(gl.cm, gl.ko, gl.tt, gl.kvo, a.g, a.tm.TPS);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, j = lane & 31, wave = threadIdx.x >> 6;
-  uint2* tab = reinterpret_cast<uint2*>(gl.kvo + ((gather_slots(a.g.K2, 32) + 1) & ~1)) + wave * (2 * a.g.K2 + 32);      // SPARSE
-  const EmbedLane el = embed_lane<EMBED>(a, j);
-  long t0, t1;
-  tile_range(a.ntiles, WAVES_MLP, t0, t1);
-  long tile = t0 + wave;
-  if (tile >= t1) return;
-  // tile, sample and t are wave-uniform by construction; make them provably so (scalar registers, scalar base address)
-  int sample = __builtin_amdgcn_readfirstlane((int)(tile / a.tm.TPS));
-  int t = __builtin_amdgcn_readfirstlane((int)(tile - (long)sample * a.tm.TPS));
-  for (; tile < t1; tile += WAVES_MLP, t += WAVES_MLP) {
-    while (t >= a.tm.TPS) { t -= a.tm.TPS; ++sample; }
-    const TileCtx tc = block_decode(a.tm, gl.tt, sample, t, j);
-    gather_process_tile<EMBED, SPARSE>(a, tc, sample, gl.cm, gl.ko, gl.kvo, tab, el, lane);
-  }
-}
-
-// the 16-node-tile form of k_gather (forward conv edges)
-// (4 waves per SIMD: the embedding variant sits right at 128 VGPRs, and at 130 it loses a quarter of its waves and 10 %)
-template <bool EMBED, bool SPARSE = false>
-__global__ __launch_bounds__(WG_MLP, 4) void k_gather16(GArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const GatherLds gl = gather_lds(lds, a.g, a.tm.TPS);
-  stage_gather(gl.cm, gl.ko, gl.tt, gl.kvo, a.g, a.tm.TPS);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, j = lane & 15, wave = threadIdx.x >> 6;
-  // SPARSE: per-wave table of the live window slots, behind the shared tables
-  uint2* tab = reinterpret_cast<uint2*>(gl.kvo + ((gather_slots(a.g.K2, 16) + 1) & ~1)) + wave * (4 * a.g.K2 + 32);
-  float ew[4][3] = {}, eb[4] = {};               // EMBED: inp_f rows of this lane's channels 4i .. 4i+3
-  if (EMBED) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      eb[c] = a.es.wb[192 + 4 * j + c];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) ew[c][q] = a.es.wb[(4 * j + c) * 3 + q];
-    }
-  }
-  // Rounds of 8 tiles (one per wave) are dealt ROUND-ROBIN over the workgroups, in the XCD-grouped order of tile_range:
-  // at any moment the 64 workgroups of an XCD then work on 8 neighbouring rounds each side by side, i.e. on 8-16 samples
-  // whose source rows (~4 MB) stay in that XCD's L2 -- with one contiguous chunk per workgroup they covered 32 samples,
-  // 16 MB, and every window row was fetched from HBM 1.7 times.
-  int wg = blockIdx.x;
-  const int nwg = gridDim.x;
-  if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
-  const long nrounds = (a.ntiles + WAVES_MLP - 1) / WAVES_MLP;
-  for (long r = wg; r < nrounds; r += nwg) {
-    const long tile = r * WAVES_MLP + wave;
-    if (tile >= a.ntiles) break;
-    const int sample = __builtin_amdgcn_readfirstlane((int)(tile / a.tm.TPS));
-    const int t = __builtin_amdgcn_readfirstlane((int)(tile - (long)sample * a.tm.TPS));
-    const TileCtx tc = block_decode(a.tm, gl.tt, sample, t, j);
-    gather_process_tile16<EMBED, SPARSE>(a, tc, sample, gl.cm, gl.ko, gl.kvo, tab, ew, eb, lane);
-  }
-}
-
-struct GIArgs {
-  const float* pack_pre;    // PackPreInp
-  const float* pack;        // PackUpdInp (gather variant)
-  const float *lb, *ub;     // input bounds, flat (B*N0)
-  const float* mu_src; const float* sarr; float* mu; long ntiles; DTileMap tm; DGather g;
-  const float *src_lb, *src_ub;     // SPARSE: bounds of ReLU layer 1 (the rows of its dead nodes are zero and skipped)
-};
-
-// input layer: E_0 = relu(Q + inp_b2[:, 64:] . (A_1^T mu_1)),  Q = inp_b2[:, :64] . inp_b_1(relu(inp_b([l0,u0]))) + b;
-// mu_0 = inp_b2_2(E_0) is deferred into the next round's forward update of ReLU layer 1 (gnnb_pack.h).
-// graph_conv.py:361-385; the aggregate, the feature chain and the update stay in registers.
-// one tile of the fused input-layer update; lds_upd / lds_pre: PackUpdInp / PackPreInp in LDS
-template <bool SPARSE, bool BF3>
-__device__ __forceinline__ void input_update_tile(const GIArgs& a, const TileCtx& tc, int sample, const float* lds_upd, const float* lds_pre,
-                                                  const GatherLds& gl, uint2* tab, int lane) {
-  const int h = lane >> 5, j = lane & 31;
-  if (!__any(tc.valid)) return;
-  const long gc = tc.sample * a.tm.N + tc.n;
-  const int wy0 = tc.by * a.g.ystep + a.g.ybase, wx0 = tc.bx * a.g.xstep + a.g.xbase;
-  Frag X;
-  if (SPARSE)
-    gather_dispatch(X, gl.cm + tc.cg * a.g.K2 * 64, gl.ko, gl.kvo, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane, tab,
-                    a.src_lb + (long)sample * a.g.Ns, a.src_ub + (long)sample * a.g.Ns);
-  else
-    gather_dispatch(X, gl.cm + tc.cg * a.g.K2 * 64, gl.ko, gl.kvo, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane);
-  float x[1];
-  x[0] = h ? a.ub[gc] : a.lb[gc];
-  Frag H0;
-  frag_bias(H0, lds_pre + PackPreInp::B1, h);
-  gemm_small<1>(lds_pre + PackPreInp::W1, lane, H0, x);
-  frag_relu(H0);
-  Frag H;                                  // inp_b_1 and the first half of inp_b2 are folded into one 64x64 map
-  frag_bias(H, lds_pre + PackPreInp::B2, h);
-  if (BF3) gemm_w64_bf3<1>(lds_pre + PackPreInp::W23, lane, H, [&](int s) { return FRAG_AT(H0, s); });
-  else gemm_w64<32>(lds_pre + PackPreInp::W2, lane, H, [&](int s) { return FRAG_AT(H0, s); });
-  {                                          // bias term of the projection deferred in the rows of mu_1
-    const float xs[1] = {h ? 0.0f : a.sarr[gc]};
-    gemm_small<1>(lds_upd + PackUpdInp::VC, lane, H, xs);
-  }
-  // the aggregate already went through inp_b2[:, 64:].bc4_1.W on the producer side, with its rows permuted to this
-  // fragment layout (PackPostInp::WPG): register for register
-#pragma unroll
-  for (int R = 0; R < 32; ++R) FRAG_AT(H, R) += FRAG_AT(X, R);
-  frag_relu(H);
-  if (tc.valid) frag_store_rows(H, a.mu, gc, h);
-}
-
-template <bool SPARSE, bool BF3>
-__global__ __launch_bounds__(WG_MLP, 2) void k_gather_input_update(GIArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* lds_pre = lds + PackUpdInp::FLOATS;
-  const GatherLds gl = gather_lds(lds_pre + PackPreInp::FLOATS, a.g, a.tm.TPS);
-  stage_gather(gl.cm, gl.ko, gl.tt, gl.kvo, a.g, a.tm.TPS);
-  copy_to_lds(lds_pre, a.pack_pre, PackPreInp::FLOATS);
-  stage_pack(lds, a.pack, PackUpdInp::FLOATS);
-  const int lane = threadIdx.x & 63, j = lane & 31, wave = threadIdx.x >> 6;
-  uint2* tab = reinterpret_cast<uint2*>(gl.kvo + ((gather_slots(a.g.K2, 32) + 1) & ~1)) + wave * (2 * a.g.K2 + 32);      // SPARSE
-  long t0, t1;
-  tile_range(a.ntiles, WAVES_MLP, t0, t1);
-  long tile = t0 + wave;
-  if (tile >= t1) return;
-  // tile, sample and t are wave-uniform by construction; make them provably so (scalar registers, scalar base address)
-  int sample = __builtin_amdgcn_readfirstlane((int)(tile / a.tm.TPS));
-  int t = __builtin_amdgcn_readfirstlane((int)(tile - (long)sample * a.tm.TPS));
-  for (; tile < t1; tile += WAVES_MLP, t += WAVES_MLP) {
-    while (t >= a.tm.TPS) { t -= a.tm.TPS; ++sample; }
-    const TileCtx tc = block_decode(a.tm, gl.tt, sample, t, j);
-    input_update_tile<SPARSE, BF3>(a, tc, sample, lds, lds_pre, gl, tab, lane);
-  }
-}
-
-struct ScoreArgs {        // every ReLU layer in one launch
-  const float* pack; float* scores;
-  int L, R;
-  const float* mu[MAXL]; const int* list[MAXL];
-  const float* lb[MAXL]; const float* ub[MAXL];
-  const int* cnt;         // cnt[4k + 2] = number of scored nodes of layer k
-  int N[MAXL], off[MAXL]; // nodes per sample in layer k, offset of layer k in the flat ReLU index
-};
-
-// score = fscore(relu(fnode(mu_g))) for the nodes g whose BaB mask is -1 (the rest stays -inf)    graph_conv.py:445-450
-// the rows hold E_g with mu_g = (Wp.E_g + bp).live: fnode is pre-multiplied by Wp, fnode.bp.live enters as a small k-step
-// one tile (32 scored nodes `list[32 t ..]` of layer k); lds: PackScore
-__device__ __forceinline__ void score_tile(const ScoreArgs& a, const float* lds, int k, const int* list, int count, long t, int lane) {
-  const int h = lane >> 5, j = lane & 31;
-  const float bs = lds[PackScore::BS];
-  {
-    const long idx = t * 32 + j;
-    const bool valid = idx < count;
-    const long gc = list[valid ? idx : 0];
-    const int N = a.N[k];
-    const long b = gc / N;
-    Frag X;
-    frag_load_rows(X, a.mu[k], gc, h);
-    Frag H;
-    frag_bias(H, lds + PackScore::B1, h);
-    {
-      const float live = node_is_live(a.lb[k][gc], a.ub[k][gc]) ? 1.0f : 0.0f;
-      const float x[1] = {h ? 0.0f : live};
-      gemm_small<1>(lds + PackScore::V1, lane, H, x);
-    }
-    gemm_w64<32>(lds + PackScore::W1, lane, H, [&](int s) { return FRAG_AT(X, s); });
-    frag_relu(H);
-    const f32x4* w4 = reinterpret_cast<const f32x4*>(lds + PackScore::WS + h * 32);
-    float part = 0.0f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const f32x4 w = w4[q];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) part = fmaf(FRAG_AT(H, 4 * q + c), w[c], part);
-    }
-    part += __shfl_xor(part, 32);
-    if (valid && h == 0) a.scores[b * a.R + a.off[k] + (gc - b * N)] = part + bs;
-  }
-}
-
-__global__ __launch_bounds__(WG_MLP, 2) void k_score(ScoreArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  stage_pack(lds, a.pack, PackScore::FLOATS);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  long ntiles = 0;
-  for (int k = 0; k < a.L; ++k) ntiles += (a.cnt[4 * k + 2] + 31) / 32;
-  for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < ntiles; tile += (long)gridDim.x * WAVES_MLP) {
-    int k = 0, count = 0;
-    long t = tile;
-    for (; k < a.L; ++k) {
-      count = a.cnt[4 * k + 2];
-      const long tk = (count + 31) / 32;
-      if (t < tk) break;
-      t -= tk;
-    }
-    score_tile(a, lds, k, a.list[k], count, t, lane);
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// message passing (edge aggregation)
-// ------------------------------------------------------------------------------------------
-struct ConvArgs {
-  const float* src; float* dst; const float* w;
-  int B, C_in, H_in, W_in, C_out, H_out, W_out, kh, kw, stride, pad, normalise;
-};
-
-// forward: nb[b,(co,oy,ox),:] = sum_{ci,ky,kx} W[co,ci,ky,kx] * mu_src[b,(ci,iy,ix),:]   graph_conv.py:110-121
-// one wave per (b, oy, ox): lane = embedding channel, all C_out accumulators in registers,
-// the 256-B source row is loaded once per tap and reused for C_out FMAs with scalar weights.
-template <int CO>
-__global__ __launch_bounds__(256) void k_conv_fwd(ConvArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-  if (wv >= a.B * a.H_out * a.W_out) return;
-  const int ox = wv % a.W_out, oy = (wv / a.W_out) % a.H_out, b = wv / (a.W_out * a.H_out);
-  float acc[CO];
-#pragma unroll
-  for (int co = 0; co < CO; ++co) acc[co] = 0.0f;
-  const float* src = a.src + (long)b * a.C_in * a.H_in * a.W_in * 64 + lane;
-  for (int ci = 0; ci < a.C_in; ++ci)
-    for (int ky = 0; ky < a.kh; ++ky) {
-      const int iy = oy * a.stride - a.pad + ky;
-      if ((unsigned)iy >= (unsigned)a.H_in) continue;
-      for (int kx = 0; kx < a.kw; ++kx) {
-        const int ix = ox * a.stride - a.pad + kx;
-        if ((unsigned)ix >= (unsigned)a.W_in) continue;
-        const float v = src[(long)((ci * a.H_in + iy) * a.W_in + ix) * 64];
-        const float* w = a.w + ((ci * a.kh + ky) * a.kw + kx) * CO;
-#pragma unroll
-        for (int co = 0; co < CO; ++co) acc[co] = fmaf(w[co], v, acc[co]);
-      }
-    }
-  float* dst = a.dst + ((long)b * CO * a.H_out * a.W_out + (long)oy * a.W_out + ox) * 64 + lane;
-#pragma unroll
-  for (int co = 0; co < CO; ++co) dst[(long)co * a.H_out * a.W_out * 64] = acc[co];
-}
-
-// backward: nb[b,(ci,y,x),:] = sum_{co,ky,kx} W[co,ci,ky,kx] * mu_up[b,(co,oy,ox),:] with y = oy*s - p + ky,
-// divided by the number of taps touching (y,x) when `normalise`         graph_conv.py:299-318 (and :361-372 without)
-template <int CI>
-__global__ __launch_bounds__(256) void k_convT_bwd(ConvArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-  if (wv >= a.B * a.H_in * a.W_in) return;
-  const int x = wv % a.W_in, y = (wv / a.W_in) % a.H_in, b = wv / (a.W_in * a.H_in);
-  float acc[CI];
-#pragma unroll
-  for (int ci = 0; ci < CI; ++ci) acc[ci] = 0.0f;
-  const float* src = a.src + (long)b * a.C_out * a.H_out * a.W_out * 64 + lane;
-  int ny = 0, nx = 0;
-  for (int ky = 0; ky < a.kh; ++ky) {
-    const int t = y + a.pad - ky;
-    if (t >= 0 && t % a.stride == 0 && t / a.stride < a.H_out) ++ny;
-  }
-  for (int kx = 0; kx < a.kw; ++kx) {
-    const int t = x + a.pad - kx;
-    if (t >= 0 && t % a.stride == 0 && t / a.stride < a.W_out) ++nx;
-  }
-  for (int co = 0; co < a.C_out; ++co)
-    for (int ky = 0; ky < a.kh; ++ky) {
-      const int ty = y + a.pad - ky;
-      if (ty < 0 || ty % a.stride != 0 || ty / a.stride >= a.H_out) continue;
-      const int oy = ty / a.stride;
-      for (int kx = 0; kx < a.kw; ++kx) {
-        const int tx = x + a.pad - kx;
-        if (tx < 0 || tx % a.stride != 0 || tx / a.stride >= a.W_out) continue;
-        const int ox = tx / a.stride;
-        const float v = src[(long)((co * a.H_out + oy) * a.W_out + ox) * 64];
-        const float* w = a.w + ((co * a.kh + ky) * a.kw + kx) * CI;
-#pragma unroll
-        for (int ci = 0; ci < CI; ++ci) acc[ci] = fmaf(w[ci], v, acc[ci]);
-      }
-    }
-  const float freq = a.normalise ? (float)(ny * nx) : 1.0f;
-  float* dst = a.dst + ((long)b * CI * a.H_in * a.W_in + (long)y * a.W_in + x) * 64 + lane;
-#pragma unroll
-  for (int ci = 0; ci < CI; ++ci) dst[(long)ci * a.H_in * a.W_in * 64] = a.normalise ? acc[ci] / freq : acc[ci];
-}
-
-struct DenseArgs {
-  const float* At;   // (8*ksq, ldA) zero-padded: At[k][i] = A[i][k]
-  const float* X;    // (B, K, 64)
-  float* out;        // (B, M, 64)
-  const float* zero; // 64 zero floats
-  int B, K, M, ldA, MT, ksq;
-};
-
-// dense edge: out[b, i, :] = sum_k A[i][k] X[b, k, :]   (graph_conv.py:131 forward, :321 backward)
-// one workgroup per (b, 32-row tile of i); its 4 waves split K and are summed through LDS in a fixed order.
-// D_it[i][j] on the MFMA for both channel tiles (lane j holds channels 2j, 2j+1 of the source row: one coalesced
-// 256-B row per half-wave and k-step), A from L2; loads run one 8-k-step chunk ahead.
-#define DENSE_CH 8
-// SPLIT = true: the 4 waves of a workgroup share one (b, row tile) and split K (long K, few tiles: the forward edge);
-// SPLIT = false: every wave owns its own (b, row tile) and walks all of K (short K: the transposed edge).
-template <bool SPLIT>
-__global__ __launch_bounds__(256) void k_dense_agg(DenseArgs a) {
-  __shared__ float red[SPLIT ? 4 : 1][32][64];
-  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // the MT row tiles of one sample all stream the same source rows: keep them on one XCD (blockIdx % 8 labels the
-  // XCD group), so that sample is fetched into one L2 instead of up to MT of them
-  int bid = blockIdx.x;
-  if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
-  const int tile = SPLIT ? bid : bid * 4 + wave;
-  if (tile >= a.B * a.MT) return;
-  const int mt = tile % a.MT, b = tile / a.MT;
-  // At is zero-padded on the host to MT*32 columns and enough rows, the k padding of X reads a zero row: no select
-  // touches a loaded value
-  const float* At = a.At + mt * 32 + j;
-  const float* X = a.X + (long)b * a.K * 64 + 2 * j;
-  const long zdelta = (a.zero + 2 * j) - X;
-  f32x16 acc0, acc1;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
-  const int nks = SPLIT ? a.ksq : 4 * a.ksq;            // k-steps this wave walks (a multiple of DENSE_CH)
-  const int s_begin = SPLIT ? wave * a.ksq : 0;
-  float av[DENSE_CH];
-  float2 bv[DENSE_CH];
-  // measured: with 16 resident waves per CU the other waves cover a chunk's load latency; keeping a second chunk in
-  // flight per wave made this kernel slower
-  for (int s0 = s_begin; s0 < s_begin + nks; s0 += DENSE_CH) {
-#pragma unroll
-    for (int u = 0; u < DENSE_CH; ++u) {
-      const int k = 2 * (s0 + u) + h;
-      av[u] = At[(long)k * a.ldA];
-      const long o = k < a.K ? (long)k * 64 : zdelta;
-      bv[u] = *reinterpret_cast<const float2*>(X + o);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < DENSE_CH; ++u) {
-      acc0 = mfma32(av[u], bv[u].x, acc0);
-      acc1 = mfma32(av[u], bv[u].y, acc1);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  float* out = a.out + (long)b * a.M * 64 + 2 * j;
-  if (SPLIT) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { red[wave][r][lane] = acc0[r]; red[wave][16 + r][lane] = acc1[r]; }
-    __syncthreads();
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int r = wave * 4 + rr;
-      const float v0 = ((red[0][r][lane] + red[SPLIT ? 1 : 0][r][lane]) + red[SPLIT ? 2 : 0][r][lane]) + red[SPLIT ? 3 : 0][r][lane];
-      const float v1 = ((red[0][16 + r][lane] + red[SPLIT ? 1 : 0][16 + r][lane]) + red[SPLIT ? 2 : 0][16 + r][lane]) +
-                       red[SPLIT ? 3 : 0][16 + r][lane];
-      const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (row < a.M) *reinterpret_cast<float2*>(out + (long)row * 64) = make_float2(v0, v1);
-    }
-  } else {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (row < a.M) *reinterpret_cast<float2*>(out + (long)row * 64) = make_float2(acc0[r], acc1[r]);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// dense edges, one workgroup per sample: the source rows of the sample are staged in LDS once and shared by all its
-// row tiles (stand-alone tiles re-fetched them through L2 up to MT times: ~40 % L2 misses, 95 us per launch).
-// B operand (source row, channels 2j, 2j+1) = one conflict-free ds_read_b64 per k-step; A operand (weights, shared by
-// all samples) streams from L2 one chunk ahead.
-// ------------------------------------------------------------------------------------------
-struct DenseLArgs {
-  const float* At;    // zero-padded (rows >= K_pad + 16, ldA columns): At[k][i] = A[i][k]
-  const float* X;     // (B, K, 64)
-  float* out;         // (B, M, 64)
-  int B, K, M, ldA, MT, Kpad;
-};
-
-#define DL_CH 8
-#define DENSE_FWD_LDS_FLOATS (2 * 2 * 32 * 64 + 4 * 32 * 64)     // xs + red = 64 KB
-#define DENSE_BWD_ROWS (128 + 16)
-// forward edge (long K) of sample b: 8 waves = 4 row tiles x 2 K-halves; X streams through LDS in double-buffered chunks
-// of 2 x 32 rows (one slab per K-half), the two halves are summed through LDS in a fixed order.  Requires MT <= 4 and 512
-// threads.  `scratch`: DENSE_FWD_LDS_FLOATS floats of LDS; store(row, channel pair index j, value pair).
-// klist (LDS) != nullptr: only the K_eff source rows klist[0..K_eff) are walked (the caller dropped the all-zero rows of dead
-// nodes); klist must be padded with a.Kpad (a zero row of At) up to round_up(K_eff, 64) + 32 entries.
-template <class Store>
-__device__ __forceinline__ void dense_fwd_sample(const DenseLArgs& a, int b, float* scratch, Store store, const int* klist = nullptr,
-                                                 int K_eff = 0) {
-  float (*xs)[2][32][64] = reinterpret_cast<float (*)[2][32][64]>(scratch);                 // [buffer][K-half][row][channel]  32 KB
-  float (*red)[32][64] = reinterpret_cast<float (*)[32][64]>(scratch + 2 * 2 * 32 * 64);    // 32 KB
-  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int mt = wave & 3, kh = wave >> 2;
-  const int Kw = klist ? K_eff : a.K;            // source rows walked
-  const int khalf = (klist ? (K_eff + 63) / 64 * 64 : a.Kpad) / 2;      // rows per K-half, a multiple of 32
-  const int nchunks = khalf / 32;
-  const float* Xb = a.X + (long)b * a.K * 64;
-  // cooperative stage of chunk c: 2 slabs x 32 rows x 256 B = 16 KB, 512 threads x 2 x 16 B.  The global loads are issued
-  // BEFORE the MFMAs of the running chunk and written to LDS after them, so their latency is not exposed once per chunk
-  // (as one load-then-store step this kernel ran at half its MFMA rate).
-  f32x4 sv[2];
-  auto gload = [&](int c) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int e = threadIdx.x + 512 * r;        // 16-B piece index, 0..1023
-      const int slab = e >> 9, row = (e >> 4) & 31, piece = e & 15;
-      const int k = slab * khalf + c * 32 + row;
-      const int krow = k < Kw ? (klist ? klist[k] : k) : 0;
-      const f32x4* src = reinterpret_cast<const f32x4*>(Xb + (long)krow * 64 + piece * 4);
-      const f32x4 v = *src;
-      sv[r] = k < Kw ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int e = threadIdx.x + 512 * r;
-      const int slab = e >> 9, row = (e >> 4) & 31, piece = e & 15;
-      *reinterpret_cast<f32x4*>(&xs[buf][slab][row][piece * 4]) = sv[r];
-    }
-  };
-  const float* At = a.At + (klist ? 0 : (long)(kh * khalf) * a.ldA) + (mt < a.MT ? mt : 0) * 32 + j;   // waves beyond MT idle on tile 0
-  const int* kl = klist ? klist + kh * khalf : nullptr;
-  f32x16 acc0, acc1;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
-  float av[16], nav[16];
-  auto loadA = [&](float (&A)[16], int c) {
-#pragma unroll
-    for (int u = 0; u < 16; ++u) A[u] = At[(long)(kl ? kl[c * 32 + 2 * u + h] : c * 32 + 2 * u + h) * a.ldA];
-  };
-  auto mma = [&](const float (&A)[16], int buf) {
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const float2 bv = *reinterpret_cast<const float2*>(&xs[buf][kh][2 * u + h][2 * j]);
-      acc0 = mfma32(A[u], bv.x, acc0);
-      acc1 = mfma32(A[u], bv.y, acc1);
-    }
-  };
-  gload(0);
-  lstore(0);
-  loadA(av, 0);
-  __syncthreads();
-  for (int c = 0; c < nchunks; c += 2) {
-    const bool more1 = c + 1 < nchunks;
-    if (more1) gload(c + 1);
-    loadA(nav, c + 1);                      // At carries 32 extra zero rows: reading one chunk past the end is harmless
-    __builtin_amdgcn_sched_barrier(0);
-    mma(av, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (more1) lstore(1);
-    __syncthreads();
-    if (!more1) break;
-    const bool more2 = c + 2 < nchunks;
-    if (more2) gload(c + 2);
-    loadA(av, c + 2);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(nav, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (more2) lstore(0);
-    __syncthreads();
-  }
-  if (kh == 1) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { red[mt][r][lane] = acc0[r]; red[mt][16 + r][lane] = acc1[r]; }
-  }
-  __syncthreads();
-  if (kh == 0 && mt < a.MT) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (row < a.M) store(row, j, make_float2(acc0[r] + red[mt][r][lane], acc1[r] + red[mt][16 + r][lane]));
-    }
-  }
-}
-
-__global__ __launch_bounds__(512, 2) void k_dense_fwd_lds(DenseLArgs a) {
-  __shared__ __attribute__((aligned(16))) float scratch[DENSE_FWD_LDS_FLOATS];
-  const int b = blockIdx.x;
-  float* out = a.out + (long)b * a.M * 64;
-  dense_fwd_sample(a, b, scratch, [&](int row, int j, float2 v) { *reinterpret_cast<float2*>(out + (long)row * 64 + 2 * j) = v; });
-}
-
-// transposed edge (short K <= 128) of one sample whose source rows sit in LDS (`xs`: DENSE_BWD_ROWS x 64, rows >= K zero);
-// 8 waves walk the MT row tiles.
-// Optional compaction (lists in LDS): `rlist` / n_rows -- only these output rows are computed (the live nodes of the layer
-// below; the others are never read); `klist` / K_eff -- only these source rows are walked (the live nodes of this layer; the
-// rows of dead ones are zero), padded with a.Kpad (a zero row of At and of xs) up to round_up(K_eff, 16) + 32 entries.
-template <class Store>
-__device__ __forceinline__ void dense_bwd_sample(const DenseLArgs& a, const float* xs_raw, Store store, const int* rlist = nullptr,
-                                                 int n_rows = 0, const int* klist = nullptr, int K_eff = 0) {
-  const float (*xs)[64] = reinterpret_cast<const float (*)[64]>(xs_raw);
-  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nch = (klist ? (K_eff + 15) / 16 * 16 : a.Kpad) / 16;      // chunks of 8 k-steps
-  const int M = rlist ? n_rows : a.M, MT = rlist ? (n_rows + 31) / 32 : a.MT;
-  for (int mt = wave; mt < MT; mt += 8) {
-    const int arow = rlist ? rlist[mt * 32 + j < M ? mt * 32 + j : 0] : mt * 32 + j;
-    const float* At = a.At + arow;
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
-    // three A buffers in rotation: a chunk of 8 k-steps is only 16 MFMAs (~0.4 us), less than an L2 round trip, so the
-    // weights are fetched TWO chunks ahead.  At carries 48 extra zero rows for the loads issued past the end.
-    float a0[DL_CH], a1[DL_CH], a2[DL_CH];
-    auto loadA = [&](float (&A)[DL_CH], int c) {
-#pragma unroll
-      for (int u = 0; u < DL_CH; ++u) A[u] = At[(long)(klist ? klist[c * 16 + 2 * u + h] : c * 16 + 2 * u + h) * a.ldA];
-    };
-    auto mma = [&](const float (&A)[DL_CH], int c) {
-#pragma unroll
-      for (int u = 0; u < DL_CH; ++u) {
-        const float2 bv = *reinterpret_cast<const float2*>(&xs[klist ? klist[c * 16 + 2 * u + h] : c * 16 + 2 * u + h][2 * j]);
-        acc0 = mfma32(A[u], bv.x, acc0);
-        acc1 = mfma32(A[u], bv.y, acc1);
-      }
-    };
-    loadA(a0, 0);
-    loadA(a1, 1);
-    for (int c = 0; c < nch; c += 3) {
-      loadA(a2, c + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(a0, c);
-      __builtin_amdgcn_sched_barrier(0);
-      if (c + 1 >= nch) break;
-      loadA(a0, c + 3);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(a1, c + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (c + 2 >= nch) break;
-      loadA(a1, c + 4);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(a2, c + 2);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (row < M) store(rlist ? rlist[row] : row, j, make_float2(acc0[r], acc1[r]));
-    }
-  }
-}
-
-__global__ __launch_bounds__(512, 2) void k_dense_bwd_lds(DenseLArgs a) {
-  __shared__ __attribute__((aligned(16))) float xs[DENSE_BWD_ROWS][64];       // 36 KB, rows >= K are zero
-  const int b = blockIdx.x;
-  const float* Xb = a.X + (long)b * a.K * 64;
-  for (int e = threadIdx.x; e < DENSE_BWD_ROWS * 16; e += 512) {
-    const int row = e >> 4, piece = e & 15;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (row < a.K) v = *reinterpret_cast<const f32x4*>(Xb + (long)row * 64 + piece * 4);
-    *reinterpret_cast<f32x4*>(&xs[row][piece * 4]) = v;
-  }
-  __syncthreads();
-  float* out = a.out + (long)b * a.M * 64;
-  dense_bwd_sample(a, &xs[0][0], [&](int row, int j, float2 v) { *reinterpret_cast<float2*>(out + (long)row * 64 + 2 * j) = v; });
-}
-
-struct PropArgs {
-  const float* pack; const float* mu_last; const float* prop_w; const float* prop_b;
-  const float *lb, *ub, *z_out; float* mu_prop; float* nb_back; int B, N_last;
-  const float *lbl, *ubl;   // bounds of the top ReLU layer (its rows have fc4_2 deferred: the bias term needs live_n)
-};
-
-// property node (graph_conv.py:194-210): nb = W_prop[b] . mu_L[b];
-// mu_K = out3(relu(out2([relu(out1([l, u, z_out, c])), nb]))), then the backward edge from it (:324-326):
-// nb_back[b, n, :] = W_prop[b][n] * mu_K[b, :].  One workgroup (4 waves) per sample, lane = channel: the waves split the
-// rows of mu_L (partial sums combined in a fixed order through LDS), wave 0 runs the three small layers with the
-// transposed weights in LDS (196 dependent FMA steps read LDS, not L2), all waves write the backward aggregate.
-__global__ __launch_bounds__(256) void k_prop(PropArgs a) {
-  __shared__ float wl[PackProp::FLOATS];
-  __shared__ float xs[128];
-  __shared__ float part[4][64];
-  __shared__ float outv[64];
-  __shared__ float spart[4];
-  for (int i = threadIdx.x; i < PackProp::FLOATS; i += 256) wl[i] = a.pack[i];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int b = blockIdx.x;
-  const float* mu = a.mu_last + (long)b * a.N_last * 64 + lane;
-  const float* pw = a.prop_w + (long)b * a.N_last;
-  float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  for (int n = w; n < a.N_last; n += 16) {             // 4 independent loads in flight per wave
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int nn = n + 4 * u;
-      if (nn < a.N_last) acc[u] = fmaf(pw[nn], mu[(long)nn * 64], acc[u]);
-    }
-  }
-  part[w][lane] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-  // sp = sum_n W_prop[n] live_n: the rows of mu_L hold E with mu = (fc4_2.E + b).live, so
-  // out2[:, 64:].nb = (out2[:, 64:].fc4_2.W).(sum_n W_prop[n] E_n) + sp.(out2[:, 64:].fc4_2.b)   (folded in PackProp)
-  float sp = 0.0f;
-  for (int n = threadIdx.x; n < a.N_last; n += 256) {
-    const long g = (long)b * a.N_last + n;
-    sp += node_is_live(a.lbl[g], a.ubl[g]) ? pw[n] : 0.0f;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) sp += __shfl_xor(sp, o);
-  if (lane == 0) spart[w] = sp;
-  __syncthreads();
-  if (w == 0) {
-    const float nb = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-    const float spt = (spart[0] + spart[1]) + (spart[2] + spart[3]);
-    const float f[4] = {a.lb[b], a.ub[b], a.z_out[b], a.prop_b[b]};
-    float h1 = wl[PackProp::B1 + lane];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) h1 = fmaf(wl[PackProp::W1T + k * 64 + lane], f[k], h1);
-    xs[lane] = relu_nan(h1);
-    xs[64 + lane] = nb;
-    __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): this wave's LDS writes are visible to its own reads
-    float h2 = fmaf(spt, wl[PackProp::V2 + lane], wl[PackProp::B2 + lane]);
-#pragma unroll 8
-    for (int k = 0; k < 128; ++k) h2 = fmaf(wl[PackProp::W2T + k * 64 + lane], xs[k], h2);
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    xs[lane] = relu_nan(h2);
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    float o = wl[PackProp::B3 + lane];
-#pragma unroll 8
-    for (int k = 0; k < 64; ++k) o = fmaf(wl[PackProp::W3T + k * 64 + lane], xs[k], o);
-    a.mu_prop[(long)b * 64 + lane] = o;
-    outv[lane] = o;
-  }
-  __syncthreads();
-  if (a.nb_back) {
-    const float o = outv[lane];
-    float* nbk = a.nb_back + (long)b * a.N_last * 64 + lane;
-    for (int n = w; n < a.N_last; n += 4) nbk[(long)n * 64] = pw[n] * o;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_top: the top of the network in one launch per round, one workgroup (8 waves) per sample.  When the last ReLU layer
-// hangs on a Linear edge and has <= 128 nodes, everything between "layer L-1 forward-updated" and "layer L-1 can be
-// backward-updated" is local to a sample and tiny:
-//   F1  nb_L   = W_L . mu_{L-1}                        (dense forward edge, graph_conv.py:130-137)
-//   F2  mu_L   <- forward node update                  (:139-186)
-//   F3  mu_K   <- property node, nb_back = W_prop^T mu_K  (:194-210, :324-326)
-//   B1  mu_L   <- backward node update                 (:253-350)
-//   B2  nb_{L-1} = W_L^T . mu_L                        (dense transposed edge, :320-322)
-// As five launches these cost ~160 us of mostly launch ramps, weight staging and latency; here the layer's rows never
-// leave LDS.  LDS map (floats): A = weight pack of the running phase (first the dense-forward staging buffers),
-// Bp = PackProp, C = the rows of layer L (DENSE_BWD_ROWS x 64, rows >= N zero), sm = small vectors.
-// ------------------------------------------------------------------------------------------
-struct TopArgs {
-  DenseLArgs df;            // forward edge L (out unused)
-  DenseLArgs db;            // transposed edge L (X unused: the rows come from LDS), out = aggregate rows of layer L-1
-  const float *pack_f, *pack_b, *pack_p;
-  const float *Pf, *Pb;     // cached P' rows of layer L (by node id), forward / backward
-  const float* sf;          // bias-sum scalars of the forward edge (B, N)
-  const float *lb, *ub;     // bounds of layer L, flat (B*N)
-  const float *lbm, *ubm;   // bounds of layer L-1, flat (B*K): its dead rows (all zero) are skipped by the forward edge
-  const float *prop_w, *prop_b, *lbK, *ubK, *z_out;
-  float* mu_prop;           // (B, 64)
-  float* mu;                // (B, N, 64) rows of layer L (backward-produced)
-  int* status;
-  int N;
-};
-#define TOP_A_FLOATS (PackUpd::FLOATS > DENSE_FWD_LDS_FLOATS ? PackUpd::FLOATS : DENSE_FWD_LDS_FLOATS)
-#define TOP_FIXED_FLOATS (TOP_A_FLOATS + PackProp::FLOATS + DENSE_BWD_ROWS * 64 + 8 * 64 + 128 + 64 + 64)
-#define TOP_LDS_FLOATS 40960                   // all 160 KB: what the fixed regions leave holds the live-row lists
-#define TOP_K2_INTS (128 + 48)                  // live rows of layer L, padded for the chunks read ahead
-#define TOP_LIST_INTS (TOP_LDS_FLOATS - TOP_FIXED_FLOATS - TOP_K2_INTS)
-
-__device__ __forceinline__ void copy_to_lds_part(float* lds, const float* src, int nfloats, int tid, int nthr) {
-  const f32x4* g = reinterpret_cast<const f32x4*>(src);
-  f32x4* l = reinterpret_cast<f32x4*>(lds);
-  const int n4 = nfloats / 4;
-  for (int i0 = tid; i0 < n4; i0 += 8 * nthr) {
-    f32x4 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = i0 + u * nthr;
-      v[u] = g[i < n4 ? i : i0];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = i0 + u * nthr;
-      if (i < n4) l[i] = v[u];
-    }
-  }
-}
-
-// needs 512 threads (threads beyond that idle) and TOP_LDS_FLOATS of LDS
-__device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float* lds) {
-  float* A = lds;
-  float* Bp = A + TOP_A_FLOATS;
-  float* Cr = Bp + PackProp::FLOATS;
-  float* part = Cr + DENSE_BWD_ROWS * 64;     // [8][64]
-  float* xs = part + 8 * 64;                  // [128]
-  float* outv = xs + 128;                     // [64]
-  float* spart = outv + 64;                   // [8]
-  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int N = a.N;
-  for (int i = tid; i < DENSE_BWD_ROWS * 16; i += 512) reinterpret_cast<f32x4*>(Cr)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // live source rows of layer L-1 (the dead ones are all zero: ~45 % of the forward edge's k-steps), compacted in node order
-  // into the region PackProp takes afterwards
-  // The list goes behind the fixed regions when it fits there (then the transposed edge B2 also uses it, to compute only the
-  // live rows of layer L-1), else into the region PackProp takes after F1.
-  int* k2list = reinterpret_cast<int*>(spart + 8);        // live rows of layer L (B2)
-  int* tail = k2list + TOP_K2_INTS;
-  const bool keep = a.df.K + 96 <= TOP_LIST_INTS;
-  int* klist = keep ? tail : reinterpret_cast<int*>(Bp);
-  int K_eff = 0;
-  const bool compact = keep || a.df.K + 96 <= PackProp::FLOATS;
-  if (compact) {
-    int* wc = reinterpret_cast<int*>(part);              // per-wave counts
-    const int K = a.df.K;
-    for (int n0 = 0; n0 < K; n0 += 512) {
-      const int n = n0 + tid;
-      const long gm = (long)b * K + (n < K ? n : 0);
-      const bool live = n < K && node_is_live(a.lbm[gm], a.ubm[gm]);
-      const unsigned long long bal = __ballot(live);
-      if (lane == 0) wc[wave] = __popcll(bal);
-      __syncthreads();
-      int before = 0, total = 0;
-#pragma unroll
-      for (int w8 = 0; w8 < 8; ++w8) { before += w8 < wave ? wc[w8] : 0; total += wc[w8]; }
-      if (live) klist[K_eff + before + __popcll(bal & ((1ull << lane) - 1ull))] = n;
-      K_eff += total;
-      __syncthreads();
-    }
-    for (int i = K_eff + tid; i < (K_eff + 63) / 64 * 64 + 32; i += 512) klist[i] = a.df.Kpad;     // a zero row of At
-  }
-  __syncthreads();
-
-  // ---- F1: rows of C <- W_L . mu_{L-1}
-  dense_fwd_sample(a.df, b, A, [&](int row, int jj, float2 v) { *reinterpret_cast<float2*>(Cr + row * 64 + 2 * jj) = v; },
-                   compact ? klist : nullptr, K_eff);
-  __syncthreads();
-  copy_to_lds(Bp, a.pack_p, PackProp::FLOATS);            // (read from F3 on, behind two more barriers)
-
-  // per-lane node of the update phases (waves 0..3: one tile of 32 nodes each)
-  const int n = wave * 32 + j;
-  const bool upd_wave = wave * 32 < N;
-  const bool valid = n < N;
-  const long g = (long)b * N + (valid ? n : 0);
-  const float* pw = a.prop_w + (long)b * N;
-  Ratio r{};
-  if (upd_wave) r = compute_ratio(a.lb[g], a.ub[g]);
-  auto load_row = [&](Frag& x_, int row) {       // fragment <- LDS row (row-major 64 floats)
-    const f32x4* p = reinterpret_cast<const f32x4*>(Cr + row * 64 + 4 * h);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const f32x4 v = p[2 * q];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) FRAG_AT(x_, 4 * q + c) = v[c];
-    }
-  };
-  auto store_row = [&](const Frag& x_, float* base) {
-    f32x4* p = reinterpret_cast<f32x4*>(base + 4 * h);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      f32x4 v;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) v[c] = FRAG_AT(x_, 4 * q + c);
-      p[2 * q] = v;
-    }
-  };
-  // general folded node chain on fragment X (k_node_update, kind 1); `sx`: small k-step input of a deferred projection
-  auto chain = [&](const Frag& X, const float* Prow, bool deferred, float sx, Frag& H2) {
-    Frag H;
-    frag_bias(H, A + PackUpd::BA, h);
-    if (deferred) {
-      const float x1[1] = {sx};
-      gemm_small<1>(A + PackUpd::VAW, lane, H, x1);
-    }
-    const float r0 = r.r0, r1 = r.r1;
-    gemm_w64<64>(A + PackUpd::WA, lane, H, [&](int s) { return FRAG_AT(X, s & 31) * (s < 32 ? r0 : r1); });
-    frag_relu(H);
-    frag_load_rowptr(H2, Prow, h);
-    gemm_w64<32>(A + PackUpd::WCB, lane, H2, [&](int s) { return FRAG_AT(H, s); });
-    frag_relu(H2);
-    frag_scale(H2, r.live);
-  };
-
-  // ---- F2: forward node update of layer L (rows stay in C)
-  stage_pack(A, a.pack_f, PackUpd::FLOATS);
-  if (upd_wave) {
-    Frag X, E;
-    load_row(X, valid ? n : 0);
-    chain(X, r.amb != 0.0f ? a.Pf + g * 64 : a.pack_f + PackUpd::BCBROW, true, (h ? r.r1 : r.r0) * a.sf[g], E);
-    if (valid) {
-      if (frag_has_nan(E)) atomicOr(a.status, 1);
-      store_row(E, Cr + n * 64);
-    }
-  }
-  __syncthreads();
-
-  // ---- F3: property node (k_prop) on the rows in C; meanwhile waves 1..7 stage the backward pack
-  {
-    float acc = 0.0f;
-    for (int m = wave; m < N; m += 8) acc = fmaf(pw[m], Cr[m * 64 + lane], acc);
-    part[wave * 64 + lane] = acc;
-    float sp = 0.0f;
-    for (int m = tid; m < N; m += 512) {
-      const long gm = (long)b * N + m;
-      sp += node_is_live(a.lb[gm], a.ub[gm]) ? pw[m] : 0.0f;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sp += __shfl_xor(sp, o);
-    if (lane == 0) spart[wave] = sp;
-  }
-  __syncthreads();
-  if (wave == 0) {
-    float nbv = 0.0f, spt = 0.0f;
-#pragma unroll
-    for (int w8 = 0; w8 < 8; ++w8) { nbv += part[w8 * 64 + lane]; spt += spart[w8]; }
-    const float f[4] = {a.lbK[b], a.ubK[b], a.z_out[b], a.prop_b[b]};
-    float h1 = Bp[PackProp::B1 + lane];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) h1 = fmaf(Bp[PackProp::W1T + k * 64 + lane], f[k], h1);
-    xs[lane] = relu_nan(h1);
-    xs[64 + lane] = nbv;
-    __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): this wave's LDS writes are visible to its own reads
-    float h2 = fmaf(spt, Bp[PackProp::V2 + lane], Bp[PackProp::B2 + lane]);
-#pragma unroll 8
-    for (int k = 0; k < 128; ++k) h2 = fmaf(Bp[PackProp::W2T + k * 64 + lane], xs[k], h2);
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    xs[lane] = relu_nan(h2);
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    float o = Bp[PackProp::B3 + lane];
-#pragma unroll 8
-    for (int k = 0; k < 64; ++k) o = fmaf(Bp[PackProp::W3T + k * 64 + lane], xs[k], o);
-    a.mu_prop[(long)b * 64 + lane] = o;
-    outv[lane] = o;
-  } else {
-    copy_to_lds_part(A, a.pack_b, PackUpd::FLOATS, tid - 64, 448);
-  }
-  __syncthreads();
-
-  // ---- B1: backward node update of layer L; its aggregate is the rank-1 edge from the property node
-  if (upd_wave) {
-    Frag X, E;
-    const float wn = valid ? pw[n] : 0.0f;
-    {
-      const f32x4* o4 = reinterpret_cast<const f32x4*>(outv + 4 * h);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const f32x4 v = o4[2 * q];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) FRAG_AT(X, 4 * q + c) = wn * v[c];
-      }
-    }
-    chain(X, r.amb != 0.0f ? a.Pb + g * 64 : a.pack_b + PackUpd::BCBROW, false, 0.0f, E);
-    if (valid) {
-      if (frag_has_nan(E)) atomicOr(a.status, 1);
-      store_row(E, Cr + n * 64);
-      store_row(E, a.mu + g * 64);
-    }
-  }
-  __syncthreads();
-
-  // ---- B2: aggregate rows of layer L-1 <- W_L^T . rows of C: only the live rows of layer L-1 (nothing reads the others), only
-  // the live (non-zero) rows of layer L
-  int K2 = 0;
-  if (keep) {
-    int* wc = reinterpret_cast<int*>(part);
-    const unsigned long long bal = __ballot(upd_wave && valid && r.live != 0.0f && (lane < 32));
-    if (lane == 0) wc[wave] = __popcll(bal);
-    __syncthreads();
-    int before = 0;
-#pragma unroll
-    for (int w8 = 0; w8 < 8; ++w8) { before += w8 < wave ? wc[w8] : 0; K2 += wc[w8]; }
-    if (upd_wave && valid && r.live != 0.0f && lane < 32) k2list[before + __popcll(bal & ((1ull << lane) - 1ull))] = n;
-    for (int i = K2 + tid; i < TOP_K2_INTS; i += 512) k2list[i] = a.db.Kpad;   // zero row of At and of C
-    __syncthreads();
-  }
-  float* out = a.db.out + (long)b * a.db.M * 64;
-  auto put = [&](int row, int jj, float2 v) { *reinterpret_cast<float2*>(out + (long)row * 64 + 2 * jj) = v; };
-  if (keep) dense_bwd_sample(a.db, Cr, put, klist, K_eff, k2list, K2);
-  else dense_bwd_sample(a.db, Cr, put);
-}
-
-__global__ __launch_bounds__(512, 1) void k_top(TopArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  top_sample(a, blockIdx.x, lds);
-}
-
-// ------------------------------------------------------------------------------------------
-// k_livesum: s[b, n'] = sum_n A[n', n] live[b, n] for every edge and direction (gnnb_pack.h "deferred projection"):
-// the bias of a producer's deferred last layer reaches a consumer multiplied by this scalar.  Static over the rounds
-// (live depends on the bounds only), so it runs once per forward.  Scalar stencil work (HBM/L2-bound, one thread per
-// destination node), all edges in one launch.  Transposed conv edges are divided by the tap count exactly like their
-// aggregate (graph_conv.py:306-312) unless the destination is the input layer (:361-372).
-// ------------------------------------------------------------------------------------------
-struct LiveSumJob {
-  int kind;                 // 0 conv forward, 1 dense forward, 2 conv transposed, 3 dense transposed
-  const float* w;           // conv fwd [ci][ky][kx][co]; conv bwd [co][ky][kx][ci]; dense (both directions) W[o][ld]
-  const float* lf;          // live flags of the SOURCE layer (B, Nsrc), written by k_classify; null: all live (input layer)
-  float* out;               // (B, Ndst)
-  int Ndst, Nsrc, ld, normalise;
-  int c_in, h_in, w_in, c_out, h_out, w_out, kh, kw, stride, pad;   // geometry of the conv edge (forward orientation)
-  int wlds;                 // conv: number of weights to stage in LDS (0: read them from global memory)
-};
-struct LiveSumArgs { int njobs, B, lv_floats; LiveSumJob job[2 * MAXL]; };
-#define LIVESUM_MAXW 16384    // conv weights staged in LDS (64 KB)
-
-#define LIVESUM_MAXSRC 40000  // source nodes per sample that fit the 160 KB LDS (bind rejects larger layers)
-#define LS_CC 4
-#define LS_DO 9
-// conv / transposed-conv stencil of one sample out of LDS.  KH, KW, S > 0: compile-time kernel size and stride, so the tap
-// loops unroll completely and all LDS reads of a source channel are issued before their FMAs (masked, no branches);
-// KH = 0: run-time geometry (any other conv).
-// NT: threads taking part; lv == nullptr: every source node is live (the input layer)
-template <int KH, int KW, int S, bool FWD, int NT>
-__device__ __forceinline__ void livesum_conv(const LiveSumJob& jb, const float* lv, const float* W, float* out, int tid) {
-  const int kh = KH ? KH : jb.kh, kw = KH ? KW : jb.kw, st = KH ? S : jb.stride;
-  const int Hd = FWD ? jb.h_out : jb.h_in, Wd = FWD ? jb.w_out : jb.w_in, Cd = FWD ? jb.c_out : jb.c_in;   // destination side
-  const int Hs = FWD ? jb.h_in : jb.h_out, Ws = FWD ? jb.w_in : jb.w_out, Cs = FWD ? jb.c_in : jb.c_out;   // source side
-  const int npos = Hd * Wd;
-  const int P = npos < NT ? npos : NT;                 // positions handled per pass
-  const int ngrp = NT / P;                             // thread groups that split the channel chunks
-  const int grp = tid / P;
-  if (grp >= ngrp) return;
-  const int nchunk = (Cd + LS_CC - 1) / LS_CC;
-  // taps walked per axis.  forward: every ky, source row sy = y*s - p + ky; transposed: ky = ky0 + s*t, sy = sy0 - t
-  const int TY = FWD ? kh : (kh + st - 1) / st, TX = FWD ? kw : (kw + st - 1) / st;
-  constexpr int TYC = KH ? (FWD ? KH : (KH + S - 1) / S) : 1, TXC = KH ? (FWD ? KW : (KW + S - 1) / S) : 1;
-  for (int pos = tid - grp * P; pos < npos; pos += NT) {      // one pass unless the layer has more than NT positions
-    const int y = pos / Wd, x = pos - y * Wd;
-    int ky0 = 0, kx0 = 0, sy0, sx0;
-    if (FWD) {
-      sy0 = y * st - jb.pad; sx0 = x * st - jb.pad;
-    } else {
-      ky0 = (y + jb.pad) % st; kx0 = (x + jb.pad) % st;
-      sy0 = (y + jb.pad - ky0) / st; sx0 = (x + jb.pad - kx0) / st;
-    }
-    const int kstep = FWD ? 1 : st, sstep = FWD ? 1 : -1;
-    int cnt_y = 0, cnt_x = 0;
-    for (int t = 0; t < TY; ++t) cnt_y += ((unsigned)(sy0 + sstep * t) < (unsigned)Hs && ky0 + kstep * t < kh) ? 1 : 0;
-    for (int t = 0; t < TX; ++t) cnt_x += ((unsigned)(sx0 + sstep * t) < (unsigned)Ws && kx0 + kstep * t < kw) ? 1 : 0;
-    for (int ch = grp; ch < nchunk; ch += ngrp) {
-      const int c0 = ch * LS_CC;
-      float acc[LS_CC];
-#pragma unroll
-      for (int u = 0; u < LS_CC; ++u) acc[u] = 0.0f;
-      for (int cs = 0; cs < Cs; ++cs) {
-        if (KH) {
-#pragma unroll
-          for (int t = 0; t < TYC; ++t)
-#pragma unroll
-            for (int u2 = 0; u2 < TXC; ++u2) {
-              const int sy = sy0 + sstep * t, ky = ky0 + kstep * t, sx = sx0 + sstep * u2, kx = kx0 + kstep * u2;
-              const bool v = (unsigned)sy < (unsigned)Hs && (unsigned)sx < (unsigned)Ws && ky < kh && kx < kw;
-              const float l = v ? (lv ? lv[(cs * Hs + (v ? sy : 0)) * Ws + (v ? sx : 0)] : 1.0f) : 0.0f;
-              const float* wr = W + ((cs * kh + (v ? ky : 0)) * kw + (v ? kx : 0)) * Cd + c0;
-#pragma unroll
-              for (int u = 0; u < LS_CC; ++u) acc[u] = fmaf(c0 + u < Cd ? wr[u] : 0.0f, l, acc[u]);
-            }
-        } else {
-          for (int t = 0; t < TY; ++t) {
-            const int sy = sy0 + sstep * t, ky = ky0 + kstep * t;
-            if ((unsigned)sy >= (unsigned)Hs || ky >= kh) continue;
-            for (int u2 = 0; u2 < TX; ++u2) {
-              const int sx = sx0 + sstep * u2, kx = kx0 + kstep * u2;
-              if ((unsigned)sx >= (unsigned)Ws || kx >= kw) continue;
-              const float l = lv ? lv[(cs * Hs + sy) * Ws + sx] : 1.0f;
-              const float* wr = W + ((cs * kh + ky) * kw + kx) * Cd + c0;
-#pragma unroll
-              for (int u = 0; u < LS_CC; ++u) acc[u] = fmaf(c0 + u < Cd ? wr[u] : 0.0f, l, acc[u]);
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < LS_CC; ++u)
-        if (c0 + u < Cd) {
-          float v = acc[u];
-          if (!FWD && jb.normalise) v = v / (float)(cnt_y * cnt_x);
-          out[(c0 + u) * npos + pos] = v;
-        }
-    }
-  }
-}
-
-// grid (sample, job): the live flags of the sample's source layer and the conv weights are staged in LDS once.  The stencil
-// is ALU-bound (an FMA per tap), so the loops are built to spend few instructions per FMA: a thread owns one pixel position
-// and 8 channels at a time (one LDS read of the flag + two 16-B reads of 8 consecutive weights feed 8 FMAs), positions and
-// tap ranges are decoded once per thread, transposed edges walk only the taps of the lane's stride phase.
-// one job (edge, direction) of one sample: lv = live flags of the source layer in LDS (nullptr: all live), W = the job's
-// weights (conv: in LDS when staged), out = the sample's (Ndst) output row
-template <int NT>
-__device__ __forceinline__ void livesum_job(const LiveSumJob& jb, const float* lv, const float* W, float* out, int tid) {
-  if (jb.kind == 0 || jb.kind == 2) {
-    const bool fwd = jb.kind == 0;
-    const int key = jb.kh * 100 + jb.kw * 10 + jb.stride;
-    if (fwd) {
-      if (key == 442) livesum_conv<4, 4, 2, true, NT>(jb, lv, W, out, tid);
-      else if (key == 331) livesum_conv<3, 3, 1, true, NT>(jb, lv, W, out, tid);
-      else livesum_conv<0, 0, 0, true, NT>(jb, lv, W, out, tid);
-    } else {
-      if (key == 442) livesum_conv<4, 4, 2, false, NT>(jb, lv, W, out, tid);
-      else if (key == 331) livesum_conv<3, 3, 1, false, NT>(jb, lv, W, out, tid);
-      else livesum_conv<0, 0, 0, false, NT>(jb, lv, W, out, tid);
-    }
-  } else if (jb.kind == 1) {
-    // few outputs, long K: a wave per LS_DO outputs at a time (that many x 4 independent loads in flight), lanes stride over
-    // the sources, shuffle reduction
-    const int lane = tid & 63, wv = tid >> 6;
-    for (int o0 = wv * LS_DO; o0 < jb.Ndst; o0 += (NT / 64) * LS_DO) {
-      float acc[LS_DO];
-      const float* wrow[LS_DO];
-#pragma unroll
-      for (int u = 0; u < LS_DO; ++u) { acc[u] = 0.0f; wrow[u] = jb.w + (long)(o0 + u < jb.Ndst ? o0 + u : o0) * jb.ld; }
-#pragma unroll 4
-      for (int i = lane; i < jb.Nsrc; i += 64) {
-        const float l = lv ? lv[i] : 1.0f;
-#pragma unroll
-        for (int u = 0; u < LS_DO; ++u) acc[u] = fmaf(wrow[u][i], l, acc[u]);
-      }
-#pragma unroll
-      for (int u = 0; u < LS_DO; ++u) {
-        float v = acc[u];
-#pragma unroll
-        for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
-        if (lane == 0 && o0 + u < jb.Ndst) out[o0 + u] = v;
-      }
-    }
-  } else {
-    // dense transposed: thread per input node, coalesced weight rows, broadcast live flags
-    for (int n0 = tid; n0 < jb.Ndst; n0 += 4 * NT) {         // 4 nodes per thread at a time: 40 independent loads in flight
-      float acc[4] = {0.f, 0.f, 0.f, 0.f};
-      int nn[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) nn[u] = n0 + NT * u < jb.Ndst ? n0 + NT * u : n0;
-#pragma unroll 10
-      for (int o = 0; o < jb.Nsrc; ++o) {
-        const float l = lv ? lv[o] : 1.0f;
-        const float* wr = jb.w + (long)o * jb.ld;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] = fmaf(wr[nn[u]], l, acc[u]);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (n0 + NT * u < jb.Ndst) out[n0 + NT * u] = acc[u];
-    }
-  }
-}
-
-__global__ __launch_bounds__(256) void k_livesum(LiveSumArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lv[];     // [lv_floats] flags, then the conv weights
-  const LiveSumJob& jb = a.job[blockIdx.y];
-  const long b = blockIdx.x;
-  const int tid = threadIdx.x;
-  if (jb.lf && (jb.Nsrc & 3) == 0) {
-    copy_to_lds(lv, jb.lf + b * jb.Nsrc, jb.Nsrc);       // (B, Nsrc) rows stay 16-B aligned when Nsrc % 4 == 0
-  } else if (jb.lf) {
-    const float* lf = jb.lf + b * jb.Nsrc;
-    for (int i = tid; i < jb.Nsrc; i += 256) lv[i] = lf[i];
-  }
-  float* wl = lv + a.lv_floats;
-  if ((jb.wlds & 3) == 0) copy_to_lds(wl, jb.w, jb.wlds);
-  else for (int i = tid; i < jb.wlds; i += 256) wl[i] = jb.w[i];
-  const float* W = jb.wlds ? wl : jb.w;
-  __syncthreads();
-  float* out = jb.out + b * jb.Ndst;
-  livesum_job<256>(jb, jb.lf ? lv : nullptr, W, out, tid);
-}
-
-// ------------------------------------------------------------------------------------------
-// BaBSR ("KW") branching heuristic -- reference plnn/kw_score_conv.py choose_node_conv :41-113.
-// A scalar `ratio` per node is swept backwards through the verified network (W^T / transposed conv, times the
-// relaxation slope at every ReLU); each ReLU gets |max(b ratio (r0-1), b ratio r0) + min(ratio, 0) intercept| as score.
-// One workgroup per subproblem, the ratio vector of the current layer lives in LDS (two buffers).
-// ------------------------------------------------------------------------------------------
-struct BabsrArgs {
-  int L, R;
-  const float* lb[MAXL]; const float* ub[MAXL]; const float* bias[MAXL];   // ReLU layer k at index k-1
-  int N[MAXL], hw[MAXL], off[MAXL];
-  // edge between layer k and k+1 at index k-1 (k = 1..L-1), walked transposed
-  int ekind[MAXL];              // 0 conv, 1 linear
-  const float* ew[MAXL];        // conv: [co][ky][kx][ci]; linear: W[o][i] with row stride ld
-  int c_in[MAXL], h_in[MAXL], w_in[MAXL], c_out[MAXL], h_out[MAXL], w_out[MAXL], kh[MAXL], kw[MAXL], stride[MAXL], pad[MAXL], ld[MAXL];
-  const float* prop_w;          // (B, N_L)
-  const float* mask;            // (B, R): 1 where the BaB mask is -1
-  float* scores;                // out (B, R): `score` of :103
-  float* icp;                   // out (B, R): `intercept_tb` of :86
-  int maxN;
-};
-
-__global__ __launch_bounds__(256) void k_babsr(BabsrArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* cur = lds;
-  float* nxt = lds + a.maxN;
-  const int b = blockIdx.x, tid = threadIdx.x;
-  {
-    const int NL = a.N[a.L - 1];
-    for (int n = tid; n < NL; n += 256) cur[n] = a.prop_w[(long)b * NL + n];      // Linear(., 1)^T applied to ones(1), :73-77
-  }
-  for (int k = a.L - 1; k >= 0; --k) {
-    __syncthreads();
-    const int N = a.N[k];
-    for (int n = tid; n < N; n += 256) {
-      const long g = (long)b * N + n;
-      const float lb = a.lb[k][g], ub = a.ub[k][g];
-      const float lower_temp = lb - relu_nan(lb), upper_temp = relu_nan(ub);          // compute_ratio :23-27
-      const float slope = upper_temp / (upper_temp - lower_temp);
-      const float intercept = -1.0f * lower_temp * slope;
-      const float rt = cur[n];
-      const float icand = fminf(rt, 0.0f) * intercept;                               // :84-85
-      const float m = a.mask[(long)b * a.R + a.off[k] + n];
-      const float bb = a.bias[k][n / a.hw[k]];
-      const float b1 = bb * (rt * (slope - 1.0f));                                   // :92-93
-      const float rt2 = rt * slope;                                                  // :94
-      const float b2 = bb * rt2;                                                     // :95
-      a.scores[(long)b * a.R + a.off[k] + n] = fabsf(fmaxf(b1, b2) + icand) * m;     // :96-103
-      a.icp[(long)b * a.R + a.off[k] + n] = icand * m;                               // :86
-      cur[n] = rt2;
-    }
-    if (k == 0) break;                       // nothing reads the ratio below the first ReLU layer
-    __syncthreads();
-    const int e = k - 1;                     // edge between ReLU layers k-1+1 and k+1 in 1-based numbering
-    const int Nin = a.N[k - 1];
-    if (a.ekind[e] == 1) {                   // :74-77  ratio <- W^T ratio
-      const int nout = N, ld = a.ld[e];
-      const float* W = a.ew[e];
-      for (int i = tid; i < Nin; i += 256) {
-        float acc = 0.0f;
-        for (int o = 0; o < nout; ++o) acc = fmaf(W[(long)o * ld + i], cur[o], acc);
-        nxt[i] = acc;
-      }
-    } else {                                 // :109-111  ratio <- conv_transpose2d(ratio, W)
-      const int CI = a.c_in[e], HI = a.h_in[e], WI = a.w_in[e], CO = a.c_out[e], HO = a.h_out[e], WO = a.w_out[e];
-      const int KH = a.kh[e], KW = a.kw[e], S = a.stride[e], P = a.pad[e];
-      const float* W = a.ew[e];
-      for (int i = tid; i < Nin; i += 256) {
-        const int x = i % WI, y = (i / WI) % HI, ci = i / (WI * HI);
-        float acc = 0.0f;
-        for (int ky = 0; ky < KH; ++ky) {
-          const int ty = y + P - ky;
-          if (ty < 0 || ty % S != 0 || ty / S >= HO) continue;
-          const int oy = ty / S;
-          for (int kx = 0; kx < KW; ++kx) {
-            const int tx = x + P - kx;
-            if (tx < 0 || tx % S != 0 || tx / S >= WO) continue;
-            const int ox = tx / S;
-            for (int co = 0; co < CO; ++co)
-              acc = fmaf(W[((co * KH + ky) * KW + kx) * CI + ci], cur[(co * HO + oy) * WO + ox], acc);
-          }
-        }
-        nxt[i] = acc;
-      }
-    }
-    float* t = cur; cur = nxt; nxt = t;
-  }
-}
-
-struct ArgmaxArgs { const float* scores; int* dec; int B, R, n_relu; int cum[16]; };
-
-// torch.max(scores, 0) -> first maximal index; flat index -> [layer, idx]      graph_score.py:41-47
-// first maximum of the sample's score row -> [layer, idx]; NT threads (a power of two), sv / si: NT floats / ints of LDS
-template <int NT>
-__device__ __forceinline__ void argmax_sample(const ArgmaxArgs& a, int b, float* sv, int* si) {
-  float best = -INFINITY;
-  int bi = 0x7fffffff;
-  const float* s = a.scores + (long)b * a.R;
-  for (int i = threadIdx.x; i < a.R; i += NT) {
-    const float v = s[i];
-    if (v > best) { best = v; bi = i; }     // strided ascending: keeps the first index per thread
-  }
-  sv[threadIdx.x] = best;
-  si[threadIdx.x] = bi;
-  __syncthreads();
-  for (int st = NT / 2; st > 0; st >>= 1) {
-    if ((int)threadIdx.x < st) {
-      const float v = sv[threadIdx.x + st];
-      const int i = si[threadIdx.x + st];
-      if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && i < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = i; }
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    int lay = -1, idx = -1;
-    if (si[0] != 0x7fffffff) {
-      const int flat = si[0];
-      lay = 0;
-      while (lay < a.n_relu - 1 && a.cum[lay] <= flat) ++lay;
-      idx = lay == 0 ? flat : flat - a.cum[lay - 1];
-    }
-    a.dec[b * 2] = lay;
-    a.dec[b * 2 + 1] = idx;
-  }
-}
-
-__global__ __launch_bounds__(256) void k_argmax(ArgmaxArgs a) {
-  __shared__ float sv[256];
-  __shared__ int si[256];
-  argmax_sample<256>(a, blockIdx.x, sv, si);
-}
+#include "gnnb_dev.h"
+#include "gnnb_k_mlp.h"
+#include "gnnb_k_gather.h"
+#include "gnnb_k_edges.h"
+#include "gnnb_k_misc.h"
 
 #define N_PACKS 14   // == PK_COUNT
 enum { PK_EMBED, PK_PRE_FWD, PK_PRE_BWD, PK_PRE_INP, PK_PROP, PK_UPD_FWD_E, PK_UPD_FWD_I, PK_UPD_FWD_F, PK_UPD_BWD, PK_UPD_BWD_B,

@@ -1,0 +1,679 @@
+// gnnb_k_edges.h -- part of libgnnb.so, included by gnnb.hip (one translation unit; see its header comment).
+// the other edges and the top of the network: VALU conv kernels, dense edges (per tile / per sample out of LDS), k_prop, k_top.
+#pragma once
+
+// ------------------------------------------------------------------------------------------
+// message passing (edge aggregation)
+// ------------------------------------------------------------------------------------------
+struct ConvArgs {
+  const float* src; float* dst; const float* w;
+  int B, C_in, H_in, W_in, C_out, H_out, W_out, kh, kw, stride, pad, normalise;
+};
+
+// forward: nb[b,(co,oy,ox),:] = sum_{ci,ky,kx} W[co,ci,ky,kx] * mu_src[b,(ci,iy,ix),:]   graph_conv.py:110-121
+// one wave per (b, oy, ox): lane = embedding channel, all C_out accumulators in registers,
+// the 256-B source row is loaded once per tap and reused for C_out FMAs with scalar weights.
+template <int CO>
+__global__ __launch_bounds__(256) void k_conv_fwd(ConvArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (wv >= a.B * a.H_out * a.W_out) return;
+  const int ox = wv % a.W_out, oy = (wv / a.W_out) % a.H_out, b = wv / (a.W_out * a.H_out);
+  float acc[CO];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) acc[co] = 0.0f;
+  const float* src = a.src + (long)b * a.C_in * a.H_in * a.W_in * 64 + lane;
+  for (int ci = 0; ci < a.C_in; ++ci)
+    for (int ky = 0; ky < a.kh; ++ky) {
+      const int iy = oy * a.stride - a.pad + ky;
+      if ((unsigned)iy >= (unsigned)a.H_in) continue;
+      for (int kx = 0; kx < a.kw; ++kx) {
+        const int ix = ox * a.stride - a.pad + kx;
+        if ((unsigned)ix >= (unsigned)a.W_in) continue;
+        const float v = src[(long)((ci * a.H_in + iy) * a.W_in + ix) * 64];
+        const float* w = a.w + ((ci * a.kh + ky) * a.kw + kx) * CO;
+#pragma unroll
+        for (int co = 0; co < CO; ++co) acc[co] = fmaf(w[co], v, acc[co]);
+      }
+    }
+  float* dst = a.dst + ((long)b * CO * a.H_out * a.W_out + (long)oy * a.W_out + ox) * 64 + lane;
+#pragma unroll
+  for (int co = 0; co < CO; ++co) dst[(long)co * a.H_out * a.W_out * 64] = acc[co];
+}
+
+// backward: nb[b,(ci,y,x),:] = sum_{co,ky,kx} W[co,ci,ky,kx] * mu_up[b,(co,oy,ox),:] with y = oy*s - p + ky,
+// divided by the number of taps touching (y,x) when `normalise`         graph_conv.py:299-318 (and :361-372 without)
+template <int CI>
+__global__ __launch_bounds__(256) void k_convT_bwd(ConvArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (wv >= a.B * a.H_in * a.W_in) return;
+  const int x = wv % a.W_in, y = (wv / a.W_in) % a.H_in, b = wv / (a.W_in * a.H_in);
+  float acc[CI];
+#pragma unroll
+  for (int ci = 0; ci < CI; ++ci) acc[ci] = 0.0f;
+  const float* src = a.src + (long)b * a.C_out * a.H_out * a.W_out * 64 + lane;
+  int ny = 0, nx = 0;
+  for (int ky = 0; ky < a.kh; ++ky) {
+    const int t = y + a.pad - ky;
+    if (t >= 0 && t % a.stride == 0 && t / a.stride < a.H_out) ++ny;
+  }
+  for (int kx = 0; kx < a.kw; ++kx) {
+    const int t = x + a.pad - kx;
+    if (t >= 0 && t % a.stride == 0 && t / a.stride < a.W_out) ++nx;
+  }
+  for (int co = 0; co < a.C_out; ++co)
+    for (int ky = 0; ky < a.kh; ++ky) {
+      const int ty = y + a.pad - ky;
+      if (ty < 0 || ty % a.stride != 0 || ty / a.stride >= a.H_out) continue;
+      const int oy = ty / a.stride;
+      for (int kx = 0; kx < a.kw; ++kx) {
+        const int tx = x + a.pad - kx;
+        if (tx < 0 || tx % a.stride != 0 || tx / a.stride >= a.W_out) continue;
+        const int ox = tx / a.stride;
+        const float v = src[(long)((co * a.H_out + oy) * a.W_out + ox) * 64];
+        const float* w = a.w + ((co * a.kh + ky) * a.kw + kx) * CI;
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) acc[ci] = fmaf(w[ci], v, acc[ci]);
+      }
+    }
+  const float freq = a.normalise ? (float)(ny * nx) : 1.0f;
+  float* dst = a.dst + ((long)b * CI * a.H_in * a.W_in + (long)y * a.W_in + x) * 64 + lane;
+#pragma unroll
+  for (int ci = 0; ci < CI; ++ci) dst[(long)ci * a.H_in * a.W_in * 64] = a.normalise ? acc[ci] / freq : acc[ci];
+}
+
+struct DenseArgs {
+  const float* At;   // (8*ksq, ldA) zero-padded: At[k][i] = A[i][k]
+  const float* X;    // (B, K, 64)
+  float* out;        // (B, M, 64)
+  const float* zero; // 64 zero floats
+  int B, K, M, ldA, MT, ksq;
+};
+
+// dense edge: out[b, i, :] = sum_k A[i][k] X[b, k, :]   (graph_conv.py:131 forward, :321 backward)
+// one workgroup per (b, 32-row tile of i); its 4 waves split K and are summed through LDS in a fixed order.
+// D_it[i][j] on the MFMA for both channel tiles (lane j holds channels 2j, 2j+1 of the source row: one coalesced
+// 256-B row per half-wave and k-step), A from L2; loads run one 8-k-step chunk ahead.
+#define DENSE_CH 8
+// SPLIT = true: the 4 waves of a workgroup share one (b, row tile) and split K (long K, few tiles: the forward edge);
+// SPLIT = false: every wave owns its own (b, row tile) and walks all of K (short K: the transposed edge).
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void k_dense_agg(DenseArgs a) {
+  __shared__ float red[SPLIT ? 4 : 1][32][64];
+  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // the MT row tiles of one sample all stream the same source rows: keep them on one XCD (blockIdx % 8 labels the
+  // XCD group), so that sample is fetched into one L2 instead of up to MT of them
+  int bid = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+  const int tile = SPLIT ? bid : bid * 4 + wave;
+  if (tile >= a.B * a.MT) return;
+  const int mt = tile % a.MT, b = tile / a.MT;
+  // At is zero-padded on the host to MT*32 columns and enough rows, the k padding of X reads a zero row: no select
+  // touches a loaded value
+  const float* At = a.At + mt * 32 + j;
+  const float* X = a.X + (long)b * a.K * 64 + 2 * j;
+  const long zdelta = (a.zero + 2 * j) - X;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+  const int nks = SPLIT ? a.ksq : 4 * a.ksq;            // k-steps this wave walks (a multiple of DENSE_CH)
+  const int s_begin = SPLIT ? wave * a.ksq : 0;
+  float av[DENSE_CH];
+  float2 bv[DENSE_CH];
+  // measured: with 16 resident waves per CU the other waves cover a chunk's load latency; keeping a second chunk in
+  // flight per wave made this kernel slower
+  for (int s0 = s_begin; s0 < s_begin + nks; s0 += DENSE_CH) {
+#pragma unroll
+    for (int u = 0; u < DENSE_CH; ++u) {
+      const int k = 2 * (s0 + u) + h;
+      av[u] = At[(long)k * a.ldA];
+      const long o = k < a.K ? (long)k * 64 : zdelta;
+      bv[u] = *reinterpret_cast<const float2*>(X + o);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < DENSE_CH; ++u) {
+      acc0 = mfma32(av[u], bv[u].x, acc0);
+      acc1 = mfma32(av[u], bv[u].y, acc1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  float* out = a.out + (long)b * a.M * 64 + 2 * j;
+  if (SPLIT) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { red[wave][r][lane] = acc0[r]; red[wave][16 + r][lane] = acc1[r]; }
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int r = wave * 4 + rr;
+      const float v0 = ((red[0][r][lane] + red[SPLIT ? 1 : 0][r][lane]) + red[SPLIT ? 2 : 0][r][lane]) + red[SPLIT ? 3 : 0][r][lane];
+      const float v1 = ((red[0][16 + r][lane] + red[SPLIT ? 1 : 0][16 + r][lane]) + red[SPLIT ? 2 : 0][16 + r][lane]) +
+                       red[SPLIT ? 3 : 0][16 + r][lane];
+      const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < a.M) *reinterpret_cast<float2*>(out + (long)row * 64) = make_float2(v0, v1);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < a.M) *reinterpret_cast<float2*>(out + (long)row * 64) = make_float2(acc0[r], acc1[r]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// dense edges, one workgroup per sample: the source rows of the sample are staged in LDS once and shared by all its
+// row tiles (stand-alone tiles re-fetched them through L2 up to MT times: ~40 % L2 misses, 95 us per launch).
+// B operand (source row, channels 2j, 2j+1) = one conflict-free ds_read_b64 per k-step; A operand (weights, shared by
+// all samples) streams from L2 one chunk ahead.
+// ------------------------------------------------------------------------------------------
+struct DenseLArgs {
+  const float* At;    // zero-padded (rows >= K_pad + 16, ldA columns): At[k][i] = A[i][k]
+  const float* X;     // (B, K, 64)
+  float* out;         // (B, M, 64)
+  int B, K, M, ldA, MT, Kpad;
+};
+
+#define DL_CH 8
+#define DENSE_FWD_LDS_FLOATS (2 * 2 * 32 * 64 + 4 * 32 * 64)     // xs + red = 64 KB
+#define DENSE_BWD_ROWS (128 + 16)
+// forward edge (long K) of sample b: 8 waves = 4 row tiles x 2 K-halves; X streams through LDS in double-buffered chunks
+// of 2 x 32 rows (one slab per K-half), the two halves are summed through LDS in a fixed order.  Requires MT <= 4 and 512
+// threads.  `scratch`: DENSE_FWD_LDS_FLOATS floats of LDS; store(row, channel pair index j, value pair).
+// klist (LDS) != nullptr: only the K_eff source rows klist[0..K_eff) are walked (the caller dropped the all-zero rows of dead
+// nodes); klist must be padded with a.Kpad (a zero row of At) up to round_up(K_eff, 64) + 32 entries.
+template <class Store>
+__device__ __forceinline__ void dense_fwd_sample(const DenseLArgs& a, int b, float* scratch, Store store, const int* klist = nullptr,
+                                                 int K_eff = 0) {
+  float (*xs)[2][32][64] = reinterpret_cast<float (*)[2][32][64]>(scratch);                 // [buffer][K-half][row][channel]  32 KB
+  float (*red)[32][64] = reinterpret_cast<float (*)[32][64]>(scratch + 2 * 2 * 32 * 64);    // 32 KB
+  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int mt = wave & 3, kh = wave >> 2;
+  const int Kw = klist ? K_eff : a.K;            // source rows walked
+  const int khalf = (klist ? (K_eff + 63) / 64 * 64 : a.Kpad) / 2;      // rows per K-half, a multiple of 32
+  const int nchunks = khalf / 32;
+  const float* Xb = a.X + (long)b * a.K * 64;
+  // cooperative stage of chunk c: 2 slabs x 32 rows x 256 B = 16 KB, 512 threads x 2 x 16 B.  The global loads are issued
+  // BEFORE the MFMAs of the running chunk and written to LDS after them, so their latency is not exposed once per chunk
+  // (as one load-then-store step this kernel ran at half its MFMA rate).
+  f32x4 sv[2];
+  auto gload = [&](int c) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int e = threadIdx.x + 512 * r;        // 16-B piece index, 0..1023
+      const int slab = e >> 9, row = (e >> 4) & 31, piece = e & 15;
+      const int k = slab * khalf + c * 32 + row;
+      const int krow = k < Kw ? (klist ? klist[k] : k) : 0;
+      const f32x4* src = reinterpret_cast<const f32x4*>(Xb + (long)krow * 64 + piece * 4);
+      const f32x4 v = *src;
+      sv[r] = k < Kw ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int e = threadIdx.x + 512 * r;
+      const int slab = e >> 9, row = (e >> 4) & 31, piece = e & 15;
+      *reinterpret_cast<f32x4*>(&xs[buf][slab][row][piece * 4]) = sv[r];
+    }
+  };
+  const float* At = a.At + (klist ? 0 : (long)(kh * khalf) * a.ldA) + (mt < a.MT ? mt : 0) * 32 + j;   // waves beyond MT idle on tile 0
+  const int* kl = klist ? klist + kh * khalf : nullptr;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+  float av[16], nav[16];
+  auto loadA = [&](float (&A)[16], int c) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) A[u] = At[(long)(kl ? kl[c * 32 + 2 * u + h] : c * 32 + 2 * u + h) * a.ldA];
+  };
+  auto mma = [&](const float (&A)[16], int buf) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const float2 bv = *reinterpret_cast<const float2*>(&xs[buf][kh][2 * u + h][2 * j]);
+      acc0 = mfma32(A[u], bv.x, acc0);
+      acc1 = mfma32(A[u], bv.y, acc1);
+    }
+  };
+  gload(0);
+  lstore(0);
+  loadA(av, 0);
+  __syncthreads();
+  for (int c = 0; c < nchunks; c += 2) {
+    const bool more1 = c + 1 < nchunks;
+    if (more1) gload(c + 1);
+    loadA(nav, c + 1);                      // At carries 32 extra zero rows: reading one chunk past the end is harmless
+    __builtin_amdgcn_sched_barrier(0);
+    mma(av, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more1) lstore(1);
+    __syncthreads();
+    if (!more1) break;
+    const bool more2 = c + 2 < nchunks;
+    if (more2) gload(c + 2);
+    loadA(av, c + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(nav, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more2) lstore(0);
+    __syncthreads();
+  }
+  if (kh == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { red[mt][r][lane] = acc0[r]; red[mt][16 + r][lane] = acc1[r]; }
+  }
+  __syncthreads();
+  if (kh == 0 && mt < a.MT) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < a.M) store(row, j, make_float2(acc0[r] + red[mt][r][lane], acc1[r] + red[mt][16 + r][lane]));
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void k_dense_fwd_lds(DenseLArgs a) {
+  __shared__ __attribute__((aligned(16))) float scratch[DENSE_FWD_LDS_FLOATS];
+  const int b = blockIdx.x;
+  float* out = a.out + (long)b * a.M * 64;
+  dense_fwd_sample(a, b, scratch, [&](int row, int j, float2 v) { *reinterpret_cast<float2*>(out + (long)row * 64 + 2 * j) = v; });
+}
+
+// transposed edge (short K <= 128) of one sample whose source rows sit in LDS (`xs`: DENSE_BWD_ROWS x 64, rows >= K zero);
+// 8 waves walk the MT row tiles.
+// Optional compaction (lists in LDS): `rlist` / n_rows -- only these output rows are computed (the live nodes of the layer
+// below; the others are never read); `klist` / K_eff -- only these source rows are walked (the live nodes of this layer; the
+// rows of dead ones are zero), padded with a.Kpad (a zero row of At and of xs) up to round_up(K_eff, 16) + 32 entries.
+template <class Store>
+__device__ __forceinline__ void dense_bwd_sample(const DenseLArgs& a, const float* xs_raw, Store store, const int* rlist = nullptr,
+                                                 int n_rows = 0, const int* klist = nullptr, int K_eff = 0) {
+  const float (*xs)[64] = reinterpret_cast<const float (*)[64]>(xs_raw);
+  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nch = (klist ? (K_eff + 15) / 16 * 16 : a.Kpad) / 16;      // chunks of 8 k-steps
+  const int M = rlist ? n_rows : a.M, MT = rlist ? (n_rows + 31) / 32 : a.MT;
+  for (int mt = wave; mt < MT; mt += 8) {
+    const int arow = rlist ? rlist[mt * 32 + j < M ? mt * 32 + j : 0] : mt * 32 + j;
+    const float* At = a.At + arow;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+    // three A buffers in rotation: a chunk of 8 k-steps is only 16 MFMAs (~0.4 us), less than an L2 round trip, so the
+    // weights are fetched TWO chunks ahead.  At carries 48 extra zero rows for the loads issued past the end.
+    float a0[DL_CH], a1[DL_CH], a2[DL_CH];
+    auto loadA = [&](float (&A)[DL_CH], int c) {
+#pragma unroll
+      for (int u = 0; u < DL_CH; ++u) A[u] = At[(long)(klist ? klist[c * 16 + 2 * u + h] : c * 16 + 2 * u + h) * a.ldA];
+    };
+    auto mma = [&](const float (&A)[DL_CH], int c) {
+#pragma unroll
+      for (int u = 0; u < DL_CH; ++u) {
+        const float2 bv = *reinterpret_cast<const float2*>(&xs[klist ? klist[c * 16 + 2 * u + h] : c * 16 + 2 * u + h][2 * j]);
+        acc0 = mfma32(A[u], bv.x, acc0);
+        acc1 = mfma32(A[u], bv.y, acc1);
+      }
+    };
+    loadA(a0, 0);
+    loadA(a1, 1);
+    for (int c = 0; c < nch; c += 3) {
+      loadA(a2, c + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a0, c);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 1 >= nch) break;
+      loadA(a0, c + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a1, c + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 2 >= nch) break;
+      loadA(a1, c + 4);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a2, c + 2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < M) store(rlist ? rlist[row] : row, j, make_float2(acc0[r], acc1[r]));
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void k_dense_bwd_lds(DenseLArgs a) {
+  __shared__ __attribute__((aligned(16))) float xs[DENSE_BWD_ROWS][64];       // 36 KB, rows >= K are zero
+  const int b = blockIdx.x;
+  const float* Xb = a.X + (long)b * a.K * 64;
+  for (int e = threadIdx.x; e < DENSE_BWD_ROWS * 16; e += 512) {
+    const int row = e >> 4, piece = e & 15;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < a.K) v = *reinterpret_cast<const f32x4*>(Xb + (long)row * 64 + piece * 4);
+    *reinterpret_cast<f32x4*>(&xs[row][piece * 4]) = v;
+  }
+  __syncthreads();
+  float* out = a.out + (long)b * a.M * 64;
+  dense_bwd_sample(a, &xs[0][0], [&](int row, int j, float2 v) { *reinterpret_cast<float2*>(out + (long)row * 64 + 2 * j) = v; });
+}
+
+struct PropArgs {
+  const float* pack; const float* mu_last; const float* prop_w; const float* prop_b;
+  const float *lb, *ub, *z_out; float* mu_prop; float* nb_back; int B, N_last;
+  const float *lbl, *ubl;   // bounds of the top ReLU layer (its rows have fc4_2 deferred: the bias term needs live_n)
+};
+
+// property node (graph_conv.py:194-210): nb = W_prop[b] . mu_L[b];
+// mu_K = out3(relu(out2([relu(out1([l, u, z_out, c])), nb]))), then the backward edge from it (:324-326):
+// nb_back[b, n, :] = W_prop[b][n] * mu_K[b, :].  One workgroup (4 waves) per sample, lane = channel: the waves split the
+// rows of mu_L (partial sums combined in a fixed order through LDS), wave 0 runs the three small layers with the
+// transposed weights in LDS (196 dependent FMA steps read LDS, not L2), all waves write the backward aggregate.
+__global__ __launch_bounds__(256) void k_prop(PropArgs a) {
+  __shared__ float wl[PackProp::FLOATS];
+  __shared__ float xs[128];
+  __shared__ float part[4][64];
+  __shared__ float outv[64];
+  __shared__ float spart[4];
+  for (int i = threadIdx.x; i < PackProp::FLOATS; i += 256) wl[i] = a.pack[i];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = blockIdx.x;
+  const float* mu = a.mu_last + (long)b * a.N_last * 64 + lane;
+  const float* pw = a.prop_w + (long)b * a.N_last;
+  float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  for (int n = w; n < a.N_last; n += 16) {             // 4 independent loads in flight per wave
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int nn = n + 4 * u;
+      if (nn < a.N_last) acc[u] = fmaf(pw[nn], mu[(long)nn * 64], acc[u]);
+    }
+  }
+  part[w][lane] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  // sp = sum_n W_prop[n] live_n: the rows of mu_L hold E with mu = (fc4_2.E + b).live, so
+  // out2[:, 64:].nb = (out2[:, 64:].fc4_2.W).(sum_n W_prop[n] E_n) + sp.(out2[:, 64:].fc4_2.b)   (folded in PackProp)
+  float sp = 0.0f;
+  for (int n = threadIdx.x; n < a.N_last; n += 256) {
+    const long g = (long)b * a.N_last + n;
+    sp += node_is_live(a.lbl[g], a.ubl[g]) ? pw[n] : 0.0f;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sp += __shfl_xor(sp, o);
+  if (lane == 0) spart[w] = sp;
+  __syncthreads();
+  if (w == 0) {
+    const float nb = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    const float spt = (spart[0] + spart[1]) + (spart[2] + spart[3]);
+    const float f[4] = {a.lb[b], a.ub[b], a.z_out[b], a.prop_b[b]};
+    float h1 = wl[PackProp::B1 + lane];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) h1 = fmaf(wl[PackProp::W1T + k * 64 + lane], f[k], h1);
+    xs[lane] = relu_nan(h1);
+    xs[64 + lane] = nb;
+    __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): this wave's LDS writes are visible to its own reads
+    float h2 = fmaf(spt, wl[PackProp::V2 + lane], wl[PackProp::B2 + lane]);
+#pragma unroll 8
+    for (int k = 0; k < 128; ++k) h2 = fmaf(wl[PackProp::W2T + k * 64 + lane], xs[k], h2);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    xs[lane] = relu_nan(h2);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    float o = wl[PackProp::B3 + lane];
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) o = fmaf(wl[PackProp::W3T + k * 64 + lane], xs[k], o);
+    a.mu_prop[(long)b * 64 + lane] = o;
+    outv[lane] = o;
+  }
+  __syncthreads();
+  if (a.nb_back) {
+    const float o = outv[lane];
+    float* nbk = a.nb_back + (long)b * a.N_last * 64 + lane;
+    for (int n = w; n < a.N_last; n += 4) nbk[(long)n * 64] = pw[n] * o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_top: the top of the network in one launch per round, one workgroup (8 waves) per sample.  When the last ReLU layer
+// hangs on a Linear edge and has <= 128 nodes, everything between "layer L-1 forward-updated" and "layer L-1 can be
+// backward-updated" is local to a sample and tiny:
+//   F1  nb_L   = W_L . mu_{L-1}                        (dense forward edge, graph_conv.py:130-137)
+//   F2  mu_L   <- forward node update                  (:139-186)
+//   F3  mu_K   <- property node, nb_back = W_prop^T mu_K  (:194-210, :324-326)
+//   B1  mu_L   <- backward node update                 (:253-350)
+//   B2  nb_{L-1} = W_L^T . mu_L                        (dense transposed edge, :320-322)
+// As five launches these cost ~160 us of mostly launch ramps, weight staging and latency; here the layer's rows never
+// leave LDS.  LDS map (floats): A = weight pack of the running phase (first the dense-forward staging buffers),
+// Bp = PackProp, C = the rows of layer L (DENSE_BWD_ROWS x 64, rows >= N zero), sm = small vectors.
+// ------------------------------------------------------------------------------------------
+struct TopArgs {
+  DenseLArgs df;            // forward edge L (out unused)
+  DenseLArgs db;            // transposed edge L (X unused: the rows come from LDS), out = aggregate rows of layer L-1
+  const float *pack_f, *pack_b, *pack_p;
+  const float *Pf, *Pb;     // cached P' rows of layer L (by node id), forward / backward
+  const float* sf;          // bias-sum scalars of the forward edge (B, N)
+  const float *lb, *ub;     // bounds of layer L, flat (B*N)
+  const float *lbm, *ubm;   // bounds of layer L-1, flat (B*K): its dead rows (all zero) are skipped by the forward edge
+  const float *prop_w, *prop_b, *lbK, *ubK, *z_out;
+  float* mu_prop;           // (B, 64)
+  float* mu;                // (B, N, 64) rows of layer L (backward-produced)
+  int* status;
+  int N;
+};
+#define TOP_A_FLOATS (PackUpd::FLOATS > DENSE_FWD_LDS_FLOATS ? PackUpd::FLOATS : DENSE_FWD_LDS_FLOATS)
+#define TOP_FIXED_FLOATS (TOP_A_FLOATS + PackProp::FLOATS + DENSE_BWD_ROWS * 64 + 8 * 64 + 128 + 64 + 64)
+#define TOP_LDS_FLOATS 40960                   // all 160 KB: what the fixed regions leave holds the live-row lists
+#define TOP_K2_INTS (128 + 48)                  // live rows of layer L, padded for the chunks read ahead
+#define TOP_LIST_INTS (TOP_LDS_FLOATS - TOP_FIXED_FLOATS - TOP_K2_INTS)
+
+__device__ __forceinline__ void copy_to_lds_part(float* lds, const float* src, int nfloats, int tid, int nthr) {
+  const f32x4* g = reinterpret_cast<const f32x4*>(src);
+  f32x4* l = reinterpret_cast<f32x4*>(lds);
+  const int n4 = nfloats / 4;
+  for (int i0 = tid; i0 < n4; i0 += 8 * nthr) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * nthr;
+      v[u] = g[i < n4 ? i : i0];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * nthr;
+      if (i < n4) l[i] = v[u];
+    }
+  }
+}
+
+// needs 512 threads (threads beyond that idle) and TOP_LDS_FLOATS of LDS
+__device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float* lds) {
+  float* A = lds;
+  float* Bp = A + TOP_A_FLOATS;
+  float* Cr = Bp + PackProp::FLOATS;
+  float* part = Cr + DENSE_BWD_ROWS * 64;     // [8][64]
+  float* xs = part + 8 * 64;                  // [128]
+  float* outv = xs + 128;                     // [64]
+  float* spart = outv + 64;                   // [8]
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int N = a.N;
+  for (int i = tid; i < DENSE_BWD_ROWS * 16; i += 512) reinterpret_cast<f32x4*>(Cr)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // live source rows of layer L-1 (the dead ones are all zero: ~45 % of the forward edge's k-steps), compacted in node order
+  // into the region PackProp takes afterwards
+  // The list goes behind the fixed regions when it fits there (then the transposed edge B2 also uses it, to compute only the
+  // live rows of layer L-1), else into the region PackProp takes after F1.
+  int* k2list = reinterpret_cast<int*>(spart + 8);        // live rows of layer L (B2)
+  int* tail = k2list + TOP_K2_INTS;
+  const bool keep = a.df.K + 96 <= TOP_LIST_INTS;
+  int* klist = keep ? tail : reinterpret_cast<int*>(Bp);
+  int K_eff = 0;
+  const bool compact = keep || a.df.K + 96 <= PackProp::FLOATS;
+  if (compact) {
+    int* wc = reinterpret_cast<int*>(part);              // per-wave counts
+    const int K = a.df.K;
+    for (int n0 = 0; n0 < K; n0 += 512) {
+      const int n = n0 + tid;
+      const long gm = (long)b * K + (n < K ? n : 0);
+      const bool live = n < K && node_is_live(a.lbm[gm], a.ubm[gm]);
+      const unsigned long long bal = __ballot(live);
+      if (lane == 0) wc[wave] = __popcll(bal);
+      __syncthreads();
+      int before = 0, total = 0;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) { before += w8 < wave ? wc[w8] : 0; total += wc[w8]; }
+      if (live) klist[K_eff + before + __popcll(bal & ((1ull << lane) - 1ull))] = n;
+      K_eff += total;
+      __syncthreads();
+    }
+    for (int i = K_eff + tid; i < (K_eff + 63) / 64 * 64 + 32; i += 512) klist[i] = a.df.Kpad;     // a zero row of At
+  }
+  __syncthreads();
+
+  // ---- F1: rows of C <- W_L . mu_{L-1}
+  dense_fwd_sample(a.df, b, A, [&](int row, int jj, float2 v) { *reinterpret_cast<float2*>(Cr + row * 64 + 2 * jj) = v; },
+                   compact ? klist : nullptr, K_eff);
+  __syncthreads();
+  copy_to_lds(Bp, a.pack_p, PackProp::FLOATS);            // (read from F3 on, behind two more barriers)
+
+  // per-lane node of the update phases (waves 0..3: one tile of 32 nodes each)
+  const int n = wave * 32 + j;
+  const bool upd_wave = wave * 32 < N;
+  const bool valid = n < N;
+  const long g = (long)b * N + (valid ? n : 0);
+  const float* pw = a.prop_w + (long)b * N;
+  Ratio r{};
+  if (upd_wave) r = compute_ratio(a.lb[g], a.ub[g]);
+  auto load_row = [&](Frag& x_, int row) {       // fragment <- LDS row (row-major 64 floats)
+    const f32x4* p = reinterpret_cast<const f32x4*>(Cr + row * 64 + 4 * h);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const f32x4 v = p[2 * q];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) FRAG_AT(x_, 4 * q + c) = v[c];
+    }
+  };
+  auto store_row = [&](const Frag& x_, float* base) {
+    f32x4* p = reinterpret_cast<f32x4*>(base + 4 * h);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      f32x4 v;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = FRAG_AT(x_, 4 * q + c);
+      p[2 * q] = v;
+    }
+  };
+  // general folded node chain on fragment X (k_node_update, kind 1); `sx`: small k-step input of a deferred projection
+  auto chain = [&](const Frag& X, const float* Prow, bool deferred, float sx, Frag& H2) {
+    Frag H;
+    frag_bias(H, A + PackUpd::BA, h);
+    if (deferred) {
+      const float x1[1] = {sx};
+      gemm_small<1>(A + PackUpd::VAW, lane, H, x1);
+    }
+    const float r0 = r.r0, r1 = r.r1;
+    gemm_w64<64>(A + PackUpd::WA, lane, H, [&](int s) { return FRAG_AT(X, s & 31) * (s < 32 ? r0 : r1); });
+    frag_relu(H);
+    frag_load_rowptr(H2, Prow, h);
+    gemm_w64<32>(A + PackUpd::WCB, lane, H2, [&](int s) { return FRAG_AT(H, s); });
+    frag_relu(H2);
+    frag_scale(H2, r.live);
+  };
+
+  // ---- F2: forward node update of layer L (rows stay in C)
+  stage_pack(A, a.pack_f, PackUpd::FLOATS);
+  if (upd_wave) {
+    Frag X, E;
+    load_row(X, valid ? n : 0);
+    chain(X, r.amb != 0.0f ? a.Pf + g * 64 : a.pack_f + PackUpd::BCBROW, true, (h ? r.r1 : r.r0) * a.sf[g], E);
+    if (valid) {
+      if (frag_has_nan(E)) atomicOr(a.status, 1);
+      store_row(E, Cr + n * 64);
+    }
+  }
+  __syncthreads();
+
+  // ---- F3: property node (k_prop) on the rows in C; meanwhile waves 1..7 stage the backward pack
+  {
+    float acc = 0.0f;
+    for (int m = wave; m < N; m += 8) acc = fmaf(pw[m], Cr[m * 64 + lane], acc);
+    part[wave * 64 + lane] = acc;
+    float sp = 0.0f;
+    for (int m = tid; m < N; m += 512) {
+      const long gm = (long)b * N + m;
+      sp += node_is_live(a.lb[gm], a.ub[gm]) ? pw[m] : 0.0f;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sp += __shfl_xor(sp, o);
+    if (lane == 0) spart[wave] = sp;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float nbv = 0.0f, spt = 0.0f;
+#pragma unroll
+    for (int w8 = 0; w8 < 8; ++w8) { nbv += part[w8 * 64 + lane]; spt += spart[w8]; }
+    const float f[4] = {a.lbK[b], a.ubK[b], a.z_out[b], a.prop_b[b]};
+    float h1 = Bp[PackProp::B1 + lane];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) h1 = fmaf(Bp[PackProp::W1T + k * 64 + lane], f[k], h1);
+    xs[lane] = relu_nan(h1);
+    xs[64 + lane] = nbv;
+    __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): this wave's LDS writes are visible to its own reads
+    float h2 = fmaf(spt, Bp[PackProp::V2 + lane], Bp[PackProp::B2 + lane]);
+#pragma unroll 8
+    for (int k = 0; k < 128; ++k) h2 = fmaf(Bp[PackProp::W2T + k * 64 + lane], xs[k], h2);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    xs[lane] = relu_nan(h2);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    float o = Bp[PackProp::B3 + lane];
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) o = fmaf(Bp[PackProp::W3T + k * 64 + lane], xs[k], o);
+    a.mu_prop[(long)b * 64 + lane] = o;
+    outv[lane] = o;
+  } else {
+    copy_to_lds_part(A, a.pack_b, PackUpd::FLOATS, tid - 64, 448);
+  }
+  __syncthreads();
+
+  // ---- B1: backward node update of layer L; its aggregate is the rank-1 edge from the property node
+  if (upd_wave) {
+    Frag X, E;
+    const float wn = valid ? pw[n] : 0.0f;
+    {
+      const f32x4* o4 = reinterpret_cast<const f32x4*>(outv + 4 * h);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const f32x4 v = o4[2 * q];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) FRAG_AT(X, 4 * q + c) = wn * v[c];
+      }
+    }
+    chain(X, r.amb != 0.0f ? a.Pb + g * 64 : a.pack_b + PackUpd::BCBROW, false, 0.0f, E);
+    if (valid) {
+      if (frag_has_nan(E)) atomicOr(a.status, 1);
+      store_row(E, Cr + n * 64);
+      store_row(E, a.mu + g * 64);
+    }
+  }
+  __syncthreads();
+
+  // ---- B2: aggregate rows of layer L-1 <- W_L^T . rows of C: only the live rows of layer L-1 (nothing reads the others), only
+  // the live (non-zero) rows of layer L
+  int K2 = 0;
+  if (keep) {
+    int* wc = reinterpret_cast<int*>(part);
+    const unsigned long long bal = __ballot(upd_wave && valid && r.live != 0.0f && (lane < 32));
+    if (lane == 0) wc[wave] = __popcll(bal);
+    __syncthreads();
+    int before = 0;
+#pragma unroll
+    for (int w8 = 0; w8 < 8; ++w8) { before += w8 < wave ? wc[w8] : 0; K2 += wc[w8]; }
+    if (upd_wave && valid && r.live != 0.0f && lane < 32) k2list[before + __popcll(bal & ((1ull << lane) - 1ull))] = n;
+    for (int i = K2 + tid; i < TOP_K2_INTS; i += 512) k2list[i] = a.db.Kpad;   // zero row of At and of C
+    __syncthreads();
+  }
+  float* out = a.db.out + (long)b * a.db.M * 64;
+  auto put = [&](int row, int jj, float2 v) { *reinterpret_cast<float2*>(out + (long)row * 64 + 2 * jj) = v; };
+  if (keep) dense_bwd_sample(a.db, Cr, put, klist, K_eff, k2list, K2);
+  else dense_bwd_sample(a.db, Cr, put);
+}
+
+__global__ __launch_bounds__(512, 1) void k_top(TopArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  top_sample(a, blockIdx.x, lds);
+}

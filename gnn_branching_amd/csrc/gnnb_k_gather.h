@@ -1,0 +1,856 @@
+// gnnb_k_gather.h -- part of libgnnb.so, included by gnnb.hip (one translation unit; see its header comment).
+// conv-edge message passing on the MFMA: k_gather, k_gather16, k_gather_input_update; the score head k_score.
+#pragma once
+
+// ------------------------------------------------------------------------------------------
+// fused message passing + node update for conv edges: the neighbour aggregate never leaves registers.
+//   nb^T (64 ch x 32 dst) = mu_src^T (64 ch x K window nodes) . Cmat (K x 32 dst)      on the MFMA,
+// A operand = source embedding rows straight from HBM/L2 (one coalesced 256-B row per lane half and k-step:
+// lane i holds channels 2i, 2i+1), B operand = the tap matrix of the tile shape, resident in LDS.
+// Forward edges: graph_conv.py:110-127; transposed edges + tap-count division: :299-318; input layer :361-372.
+// ------------------------------------------------------------------------------------------
+struct DGather {
+  const float* cmat;     // [NCG][K2][64]
+  const int2* koff;      // [2*K2]: {row offset relative to the window origin, wy | wx << 16}
+  const int* ttab;       // [TPS]: cg | by << 8 | bx << 20
+  const float* zero;     // 64 zero floats
+  int K2, ncg_k2, Hs, Ws, Ns, ystep, ybase, xstep, xbase, WY, WX, normalise, kh, kw, stride, pad;
+  int lanes;             // dst nodes per tile: 32 (32x32x2 MFMA, 2 window slots per k-step) or 16 (16x16x4, 4 slots per k-step)
+};
+
+#define GATHER_CH 8   // k-steps per prefetch chunk
+#define KOFF_PAD (2 * GATHER_CH)   // always-masked koff entries behind the table (one chunk is loaded past the end)
+// window slots in the koff / kvo tables, padding included (gnnb_pack.h fill_gather_tables)
+__host__ __device__ inline int gather_slots(int K2, int lanes) { return lanes == 32 ? 2 * K2 + KOFF_PAD : 4 * K2 + 2 * KOFF_PAD; }
+
+// Source rows are read with buffer loads: the descriptor covers exactly this sample's source layer (wave-uniform base
+// in SGPRs), the per-lane part is a 32-bit byte offset, and a masked window node / the k padding simply gets an
+// offset beyond the descriptor's range -- the hardware returns 0 for it without touching memory.  So nothing (no
+// select, no copy) is applied to a loaded value before its MFMA and there is no control flow around the loads, which is
+// what lets hipcc keep the next chunk in flight behind counted vmcnt waits (the koff table carries 16 always-masked
+// entries for the one chunk issued past the end).
+// INTERIOR = the whole window lies inside the source layer (wave-uniform; ~3/4 of the tiles): no bounds arithmetic.
+#define BUF_OOB 0x80000000u
+__device__ __forceinline__ float2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0);
+  return make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
+}
+
+template <bool INTERIOR>
+__device__ __forceinline__ void gather_tile(Frag& X, const float* cm, const int2* ko, const unsigned* kvo, int K2,
+                                            __amdgpu_buffer_rsrc_t rsrc, int j, int wy0, int wx0, int Hs, int Ws, int lane) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = 0.0f;
+  const int origin = wy0 * Ws + wx0;
+  const unsigned lane_off = 8u * (unsigned)j;        // channels 2j, 2j+1 of the row
+  const unsigned soff = (unsigned)origin * 256u;     // INTERIOR: wave-uniform window origin goes into the scalar offset
+  float2 cur[GATHER_CH], nxt[GATHER_CH];
+  auto load = [&](float2 (&dst)[GATHER_CH], int s0) {
+#pragma unroll
+    for (int u = 0; u < GATHER_CH; ++u) {
+      if (INTERIOR) {
+        // per k-step: one LDS read of the tile-invariant byte offset + one add; no bounds arithmetic.  k padding
+        // reads row `origin` (in range for an interior tile; its tap-matrix column is zero)
+        const unsigned vo = kvo[2 * (s0 + u) + h] + lane_off;
+        const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, vo, soff, 0);
+        dst[u] = make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
+      } else {
+        // one 64-bit LDS read per entry: with two 32-bit halves hipcc branches around the second one
+        const unsigned long long ev = reinterpret_cast<const unsigned long long*>(ko)[2 * (s0 + u) + h];
+        const int ex = (int)(unsigned)ev, ey = (int)(unsigned)(ev >> 32);
+        const int wy = wy0 + (ey & 0xffff), wx = wx0 + (ey >> 16);
+        unsigned o = (unsigned)(origin + ex) * 256u + lane_off;
+        o = ((unsigned)wy < (unsigned)Hs && (unsigned)wx < (unsigned)Ws) ? o : BUF_OOB;
+        dst[u] = buf_load2(rsrc, o);
+      }
+    }
+  };
+  auto mma = [&](const float2 (&v)[GATHER_CH], int s0) {
+#pragma unroll
+    for (int u = 0; u < GATHER_CH; ++u) {
+      const float b = cm[(s0 + u) * 64 + lane];
+      X.t[0] = mfma32(v[u].x, b, X.t[0]);
+      X.t[1] = mfma32(v[u].y, b, X.t[1]);
+    }
+  };
+  // Two register buffers in ping-pong (a rotating copy would have to wait for the data it copies); the sched_barriers
+  // pin "issue the next chunk's loads, THEN this chunk's MFMAs".
+  load(cur, 0);
+  const int npairs = K2 / (2 * GATHER_CH);
+  int s0 = 0;
+  for (int pr = 0; pr < npairs; ++pr, s0 += 2 * GATHER_CH) {
+    load(nxt, s0 + GATHER_CH);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(cur, s0);
+    __builtin_amdgcn_sched_barrier(0);
+    load(cur, s0 + 2 * GATHER_CH);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(nxt, s0 + GATHER_CH);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (K2 & GATHER_CH) mma(cur, s0);
+}
+
+__device__ __forceinline__ bool node_is_live(float lb, float ub);
+
+// Sparse variant (source = a ReLU layer): the rows of its dead nodes are exactly zero, so the tile first compacts the live,
+// in-range slots of its window into a per-wave LDS table {byte offset of the row, tap-matrix row} and walks only those.
+// `tab`: 2*K2 + 32 entries of this wave; slb / sub: bounds of the source layer of this sample.
+#ifndef GATHER_CHS
+#define GATHER_CHS 4    // k-steps per prefetch chunk of the sparse walk (8 live slots: 3 % faster than 16)
+#endif
+__device__ __forceinline__ void gather_tile_sparse(Frag& X, const float* cm, const int2* ko, uint2* tab, int K2, __amdgpu_buffer_rsrc_t rsrc,
+                                                   const float* slb, const float* sub, int j, int wy0, int wx0, int Hs, int Ws, int lane) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = 0.0f;
+  const int origin = wy0 * Ws + wx0;
+  int n = 0;
+  for (int base = 0; base < 2 * K2; base += 64) {
+    const int sl = base + lane;
+    const unsigned long long ev = reinterpret_cast<const unsigned long long*>(ko)[sl];
+    const int ex = (int)(unsigned)ev, ey = (int)(unsigned)(ev >> 32);
+    const int wy = wy0 + (ey & 0xffff), wx = wx0 + (ey >> 16);
+    const bool inb = sl < 2 * K2 && (unsigned)wy < (unsigned)Hs && (unsigned)wx < (unsigned)Ws;      // (table padding: 0x7fff, never in range)
+    const int row = inb ? origin + ex : 0;
+    const bool live = inb && node_is_live(slb[row], sub[row]);
+    const unsigned long long bal = __ballot(live);
+    if (live) tab[n + __popcll(bal & ((1ull << lane) - 1ull))] = make_uint2((unsigned)row * 256u, (unsigned)sl * 32u);
+    n += __popcll(bal);
+  }
+  constexpr int CS = 2 * GATHER_CHS;                     // slots per chunk
+  const int npad = (n + CS - 1) / CS * CS;
+  for (int q = n + lane; q < npad + CS; q += 64) tab[q] = make_uint2(BUF_OOB, 0u);       // out-of-range offset: the load returns 0
+  const int K2e = npad / 2;
+  const unsigned lane_off = 8u * (unsigned)j;
+  struct Chunk { float2 v[GATHER_CHS]; unsigned cr[GATHER_CHS]; };
+  Chunk cur, nxt;
+  auto load = [&](Chunk& c, int s0) {
+#pragma unroll
+    for (int u = 0; u < GATHER_CHS; ++u) {
+      const uint2 e = tab[2 * (s0 + u) + h];
+      c.v[u] = buf_load2(rsrc, e.x == BUF_OOB ? BUF_OOB : e.x + lane_off);
+      c.cr[u] = e.y;
+    }
+  };
+  auto mma = [&](const Chunk& c) {
+#pragma unroll
+    for (int u = 0; u < GATHER_CHS; ++u) {
+      const float b = cm[c.cr[u] + j];
+      X.t[0] = mfma32(c.v[u].x, b, X.t[0]);
+      X.t[1] = mfma32(c.v[u].y, b, X.t[1]);
+    }
+  };
+  load(cur, 0);
+  const int npairs = K2e / (2 * GATHER_CHS);
+  int s0 = 0;
+  for (int pr = 0; pr < npairs; ++pr, s0 += 2 * GATHER_CHS) {
+    load(nxt, s0 + GATHER_CHS);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(cur);
+    __builtin_amdgcn_sched_barrier(0);
+    load(cur, s0 + 2 * GATHER_CHS);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(nxt);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (K2e & GATHER_CHS) mma(cur);
+}
+
+// `sbase` = first row of this sample's source layer; must be built from wave-uniform values
+// tab != nullptr: sparse walk (slb / sub = bounds of the source layer of this sample)
+__device__ __forceinline__ void gather_dispatch(Frag& X, const float* cm, const int2* ko, const unsigned* kvo, const DGather& g,
+                                                const float* sbase, int j, int wy0, int wx0, int lane,
+                                                uint2* tab = nullptr, const float* slb = nullptr, const float* sub = nullptr) {
+  const int uy = __builtin_amdgcn_readfirstlane(wy0), ux = __builtin_amdgcn_readfirstlane(wx0);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)sbase, 0, g.Ns * 256, 0x00020000);
+  if (tab) { gather_tile_sparse(X, cm, ko, tab, g.K2, rsrc, slb, sub, j, uy, ux, g.Hs, g.Ws, lane); return; }
+  if (uy >= 0 && ux >= 0 && uy + g.WY <= g.Hs && ux + g.WX <= g.Ws)
+    gather_tile<true>(X, cm, ko, kvo, g.K2, rsrc, j, uy, ux, g.Hs, g.Ws, lane);
+  else
+    gather_tile<false>(X, cm, ko, kvo, g.K2, rsrc, j, uy, ux, g.Hs, g.Ws, lane);
+}
+
+// Round 0, forward edge into ReLU layer 1: the source rows are the input embedding E0 = relu(inp_f([l0, x, u0]))
+// (graph_conv.py:90-95), 6 FMAs per row and channel pair -- cheaper to recompute per k-step under the MFMAs than to write
+// 201 MB of rows (k_embed) and read them back.  Same structure as gather_tile; the three scalars of a window node come
+// from buffer loads (out-of-range -> masked explicitly, since relu(bias) of a zero input is not zero).
+struct EmbedSrc { const float *lb, *x, *ub; const float* wb; };     // (B, Ns) scalars; inp_f weight (64 x 3) then bias (64)
+
+template <bool INTERIOR>
+__device__ __forceinline__ void gather_tile_embed(Frag& X, const float* cm, const int2* ko, const unsigned* kvo, int K2,
+                                                  __amdgpu_buffer_rsrc_t rl, __amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t ru,
+                                                  const float (&w)[2][3], const float (&bias)[2], int wy0, int wx0, int Hs, int Ws, int lane) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = 0.0f;
+  const int origin = wy0 * Ws + wx0;
+  const unsigned soff = (unsigned)origin * 4u;
+  struct Chunk { float l[GATHER_CH], x[GATHER_CH], u[GATHER_CH]; unsigned o[GATHER_CH]; };
+  Chunk cur, nxt;
+  auto load = [&](Chunk& c, int s0) {
+#pragma unroll
+    for (int q = 0; q < GATHER_CH; ++q) {
+      unsigned o;
+      if (INTERIOR) {
+        o = kvo[2 * (s0 + q) + h] >> 6;                 // byte offset of the window node in a float array
+        c.l[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rl, o, soff, 0));
+        c.x[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, o, soff, 0));
+        c.u[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, o, soff, 0));
+      } else {
+        const unsigned long long ev = reinterpret_cast<const unsigned long long*>(ko)[2 * (s0 + q) + h];
+        const int ex = (int)(unsigned)ev, ey = (int)(unsigned)(ev >> 32);
+        const int wy = wy0 + (ey & 0xffff), wx = wx0 + (ey >> 16);
+        o = (unsigned)(origin + ex) * 4u;
+        o = ((unsigned)wy < (unsigned)Hs && (unsigned)wx < (unsigned)Ws) ? o : BUF_OOB;
+        c.l[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rl, o, 0, 0));
+        c.x[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, 0));
+        c.u[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, o, 0, 0));
+      }
+      c.o[q] = o;
+    }
+  };
+  auto mma = [&](const Chunk& c, int s0) {
+#pragma unroll
+    for (int q = 0; q < GATHER_CH; ++q) {
+      const float b = cm[(s0 + q) * 64 + lane];
+      float e0 = relu_nan(fmaf(c.u[q], w[0][2], fmaf(c.x[q], w[0][1], fmaf(c.l[q], w[0][0], bias[0]))));
+      float e1 = relu_nan(fmaf(c.u[q], w[1][2], fmaf(c.x[q], w[1][1], fmaf(c.l[q], w[1][0], bias[1]))));
+      if (!INTERIOR) {
+        const bool v = c.o[q] != BUF_OOB;
+        e0 = v ? e0 : 0.0f;
+        e1 = v ? e1 : 0.0f;
+      }
+      X.t[0] = mfma32(e0, b, X.t[0]);
+      X.t[1] = mfma32(e1, b, X.t[1]);
+    }
+  };
+  load(cur, 0);
+  const int npairs = K2 / (2 * GATHER_CH);
+  int s0 = 0;
+  for (int pr = 0; pr < npairs; ++pr, s0 += 2 * GATHER_CH) {
+    load(nxt, s0 + GATHER_CH);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(cur, s0);
+    __builtin_amdgcn_sched_barrier(0);
+    load(cur, s0 + 2 * GATHER_CH);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(nxt, s0 + GATHER_CH);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (K2 & GATHER_CH) mma(cur, s0);
+}
+
+// ---- 16-node tiles on v_mfma_f32_16x16x4_f32 (forward conv edges: a third less window per node than 32-node tiles) ----
+// lane l = (i = l & 15, g = l >> 4).  k-step s covers window slots 4s .. 4s+3; lane (i, g) loads channels 4i .. 4i+3 of slot 4s+g
+// (one b128; the 16 lanes of a group read one whole 256-B row) and feeds channel 4i+t to the MFMA of M-tile t; the B operand
+// is the tap weight of (slot 4s+g, dst node i).  D of tile t: lane (j, g'), register r = channel 16g' + 4r + t of dst node j,
+// so a lane ends up with 16 consecutive channels of its node.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+#define GATHER_CH16 4   // k-steps per prefetch chunk (16 window slots, as in the 32-lane variant)
+#ifndef EMBED_MFMA
+#define EMBED_MFMA 1    // round 0: the input embedding inside the first gather on the matrix pipe (0: VALU form)
+#endif
+
+template <bool INTERIOR>
+__device__ __forceinline__ void gather_tile16(f32x4 (&acc)[4], const float* cm, const int2* ko, const unsigned* kvo, int K2,
+                                              __amdgpu_buffer_rsrc_t rsrc, int wy0, int wx0, int Hs, int Ws, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int origin = wy0 * Ws + wx0;
+  const unsigned lane_off = 16u * (unsigned)i;
+  const unsigned soff = (unsigned)origin * 256u;
+  f32x4 cur[GATHER_CH16], nxt[GATHER_CH16];
+  auto load = [&](f32x4 (&dst)[GATHER_CH16], int s0) {
+#pragma unroll
+    for (int u = 0; u < GATHER_CH16; ++u) {
+      if (INTERIOR) {
+        const unsigned vo = kvo[4 * (s0 + u) + g] + lane_off;
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, soff, 0);
+        dst[u] = f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+      } else {
+        const unsigned long long ev = reinterpret_cast<const unsigned long long*>(ko)[4 * (s0 + u) + g];
+        const int ex = (int)(unsigned)ev, ey = (int)(unsigned)(ev >> 32);
+        const int wy = wy0 + (ey & 0xffff), wx = wx0 + (ey >> 16);
+        unsigned o = (unsigned)(origin + ex) * 256u + lane_off;
+        o = ((unsigned)wy < (unsigned)Hs && (unsigned)wx < (unsigned)Ws) ? o : BUF_OOB;
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, 0, 0);
+        dst[u] = f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+      }
+    }
+  };
+  auto mma = [&](const f32x4 (&v)[GATHER_CH16], int s0) {
+#pragma unroll
+    for (int u = 0; u < GATHER_CH16; ++u) {
+      const float b = cm[(s0 + u) * 64 + lane];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = mfma16(v[u][t], b, acc[t]);
+    }
+  };
+  load(cur, 0);
+  const int npairs = K2 / (2 * GATHER_CH16);
+  int s0 = 0;
+  for (int pr = 0; pr < npairs; ++pr, s0 += 2 * GATHER_CH16) {
+    load(nxt, s0 + GATHER_CH16);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(cur, s0);
+    __builtin_amdgcn_sched_barrier(0);
+    load(cur, s0 + 2 * GATHER_CH16);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(nxt, s0 + GATHER_CH16);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (K2 & GATHER_CH16) mma(cur, s0);
+}
+
+// Sparse variant: the rows of dead source nodes are exactly zero, so a tile first compacts the live, in-range slots of its
+// window into a per-wave LDS table {byte offset of the row, tap-matrix row} and then walks only those (-35..45 % k-steps
+// behind a ReLU layer).  `tab`: 4*K2 + 32 entries of this wave; slb / sub: bounds of the source layer of this sample.
+#ifndef GATHER_CHS16
+#define GATHER_CHS16 4
+#endif
+__device__ __forceinline__ void gather_tile16_sparse(f32x4 (&acc)[4], const float* cm, const int2* ko, uint2* tab, int K2,
+                                                     __amdgpu_buffer_rsrc_t rsrc, const float* slb, const float* sub, int wy0, int wx0,
+                                                     int Hs, int Ws, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int origin = wy0 * Ws + wx0;
+  int n = 0;
+  for (int base = 0; base < 4 * K2; base += 64) {
+    const int sl = base + lane;
+    const unsigned long long ev = reinterpret_cast<const unsigned long long*>(ko)[sl];
+    const int ex = (int)(unsigned)ev, ey = (int)(unsigned)(ev >> 32);
+    const int wy = wy0 + (ey & 0xffff), wx = wx0 + (ey >> 16);
+    const bool inb = sl < 4 * K2 && (unsigned)wy < (unsigned)Hs && (unsigned)wx < (unsigned)Ws;      // (table padding: 0x7fff, never in range)
+    const int row = inb ? origin + ex : 0;
+    const bool live = inb && node_is_live(slb[row], sub[row]);
+    const unsigned long long bal = __ballot(live);
+    if (live) tab[n + __popcll(bal & ((1ull << lane) - 1ull))] = make_uint2((unsigned)row * 256u, (unsigned)sl * 16u);
+    n += __popcll(bal);
+  }
+  constexpr int CS = 4 * GATHER_CHS16;
+  const int npad = (n + CS - 1) / CS * CS;
+  for (int q = n + lane; q < npad + CS; q += 64) tab[q] = make_uint2(BUF_OOB, 0u);       // out-of-range offset: the load returns 0
+  const int K2e = npad / 4;
+  const unsigned lane_off = 16u * (unsigned)i;
+  struct Chunk { f32x4 v[GATHER_CHS16]; unsigned cr[GATHER_CHS16]; };
+  Chunk cur, nxt;
+  auto load = [&](Chunk& c, int s0) {
+#pragma unroll
+    for (int u = 0; u < GATHER_CHS16; ++u) {
+      const uint2 e = tab[4 * (s0 + u) + g];
+      const unsigned o = e.x == BUF_OOB ? BUF_OOB : e.x + lane_off;
+      const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, 0, 0);
+      c.v[u] = f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+      c.cr[u] = e.y;
+    }
+  };
+  auto mma = [&](const Chunk& c, int) {
+#pragma unroll
+    for (int u = 0; u < GATHER_CHS16; ++u) {
+      const float b = cm[c.cr[u] + i];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = mfma16(c.v[u][t], b, acc[t]);
+    }
+  };
+  load(cur, 0);
+  const int npairs = K2e / (2 * GATHER_CHS16);
+  int s0 = 0;
+  for (int pr = 0; pr < npairs; ++pr, s0 += 2 * GATHER_CHS16) {
+    load(nxt, s0 + GATHER_CHS16);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(cur, s0);
+    __builtin_amdgcn_sched_barrier(0);
+    load(cur, s0 + 2 * GATHER_CHS16);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(nxt, s0 + GATHER_CHS16);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (K2e & GATHER_CHS16) mma(cur, s0);
+}
+
+// the embedding variant (round 0, first edge): the four channels of a slot are computed from its three input scalars
+template <bool INTERIOR>
+__device__ __forceinline__ void gather_tile16_embed(f32x4 (&acc)[4], const float* cm, const int2* ko, const unsigned* kvo, int K2,
+                                                    __amdgpu_buffer_rsrc_t rl, __amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t ru,
+                                                    const float (&w)[4][3], const float (&bias)[4], int wy0, int wx0, int Hs, int Ws, int lane) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int origin = wy0 * Ws + wx0;
+  const unsigned soff = (unsigned)origin * 4u;
+  struct Chunk { float l[GATHER_CH16], x[GATHER_CH16], u[GATHER_CH16]; unsigned o[GATHER_CH16]; };
+  Chunk cur, nxt;
+  auto load = [&](Chunk& c, int s0) {
+#pragma unroll
+    for (int q = 0; q < GATHER_CH16; ++q) {
+      unsigned o;
+      if (INTERIOR) {
+        o = kvo[4 * (s0 + q) + g] >> 6;                 // byte offset of the window node in a float array
+        c.l[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rl, o, soff, 0));
+        c.x[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, o, soff, 0));
+        c.u[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, o, soff, 0));
+      } else {
+        const unsigned long long ev = reinterpret_cast<const unsigned long long*>(ko)[4 * (s0 + q) + g];
+        const int ex = (int)(unsigned)ev, ey = (int)(unsigned)(ev >> 32);
+        const int wy = wy0 + (ey & 0xffff), wx = wx0 + (ey >> 16);
+        o = (unsigned)(origin + ex) * 4u;
+        o = ((unsigned)wy < (unsigned)Hs && (unsigned)wx < (unsigned)Ws) ? o : BUF_OOB;
+        c.l[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rl, o, 0, 0));
+        c.x[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, 0));
+        c.u[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, o, 0, 0));
+      }
+      c.o[q] = o;
+    }
+  };
+  auto mma = [&](const Chunk& c, int s0) {
+#pragma unroll
+    for (int q = 0; q < GATHER_CH16; ++q) {
+      const float b = cm[(s0 + q) * 64 + lane];
+      const bool v = INTERIOR || c.o[q] != BUF_OOB;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float e = relu_nan(fmaf(c.u[q], w[t][2], fmaf(c.x[q], w[t][1], fmaf(c.l[q], w[t][0], bias[t]))));
+        e = v ? e : 0.0f;
+        acc[t] = mfma16(e, b, acc[t]);
+      }
+    }
+  };
+  load(cur, 0);
+  const int npairs = K2 / (2 * GATHER_CH16);
+  int s0 = 0;
+  for (int pr = 0; pr < npairs; ++pr, s0 += 2 * GATHER_CH16) {
+    load(nxt, s0 + GATHER_CH16);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(cur, s0);
+    __builtin_amdgcn_sched_barrier(0);
+    load(cur, s0 + 2 * GATHER_CH16);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(nxt, s0 + GATHER_CH16);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (K2 & GATHER_CH16) mma(cur, s0);
+}
+
+// number of kernel taps that touch dst position t along one axis (the reference's `freq`, graph_conv.py:306-311)
+__device__ __forceinline__ int tap_count(int t, int w0, int WN, int Hs, int k, int stride, int pad) {
+  int n = 0;
+  for (int w = 0; w < WN; ++w) {
+    const int o = w0 + w;
+    const int kk = t + pad - o * stride;
+    n += ((unsigned)o < (unsigned)Hs && kk >= 0 && kk < k) ? 1 : 0;
+  }
+  return n;
+}
+
+__device__ __forceinline__ void stage_gather(float* lds_cm, int2* lds_ko, int* lds_tt, unsigned* lds_kvo, const DGather& g, int TPS) {
+  copy_to_lds(lds_cm, g.cmat, g.ncg_k2 * 64);
+  for (int i = threadIdx.x; i < gather_slots(g.K2, g.lanes); i += blockDim.x) {
+    const int2 e = g.koff[i];
+    lds_ko[i] = e;
+    lds_kvo[i] = (e.y & 0xffff) == 0x7fff ? 0u : (unsigned)e.x * 256u;      // byte offset of window node i from the window origin
+  }
+  for (int i = threadIdx.x; i < TPS; i += blockDim.x) lds_tt[i] = g.ttab[i];
+}
+
+// [r0 != 0] without the division: r0 = u+/(u+ - l-) is zero iff u+ == 0 and l- != 0 (0/0 is NaN, and NaN != 0)
+__device__ __forceinline__ bool node_is_live(float lb, float ub) {
+  const float lower_temp = lb - relu_nan(lb);
+  const float upper_temp = relu_nan(ub);
+  return !(upper_temp == 0.0f) || lower_temp == 0.0f;
+}
+
+// rows of the gathered fragment (gather channel map) -> row-major (.., 64): lane (j,h) owns channels [16q+8h, 16q+8h+8)
+__device__ __forceinline__ void frag_store_rows_gathered(const Frag& x, float* base, long row, int h) {
+  f32x4* p = reinterpret_cast<f32x4*>(base + row * 64 + 8 * h);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 v0, v1;
+    v0[0] = x.t[0][4 * q + 0]; v0[1] = x.t[1][4 * q + 0]; v0[2] = x.t[0][4 * q + 1]; v0[3] = x.t[1][4 * q + 1];
+    v1[0] = x.t[0][4 * q + 2]; v1[1] = x.t[1][4 * q + 2]; v1[2] = x.t[0][4 * q + 3]; v1[3] = x.t[1][4 * q + 3];
+    p[4 * q] = v0;
+    p[4 * q + 1] = v1;
+  }
+}
+
+struct GArgs {
+  const float *lb, *ub;     // bounds of the dst layer, flat (B*N)
+  const float* mask;        // (B, R) BaB mask, used when `need_scored`
+  const float* mu_src;      // (B, Ns, 64)
+  float* nb;                // out: rows by node id (B*N, 64), written for the lanes that need it
+  long ntiles;
+  int need_scored, R, off;  // 0: every live node needs its aggregate; 1: only the scored nodes (last backward step)
+  DTileMap tm;
+  DGather g;
+  EmbedSrc es;              // EMBED: the source rows are computed from the input scalars (mu_src unused)
+  const float *src_lb, *src_ub;   // SPARSE: bounds of the source layer (B, Ns): the rows of its dead nodes are zero and skipped
+};
+
+// EMBED: inp_f rows of this lane's channels 2j, 2j+1
+struct EmbedLane { float w[2][3], b[2]; };
+template <bool EMBED>
+__device__ __forceinline__ EmbedLane embed_lane(const GArgs& a, int j) {
+  EmbedLane e{};
+  if (EMBED) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      e.b[c] = a.es.wb[192 + 2 * j + c];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) e.w[c][i] = a.es.wb[(2 * j + c) * 3 + i];
+    }
+  }
+  return e;
+}
+
+// one tile of phase A: the aggregate rows of the tile's dst nodes that will be updated
+template <bool EMBED, bool SPARSE>
+__device__ __forceinline__ void gather_process_tile(const GArgs& a, const TileCtx& tc, int sample, const float* lds_cm, const int2* lds_ko,
+                                                    const unsigned* lds_kvo, uint2* tab, const EmbedLane& el, int lane) {
+  const int h = lane >> 5, j = lane & 31;
+  const long gc = tc.sample * a.tm.N + tc.n;
+  bool need;
+  if (a.need_scored) need = tc.valid && a.mask[tc.sample * a.R + a.off + tc.n] != 0.0f;
+  else need = tc.valid && node_is_live(a.lb[gc], a.ub[gc]);    // (one load of k_classify's live flag instead: measured 1.7 % slower)
+  if (!__any(need)) return;
+  const int wy0 = tc.by * a.g.ystep + a.g.ybase, wx0 = tc.bx * a.g.xstep + a.g.xbase;
+  Frag X;
+  if (EMBED) {
+    const int uy = __builtin_amdgcn_readfirstlane(wy0), ux = __builtin_amdgcn_readfirstlane(wx0);
+    const long sb = (long)sample * a.g.Ns;
+    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(a.es.lb + sb), 0, a.g.Ns * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.es.x + sb), 0, a.g.Ns * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)(a.es.ub + sb), 0, a.g.Ns * 4, 0x00020000);
+    const float* cmt = lds_cm + tc.cg * a.g.K2 * 64;
+    if (uy >= 0 && ux >= 0 && uy + a.g.WY <= a.g.Hs && ux + a.g.WX <= a.g.Ws)
+      gather_tile_embed<true>(X, cmt, lds_ko, lds_kvo, a.g.K2, rl, rx, ru, el.w, el.b, uy, ux, a.g.Hs, a.g.Ws, lane);
+    else
+      gather_tile_embed<false>(X, cmt, lds_ko, lds_kvo, a.g.K2, rl, rx, ru, el.w, el.b, uy, ux, a.g.Hs, a.g.Ws, lane);
+  } else {
+    if (SPARSE)
+      gather_dispatch(X, lds_cm + tc.cg * a.g.K2 * 64, lds_ko, lds_kvo, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane, tab,
+                      a.src_lb + (long)sample * a.g.Ns, a.src_ub + (long)sample * a.g.Ns);
+    else
+      gather_dispatch(X, lds_cm + tc.cg * a.g.K2 * 64, lds_ko, lds_kvo, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane);
+  }
+  if (a.g.normalise) {
+    const int ny = tap_count(tc.y, wy0, a.g.WY, a.g.Hs, a.g.kh, a.g.stride, a.g.pad);
+    const int nx = tap_count(tc.x, wx0, a.g.WX, a.g.Ws, a.g.kw, a.g.stride, a.g.pad);
+    const int f = tc.valid ? ny * nx : 1;
+    const float freq = (float)f;
+    if (__all((f & (f - 1)) == 0)) {         // power of two: x * (1/f) is exactly x / f
+      const float inv = 1.0f / freq;
+#pragma unroll
+      for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = FRAG_AT(X, R) * inv;
+    } else {
+#pragma unroll
+      for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = FRAG_AT(X, R) / freq;
+    }
+  }
+  if (need) frag_store_rows_gathered(X, a.nb, gc, h);
+}
+
+// The embedding on the matrix pipe: E0 = relu(inp_f [l, x, u] + b) is itself a K = 4 product ([l, x, u, 1] against [W | b]),
+// and the result layout of v_mfma_f32_16x16x4_f32 (lane (i, g), register r = row 4g + r, column i) is the A-operand layout
+// of the tap MFMA (lane (i, g) = channel of row i at the slot of k-index g) if the embedding MFMA's row 4g + r is the window
+// slot that k-step 4 grp + r wants at k-index g, i.e. slot 16 grp + 4 r + g.  So per group of 4 k-steps: one scalar load per
+// lane (lane group 0 / 1 / 2 reads l / x / u of its row's slot, group 3 supplies the 1 of the bias), 4 embedding MFMAs (one
+// per 16-channel tile), 16 v_max, 16 tap MFMAs -- instead of 64 FMAs + 16 v_max + 12 loads per lane.  An out-of-range slot
+// feeds zeros (including its "1"), so its embedding is relu(0) = 0.
+__device__ __forceinline__ void gather_tile16_embed_mfma(f32x4 (&acc)[4], const float* cm, const int2* ko, int K2, __amdgpu_buffer_rsrc_t rl,
+                                                         __amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t ru, const float (&bw)[4],
+                                                         int wy0, int wx0, int Hs, int Ws, int lane) {
+  const int m = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int origin = wy0 * Ws + wx0;
+  const int sl = 4 * (m & 3) + (m >> 2);            // slot of embedding row m inside a group of 16
+  auto load = [&](int grp) -> float {
+    const unsigned long long ev = reinterpret_cast<const unsigned long long*>(ko)[16 * grp + sl];
+    const int ex = (int)(unsigned)ev, ey = (int)(unsigned)(ev >> 32);
+    const int wy = wy0 + (ey & 0xffff), wx = wx0 + (ey >> 16);
+    const bool inb = (unsigned)wy < (unsigned)Hs && (unsigned)wx < (unsigned)Ws;      // (table padding: 0x7fff, never in range)
+    const unsigned o = inb ? (unsigned)(origin + ex) * 4u : BUF_OOB;
+    const float vl = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rl, o, 0, 0));
+    const float vx = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, 0));
+    const float vu = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, o, 0, 0));
+    return kq == 0 ? vl : kq == 1 ? vx : kq == 2 ? vu : (inb ? 1.0f : 0.0f);
+  };
+  const int ngrp = K2 / 4;
+  float ain = load(0);
+  for (int grp = 0; grp < ngrp; ++grp) {
+    const float cur = ain;
+    if (grp + 1 < ngrp) ain = load(grp + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 e[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      e[t] = mfma16(cur, bw[t], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+      for (int r = 0; r < 4; ++r) e[t][r] = relu_nan(e[t][r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float b = cm[(4 * grp + r) * 64 + lane];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = mfma16(e[t][r], b, acc[t]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// one 16-node tile of phase A (forward edges only: no tap-count division)
+template <bool EMBED, bool SPARSE>
+__device__ __forceinline__ void gather_process_tile16(const GArgs& a, const TileCtx& tc, int sample, const float* lds_cm, const int2* lds_ko,
+                                                      const unsigned* lds_kvo, uint2* tab, const float (&ew)[4][3], const float (&eb)[4], int lane) {
+  const int gq = lane >> 4;
+  const long gc = tc.sample * a.tm.N + tc.n;
+  bool need;
+  if (a.need_scored) need = tc.valid && a.mask[tc.sample * a.R + a.off + tc.n] != 0.0f;
+  else need = tc.valid && node_is_live(a.lb[gc], a.ub[gc]);
+  if (!__any(need)) return;
+  const int wy0 = tc.by * a.g.ystep + a.g.ybase, wx0 = tc.bx * a.g.xstep + a.g.xbase;
+  const int uy = __builtin_amdgcn_readfirstlane(wy0), ux = __builtin_amdgcn_readfirstlane(wx0);
+  const bool interior = uy >= 0 && ux >= 0 && uy + a.g.WY <= a.g.Hs && ux + a.g.WX <= a.g.Ws;
+  const float* cmt = lds_cm + tc.cg * a.g.K2 * 64;
+  f32x4 acc[4];
+  if (EMBED) {
+    const long sb = (long)sample * a.g.Ns;
+    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(a.es.lb + sb), 0, a.g.Ns * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.es.x + sb), 0, a.g.Ns * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)(a.es.ub + sb), 0, a.g.Ns * 4, 0x00020000);
+    if (EMBED_MFMA) {
+      // B operand of the embedding MFMA of channel tile t: lane (n, k) = inp_f weight k of channel 4n + t, k = 3: its bias
+      const int n = lane & 15, k = lane >> 4;
+      float bw[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) bw[t] = k < 3 ? a.es.wb[(4 * n + t) * 3 + k] : a.es.wb[192 + 4 * n + t];
+      gather_tile16_embed_mfma(acc, cmt, lds_ko, a.g.K2, rl, rx, ru, bw, uy, ux, a.g.Hs, a.g.Ws, lane);
+    } else if (interior) gather_tile16_embed<true>(acc, cmt, lds_ko, lds_kvo, a.g.K2, rl, rx, ru, ew, eb, uy, ux, a.g.Hs, a.g.Ws, lane);
+    else gather_tile16_embed<false>(acc, cmt, lds_ko, lds_kvo, a.g.K2, rl, rx, ru, ew, eb, uy, ux, a.g.Hs, a.g.Ws, lane);
+  } else {
+    const float* sbase = a.mu_src + (long)sample * a.g.Ns * 64;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)sbase, 0, a.g.Ns * 256, 0x00020000);
+    if (SPARSE) {
+      const long sb = (long)sample * a.g.Ns;
+      gather_tile16_sparse(acc, cmt, lds_ko, tab, a.g.K2, rsrc, a.src_lb + sb, a.src_ub + sb, uy, ux, a.g.Hs, a.g.Ws, lane);
+    } else if (interior) gather_tile16<true>(acc, cmt, lds_ko, lds_kvo, a.g.K2, rsrc, uy, ux, a.g.Hs, a.g.Ws, lane);
+    else gather_tile16<false>(acc, cmt, lds_ko, lds_kvo, a.g.K2, rsrc, uy, ux, a.g.Hs, a.g.Ws, lane);
+  }
+  if (need) {                                  // lane (j, g'): channels 16g' + 4r + t of its node
+    f32x4* p = reinterpret_cast<f32x4*>(a.nb + gc * 64 + 16 * gq);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[r] = f32x4{acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+  }
+}
+
+// LDS image of a gather's tables: tap matrix, window offsets (two forms), tile table
+struct GatherLds { float* cm; int2* ko; int* tt; unsigned* kvo; };
+__device__ __forceinline__ GatherLds gather_lds(float* base, const DGather& g, int TPS) {
+  GatherLds l;
+  l.cm = base;
+  l.ko = reinterpret_cast<int2*>(l.cm + g.ncg_k2 * 64);
+  l.tt = reinterpret_cast<int*>(l.ko + gather_slots(g.K2, g.lanes));
+  l.kvo = reinterpret_cast<unsigned*>(l.tt + ((TPS + 3) & ~3));
+  return l;
+}
+
+// phase A of a half-pass over a conv edge: nb[g] = sum over the window for the dst nodes that will be updated
+template <bool EMBED, bool SPARSE = false>
+__global__ __launch_bounds__(WG_MLP, 2) void k_gather(GArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const GatherLds gl = gather_lds(lds, a.g, a.tm.TPS);
+  stage_gather(gl.cm, gl.ko, gl.tt, gl.kvo, a.g, a.tm.TPS);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, j = lane & 31, wave = threadIdx.x >> 6;
+  uint2* tab = reinterpret_cast<uint2*>(gl.kvo + ((gather_slots(a.g.K2, 32) + 1) & ~1)) + wave * (2 * a.g.K2 + 32);      // SPARSE
+  const EmbedLane el = embed_lane<EMBED>(a, j);
+  long t0, t1;
+  tile_range(a.ntiles, WAVES_MLP, t0, t1);
+  long tile = t0 + wave;
+  if (tile >= t1) return;
+  // tile, sample and t are wave-uniform by construction; make them provably so (scalar registers, scalar base address)
+  int sample = __builtin_amdgcn_readfirstlane((int)(tile / a.tm.TPS));
+  int t = __builtin_amdgcn_readfirstlane((int)(tile - (long)sample * a.tm.TPS));
+  for (; tile < t1; tile += WAVES_MLP, t += WAVES_MLP) {
+    while (t >= a.tm.TPS) { t -= a.tm.TPS; ++sample; }
+    const TileCtx tc = block_decode(a.tm, gl.tt, sample, t, j);
+    gather_process_tile<EMBED, SPARSE>(a, tc, sample, gl.cm, gl.ko, gl.kvo, tab, el, lane);
+  }
+}
+
+// the 16-node-tile form of k_gather (forward conv edges)
+// (4 waves per SIMD: the embedding variant sits right at 128 VGPRs, and at 130 it loses a quarter of its waves and 10 %)
+template <bool EMBED, bool SPARSE = false>
+__global__ __launch_bounds__(WG_MLP, 4) void k_gather16(GArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const GatherLds gl = gather_lds(lds, a.g, a.tm.TPS);
+  stage_gather(gl.cm, gl.ko, gl.tt, gl.kvo, a.g, a.tm.TPS);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, j = lane & 15, wave = threadIdx.x >> 6;
+  // SPARSE: per-wave table of the live window slots, behind the shared tables
+  uint2* tab = reinterpret_cast<uint2*>(gl.kvo + ((gather_slots(a.g.K2, 16) + 1) & ~1)) + wave * (4 * a.g.K2 + 32);
+  float ew[4][3] = {}, eb[4] = {};               // EMBED: inp_f rows of this lane's channels 4i .. 4i+3
+  if (EMBED) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      eb[c] = a.es.wb[192 + 4 * j + c];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) ew[c][q] = a.es.wb[(4 * j + c) * 3 + q];
+    }
+  }
+  // Rounds of 8 tiles (one per wave) are dealt ROUND-ROBIN over the workgroups, in the XCD-grouped order of tile_range:
+  // at any moment the 64 workgroups of an XCD then work on 8 neighbouring rounds each side by side, i.e. on 8-16 samples
+  // whose source rows (~4 MB) stay in that XCD's L2 -- with one contiguous chunk per workgroup they covered 32 samples,
+  // 16 MB, and every window row was fetched from HBM 1.7 times.
+  int wg = blockIdx.x;
+  const int nwg = gridDim.x;
+  if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
+  const long nrounds = (a.ntiles + WAVES_MLP - 1) / WAVES_MLP;
+  for (long r = wg; r < nrounds; r += nwg) {
+    const long tile = r * WAVES_MLP + wave;
+    if (tile >= a.ntiles) break;
+    const int sample = __builtin_amdgcn_readfirstlane((int)(tile / a.tm.TPS));
+    const int t = __builtin_amdgcn_readfirstlane((int)(tile - (long)sample * a.tm.TPS));
+    const TileCtx tc = block_decode(a.tm, gl.tt, sample, t, j);
+    gather_process_tile16<EMBED, SPARSE>(a, tc, sample, gl.cm, gl.ko, gl.kvo, tab, ew, eb, lane);
+  }
+}
+
+struct GIArgs {
+  const float* pack_pre;    // PackPreInp
+  const float* pack;        // PackUpdInp (gather variant)
+  const float *lb, *ub;     // input bounds, flat (B*N0)
+  const float* mu_src; const float* sarr; float* mu; long ntiles; DTileMap tm; DGather g;
+  const float *src_lb, *src_ub;     // SPARSE: bounds of ReLU layer 1 (the rows of its dead nodes are zero and skipped)
+};
+
+// input layer: E_0 = relu(Q + inp_b2[:, 64:] . (A_1^T mu_1)),  Q = inp_b2[:, :64] . inp_b_1(relu(inp_b([l0,u0]))) + b;
+// mu_0 = inp_b2_2(E_0) is deferred into the next round's forward update of ReLU layer 1 (gnnb_pack.h).
+// graph_conv.py:361-385; the aggregate, the feature chain and the update stay in registers.
+// one tile of the fused input-layer update; lds_upd / lds_pre: PackUpdInp / PackPreInp in LDS
+template <bool SPARSE, bool BF3>
+__device__ __forceinline__ void input_update_tile(const GIArgs& a, const TileCtx& tc, int sample, const float* lds_upd, const float* lds_pre,
+                                                  const GatherLds& gl, uint2* tab, int lane) {
+  const int h = lane >> 5, j = lane & 31;
+  if (!__any(tc.valid)) return;
+  const long gc = tc.sample * a.tm.N + tc.n;
+  const int wy0 = tc.by * a.g.ystep + a.g.ybase, wx0 = tc.bx * a.g.xstep + a.g.xbase;
+  Frag X;
+  if (SPARSE)
+    gather_dispatch(X, gl.cm + tc.cg * a.g.K2 * 64, gl.ko, gl.kvo, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane, tab,
+                    a.src_lb + (long)sample * a.g.Ns, a.src_ub + (long)sample * a.g.Ns);
+  else
+    gather_dispatch(X, gl.cm + tc.cg * a.g.K2 * 64, gl.ko, gl.kvo, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane);
+  float x[1];
+  x[0] = h ? a.ub[gc] : a.lb[gc];
+  Frag H0;
+  frag_bias(H0, lds_pre + PackPreInp::B1, h);
+  gemm_small<1>(lds_pre + PackPreInp::W1, lane, H0, x);
+  frag_relu(H0);
+  Frag H;                                  // inp_b_1 and the first half of inp_b2 are folded into one 64x64 map
+  frag_bias(H, lds_pre + PackPreInp::B2, h);
+  if (BF3) gemm_w64_bf3<1>(lds_pre + PackPreInp::W23, lane, H, [&](int s) { return FRAG_AT(H0, s); });
+  else gemm_w64<32>(lds_pre + PackPreInp::W2, lane, H, [&](int s) { return FRAG_AT(H0, s); });
+  {                                          // bias term of the projection deferred in the rows of mu_1
+    const float xs[1] = {h ? 0.0f : a.sarr[gc]};
+    gemm_small<1>(lds_upd + PackUpdInp::VC, lane, H, xs);
+  }
+  // the aggregate already went through inp_b2[:, 64:].bc4_1.W on the producer side, with its rows permuted to this
+  // fragment layout (PackPostInp::WPG): register for register
+#pragma unroll
+  for (int R = 0; R < 32; ++R) FRAG_AT(H, R) += FRAG_AT(X, R);
+  frag_relu(H);
+  if (tc.valid) frag_store_rows(H, a.mu, gc, h);
+}
+
+template <bool SPARSE, bool BF3>
+__global__ __launch_bounds__(WG_MLP, 2) void k_gather_input_update(GIArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* lds_pre = lds + PackUpdInp::FLOATS;
+  const GatherLds gl = gather_lds(lds_pre + PackPreInp::FLOATS, a.g, a.tm.TPS);
+  stage_gather(gl.cm, gl.ko, gl.tt, gl.kvo, a.g, a.tm.TPS);
+  copy_to_lds(lds_pre, a.pack_pre, PackPreInp::FLOATS);
+  stage_pack(lds, a.pack, PackUpdInp::FLOATS);
+  const int lane = threadIdx.x & 63, j = lane & 31, wave = threadIdx.x >> 6;
+  uint2* tab = reinterpret_cast<uint2*>(gl.kvo + ((gather_slots(a.g.K2, 32) + 1) & ~1)) + wave * (2 * a.g.K2 + 32);      // SPARSE
+  long t0, t1;
+  tile_range(a.ntiles, WAVES_MLP, t0, t1);
+  long tile = t0 + wave;
+  if (tile >= t1) return;
+  // tile, sample and t are wave-uniform by construction; make them provably so (scalar registers, scalar base address)
+  int sample = __builtin_amdgcn_readfirstlane((int)(tile / a.tm.TPS));
+  int t = __builtin_amdgcn_readfirstlane((int)(tile - (long)sample * a.tm.TPS));
+  for (; tile < t1; tile += WAVES_MLP, t += WAVES_MLP) {
+    while (t >= a.tm.TPS) { t -= a.tm.TPS; ++sample; }
+    const TileCtx tc = block_decode(a.tm, gl.tt, sample, t, j);
+    input_update_tile<SPARSE, BF3>(a, tc, sample, lds, lds_pre, gl, tab, lane);
+  }
+}
+
+struct ScoreArgs {        // every ReLU layer in one launch
+  const float* pack; float* scores;
+  int L, R;
+  const float* mu[MAXL]; const int* list[MAXL];
+  const float* lb[MAXL]; const float* ub[MAXL];
+  const int* cnt;         // cnt[4k + 2] = number of scored nodes of layer k
+  int N[MAXL], off[MAXL]; // nodes per sample in layer k, offset of layer k in the flat ReLU index
+};
+
+// score = fscore(relu(fnode(mu_g))) for the nodes g whose BaB mask is -1 (the rest stays -inf)    graph_conv.py:445-450
+// the rows hold E_g with mu_g = (Wp.E_g + bp).live: fnode is pre-multiplied by Wp, fnode.bp.live enters as a small k-step
+// one tile (32 scored nodes `list[32 t ..]` of layer k); lds: PackScore
+__device__ __forceinline__ void score_tile(const ScoreArgs& a, const float* lds, int k, const int* list, int count, long t, int lane) {
+  const int h = lane >> 5, j = lane & 31;
+  const float bs = lds[PackScore::BS];
+  {
+    const long idx = t * 32 + j;
+    const bool valid = idx < count;
+    const long gc = list[valid ? idx : 0];
+    const int N = a.N[k];
+    const long b = gc / N;
+    Frag X;
+    frag_load_rows(X, a.mu[k], gc, h);
+    Frag H;
+    frag_bias(H, lds + PackScore::B1, h);
+    {
+      const float live = node_is_live(a.lb[k][gc], a.ub[k][gc]) ? 1.0f : 0.0f;
+      const float x[1] = {h ? 0.0f : live};
+      gemm_small<1>(lds + PackScore::V1, lane, H, x);
+    }
+    gemm_w64<32>(lds + PackScore::W1, lane, H, [&](int s) { return FRAG_AT(X, s); });
+    frag_relu(H);
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(lds + PackScore::WS + h * 32);
+    float part = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const f32x4 w = w4[q];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) part = fmaf(FRAG_AT(H, 4 * q + c), w[c], part);
+    }
+    part += __shfl_xor(part, 32);
+    if (valid && h == 0) a.scores[b * a.R + a.off[k] + (gc - b * N)] = part + bs;
+  }
+}
+
+__global__ __launch_bounds__(WG_MLP, 2) void k_score(ScoreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_pack(lds, a.pack, PackScore::FLOATS);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long ntiles = 0;
+  for (int k = 0; k < a.L; ++k) ntiles += (a.cnt[4 * k + 2] + 31) / 32;
+  for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < ntiles; tile += (long)gridDim.x * WAVES_MLP) {
+    int k = 0, count = 0;
+    long t = tile;
+    for (; k < a.L; ++k) {
+      count = a.cnt[4 * k + 2];
+      const long tk = (count + 31) / 32;
+      if (t < tk) break;
+      t -= tk;
+    }
+    score_tile(a, lds, k, a.list[k], count, t, lane);
+  }
+}

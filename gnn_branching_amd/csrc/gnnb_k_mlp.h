@@ -1,0 +1,421 @@
+// gnnb_k_mlp.h -- part of libgnnb.so, included by gnnb.hip (one translation unit; see its header comment).
+// setup and node-MLP kernels: k_embed, k_classify, k_pre, k_pre_inp, k_node_update, k_input_update.
+#pragma once
+
+// ------------------------------------------------------------------------------------------
+// MFMA node-MLP kernels.  One wave = one tile of 32 consecutive nodes of a (B*N_k) flat layer.
+// ------------------------------------------------------------------------------------------
+struct EmbedArgs { const float* w; const float* b; const float* lb; const float* x; const float* ub; float* mu; long G; };
+
+// E0 = relu(inp_f([l0, x_LP, u0])); mu0 = inp_f_1(E0) is deferred into the forward update of ReLU layer 1
+// (gnnb_pack.h "deferred projection")   graph_conv.py:90-95
+// 3 -> 64 features per node: 192 FMAs against a 256-B row written, i.e. HBM-write-bound VALU work, not an MFMA job.
+// A thread owns 4 consecutive features (its 12 weights + 4 biases stay in registers) and walks nodes; 16 threads
+// write one 256-B row, one wave instruction writes 1 KiB contiguous.
+#define EMBED_UNROLL 4
+__global__ __launch_bounds__(256) void k_embed(EmbedArgs a) {
+  const int q = threadIdx.x & 15;                       // feature quad
+  float w[4][3], bias[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    bias[c] = a.b[4 * q + c];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) w[c][i] = a.w[(4 * q + c) * 3 + i];
+  }
+  const long nodes_per_pass = (long)gridDim.x * 16;      // 16 nodes per workgroup and pass
+  long g = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  for (; g < a.G; g += nodes_per_pass * EMBED_UNROLL) {
+    float l[EMBED_UNROLL], x[EMBED_UNROLL], u[EMBED_UNROLL];
+#pragma unroll
+    for (int r = 0; r < EMBED_UNROLL; ++r) {
+      const long gg = g + r * nodes_per_pass;
+      const long gc = gg < a.G ? gg : a.G - 1;
+      l[r] = a.lb[gc]; x[r] = a.x[gc]; u[r] = a.ub[gc];
+    }
+#pragma unroll
+    for (int r = 0; r < EMBED_UNROLL; ++r) {
+      const long gg = g + r * nodes_per_pass;
+      f32x4 o;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        // torch addmm order: bias + sum_k in_k w_k
+        o[c] = relu_nan(fmaf(u[r], w[c][2], fmaf(x[r], w[c][1], fmaf(l[r], w[c][0], bias[c]))));
+      }
+      if (gg < a.G) *reinterpret_cast<f32x4*>(a.mu + gg * 64 + 4 * q) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// classification: what each ReLU node needs this forward (static over the T rounds)
+//   live  = [r0 != 0]  (graph_conv.py:178/:347): only these rows of mu can be non-zero -> node MLP runs on them only
+//   amb   = [beta > 0] (:504): only these have a non-zero relaxation term -> the hoisted feature chains run on them only
+//   score = BaB mask == -1 (:447): only these are scored
+// Each class is compacted into a list of flat node ids (wave-aggregated atomics; the order inside a list does not
+// affect any result: every lane of an MLP tile computes its own column).  Dead rows of mu are zeroed here, once,
+// and scores are preset to -inf.
+// ------------------------------------------------------------------------------------------
+#define MAXL 8            // ReLU layers handled by the merged per-layer kernels (bind rejects deeper networks for them)
+struct ClassifyArgs {    // every ReLU layer of the network in one launch
+  int L;
+  const float* lb[MAXL]; const float* ub[MAXL];
+  float* mu[MAXL];                 // (B*N_k, 64) rows of layer k
+  float* mu2;                      // second row buffer of layer 1 (F1, PackPostInp) whose dead rows must read as zero too, or null
+  int* live[MAXL]; int* amb[MAXL]; int* score[MAXL];
+  float* livef[MAXL];              // (B*N_k) 1.0 / 0.0: [r0 != 0], read by k_livesum
+  long G[MAXL];
+  int N[MAXL], off[MAXL], blk0[MAXL + 1];   // first workgroup of each layer
+  const float* mask;
+  float* scores;                   // (B, R)
+  int* cnt;                        // 4 ints per layer: plain (live, not ambiguous), ambiguous, scored, 0
+  int R;
+};
+
+#define CLS_THREADS 1024
+// one global atomic per list and workgroup (a single counter word only sustains ~90 atomics/us)
+__global__ __launch_bounds__(CLS_THREADS) void k_classify(ClassifyArgs a) {
+  __shared__ int wcnt[3][CLS_THREADS / 64];
+  __shared__ int wbase[3][CLS_THREADS / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int k = 0;
+  while (k + 1 < a.L && (int)blockIdx.x >= a.blk0[k + 1]) ++k;
+  const long G = a.G[k];
+  const int N = a.N[k];
+  const long g = (long)(blockIdx.x - a.blk0[k]) * CLS_THREADS + threadIdx.x;
+  const bool valid = g < G;
+  const long gc = valid ? g : G - 1;
+  const Ratio r = compute_ratio(a.lb[k][gc], a.ub[k][gc]);
+  const long b = gc / N;
+  const long sidx = b * a.R + a.off[k] + (gc - b * N);
+  bool flag[3];
+  const bool live = valid && r.live != 0.0f;
+  flag[1] = valid && r.amb != 0.0f;                 // ambiguous (a subset of live)
+  flag[0] = live && !flag[1];                       // live with r0 == r1: the cheap update path
+  flag[2] = valid && a.mask[sidx] != 0.0f;
+  if (valid) {
+    a.scores[sidx] = -INFINITY;
+    a.livef[k][g] = live ? 1.0f : 0.0f;
+  }
+  unsigned long long bal[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    bal[c] = __ballot(flag[c]);
+    if (lane == 0) wcnt[c][wave] = __popcll(bal[c]);
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int c = threadIdx.x;
+    int total = 0;
+    for (int w = 0; w < CLS_THREADS / 64; ++w) { wbase[c][w] = total; total += wcnt[c][w]; }
+    const int base = total ? atomicAdd(a.cnt + 4 * k + c, total) : 0;
+    for (int w = 0; w < CLS_THREADS / 64; ++w) wbase[c][w] += base;
+  }
+  __syncthreads();
+  int* lists[3] = {a.live[k], a.amb[k], a.score[k]};
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    if (flag[c]) lists[c][wbase[c][wave] + __popcll(bal[c] & ((1ull << lane) - 1ull))] = (int)gc;
+  unsigned long long dead = __ballot(valid && !live);
+  float* mu = a.mu[k];
+  float* mu2 = k == 0 ? a.mu2 : nullptr;
+  while (dead) {                       // the whole wave zeroes one dead row per iteration (coalesced 256 B)
+    const int l = __ffsll((long long)dead) - 1;
+    dead &= dead - 1;
+    const long row = g - lane + l;
+    mu[row * 64 + lane] = 0.0f;
+    if (mu2) mu2[row * 64 + lane] = 0.0f;
+  }
+}
+
+struct PreArgs {
+  const float* pack;
+  const float *lb, *ub, *dual, *z_pre, *z_post, *bias;   // per-node scalars (flat B*N), bias per channel
+  float* P;                                               // out: tile-major (k_pre_inp) or rows by node id (k_pre_fwd/bwd)
+  long G, ntiles;
+  int N, hw;                                              // nodes per sample; nodes per bias entry (H*W or 1)
+  DTileMap tm;                                            // k_pre_inp: which node sits on which (tile, lane)
+  const int* list;                                        // k_pre_fwd/bwd: ambiguous nodes of the layer
+  const int* cnt;
+};
+
+struct PreAllArgs {       // hoisted feature chains of every ReLU layer, forward and backward, in one launch
+  const float* pack_f;   // PackPreFwd
+  const float* pack_b;   // PackPreBwd
+  int L, do_bwd;
+  const float* lb[MAXL]; const float* ub[MAXL]; const float* dual[MAXL];
+  const float* z_pre[MAXL]; const float* z_post[MAXL]; const float* bias[MAXL];
+  float* Pf[MAXL]; float* Pb[MAXL];            // out: P' rows by node id
+  const int* list[MAXL];                       // ambiguous nodes of layer k
+  const int* cnt;                              // cnt[4k + 1] = number of ambiguous nodes of layer k
+  int N[MAXL], hw[MAXL];
+};
+
+// tile space: (do_bwd) the backward tiles of all layers, ceil(c_k/32) each, then the forward tiles of all layers: a
+// backward tile is 392 MFMAs, a forward tile 72, and there are only a few tiles per wave, so the strided dealing below
+// hands every wave its share of the long ones first
+//   forward  P'_f[g] = fc4[:, :64] . fc1_1(relu(fc1(feat7))) + bcb_f                           graph_conv.py:153-161,176-177
+//   backward P'_b[g] = bc4[:, :64] . bc2_1(relu(bc2([s, -d2 s, d1 s]))) + bcb_b,
+//            s = bc1_2(relu(bc1_1(relu(bc1(feat7')))))                                        graph_conv.py:273-293,344-345
+// for the ambiguous nodes g (everywhere else the relaxation term is multiplied by amb = 0, :161 / :293)
+// one tile (32 ambiguous nodes `list[32 t ..]` of layer k) of the hoisted chains; lds / lds_b: PackPreFwd / PackPreBwd in LDS
+__device__ __forceinline__ void pre_tile(const PreAllArgs& a, const float* lds, const float* lds_b, int k, bool bwd, const int* list, int count,
+                                         long t, int lane) {
+  const int h = lane >> 5, j = lane & 31;
+  {
+    const long idx = t * 32 + j;
+    const bool valid = idx < count;
+    const long gc = list[valid ? idx : 0];
+    const int n = (int)(gc % a.N[k]);
+    const float lb = a.lb[k][gc], ub = a.ub[k][gc];
+    const Ratio r = compute_ratio(lb, ub);
+    const float d1 = a.dual[k][gc * 3 + 1], d2 = a.dual[k][gc * 3 + 2];
+    const float c = a.bias[k][n / a.hw[k]];
+    const float zpre = a.z_pre[k][gc], zpost = a.z_post[k][gc];
+    float x[4];
+    if (!bwd) {
+      // feat7 = [beta, l, u, d1-d2, z_pre, z_post, c]: even features on half 0, odd on half 1
+      x[0] = h ? lb : r.beta;
+      x[1] = h ? (d1 - d2) : ub;
+      x[2] = h ? zpost : zpre;
+      x[3] = h ? 0.0f : c;
+      Frag H;
+      frag_bias(H, lds + PackPreFwd::B1, h);
+      gemm_small<4>(lds + PackPreFwd::W1, lane, H, x);
+      frag_relu(H);
+      Frag Pf;                                   // fc1_1 and the first half of fc4 are one folded 64x64 map
+      frag_bias(Pf, lds + PackPreFwd::B2, h);
+      gemm_w64<32>(lds + PackPreFwd::W2, lane, Pf, [&](int s) { return FRAG_AT(H, s); });
+      if (valid) frag_store_rows(Pf, a.Pf[k], gc, h);
+    } else {
+      // feat7' = [l, u, beta, -d2+d1, z_post, z_pre, c]
+      x[0] = h ? ub : lb;
+      x[1] = h ? (-d2 + d1) : r.beta;
+      x[2] = h ? zpre : zpost;
+      x[3] = h ? 0.0f : c;
+      Frag H1;
+      frag_bias(H1, lds_b + PackPreBwd::B1, h);
+      gemm_small<4>(lds_b + PackPreBwd::W1, lane, H1, x);
+      frag_relu(H1);
+      Frag H2;
+      frag_bias(H2, lds_b + PackPreBwd::B2, h);
+      gemm_w64<32>(lds_b + PackPreBwd::W2, lane, H2, [&](int s) { return FRAG_AT(H1, s); });
+      frag_relu(H2);
+      Frag S;
+      frag_bias(S, lds_b + PackPreBwd::B3, h);
+      gemm_w64<32>(lds_b + PackPreBwd::W3, lane, S, [&](int s) { return FRAG_AT(H2, s); });
+      // bc2 on [s, s*(-d2), s*d1]  (:287-291)
+      const float nd2 = -d2;
+      Frag H4;
+      frag_bias(H4, lds_b + PackPreBwd::B4, h);
+      gemm_w64<96>(lds_b + PackPreBwd::W4, lane, H4, [&](int s) {
+        const float v = FRAG_AT(S, s & 31);
+        return s < 32 ? v : (s < 64 ? v * nd2 : v * d1);
+      });
+      frag_relu(H4);
+      Frag Pb;                                   // bc2_1 and the first half of bc4 are one folded 64x64 map
+      frag_bias(Pb, lds_b + PackPreBwd::B5, h);
+      gemm_w64<32>(lds_b + PackPreBwd::W5, lane, Pb, [&](int s) { return FRAG_AT(H4, s); });
+      if (valid) frag_store_rows(Pb, a.Pb[k], gc, h);
+    }
+  }
+}
+
+__global__ __launch_bounds__(WG_MLP, 2) void k_pre(PreAllArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* lds_b = lds + PackPreFwd::FLOATS;
+  copy_to_lds(lds_b, a.pack_b, PackPreBwd::FLOATS);
+  stage_pack(lds, a.pack_f, PackPreFwd::FLOATS);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long nhalf = 0;
+  for (int k = 0; k < a.L; ++k) nhalf += (long)((a.cnt[4 * k + 1] + 31) / 32);
+  const long ntiles = nhalf * (a.do_bwd ? 2 : 1);
+  for (long tile = (long)wave * gridDim.x + blockIdx.x; tile < ntiles; tile += (long)gridDim.x * WAVES_MLP) {
+    // which layer / direction (wave-uniform)
+    const bool bwd = a.do_bwd && tile < nhalf;
+    int k = 0, count = 0;
+    long t = (a.do_bwd && !bwd) ? tile - nhalf : tile;
+    for (; k < a.L; ++k) {
+      count = a.cnt[4 * k + 1];
+      const long tk = (count + 31) / 32;
+      if (t < tk) break;
+      t -= tk;
+    }
+    pre_tile(a, lds, lds_b, k, bwd, a.list[k], count, t, lane);
+  }
+}
+
+// Q = inp_b2[:, :64] . inp_b_1(relu(inp_b([l0, u0]))) + inp_b2.bias       graph_conv.py:380-384
+__global__ __launch_bounds__(WG_MLP, 2) void k_pre_inp(PreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_pack(lds, a.pack, PackPreInp::FLOATS);
+  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
+  for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < a.ntiles; tile += (long)gridDim.x * WAVES_MLP) {
+    const TileCtx tc = tile_decode(a.tm, tile, j, a.G);
+    const long gc = tc.sample * a.N + tc.n;
+    float x[1];
+    x[0] = h ? a.ub[gc] : a.lb[gc];
+    Frag H;
+    frag_bias(H, lds + PackPreInp::B1, h);
+    gemm_small<1>(lds + PackPreInp::W1, lane, H, x);
+    frag_relu(H);
+    Frag Q;                                  // inp_b_1 and the first half of inp_b2 are folded into one 64x64 map
+    frag_bias(Q, lds + PackPreInp::B2, h);
+    gemm_w64<32>(lds + PackPreInp::W2, lane, Q, [&](int s) { return FRAG_AT(H, s); });
+    frag_store_tiled(Q, a.P, tile, lane);
+  }
+}
+
+struct UpdArgs {
+  const float* pack;
+  const float *lb, *ub;     // pre-activation bounds of this layer, flat (B*N)
+  const float* nb;          // aggregated neighbour embeddings, rows by node id (B*N, 64)
+  const float* P;           // cached P' of the ambiguous nodes, rows by node id
+  float* mu;                // out: rows by node id
+  int* status;
+  const int *list0, *cnt0;  // nodes with r0 == r1 and no relaxation term (live, not ambiguous): short chain
+  const int *list1, *cnt1;  // general nodes (ambiguous; or the scored nodes for the last backward step of layer 1)
+  const float* sarr;        // DEFERRED: s[g] = sum over the edge of live_src (k_livesum), the bias term of the source rows' projection
+  // POST (layer 1, backward, an input-layer update follows): the consumer's 64x64 map inp_b2[:, 64:].bc4_1.W is applied here,
+  // on the ~3x fewer producer nodes: F = WP.E goes to `post` (rows by node id), and `mu` may be null (nothing else reads E)
+  float* post;
+  const float* wp;          // PackPostInp block (WPN or WPG), staged behind the update pack
+};
+
+// folded node update (gnnb_pack.h PackUpd):  E_g = relu(P'_g + Wcb.h) [r0 != 0],  h = relu(Wa.[r0 nb_g, r1 nb_g] + ba);
+// the last layer, mu_g = (Wd.E_g + bd) [r0 != 0], is deferred into the consumers of the rows ("deferred projection").
+//   kind 0 tiles (list0): r0 == r1, P' = bcb:  h = relu(WAS.(r0 nb_g) + ba)                      128 MFMAs per 32 nodes
+//   kind 1 tiles (list1): general                                                              192 MFMAs per 32 nodes
+// DEFERRED: nb is an aggregate G of rows whose own last layer Wp is deferred: Wa is pre-multiplied by Wp and the bias
+// term s.(r0 Wa0.bp + r1 Wa1.bp) enters as one small k-step.
+// forward:  fc3, fc3_2, fc4, fc4_2   graph_conv.py:169-181        backward: bc3, bc3_1, bc4, bc4_1   :331-349
+// The tile loop of the node update: tiles `tile`, `tile + stride`, ... of the lists in `a` (c0 / c1 entries); the weight
+// pack is staged into `lds` here (the first fetch overlaps it).
+// BF3: the 64x64 blocks of the short chain (WAS, WCB) and of POST run on the bf16 matrix rate with three-piece operands
+// (gemm_w64_bf3; LDS image PackUpdL3); the general chain's 128-wide first layer stays on the fp32 MFMA (6-11 % of the tiles).
+template <bool DEFERRED, bool POST = false, bool BF3 = false>
+__device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, int c0, int c1, long tile, long stride, int lane) {
+  constexpr int O_WA = BF3 ? (int)PackUpdL3::WA : (int)PackUpd::WA, O_BA = BF3 ? (int)PackUpdL3::BA : (int)PackUpd::BA;
+  constexpr int O_BCB = BF3 ? (int)PackUpdL3::BCB : (int)PackUpd::BCB, O_VAW = BF3 ? (int)PackUpdL3::VAW : (int)PackUpd::VAW;
+  constexpr int O_END = BF3 ? (int)PackUpdL3::FLOATS : (int)PackUpd::FLOATS;
+  const int h = lane >> 5, j = lane & 31;
+  // the general tiles (1.5-3x the work of a short-chain tile) come FIRST in the tile order, so they are never a SIMD's tail
+  const long n1 = (c1 + 31) / 32, n0 = (c0 + 31) / 32, ntiles = n0 + n1;
+  const float* bias_row = a.pack + PackUpd::BCBROW;
+  long gc = 0, gc_n = 0;
+  bool valid = false, valid_n = false;
+  float lb = 0.0f, ub = 0.0f, lb_n = 0.0f, ub_n = 0.0f, sw = 0.0f, sw_n = 0.0f;
+  Frag X, Xn;
+  constexpr bool deferred = DEFERRED;            // the aggregate is built from rows with a deferred projection (gnnb_pack.h)
+  auto fetch = [&](long tl, long& g_, bool& v_, float& l_, float& u_, float& s_, Frag& x_) {
+    const bool k0 = tl >= n1;
+    const long idx = (k0 ? tl - n1 : tl) * 32 + j;
+    v_ = idx < (k0 ? c0 : c1);
+    g_ = (k0 ? a.list0 : a.list1)[v_ ? idx : 0];
+    l_ = a.lb[g_];
+    u_ = a.ub[g_];
+    if (deferred) s_ = a.sarr[g_];
+    frag_load_rows(x_, a.nb, g_, h);
+  };
+  if (tile < ntiles) fetch(tile, gc, valid, lb, ub, sw, X);
+  constexpr bool post = POST;
+  if (post) copy_to_lds(lds + O_END, a.wp, BF3 ? 6144 : 4096);
+  if (BF3) {
+    copy_to_lds(lds + PackUpdL3::WA, a.pack + PackUpd::WA, 8192);
+    copy_to_lds(lds + PackUpdL3::BA, a.pack + PackUpd::BA, 64);
+    copy_to_lds(lds + PackUpdL3::BCB, a.pack + PackUpd::BCB, 64 + 64 + 128);          // BCB, BCBROW, VAW
+    stage_pack(lds + PackUpdL3::WAS3, a.pack + PackUpd::WAS3, 2 * 6144);               // WAS3, WCB3
+  } else stage_pack(lds, a.pack, PackUpd::FLOATS);
+  if (tile >= ntiles) return;
+  for (;;) {
+    const Ratio r = compute_ratio(lb, ub);
+    const bool kind0 = tile >= n1;             // wave-uniform
+    const long next = tile + stride;
+    const bool has_next = next < ntiles;
+    Frag H, H2;
+    frag_bias(H, lds + O_BA, h);
+    if (kind0) {
+      if (has_next) fetch(next, gc_n, valid_n, lb_n, ub_n, sw_n, Xn);
+      const float r0 = r.r0;
+      if (deferred) {                        // + s.(r0 Wa0.bp + r1 Wa1.bp), r0 == r1: one small k-step
+        const float x[1] = {r0 * sw};
+        gemm_small<1>(lds + O_VAW, lane, H, x);
+      }
+      if (BF3) gemm_w64_bf3<1>(lds + PackUpdL3::WAS3, lane, H, [&](int s) { return FRAG_AT(X, s) * r0; });
+      else gemm_w64<32>(lds + PackUpd::WAS, lane, H, [&](int s) { return FRAG_AT(X, s) * r0; });
+      frag_bias(H2, lds + O_BCB, h);
+    } else {
+      // nodes without a relaxation term (amb = 0) read the bias row instead of their (never written) P' row
+      frag_load_rowptr(H2, r.amb != 0.0f ? a.P + gc * 64 : bias_row, h);
+      if (has_next) fetch(next, gc_n, valid_n, lb_n, ub_n, sw_n, Xn);
+      const float r0 = r.r0, r1 = r.r1;
+      if (deferred) {
+        const float x[1] = {(h ? r1 : r0) * sw};
+        gemm_small<1>(lds + O_VAW, lane, H, x);
+      }
+      gemm_w64<64>(lds + O_WA, lane, H, [&](int s) { return FRAG_AT(X, s & 31) * (s < 32 ? r0 : r1); });
+    }
+    frag_relu(H);
+    if (BF3) gemm_w64_bf3<1>(lds + PackUpdL3::WCB3, lane, H2, [&](int s) { return FRAG_AT(H, s); });
+    else gemm_w64<32>(lds + PackUpd::WCB, lane, H2, [&](int s) { return FRAG_AT(H, s); });
+    frag_relu(H2);
+    if (r.live == 0.0f) {                      // a dead node's row is zero whatever its (possibly never written) aggregate held
+#pragma unroll
+      for (int R = 0; R < 32; ++R) FRAG_AT(H2, R) = 0.0f;
+    }
+    if (valid) {
+      if (frag_has_nan(H2)) atomicOr(a.status, 1);      // a NaN here is a NaN in mu = Wd.E + bd (:184-186, :339-341)
+      if (a.mu) frag_store_rows(H2, a.mu, gc, h);
+    }
+    if (post) {
+#pragma unroll
+      for (int R = 0; R < 32; ++R) FRAG_AT(H, R) = 0.0f;
+      if (BF3) gemm_w64_bf3<1>(lds + O_END, lane, H, [&](int s) { return FRAG_AT(H2, s); });
+      else gemm_w64<32>(lds + O_END, lane, H, [&](int s) { return FRAG_AT(H2, s); });
+      if (valid) frag_store_rows(H, a.post, gc, h);
+    }
+    if (!has_next) break;
+    tile = next; gc = gc_n; valid = valid_n; lb = lb_n; ub = ub_n; sw = sw_n;
+#pragma unroll
+    for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = FRAG_AT(Xn, R);
+  }
+}
+
+template <int WAVES, bool DEFERRED, bool POST = false, bool BF3 = false>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_node_update(UpdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // Only a few tiles per wave, so balance matters more than locality (rows stream): tiles are dealt round-robin over
+  // the SIMDs of the whole grid (4 per workgroup), and the two waves that share a SIMD (w, w+4) take alternate rounds,
+  // so every SIMD's MFMA pipe gets floor or ceil of the average.  The inputs of the next tile (list entry -> bounds ->
+  // aggregate row) are fetched while this tile's MFMA chain runs; the first fetch overlaps the weight staging.
+  static_assert(WAVES % 4 == 0, "tile dealing assumes whole waves per SIMD");
+  const long stride = (long)gridDim.x * 4 * (WAVES / 4);
+  const long tile = (long)(wave >> 2) * gridDim.x * 4 + (long)blockIdx.x * 4 + (wave & 3);
+  node_update_loop<DEFERRED, POST, BF3>(a, lds, *a.cnt0, *a.cnt1, tile, stride, lane);
+}
+
+struct UpdInpArgs { const float* pack; const float* nb; const float* Q; const float* sarr; float* mu; long G, ntiles; };
+
+// E_0 = relu(Q + inp_b2[:, 64:] . nb); mu_0 = inp_b2_2(E_0) is deferred (gnnb_pack.h)         graph_conv.py:383-385
+__global__ __launch_bounds__(WG_MLP, 2) void k_input_update(UpdInpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_pack(lds, a.pack, PackUpdInp::FLOATS);
+  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
+  for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < a.ntiles; tile += (long)gridDim.x * WAVES_MLP) {
+    const long g = tile * 32 + j;
+    const bool valid = g < a.G;
+    const long gc = valid ? g : a.G - 1;
+    Frag X;
+    frag_load_rows(X, a.nb, gc, h);
+    Frag H;
+    frag_load_tiled(H, a.Q, tile, lane);
+    {                                          // bias term of the projection deferred in the rows of mu_1
+      const float x[1] = {h ? 0.0f : a.sarr[gc]};
+      gemm_small<1>(lds + PackUpdInp::VC, lane, H, x);
+    }
+#pragma unroll
+    for (int R = 0; R < 32; ++R) FRAG_AT(H, R) += FRAG_AT(X, R);      // the aggregate already went through inp_b2[:, 64:].bc4_1.W (PackPostInp)
+    frag_relu(H);
+    if (valid) frag_store_rows(H, a.mu, g, h);
+  }
+}

@@ -5,8 +5,10 @@
    nomfma   : loads + stores, no MFMAs          noload : MFMAs + stores, no loads
 """
 import subprocess, sys
-base = open('/root/repo/gnn_branching_amd/csrc/gnnb.hip').read()
-base = base.replace('"../../include/gnnb.h"', '"/root/repo/include/gnnb.h"').replace('"gnnb_pack.h"', '"/root/repo/gnn_branching_amd/csrc/gnnb_pack.h"')
+import os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _flat import flat_source
+base = flat_source()
 a = base.index('template <bool INTERIOR>\n__device__ __forceinline__ void gather_tile(')
 b = base.index('// `sbase` = first row of this sample')
 tile = base[a:b]

@@ -2,11 +2,10 @@
    noload : MFMAs + stores, no source loads      nomfma : loads + stores, no MFMAs      nostore : loads + MFMAs, no stores
    none   : skeleton only"""
 import subprocess, sys
-R = '/root/repo/gnn_branching_amd/csrc/'
-base = open(R + 'gnnb.hip').read()
-for h in ('"gnnb_pack.h"', '"gnnb_train.h"'):
-    base = base.replace(h, '"' + R + h[1:])
-base = base.replace('"../../include/gnnb.h"', '"/root/repo/include/gnnb.h"')
+import os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _flat import flat_source
+base = flat_source()
 a = base.index('template <bool INTERIOR>\n__device__ __forceinline__ void gather_tile16(')
 b = base.index('#ifndef GATHER_CHS16')
 tile = base[a:b]

@@ -3,11 +3,10 @@
    noload  : no aggregate-row loads                      nostore : no row stores
    run:  KPAT=k_node_update tools/kstats.sh "X=1" "GNNB_LIB=$PWD/tools/ablate/nu_<name>.so" """
 import subprocess, sys
-R = '/root/repo/gnn_branching_amd/csrc/'
-base = open(R + 'gnnb.hip').read()
-for h in ('"gnnb_pack.h"', '"gnnb_train.h"'):
-    base = base.replace(h, '"' + R + h[1:])
-base = base.replace('"../../include/gnnb.h"', '"/root/repo/include/gnnb.h"')
+import os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _flat import flat_source
+base = flat_source()
 
 def one(s, x, y):
     assert s.count(x) == 1, x[:60]

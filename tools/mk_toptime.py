@@ -1,7 +1,9 @@
 """dev helper: build tools/ablate/toptime.so = libgnnb with wall-clock stamps at the phase boundaries of k_top (printf)."""
 import subprocess
-src = open('/root/repo/gnn_branching_amd/csrc/gnnb.hip').read()
-src = src.replace('"../../include/gnnb.h"', '"/root/repo/include/gnnb.h"').replace('"gnnb_pack.h"', '"/root/repo/gnn_branching_amd/csrc/gnnb_pack.h"').replace('"gnnb_train.h"', '"/root/repo/gnn_branching_amd/csrc/gnnb_train.h"')
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _flat import flat_source
+src = flat_source()
 a = src.index('__device__ __forceinline__ void top_sample(')
 b = src.index('__global__ __launch_bounds__(512, 1) void k_top(TopArgs a) {')
 body = src[a:b]
