@@ -102,6 +102,7 @@ struct gnnb_handle {
   int gather_occ = 2;           // workgroups per CU for k_gather (its LDS footprint is only the tap matrix)
   bool dense_lds = true;        // Linear edges: one workgroup per sample with the source rows in LDS (false: per-tile kernel)
   bool restrict_last = true;    // last backward step of layer 1 only for the scored nodes (nothing else reads it)
+  int giu_occ = 2;              // workgroups per CU of k_gather_input_update (<= 128 VGPRs: two 8-wave workgroups fit)
   bool bf3 = true;              // node update: 64x64 blocks on the bf16 matrix rate with three-piece operands (fp32 accuracy)
   int gather_sparse = 7;        // gathers behind a ReLU layer walk only the live rows of their window: bit 0 = 16-node forward
                                 // gathers, bit 1 = 32-node gathers, bit 2 = the input-layer gather
@@ -202,6 +203,7 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpdL3::FLOATS + 6144) * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpdL3::FLOATS + 6144) * 4));
   if (const char* e = getenv("GNNB_BF3")) h->bf3 = e[0] == '1';
+  if (const char* e = getenv("GNNB_GIU_OCC")) h->giu_occ = atoi(e) < 1 ? 1 : atoi(e);
   if (const char* e = getenv("GNNB_NU_WAVES")) h->nu_waves = atoi(e) == 8 ? 8 : 12;
   if (const char* e = getenv("GNNB_GATHER_OCC")) h->gather_occ = atoi(e) < 1 ? 1 : atoi(e);
   HIPCHK(hipFuncSetAttribute((const void*)k_input_update, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpdInp::FLOATS * 4));
@@ -942,11 +944,13 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       GIArgs a{h->d_pack[PK_PRE_INP], h->d_pack[PK_UPD_INP], in->lb[0], in->ub[0], rows1_for_input, ws + w.sb[0], mu(0), nt, to_dtm(d.g.tm), to_dg(d, h->d_zero),
                in->lb[1], in->ub[1]};
       const size_t lds = gather_lds_bytes(d, PackUpdInp::FLOATS + PackPreInp::FLOATS) + (sparse ? sparse_tab_bytes(d) : 0);
+      long giu_grid = (nt + WAVES_MLP - 1) / WAVES_MLP;
+      if (giu_grid > (long)h->n_cu * h->giu_occ) giu_grid = (long)h->n_cu * h->giu_occ;
       lz.run(PC_GATHER_INPUT, [&] {
-        if (sparse && h->bf3) hipLaunchKernelGGL((k_gather_input_update<true, true>), dim3(mlp_grid(h, nt)), dim3(WG_MLP), lds, st, a);
-        else if (sparse) hipLaunchKernelGGL((k_gather_input_update<true, false>), dim3(mlp_grid(h, nt)), dim3(WG_MLP), lds, st, a);
-        else if (h->bf3) hipLaunchKernelGGL((k_gather_input_update<false, true>), dim3(mlp_grid(h, nt)), dim3(WG_MLP), lds, st, a);
-        else hipLaunchKernelGGL((k_gather_input_update<false, false>), dim3(mlp_grid(h, nt)), dim3(WG_MLP), lds, st, a);
+        if (sparse && h->bf3) hipLaunchKernelGGL((k_gather_input_update<true, true>), dim3(giu_grid), dim3(WG_MLP), lds, st, a);
+        else if (sparse) hipLaunchKernelGGL((k_gather_input_update<true, false>), dim3(giu_grid), dim3(WG_MLP), lds, st, a);
+        else if (h->bf3) hipLaunchKernelGGL((k_gather_input_update<false, true>), dim3(giu_grid), dim3(WG_MLP), lds, st, a);
+        else hipLaunchKernelGGL((k_gather_input_update<false, false>), dim3(giu_grid), dim3(WG_MLP), lds, st, a);
       });
       return;
     }

@@ -38,10 +38,12 @@ __device__ __forceinline__ float2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned v
 
 template <bool INTERIOR>
 __device__ __forceinline__ void gather_tile(Frag& X, const float* cm, const int2* ko, const unsigned* kvo, int K2,
-                                            __amdgpu_buffer_rsrc_t rsrc, int j, int wy0, int wx0, int Hs, int Ws, int lane) {
+                                            __amdgpu_buffer_rsrc_t rsrc, int j, int wy0, int wx0, int Hs, int Ws, int lane, bool keep = false) {
   const int h = lane >> 5;
+  if (!keep) {                                      // keep: the aggregate is added onto what X already holds
 #pragma unroll
-  for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = 0.0f;
+    for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = 0.0f;
+  }
   const int origin = wy0 * Ws + wx0;
   const unsigned lane_off = 8u * (unsigned)j;        // channels 2j, 2j+1 of the row
   const unsigned soff = (unsigned)origin * 256u;     // INTERIOR: wave-uniform window origin goes into the scalar offset
@@ -101,10 +103,13 @@ __device__ __forceinline__ bool node_is_live(float lb, float ub);
 #define GATHER_CHS 4    // k-steps per prefetch chunk of the sparse walk (8 live slots: 3 % faster than 16)
 #endif
 __device__ __forceinline__ void gather_tile_sparse(Frag& X, const float* cm, const int2* ko, uint2* tab, int K2, __amdgpu_buffer_rsrc_t rsrc,
-                                                   const float* slb, const float* sub, int j, int wy0, int wx0, int Hs, int Ws, int lane) {
+                                                   const float* slb, const float* sub, int j, int wy0, int wx0, int Hs, int Ws, int lane,
+                                                   bool keep = false) {
   const int h = lane >> 5;
+  if (!keep) {
 #pragma unroll
-  for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = 0.0f;
+    for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = 0.0f;
+  }
   const int origin = wy0 * Ws + wx0;
   int n = 0;
   for (int base = 0; base < 2 * K2; base += 64) {
@@ -162,14 +167,14 @@ __device__ __forceinline__ void gather_tile_sparse(Frag& X, const float* cm, con
 // tab != nullptr: sparse walk (slb / sub = bounds of the source layer of this sample)
 __device__ __forceinline__ void gather_dispatch(Frag& X, const float* cm, const int2* ko, const unsigned* kvo, const DGather& g,
                                                 const float* sbase, int j, int wy0, int wx0, int lane,
-                                                uint2* tab = nullptr, const float* slb = nullptr, const float* sub = nullptr) {
+                                                uint2* tab = nullptr, const float* slb = nullptr, const float* sub = nullptr, bool keep = false) {
   const int uy = __builtin_amdgcn_readfirstlane(wy0), ux = __builtin_amdgcn_readfirstlane(wx0);
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)sbase, 0, g.Ns * 256, 0x00020000);
-  if (tab) { gather_tile_sparse(X, cm, ko, tab, g.K2, rsrc, slb, sub, j, uy, ux, g.Hs, g.Ws, lane); return; }
+  if (tab) { gather_tile_sparse(X, cm, ko, tab, g.K2, rsrc, slb, sub, j, uy, ux, g.Hs, g.Ws, lane, keep); return; }
   if (uy >= 0 && ux >= 0 && uy + g.WY <= g.Hs && ux + g.WX <= g.Ws)
-    gather_tile<true>(X, cm, ko, kvo, g.K2, rsrc, j, uy, ux, g.Hs, g.Ws, lane);
+    gather_tile<true>(X, cm, ko, kvo, g.K2, rsrc, j, uy, ux, g.Hs, g.Ws, lane, keep);
   else
-    gather_tile<false>(X, cm, ko, kvo, g.K2, rsrc, j, uy, ux, g.Hs, g.Ws, lane);
+    gather_tile<false>(X, cm, ko, kvo, g.K2, rsrc, j, uy, ux, g.Hs, g.Ws, lane, keep);
 }
 
 // Round 0, forward edge into ReLU layer 1: the source rows are the input embedding E0 = relu(inp_f([l0, x, u0]))
@@ -739,12 +744,6 @@ __device__ __forceinline__ void input_update_tile(const GIArgs& a, const TileCtx
   if (!__any(tc.valid)) return;
   const long gc = tc.sample * a.tm.N + tc.n;
   const int wy0 = tc.by * a.g.ystep + a.g.ybase, wx0 = tc.bx * a.g.xstep + a.g.xbase;
-  Frag X;
-  if (SPARSE)
-    gather_dispatch(X, gl.cm + tc.cg * a.g.K2 * 64, gl.ko, gl.kvo, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane, tab,
-                    a.src_lb + (long)sample * a.g.Ns, a.src_ub + (long)sample * a.g.Ns);
-  else
-    gather_dispatch(X, gl.cm + tc.cg * a.g.K2 * 64, gl.ko, gl.kvo, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane);
   float x[1];
   x[0] = h ? a.ub[gc] : a.lb[gc];
   Frag H0;
@@ -759,10 +758,14 @@ __device__ __forceinline__ void input_update_tile(const GIArgs& a, const TileCtx
     const float xs[1] = {h ? 0.0f : a.sarr[gc]};
     gemm_small<1>(lds_upd + PackUpdInp::VC, lane, H, xs);
   }
-  // the aggregate already went through inp_b2[:, 64:].bc4_1.W on the producer side, with its rows permuted to this
-  // fragment layout (PackPostInp::WPG): register for register
-#pragma unroll
-  for (int R = 0; R < 32; ++R) FRAG_AT(H, R) += FRAG_AT(X, R);
+  // The aggregate already went through inp_b2[:, 64:].bc4_1.W on the producer side, with its rows permuted to this fragment
+  // layout (PackPostInp::WPG), register for register: the gather accumulates straight onto H (one fragment less alive).
+  if (SPARSE)
+    gather_dispatch(H, gl.cm + tc.cg * a.g.K2 * 64, gl.ko, gl.kvo, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane, tab,
+                    a.src_lb + (long)sample * a.g.Ns, a.src_ub + (long)sample * a.g.Ns, true);
+  else
+    gather_dispatch(H, gl.cm + tc.cg * a.g.K2 * 64, gl.ko, gl.kvo, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane, nullptr,
+                    nullptr, nullptr, true);
   frag_relu(H);
   if (tc.valid) frag_store_rows(H, a.mu, gc, h);
 }
