@@ -102,6 +102,7 @@ struct gnnb_handle {
   int gather_occ = 2;           // workgroups per CU for k_gather (its LDS footprint is only the tap matrix)
   bool dense_lds = true;        // Linear edges: one workgroup per sample with the source rows in LDS (false: per-tile kernel)
   bool restrict_last = true;    // last backward step of layer 1 only for the scored nodes (nothing else reads it)
+  bool zero_dead = false;       // GNNB_ZERO_DEAD=1: always write the zero rows of dead nodes (default: only where something reads them)
   int giu_occ = 2;              // workgroups per CU of k_gather_input_update (<= 128 VGPRs: two 8-wave workgroups fit)
   bool bf3 = true;              // node update: 64x64 blocks on the bf16 matrix rate with three-piece operands (fp32 accuracy)
   int gather_sparse = 7;        // gathers behind a ReLU layer walk only the live rows of their window: bit 0 = 16-node forward
@@ -203,6 +204,7 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpdL3::FLOATS + 6144) * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpdL3::FLOATS + 6144) * 4));
   if (const char* e = getenv("GNNB_BF3")) h->bf3 = e[0] == '1';
+  if (const char* e = getenv("GNNB_ZERO_DEAD")) h->zero_dead = e[0] == '1';
   if (const char* e = getenv("GNNB_GIU_OCC")) h->giu_occ = atoi(e) < 1 ? 1 : atoi(e);
   if (const char* e = getenv("GNNB_NU_WAVES")) h->nu_waves = atoi(e) == 8 ? 8 : 12;
   if (const char* e = getenv("GNNB_GATHER_OCC")) h->gather_occ = atoi(e) < 1 ? 1 : atoi(e);
@@ -712,6 +714,23 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   float* const rows1_for_input = debug_full ? ws + w.F1 : mu(1);
 
   const bool embed_in_gather = h->embed_fuse && !debug_full && h->gf[1].ok;
+  const bool top_fused = h->use_top && h->top_ok && !debug_full && per_sample;
+  // The rows of dead nodes are zero by definition (mu = (.) * live).  Every default consumer of a layer's rows walks only the
+  // live ones (sparse gathers, the compacted Linear edges of k_top, the score head), so nothing needs them in memory; they
+  // are written (k_classify) only for a layer with a consumer that reads every row: VALU / non-sparse gathers, the
+  // per-sample / per-tile dense kernels, k_prop, inspection runs.
+  auto reads_live_rows_only = [&](int e, bool transposed) {      // edge e between layers e-1 and e; transposed: reads layer e
+    if (e == L && top_fused) return transposed || h->edges[L].n_in + 96 <= (int)TOP_LIST_INTS || h->edges[L].n_in + 96 <= (int)PackProp::FLOATS;
+    const DevGather& d = transposed ? h->gb[e] : h->gf[e];
+    if (!d.ok) return false;
+    if (transposed && e == 1) return (h->gather_sparse & 4) != 0;
+    return (h->gather_sparse & (d.g.lanes == 16 ? 1 : 2)) != 0;
+  };
+  auto zero_dead_rows = [&](int k) {
+    if (debug_full || h->zero_dead) return true;
+    if (k == L) return !top_fused;                                // k_top writes every row of layer L itself
+    return !(reads_live_rows_only(k + 1, false) && reads_live_rows_only(k, true));
+  };
   // ---- once per forward: classification lists, input embedding, embedding-independent feature chains ----
   {
     ClassifyArgs a{};
@@ -720,7 +739,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     int blk = 0;
     for (int k = 1; k <= L; ++k) {
       const int i = k - 1;
-      a.lb[i] = in->lb[k]; a.ub[i] = in->ub[k]; a.mu[i] = mu(k);
+      a.lb[i] = in->lb[k]; a.ub[i] = in->ub[k]; a.mu[i] = mu(k); a.zero[i] = zero_dead_rows(k) ? 1 : 0;
       a.live[i] = ilist(w.live[k]); a.amb[i] = ilist(w.amb[k]); a.score[i] = ilist(w.score[k]);
       a.livef[i] = ws + w.lf[k];
       a.G[i] = (long)B * h->N[k]; a.N[i] = h->N[k]; a.off[i] = roff[k];
@@ -961,7 +980,6 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   };
 
   // the top of the network as one launch per round (k_top); with a half-pass limit (inspection) the separate kernels run
-  const bool top_fused = h->use_top && h->top_ok && !debug_full && per_sample;
   auto top = [&]() {
     const Edge& e = h->edges[L];
     const DevEdge& de = h->dev[L];

@@ -823,6 +823,10 @@ __device__ __forceinline__ void score_tile(const ScoreArgs& a, const float* lds,
       const float live = node_is_live(a.lb[k][gc], a.ub[k][gc]) ? 1.0f : 0.0f;
       const float x[1] = {h ? 0.0f : live};
       gemm_small<1>(lds + PackScore::V1, lane, H, x);
+      if (live == 0.0f) {                      // a dead node marked undecided: its row is zero by definition (and need not be in memory)
+#pragma unroll
+        for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = 0.0f;
+      }
     }
     gemm_w64<32>(lds + PackScore::W1, lane, H, [&](int s) { return FRAG_AT(X, s); });
     frag_relu(H);

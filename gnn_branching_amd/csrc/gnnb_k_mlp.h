@@ -61,6 +61,7 @@ struct ClassifyArgs {    // every ReLU layer of the network in one launch
   const float* lb[MAXL]; const float* ub[MAXL];
   float* mu[MAXL];                 // (B*N_k, 64) rows of layer k
   float* mu2;                      // second row buffer of layer 1 (F1, PackPostInp) whose dead rows must read as zero too, or null
+  int zero[MAXL];                  // 1: some consumer of this layer's rows reads the rows of dead nodes too -> they are zeroed here
   int* live[MAXL]; int* amb[MAXL]; int* score[MAXL];
   float* livef[MAXL];              // (B*N_k) 1.0 / 0.0: [r0 != 0], read by k_livesum
   long G[MAXL];
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(CLS_THREADS) void k_classify(ClassifyArgs a) {
 #pragma unroll
   for (int c = 0; c < 3; ++c)
     if (flag[c]) lists[c][wbase[c][wave] + __popcll(bal[c] & ((1ull << lane) - 1ull))] = (int)gc;
-  unsigned long long dead = __ballot(valid && !live);
+  unsigned long long dead = a.zero[k] ? __ballot(valid && !live) : 0ull;
   float* mu = a.mu[k];
   float* mu2 = k == 0 ? a.mu2 : nullptr;
   while (dead) {                       // the whole wave zeroes one dead row per iteration (coalesced 256 B)

@@ -55,6 +55,12 @@ def test_scores_match_oracle(name):
     err = np.abs(got[fin] - want[fin]).max()
     print(f"{name}: max|score - oracle| = {err:.3e} over {int(fin.sum())} scores")
     assert err <= SCORE_ATOL
+    # nothing may depend on scratch the call did not write itself (rows of dead nodes are only written where a consumer
+    # reads them): poison the workspace and run again
+    model.engine().workspace(batch.batch_size).view(torch.float32).fill_(float("nan"))
+    with torch.no_grad():
+        again = model.forward_device(*batch.forward_args()).check()
+    assert torch.equal(again.scores, res.scores)
     shapes, _ = nets.graph_layout(batch.layers["fixed_layers"] + [batch.layers["prop_layers"][0]])
     relu_sizes = [int(np.prod(sh)) for sh in shapes[1:-1]]
     dec = [gnn_oracle.decision_from_scores(ragged[b], batch.masks[b], relu_sizes) for b in range(batch.batch_size)]

@@ -208,6 +208,28 @@ def test_bf16x3_blocks_match_the_fp32_mfma(monkeypatch, case, fam):
     assert np.abs(out["1"][fin] - out["0"][fin]).max() <= 2e-6 * max(scale, 1.0)
 
 
+@pytest.mark.parametrize("case", ["cifar_base_kw_B3", "cifar_wide_kw_B2", "cifar_deep_kw_B2"])
+def test_nothing_reads_unwritten_workspace(case):
+    """The rows of dead nodes are not written where every consumer walks live rows only, and several regions of the scratch
+    are written for some nodes only: with the whole workspace poisoned with NaN before the call the scores, decisions and
+    status must not change (twice: the second call sees the first call's leftovers plus the poison in between)."""
+    g, batch = load_golden(case)
+    model = make_model("random")
+    eng = model.engine()
+    want = g["random_scores"]
+    fin = np.isfinite(want)
+    with torch.no_grad():
+        ref = model.forward_device(*batch.forward_args()).check().scores.cpu().numpy()
+        for _ in range(2):
+            ws = eng.workspace(batch.batch_size)
+            ws.view(torch.float32).fill_(float("nan"))
+            res = model.forward_device(*batch.forward_args()).check()
+            got = res.scores.cpu().numpy()
+            assert np.array_equal(got[fin], ref[fin])
+            assert np.abs(got[fin] - want[fin]).max() <= SCORE_ATOL
+            assert res.decisions.cpu().tolist() == g["random_decisions"].tolist()
+
+
 def test_small_batch_latency_path_matches(monkeypatch):
     """GNNB_PER_SAMPLE_MIN_B=96: batches below 96 take the per-tile dense kernel and separate top kernels (18 % lower
     latency at B = 2): same scores within the budget, same decisions."""
