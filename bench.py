@@ -176,8 +176,11 @@ def main():
             parallel.gather_scores(res.scores, world * B)      # the one exchange step: ONE all-gather, scores -> branch selector
         return res
 
-    # untimed pre-warm (allocator, clocks, caches), then the W warm-up steps the contract asks for
-    for _ in range(10):
+    # Untimed pre-warm (allocator, clocks, caches, runtime pools), then the W warm-up steps the contract asks for.  It is
+    # deliberately long and un-synchronised: the HIP runtime grows one of its launch pools ONCE per process, about 1000
+    # launches (~45 queued forwards) in, with an implicit device drain that blocks the host for the ~50 ms of work queued at
+    # that moment (tools/host_stall.py) -- that one-off must not land in a K-step timed region that is only ~20 ms long.
+    for _ in range(96):
         res = step()
     torch.cuda.synchronize()
     for _ in range(args.warmup):
