@@ -697,8 +697,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   auto mu = [&](int k) { return ws + w.mu[k]; };
   float* nb = ws + w.nb;
 
-  HIPCHK(hipMemsetAsync(status, 0, sizeof(int32_t), st));
-  HIPCHK(hipMemsetAsync(ws + w.cnt, 0, 64 * sizeof(float), st));
+  hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, st, status, reinterpret_cast<int*>(ws + w.cnt));
   int* cnt = reinterpret_cast<int*>(ws + w.cnt);
   auto ilist = [&](size_t off) { return reinterpret_cast<int*>(ws + off); };
   std::vector<int> roff(L + 2, 0);          // offset of layer k inside the flat ReLU index

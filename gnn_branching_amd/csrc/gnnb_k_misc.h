@@ -313,3 +313,9 @@ __global__ __launch_bounds__(256) void k_argmax(ArgmaxArgs a) {
   __shared__ int si[256];
   argmax_sample<256>(a, blockIdx.x, sv, si);
 }
+
+// start of a forward: the status word and the list counters back to zero (one launch instead of two memset nodes)
+__global__ __launch_bounds__(64) void k_reset(int32_t* status, int* cnt) {
+  cnt[threadIdx.x] = 0;
+  if (threadIdx.x == 0) *status = 0;
+}
