@@ -159,8 +159,17 @@ struct PreAllArgs {       // hoisted feature chains of every ReLU layer, forward
 //            s = bc1_2(relu(bc1_1(relu(bc1(feat7')))))                                        graph_conv.py:273-293,344-345
 // for the ambiguous nodes g (everywhere else the relaxation term is multiplied by amb = 0, :161 / :293)
 // one tile (32 ambiguous nodes `list[32 t ..]` of layer k) of the hoisted chains; lds / lds_b: PackPreFwd / PackPreBwd in LDS
+// BF3: the 64x64 blocks (W2 forward; W2, W3, W5 backward) on the bf16 matrix rate with three-piece operands (LDS images
+// PackPreFwdL3 / PackPreBwdL3); the 192-wide W4 and the feature layers stay on the fp32 MFMA
+template <bool BF3>
 __device__ __forceinline__ void pre_tile(const PreAllArgs& a, const float* lds, const float* lds_b, int k, bool bwd, const int* list, int count,
                                          long t, int lane) {
+  constexpr int F_W1 = BF3 ? (int)PackPreFwdL3::W1 : (int)PackPreFwd::W1, F_B1 = BF3 ? (int)PackPreFwdL3::B1 : (int)PackPreFwd::B1;
+  constexpr int F_B2 = BF3 ? (int)PackPreFwdL3::B2 : (int)PackPreFwd::B2;
+  constexpr int B_W1 = BF3 ? (int)PackPreBwdL3::W1 : (int)PackPreBwd::W1, B_B1 = BF3 ? (int)PackPreBwdL3::B1 : (int)PackPreBwd::B1;
+  constexpr int B_B2 = BF3 ? (int)PackPreBwdL3::B2 : (int)PackPreBwd::B2, B_B3 = BF3 ? (int)PackPreBwdL3::B3 : (int)PackPreBwd::B3;
+  constexpr int B_W4 = BF3 ? (int)PackPreBwdL3::W4 : (int)PackPreBwd::W4, B_B4 = BF3 ? (int)PackPreBwdL3::B4 : (int)PackPreBwd::B4;
+  constexpr int B_B5 = BF3 ? (int)PackPreBwdL3::B5 : (int)PackPreBwd::B5;
   const int h = lane >> 5, j = lane & 31;
   {
     const long idx = t * 32 + j;
@@ -180,12 +189,13 @@ __device__ __forceinline__ void pre_tile(const PreAllArgs& a, const float* lds, 
       x[2] = h ? zpost : zpre;
       x[3] = h ? 0.0f : c;
       Frag H;
-      frag_bias(H, lds + PackPreFwd::B1, h);
-      gemm_small<4>(lds + PackPreFwd::W1, lane, H, x);
+      frag_bias(H, lds + F_B1, h);
+      gemm_small<4>(lds + F_W1, lane, H, x);
       frag_relu(H);
       Frag Pf;                                   // fc1_1 and the first half of fc4 are one folded 64x64 map
-      frag_bias(Pf, lds + PackPreFwd::B2, h);
-      gemm_w64<32>(lds + PackPreFwd::W2, lane, Pf, [&](int s) { return FRAG_AT(H, s); });
+      frag_bias(Pf, lds + F_B2, h);
+      if (BF3) gemm_w64_bf3<1>(lds + PackPreFwdL3::W23, lane, Pf, [&](int s) { return FRAG_AT(H, s); });
+      else gemm_w64<32>(lds + PackPreFwd::W2, lane, Pf, [&](int s) { return FRAG_AT(H, s); });
       if (valid) frag_store_rows(Pf, a.Pf[k], gc, h);
     } else {
       // feat7' = [l, u, beta, -d2+d1, z_post, z_pre, c]
@@ -194,38 +204,54 @@ __device__ __forceinline__ void pre_tile(const PreAllArgs& a, const float* lds, 
       x[2] = h ? zpre : zpost;
       x[3] = h ? 0.0f : c;
       Frag H1;
-      frag_bias(H1, lds_b + PackPreBwd::B1, h);
-      gemm_small<4>(lds_b + PackPreBwd::W1, lane, H1, x);
+      frag_bias(H1, lds_b + B_B1, h);
+      gemm_small<4>(lds_b + B_W1, lane, H1, x);
       frag_relu(H1);
       Frag H2;
-      frag_bias(H2, lds_b + PackPreBwd::B2, h);
-      gemm_w64<32>(lds_b + PackPreBwd::W2, lane, H2, [&](int s) { return FRAG_AT(H1, s); });
+      frag_bias(H2, lds_b + B_B2, h);
+      if (BF3) gemm_w64_bf3<1>(lds_b + PackPreBwdL3::W23, lane, H2, [&](int s) { return FRAG_AT(H1, s); });
+      else gemm_w64<32>(lds_b + PackPreBwd::W2, lane, H2, [&](int s) { return FRAG_AT(H1, s); });
       frag_relu(H2);
       Frag S;
-      frag_bias(S, lds_b + PackPreBwd::B3, h);
-      gemm_w64<32>(lds_b + PackPreBwd::W3, lane, S, [&](int s) { return FRAG_AT(H2, s); });
+      frag_bias(S, lds_b + B_B3, h);
+      if (BF3) gemm_w64_bf3<1>(lds_b + PackPreBwdL3::W33, lane, S, [&](int s) { return FRAG_AT(H2, s); });
+      else gemm_w64<32>(lds_b + PackPreBwd::W3, lane, S, [&](int s) { return FRAG_AT(H2, s); });
       // bc2 on [s, s*(-d2), s*d1]  (:287-291)
       const float nd2 = -d2;
       Frag H4;
-      frag_bias(H4, lds_b + PackPreBwd::B4, h);
-      gemm_w64<96>(lds_b + PackPreBwd::W4, lane, H4, [&](int s) {
+      frag_bias(H4, lds_b + B_B4, h);
+      gemm_w64<96>(lds_b + B_W4, lane, H4, [&](int s) {
         const float v = FRAG_AT(S, s & 31);
         return s < 32 ? v : (s < 64 ? v * nd2 : v * d1);
       });
       frag_relu(H4);
       Frag Pb;                                   // bc2_1 and the first half of bc4 are one folded 64x64 map
-      frag_bias(Pb, lds_b + PackPreBwd::B5, h);
-      gemm_w64<32>(lds_b + PackPreBwd::W5, lane, Pb, [&](int s) { return FRAG_AT(H4, s); });
+      frag_bias(Pb, lds_b + B_B5, h);
+      if (BF3) gemm_w64_bf3<1>(lds_b + PackPreBwdL3::W53, lane, Pb, [&](int s) { return FRAG_AT(H4, s); });
+      else gemm_w64<32>(lds_b + PackPreBwd::W5, lane, Pb, [&](int s) { return FRAG_AT(H4, s); });
       if (valid) frag_store_rows(Pb, a.Pb[k], gc, h);
     }
   }
 }
 
+template <bool BF3>
 __global__ __launch_bounds__(WG_MLP, 2) void k_pre(PreAllArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* lds_b = lds + PackPreFwd::FLOATS;
-  copy_to_lds(lds_b, a.pack_b, PackPreBwd::FLOATS);
-  stage_pack(lds, a.pack_f, PackPreFwd::FLOATS);
+  float* lds_b = lds + (BF3 ? (int)PackPreFwdL3::FLOATS : (int)PackPreFwd::FLOATS);
+  if (BF3) {
+    copy_to_lds(lds_b + PackPreBwdL3::W1, a.pack_b + PackPreBwd::W1, 512 + 64);                    // W1, B1
+    copy_to_lds(lds_b + PackPreBwdL3::B2, a.pack_b + PackPreBwd::B2, 64);
+    copy_to_lds(lds_b + PackPreBwdL3::B3, a.pack_b + PackPreBwd::B3, 64);
+    copy_to_lds(lds_b + PackPreBwdL3::W4, a.pack_b + PackPreBwd::W4, 12288 + 64);                  // W4, B4
+    copy_to_lds(lds_b + PackPreBwdL3::B5, a.pack_b + PackPreBwd::B5, 64);
+    copy_to_lds(lds_b + PackPreBwdL3::W23, a.pack_b + PackPreBwd::W23, 3 * 6144);                  // W23, W33, W53
+    copy_to_lds(lds + PackPreFwdL3::W1, a.pack_f + PackPreFwd::W1, 512 + 64);
+    copy_to_lds(lds + PackPreFwdL3::B2, a.pack_f + PackPreFwd::B2, 64);
+    stage_pack(lds + PackPreFwdL3::W23, a.pack_f + PackPreFwd::W23, 6144);
+  } else {
+    copy_to_lds(lds_b, a.pack_b, PackPreBwd::FLOATS);
+    stage_pack(lds, a.pack_f, PackPreFwd::FLOATS);
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   long nhalf = 0;
   for (int k = 0; k < a.L; ++k) nhalf += (long)((a.cnt[4 * k + 1] + 31) / 32);
@@ -241,7 +267,7 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_pre(PreAllArgs a) {
       if (t < tk) break;
       t -= tk;
     }
-    pre_tile(a, lds, lds_b, k, bwd, a.list[k], count, t, lane);
+    pre_tile<BF3>(a, lds, lds_b, k, bwd, a.list[k], count, t, lane);
   }
 }
 

@@ -156,7 +156,9 @@ inline void pack_transposed(float* dst, const float* W, int out, int in) {
 struct PackEmbed { enum { W = 0, B = W + 192, FLOATS = B + 64 }; };
 // k_pre, forward chain: P' = fc4[:, :64] (fc1_1(relu(fc1 feat7)) * amb) + bcb    (:153-161, :176-177)
 // fc1_1 feeds fc4 linearly, so W2 = fc4[:, :64].fc1_1.W (one GEMM instead of two), B2 = fc4[:, :64].fc1_1.b + bcb
-struct PackPreFwd { enum { W1 = 0, B1 = W1 + 512, W2 = B1 + 64, B2 = W2 + 4096, FLOATS = B2 + 64 }; };
+struct PackPreFwd { enum { W1 = 0, B1 = W1 + 512, W2 = B1 + 64, B2 = W2 + 4096, FLOATS = B2 + 64, W23 = FLOATS /* W2 as bf16 x 3 */,
+                           FLOATS3 = W23 + 6144 }; };
+struct PackPreFwdL3 { enum { W1 = 0, B1 = W1 + 512, B2 = B1 + 64, W23 = B2 + 64, FLOATS = W23 + 6144 }; };      // LDS image, bf16 x 3 form
 // k_node_update (forward: fc3, fc3_2, fc4[:, 64:], fc4_2; backward: bc3, bc3_1, bc4[:, 64:], bc4_1)
 // Folded form (exact algebra): e = Wb.h + bb enters the next layer linearly, so
 //   relu(W4.[relax, e] + b4) = relu(P' + Wcb.h),  Wcb = W4[:, 64:].Wb,  P' = W4[:, :64].relax + b4 + W4[:, 64:].bb
@@ -180,7 +182,12 @@ struct PackUpdL3 { enum { WA = 0, BA = WA + 8192, BCB = BA + 64, BCBROW = BCB + 
 // likewise W5 = bc4[:, :64].bc2_1.W, B5 = bc4[:, :64].bc2_1.b + bcb
 struct PackPreBwd {
   enum { W1 = 0, B1 = W1 + 512, W2 = B1 + 64, B2 = W2 + 4096, W3 = B2 + 64, B3 = W3 + 4096, W4 = B3 + 64,
-         B4 = W4 + 12288, W5 = B4 + 64, B5 = W5 + 4096, FLOATS = B5 + 64 };
+         B4 = W4 + 12288, W5 = B4 + 64, B5 = W5 + 4096, FLOATS = B5 + 64,
+         W23 = FLOATS, W33 = W23 + 6144, W53 = W33 + 6144, FLOATS3 = W53 + 6144 };      // W2, W3, W5 as bf16 x 3 (W4, 192 wide, stays fp32)
+};
+struct PackPreBwdL3 {      // LDS image, bf16 x 3 form
+  enum { W1 = 0, B1 = W1 + 512, B2 = B1 + 64, B3 = B2 + 64, W4 = B3 + 64, B4 = W4 + 12288, B5 = B4 + 64, W23 = B5 + 64, W33 = W23 + 6144,
+         W53 = W33 + 6144, FLOATS = W53 + 6144 };
 };
 // k_pre_inp: Q = inp_b2[:, :64] inp_b_1(relu(inp_b([l0,u0]))) + inp_b2.bias   (:380-384)
 // folded: Q = (inp_b2[:, :64].inp_b_1.W) relu(inp_b([l0,u0])) + (inp_b2[:, :64].inp_b_1.b + inp_b2.b)
@@ -241,7 +248,7 @@ inline void build_packs(const float* blob, Packs& pk) {
   std::memcpy(&pk.embed[PackEmbed::W], W(L_INP_F), 192 * sizeof(float));
   std::memcpy(&pk.embed[PackEmbed::B], Bv(L_INP_F), 64 * sizeof(float));
 
-  pk.pre_fwd.assign(PackPreFwd::FLOATS, 0.f);
+  pk.pre_fwd.assign(PackPreFwd::FLOATS3, 0.f);
   pack_wsmall(&pk.pre_fwd[PackPreFwd::W1], W(L_FC1), 7, 4);
   pack_vec64(&pk.pre_fwd[PackPreFwd::B1], Bv(L_FC1));
 
@@ -309,15 +316,18 @@ inline void build_packs(const float* blob, Packs& pk) {
     matmul64(w2.data(), W(L_FC4), 128, 0, W(L_FC1_1));
     matvec64(b2, W(L_FC4), 128, 0, Bv(L_FC1_1), bcb);
     pack_w64(&pk.pre_fwd[PackPreFwd::W2], w2.data(), 64, 0, 1);
+    pack_w64_bf3(&pk.pre_fwd[PackPreFwd::W23], w2.data(), 64, 0, 1);
     pack_vec64(&pk.pre_fwd[PackPreFwd::B2], b2);
   }
 
-  pk.pre_bwd.assign(PackPreBwd::FLOATS, 0.f);
+  pk.pre_bwd.assign(PackPreBwd::FLOATS3, 0.f);
   pack_wsmall(&pk.pre_bwd[PackPreBwd::W1], W(L_BC1), 7, 4);
   pack_vec64(&pk.pre_bwd[PackPreBwd::B1], Bv(L_BC1));
   pack_w64(&pk.pre_bwd[PackPreBwd::W2], W(L_BC1_1), 64, 0, 1);
+  pack_w64_bf3(&pk.pre_bwd[PackPreBwd::W23], W(L_BC1_1), 64, 0, 1);
   pack_vec64(&pk.pre_bwd[PackPreBwd::B2], Bv(L_BC1_1));
   pack_w64(&pk.pre_bwd[PackPreBwd::W3], W(L_BC1_2), 64, 0, 1);
+  pack_w64_bf3(&pk.pre_bwd[PackPreBwd::W33], W(L_BC1_2), 64, 0, 1);
   pack_vec64(&pk.pre_bwd[PackPreBwd::B3], Bv(L_BC1_2));
   pack_w64(&pk.pre_bwd[PackPreBwd::W4], W(L_BC2), 192, 0, 3);
   pack_vec64(&pk.pre_bwd[PackPreBwd::B4], Bv(L_BC2));
@@ -328,6 +338,7 @@ inline void build_packs(const float* blob, Packs& pk) {
     matmul64(w5.data(), W(L_BC4), 128, 0, W(L_BC2_1));
     matvec64(b5, W(L_BC4), 128, 0, Bv(L_BC2_1), bcb);
     pack_w64(&pk.pre_bwd[PackPreBwd::W5], w5.data(), 64, 0, 1);
+    pack_w64_bf3(&pk.pre_bwd[PackPreBwd::W53], w5.data(), 64, 0, 1);
     pack_vec64(&pk.pre_bwd[PackPreBwd::B5], b5);
   }
 
