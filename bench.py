@@ -176,17 +176,14 @@ def main():
             parallel.gather_scores(res.scores, world * B)      # the one exchange step: ONE all-gather, scores -> branch selector
         return res
 
-    # Untimed pre-warm (allocator, clocks, caches, runtime pools), then the W warm-up steps the contract asks for.  It is
-    # deliberately long and un-synchronised: the HIP runtime grows one of its launch pools ONCE per process, about 1000
-    # launches (~45 queued forwards) in, with an implicit device drain that blocks the host for the ~50 ms of work queued at
-    # that moment (tools/host_stall.py) -- that one-off must not land in a K-step timed region that is only ~20 ms long.
-    for _ in range(96):
+    # Untimed pre-warm (allocator, clocks, caches), then the W warm-up steps the contract asks for.
+    for _ in range(int(os.environ.get("BENCH_PREWARM", "32"))):
         res = step()
     torch.cuda.synchronize()
+    res.check()                 # (its device->host copy sits before the warm-up steps: the first launch after one has been seen to stall)
+    sizes = eng.sizes
     for _ in range(args.warmup):
         res = step()
-    res.check()
-    sizes = eng.sizes
 
     def sync():
         torch.cuda.synchronize()
@@ -195,11 +192,26 @@ def main():
             torch.cuda.synchronize()
 
     sync()
+    # The host only enqueues (0.2 ms per step against ~1 ms of GPU work), but a full collection of Python's cyclic GC walks
+    # every object torch and numpy created at import -- 35-100 ms, i.e. several times the whole K-step region -- and fires at
+    # an allocation count, i.e. at a fixed step index (tools/host_stall2.py: step 52 for base, 7 and 99 for deep).  Standard
+    # benchmarking hygiene: collect now, keep the collector off while the K steps are timed.
+    import gc
+    gc.collect()
+    gc.disable()
+    trace = [] if os.environ.get("BENCH_TRACE") else None      # dev: host time of every timed step() call
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        if trace is not None:
+            ta = time.perf_counter()
         res = step()
+        if trace is not None:
+            trace.append(round(1e3 * (time.perf_counter() - ta), 2))
     sync()
     elapsed = time.perf_counter() - t0
+    gc.enable()
+    if trace is not None:
+        print("host ms per timed step():", trace, file=sys.stderr)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

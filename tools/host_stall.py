@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""dev helper: does the host-side launch path stall (runtime pools growing) when many forwards are queued without a sync?"""
+"""dev helper: host time of eng.forward() over many repetitions -- shows the one-off pauses of Python's cyclic GC (a full
+collection takes 35-100 ms with torch loaded) that bench.py keeps out of its timed region."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
@@ -7,7 +8,8 @@ from gnn_branching_amd import synth
 from gnn_branching_amd.graphnet.graph_conv import GraphNet
 sd = torch.load(os.path.join(ROOT, "models/cifar_trained_gnn/best_snapshot_None_0_val_acc_0.826_loss_val_0.1036_epoch_57.pt"), map_location="cpu", weights_only=True)
 m = GraphNet(2, 64); m.load_state_dict(sd); eng = m.engine()
-batch = synth.make_batch("cifar_base_kw", 256, seed=1234)
+net = sys.argv[2] if len(sys.argv) > 2 else "cifar_base_kw"
+batch = synth.make_batch(net, int(sys.argv[3]) if len(sys.argv) > 3 else 256, seed=1234)
 dev = torch.device("cuda")
 dl = lambda ts: [t.to(dev).float().contiguous() for t in ts]
 args = (dl(batch.lower_bounds_all), dl(batch.upper_bounds_all), dl(batch.dual_vars), dl(batch.primals), batch.primal_inputs.to(dev), batch.layers, batch.masks.to(dev))
