@@ -170,11 +170,24 @@ def main():
               dev_list(batch.primals), batch.primal_inputs.to(dev), batch.layers, batch.masks.to(dev))
     from gnn_branching_amd import parallel
 
+    pending = [None]
+
     def step():
         res = eng.forward(*d_args)
         if use_dist:
-            parallel.gather_scores(res.scores, world * B)      # the one exchange step: ONE all-gather, scores -> branch selector
+            # the one exchange step: ONE all-gather per scored batch (scores -> branch selector), launched behind the scores on
+            # the communication stream; this stream only waits for the PREVIOUS batch's gather, so the collective of batch i
+            # overlaps the forward of batch i + 1.  Every one of the K gathers completes inside the timed region (sync()).
+            nxt = parallel.gather_scores_async(res.scores, world * B)
+            if pending[0] is not None:
+                pending[0].wait()
+            pending[0] = nxt
         return res
+
+    def drain():
+        if pending[0] is not None:
+            pending[0].wait()
+            pending[0] = None
 
     # Untimed pre-warm (allocator, clocks, caches), then the W warm-up steps the contract asks for.
     for _ in range(int(os.environ.get("BENCH_PREWARM", "32"))):
@@ -186,6 +199,7 @@ def main():
         res = step()
 
     def sync():
+        drain()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()

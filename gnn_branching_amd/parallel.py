@@ -45,6 +45,42 @@ def gather_scores(local_scores, batch_size, group=None):
     return torch.cat([out[r * m:r * m + sizes[r]] for r in range(world)], 0)
 
 
+class PendingScores:
+    """Handle of a score all-gather that has been launched but not waited for (``gather_scores_async``)."""
+
+    def __init__(self, work, out, local, sizes, m):
+        self._work, self._out, self._local, self._sizes, self._m = work, out, local, sizes, m
+
+    def wait(self):
+        """Make the current stream wait for the collective; returns the (batch_size, R) matrix."""
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        out, sizes, m = self._out, self._sizes, self._m
+        if all(s == m for s in sizes):
+            return out
+        return torch.cat([out[r * m:r * m + sizes[r]] for r in range(len(sizes))], 0)
+
+
+def gather_scores_async(local_scores, batch_size, group=None):
+    """``gather_scores`` without waiting: the collective is ordered behind the scores on the communication stream, and the
+    calling stream only waits when ``.wait()`` is called -- so the forward of the NEXT batch overlaps the all-gather of this
+    one (the branch selector consumes batch i while batch i + 1 is scored).  The handle keeps the buffers alive."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    sizes = shard_sizes(batch_size, world)
+    assert local_scores.shape[0] == sizes[rank], (local_scores.shape, sizes, rank)
+    R = local_scores.shape[1]
+    m = max(sizes)
+    if local_scores.shape[0] != m:
+        pad = torch.full((m - local_scores.shape[0], R), float("-inf"), dtype=local_scores.dtype, device=local_scores.device)
+        local_scores = torch.cat([local_scores, pad], 0)
+    local_scores = local_scores.contiguous()
+    out = torch.empty(world * m, R, dtype=local_scores.dtype, device=local_scores.device)
+    work = dist.all_gather_into_tensor(out, local_scores, group=group, async_op=True)
+    return PendingScores(work, out, local_scores, sizes, m)
+
+
 def score_sharded(batch, score_fn, group=None):
     """Score ``batch`` (a synth.SubproblemBatch-like object with ``.slice`` and ``.batch_size``) data-parallel.
 

@@ -44,6 +44,12 @@ def _worker(rank, world, port, case, out_dir):
             return gnn_oracle.padded_scores(s, shard.masks)
         full = parallel.score_sharded(batch, score_fn)
         dec = parallel.decisions_from_scores(full, relu_sizes(batch))
+        # the pipelined form bench.py uses (gather of batch i not waited for until batch i + 1 has been launched): same bytes
+        lo, hi = parallel.shard_bounds(batch.batch_size, world, rank)
+        local = score_fn(batch.slice(lo, hi))
+        h1 = parallel.gather_scores_async(local, batch.batch_size)
+        h2 = parallel.gather_scores_async(local + 1.0, batch.batch_size)        # a second collective in flight behind it
+        assert torch.equal(h1.wait(), full) and torch.equal(h2.wait(), full + 1.0)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), scores=full.numpy(), dec=dec.numpy())
     finally:
         dist.destroy_process_group()
