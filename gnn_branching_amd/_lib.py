@@ -71,15 +71,30 @@ def needs_build():
 
 
 def build_library(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 ... -> csrc/libgnnb.so (cross-compiles without a GPU)."""
+    """hipcc --offload-arch=gfx950 ... -> csrc/libgnnb.so (cross-compiles without a GPU).
+
+    Safe to call from several processes at once (one rank per GPU under torchrun): the build runs under a file lock, into a
+    temporary file that replaces the library atomically, and whoever gets the lock second finds the library up to date."""
     if "GNNB_LIB" in os.environ or (not force and not needs_build()):
         return LIB_PATH
-    cmd = ["hipcc"] + HIPCC_FLAGS + ["-o", LIB_PATH, os.path.join(CSRC, "gnnb.hip")]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("building libgnnb.so failed:\n" + r.stdout + r.stderr)
+    import fcntl
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():
+                return LIB_PATH
+            tmp = LIB_PATH + f".tmp{os.getpid()}"
+            cmd = ["hipcc"] + HIPCC_FLAGS + ["-o", tmp, os.path.join(CSRC, "gnnb.hip")]
+            if verbose:
+                print(" ".join(cmd).replace(tmp, LIB_PATH), file=sys.stderr)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+                raise RuntimeError("building libgnnb.so failed:\n" + r.stdout + r.stderr)
+            os.replace(tmp, LIB_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
