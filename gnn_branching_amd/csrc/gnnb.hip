@@ -102,6 +102,7 @@ struct gnnb_handle {
   int gather_occ = 2;           // workgroups per CU for k_gather (its LDS footprint is only the tap matrix)
   bool dense_lds = true;        // Linear edges: one workgroup per sample with the source rows in LDS (false: per-tile kernel)
   bool restrict_last = true;    // last backward step of layer 1 only for the scored nodes (nothing else reads it)
+  bool s_in_gather = true;      // the sparse gathers compute the bias sums of their edge themselves (fewer k_livesum jobs); GNNB_S_IN_GATHER=0
   bool zero_dead = false;       // GNNB_ZERO_DEAD=1: always write the zero rows of dead nodes (default: only where something reads them)
   int giu_occ = 2;              // workgroups per CU of k_gather_input_update (<= 128 VGPRs: two 8-wave workgroups fit)
   bool bf3 = true;              // node update: 64x64 blocks on the bf16 matrix rate with three-piece operands (fp32 accuracy)
@@ -206,6 +207,7 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpdL3::FLOATS + 6144) * 4));
   if (const char* e = getenv("GNNB_BF3")) h->bf3 = e[0] == '1';
   if (const char* e = getenv("GNNB_ZERO_DEAD")) h->zero_dead = e[0] == '1';
+  if (const char* e = getenv("GNNB_S_IN_GATHER")) h->s_in_gather = e[0] != '0';
   if (const char* e = getenv("GNNB_GIU_OCC")) h->giu_occ = atoi(e) < 1 ? 1 : atoi(e);
   if (const char* e = getenv("GNNB_NU_WAVES")) h->nu_waves = atoi(e) == 8 ? 8 : 12;
   if (const char* e = getenv("GNNB_GATHER_OCC")) h->gather_occ = atoi(e) < 1 ? 1 : atoi(e);
@@ -763,14 +765,18 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       j.wlds = (e.kind == 0 && nw <= LIVESUM_MAXW) ? (int)nw : 0;
       maxw = std::max(maxw, j.wlds);
     };
+    // edges whose aggregate comes from a sparse gather get their bias sums from that gather (GArgs.sout / GIArgs.s_from_gather)
+    auto gather_has_s = [&](const DevGather& d, int bit) { return h->s_in_gather && d.ok && (h->gather_sparse & bit) != 0; };
     for (int k = 1; k <= L; ++k) {            // forward edge k: source layer k-1 (the input layer is all live)
       const Edge& e = h->edges[k];
+      if (k >= 2 && gather_has_s(h->gf[k], h->gf[k].g.lanes == 16 ? 1 : 2)) continue;
       push(e.kind == 0 ? 0 : 1, e, e.kind == 0 ? h->dev[k].w_fwd : h->dev[k].w_bwd, h->dev[k].ld_bwd, k > 1 ? ws + w.lf[k - 1] : nullptr,
            ws + w.sf[k], h->N[k], h->N[k - 1], 0);
     }
     if (limit >= 2)
       for (int k = 0; k < L; ++k) {           // edge k+1 transposed: source layer k+1
         const Edge& e = h->edges[k + 1];
+        if (k == 0 ? gather_has_s(h->gb[1], 4) : gather_has_s(h->gb[k + 1], h->gb[k + 1].g.lanes == 16 ? 1 : 2)) continue;
         push(e.kind == 0 ? 2 : 3, e, h->dev[k + 1].w_bwd, h->dev[k + 1].ld_bwd, ws + w.lf[k + 1], ws + w.sb[k], h->N[k], h->N[k + 1],
              k >= 1 ? 1 : 0);
       }
@@ -832,12 +838,13 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   auto conv_args = [&](const Edge& e, const float* src, float* dst, const float* wt, int normalise) {
     return ConvArgs{src, dst, wt, B, e.c_in, e.h_in, e.w_in, e.c_out, e.h_out, e.w_out, e.kh, e.kw, e.stride, e.pad, normalise};
   };
-  auto gather = [&](const DevGather& d, int k, const float* src, bool scored, bool embed_src, int src_layer) {      // phase A over a conv edge, MFMA
+  auto gather = [&](const DevGather& d, int k, const float* src, bool scored, bool embed_src, int src_layer, float* sout) {      // phase A over a conv edge, MFMA
     const long nt = map_tiles(d.g.tm, B);
     // sparse: a 16-node forward gather behind a ReLU layer skips the (zero) rows of that layer's dead nodes
     const bool sparse = (h->gather_sparse & (d.g.lanes == 16 ? 1 : 2)) && !embed_src && src_layer >= 1;
     GArgs a{in->lb[k], in->ub[k], in->mask, src, nb, nt, scored ? 1 : 0, h->R, roff[k], to_dtm(d.g.tm), to_dg(d, h->d_zero),
-            EmbedSrc{in->lb[0], in->x_lp, in->ub[0], h->d_pack[PK_EMBED]}, sparse ? in->lb[src_layer] : nullptr, sparse ? in->ub[src_layer] : nullptr};
+            EmbedSrc{in->lb[0], in->x_lp, in->ub[0], h->d_pack[PK_EMBED]}, sparse ? in->lb[src_layer] : nullptr, sparse ? in->ub[src_layer] : nullptr,
+            sparse && h->s_in_gather ? sout : nullptr};
     const size_t lds = gather_lds_bytes(d, 0) + (sparse ? sparse_tab_bytes(d) : 0);
     long grid = (nt + WAVES_MLP - 1) / WAVES_MLP;
     if (grid > (long)h->n_cu * h->gather_occ) grid = (long)h->n_cu * h->gather_occ;
@@ -854,7 +861,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   // phase A: nb <- A_k mu[k-1]
   auto agg_fwd = [&](int k) {
     const Edge& e = h->edges[k];
-    if (h->gf[k].ok) { gather(h->gf[k], k, mu(k - 1), false, k == 1 && embed_in_gather && h->proj[0] == L_INP_F_1, k - 1); return; }
+    if (h->gf[k].ok) { gather(h->gf[k], k, mu(k - 1), false, k == 1 && embed_in_gather && h->proj[0] == L_INP_F_1, k - 1, ws + w.sf[k]); return; }
     if (e.kind == 0) {
       ConvArgs a = conv_args(e, mu(k - 1), nb, h->dev[k].w_fwd, 0);
       lz.run(PC_CONV_FWD, [&] {
@@ -885,7 +892,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     const Edge& e = h->edges[k + 1];
     // the input layer (k = 0) aggregates the rows of layer 1 that already went through its 64x64 map (PackPostInp)
     const float* srcb = k == 0 ? rows1_for_input : mu(k + 1);
-    if (k >= 1 && h->gb[k + 1].ok) { gather(h->gb[k + 1], k, mu(k + 1), scored, false, k + 1); return; }
+    if (k >= 1 && h->gb[k + 1].ok) { gather(h->gb[k + 1], k, mu(k + 1), scored, false, k + 1, ws + w.sb[k]); return; }
     if (e.kind == 0) {
       ConvArgs a = conv_args(e, srcb, nb, h->dev[k + 1].w_bwd, normalise);
       lz.run(PC_CONVT_BWD, [&] {
@@ -964,7 +971,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       const long nt = map_tiles(d.g.tm, B);
       const bool sparse = (h->gather_sparse & 4) != 0;
       GIArgs a{h->d_pack[PK_PRE_INP], h->d_pack[PK_UPD_INP], in->lb[0], in->ub[0], rows1_for_input, ws + w.sb[0], mu(0), nt, to_dtm(d.g.tm), to_dg(d, h->d_zero),
-               in->lb[1], in->ub[1]};
+               in->lb[1], in->ub[1], sparse && h->s_in_gather ? 1 : 0};
       const size_t lds = gather_lds_bytes(d, PackUpdInp::FLOATS + PackPreInp::FLOATS) + (sparse ? sparse_tab_bytes(d) : 0);
       long giu_grid = (nt + WAVES_MLP - 1) / WAVES_MLP;
       if (giu_grid > (long)h->n_cu * h->giu_occ) giu_grid = (long)h->n_cu * h->giu_occ;

@@ -104,8 +104,11 @@ __device__ __forceinline__ bool node_is_live(float lb, float ub);
 #endif
 __device__ __forceinline__ void gather_tile_sparse(Frag& X, const float* cm, const int2* ko, uint2* tab, int K2, __amdgpu_buffer_rsrc_t rsrc,
                                                    const float* slb, const float* sub, int j, int wy0, int wx0, int Hs, int Ws, int lane,
-                                                   bool keep = false) {
+                                                   bool keep = false, float* ssum = nullptr) {
+  // ssum: also return s[dst node j] = sum of the tap weights of the live window slots = sum_n A[n', n] live_n, the scalar the
+  // bias of the source rows' deferred projection is multiplied with (gnnb_pack.h; otherwise computed by k_livesum)
   const int h = lane >> 5;
+  float sacc = 0.0f;
   if (!keep) {
 #pragma unroll
     for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = 0.0f;
@@ -139,10 +142,11 @@ __device__ __forceinline__ void gather_tile_sparse(Frag& X, const float* cm, con
       c.cr[u] = e.y;
     }
   };
-  auto mma = [&](const Chunk& c) {
+  auto mma = [&](const Chunk& c, int s0) {
 #pragma unroll
     for (int u = 0; u < GATHER_CHS; ++u) {
       const float b = cm[c.cr[u] + j];
+      if (ssum) sacc += 2 * (s0 + u) + h < n ? b : 0.0f;        // (padding entries point at tap row 0)
       X.t[0] = mfma32(c.v[u].x, b, X.t[0]);
       X.t[1] = mfma32(c.v[u].y, b, X.t[1]);
     }
@@ -153,24 +157,26 @@ __device__ __forceinline__ void gather_tile_sparse(Frag& X, const float* cm, con
   for (int pr = 0; pr < npairs; ++pr, s0 += 2 * GATHER_CHS) {
     load(nxt, s0 + GATHER_CHS);
     __builtin_amdgcn_sched_barrier(0);
-    mma(cur);
+    mma(cur, s0);
     __builtin_amdgcn_sched_barrier(0);
     load(cur, s0 + 2 * GATHER_CHS);
     __builtin_amdgcn_sched_barrier(0);
-    mma(nxt);
+    mma(nxt, s0 + GATHER_CHS);
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (K2e & GATHER_CHS) mma(cur);
+  if (K2e & GATHER_CHS) mma(cur, s0);
+  if (ssum) *ssum = sacc + __shfl_xor(sacc, 32);
 }
 
 // `sbase` = first row of this sample's source layer; must be built from wave-uniform values
 // tab != nullptr: sparse walk (slb / sub = bounds of the source layer of this sample)
 __device__ __forceinline__ void gather_dispatch(Frag& X, const float* cm, const int2* ko, const unsigned* kvo, const DGather& g,
                                                 const float* sbase, int j, int wy0, int wx0, int lane,
-                                                uint2* tab = nullptr, const float* slb = nullptr, const float* sub = nullptr, bool keep = false) {
+                                                uint2* tab = nullptr, const float* slb = nullptr, const float* sub = nullptr, bool keep = false,
+                                                float* ssum = nullptr) {
   const int uy = __builtin_amdgcn_readfirstlane(wy0), ux = __builtin_amdgcn_readfirstlane(wx0);
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)sbase, 0, g.Ns * 256, 0x00020000);
-  if (tab) { gather_tile_sparse(X, cm, ko, tab, g.K2, rsrc, slb, sub, j, uy, ux, g.Hs, g.Ws, lane, keep); return; }
+  if (tab) { gather_tile_sparse(X, cm, ko, tab, g.K2, rsrc, slb, sub, j, uy, ux, g.Hs, g.Ws, lane, keep, ssum); return; }
   if (uy >= 0 && ux >= 0 && uy + g.WY <= g.Hs && ux + g.WX <= g.Ws)
     gather_tile<true>(X, cm, ko, kvo, g.K2, rsrc, j, uy, ux, g.Hs, g.Ws, lane, keep);
   else
@@ -319,8 +325,9 @@ __device__ __forceinline__ void gather_tile16(f32x4 (&acc)[4], const float* cm, 
 #endif
 __device__ __forceinline__ void gather_tile16_sparse(f32x4 (&acc)[4], const float* cm, const int2* ko, uint2* tab, int K2,
                                                      __amdgpu_buffer_rsrc_t rsrc, const float* slb, const float* sub, int wy0, int wx0,
-                                                     int Hs, int Ws, int lane) {
+                                                     int Hs, int Ws, int lane, float* ssum = nullptr) {
   const int g = lane >> 4, i = lane & 15;
+  float sacc = 0.0f;                                  // ssum: see gather_tile_sparse
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int origin = wy0 * Ws + wx0;
@@ -354,10 +361,11 @@ __device__ __forceinline__ void gather_tile16_sparse(f32x4 (&acc)[4], const floa
       c.cr[u] = e.y;
     }
   };
-  auto mma = [&](const Chunk& c, int) {
+  auto mma = [&](const Chunk& c, int s0) {
 #pragma unroll
     for (int u = 0; u < GATHER_CHS16; ++u) {
       const float b = cm[c.cr[u] + i];
+      if (ssum) sacc += 4 * (s0 + u) + g < n ? b : 0.0f;
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[t] = mfma16(c.v[u][t], b, acc[t]);
     }
@@ -376,6 +384,10 @@ __device__ __forceinline__ void gather_tile16_sparse(f32x4 (&acc)[4], const floa
     __builtin_amdgcn_sched_barrier(0);
   }
   if (K2e & GATHER_CHS16) mma(cur, s0);
+  if (ssum) {
+    sacc += __shfl_xor(sacc, 16);
+    *ssum = sacc + __shfl_xor(sacc, 32);
+  }
 }
 
 // the embedding variant (round 0, first edge): the four channels of a slot are computed from its three input scalars
@@ -493,6 +505,7 @@ struct GArgs {
   DGather g;
   EmbedSrc es;              // EMBED: the source rows are computed from the input scalars (mu_src unused)
   const float *src_lb, *src_ub;   // SPARSE: bounds of the source layer (B, Ns): the rows of its dead nodes are zero and skipped
+  float* sout;                    // SPARSE: (B, N) bias-sum scalars s = sum_n A[n', n] live_n written beside nb (null: k_livesum has them)
 };
 
 // EMBED: inp_f rows of this lane's channels 2j, 2j+1
@@ -517,6 +530,7 @@ __device__ __forceinline__ void gather_process_tile(const GArgs& a, const TileCt
                                                     const unsigned* lds_kvo, uint2* tab, const EmbedLane& el, int lane) {
   const int h = lane >> 5, j = lane & 31;
   const long gc = tc.sample * a.tm.N + tc.n;
+  float ssum = 0.0f;
   bool need;
   if (a.need_scored) need = tc.valid && a.mask[tc.sample * a.R + a.off + tc.n] != 0.0f;
   else need = tc.valid && node_is_live(a.lb[gc], a.ub[gc]);    // (one load of k_classify's live flag instead: measured 1.7 % slower)
@@ -537,7 +551,7 @@ __device__ __forceinline__ void gather_process_tile(const GArgs& a, const TileCt
   } else {
     if (SPARSE)
       gather_dispatch(X, lds_cm + tc.cg * a.g.K2 * 64, lds_ko, lds_kvo, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane, tab,
-                      a.src_lb + (long)sample * a.g.Ns, a.src_ub + (long)sample * a.g.Ns);
+                      a.src_lb + (long)sample * a.g.Ns, a.src_ub + (long)sample * a.g.Ns, false, a.sout ? &ssum : nullptr);
     else
       gather_dispatch(X, lds_cm + tc.cg * a.g.K2 * 64, lds_ko, lds_kvo, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane);
   }
@@ -554,8 +568,10 @@ __device__ __forceinline__ void gather_process_tile(const GArgs& a, const TileCt
 #pragma unroll
       for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = FRAG_AT(X, R) / freq;
     }
+    ssum = ssum / freq;                      // the bias sum of a transposed conv edge is normalised like its aggregate
   }
   if (need) frag_store_rows_gathered(X, a.nb, gc, h);
+  if (SPARSE && need && h == 0 && a.sout) a.sout[gc] = ssum;
 }
 
 // The embedding on the matrix pipe: E0 = relu(inp_f [l, x, u] + b) is itself a K = 4 product ([l, x, u, 1] against [W | b]),
@@ -613,6 +629,7 @@ __device__ __forceinline__ void gather_process_tile16(const GArgs& a, const Tile
                                                       const unsigned* lds_kvo, uint2* tab, const float (&ew)[4][3], const float (&eb)[4], int lane) {
   const int gq = lane >> 4;
   const long gc = tc.sample * a.tm.N + tc.n;
+  float ssum = 0.0f;
   bool need;
   if (a.need_scored) need = tc.valid && a.mask[tc.sample * a.R + a.off + tc.n] != 0.0f;
   else need = tc.valid && node_is_live(a.lb[gc], a.ub[gc]);
@@ -641,7 +658,8 @@ __device__ __forceinline__ void gather_process_tile16(const GArgs& a, const Tile
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)sbase, 0, a.g.Ns * 256, 0x00020000);
     if (SPARSE) {
       const long sb = (long)sample * a.g.Ns;
-      gather_tile16_sparse(acc, cmt, lds_ko, tab, a.g.K2, rsrc, a.src_lb + sb, a.src_ub + sb, uy, ux, a.g.Hs, a.g.Ws, lane);
+      gather_tile16_sparse(acc, cmt, lds_ko, tab, a.g.K2, rsrc, a.src_lb + sb, a.src_ub + sb, uy, ux, a.g.Hs, a.g.Ws, lane,
+                           a.sout ? &ssum : nullptr);
     } else if (interior) gather_tile16<true>(acc, cmt, lds_ko, lds_kvo, a.g.K2, rsrc, uy, ux, a.g.Hs, a.g.Ws, lane);
     else gather_tile16<false>(acc, cmt, lds_ko, lds_kvo, a.g.K2, rsrc, uy, ux, a.g.Hs, a.g.Ws, lane);
   }
@@ -649,6 +667,7 @@ __device__ __forceinline__ void gather_process_tile16(const GArgs& a, const Tile
     f32x4* p = reinterpret_cast<f32x4*>(a.nb + gc * 64 + 16 * gq);
 #pragma unroll
     for (int r = 0; r < 4; ++r) p[r] = f32x4{acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+    if (SPARSE && gq == 0 && a.sout) a.sout[gc] = ssum;
   }
 }
 
@@ -731,6 +750,7 @@ struct GIArgs {
   const float *lb, *ub;     // input bounds, flat (B*N0)
   const float* mu_src; const float* sarr; float* mu; long ntiles; DTileMap tm; DGather g;
   const float *src_lb, *src_ub;     // SPARSE: bounds of ReLU layer 1 (the rows of its dead nodes are zero and skipped)
+  int s_from_gather;                // SPARSE: the bias-sum scalar comes out of this kernel's own gather instead of sarr (k_livesum)
 };
 
 // input layer: E_0 = relu(Q + inp_b2[:, 64:] . (A_1^T mu_1)),  Q = inp_b2[:, :64] . inp_b_1(relu(inp_b([l0,u0]))) + b;
@@ -754,7 +774,9 @@ __device__ __forceinline__ void input_update_tile(const GIArgs& a, const TileCtx
   frag_bias(H, lds_pre + PackPreInp::B2, h);
   if (BF3) gemm_w64_bf3<1>(lds_pre + PackPreInp::W23, lane, H, [&](int s) { return FRAG_AT(H0, s); });
   else gemm_w64<32>(lds_pre + PackPreInp::W2, lane, H, [&](int s) { return FRAG_AT(H0, s); });
-  {                                          // bias term of the projection deferred in the rows of mu_1
+  float ssum = 0.0f;
+  const bool own_s = SPARSE && a.s_from_gather;
+  if (!own_s) {                              // bias term of the projection deferred in the rows of mu_1
     const float xs[1] = {h ? 0.0f : a.sarr[gc]};
     gemm_small<1>(lds_upd + PackUpdInp::VC, lane, H, xs);
   }
@@ -762,10 +784,14 @@ __device__ __forceinline__ void input_update_tile(const GIArgs& a, const TileCtx
   // layout (PackPostInp::WPG), register for register: the gather accumulates straight onto H (one fragment less alive).
   if (SPARSE)
     gather_dispatch(H, gl.cm + tc.cg * a.g.K2 * 64, gl.ko, gl.kvo, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane, tab,
-                    a.src_lb + (long)sample * a.g.Ns, a.src_ub + (long)sample * a.g.Ns, true);
+                    a.src_lb + (long)sample * a.g.Ns, a.src_ub + (long)sample * a.g.Ns, true, own_s ? &ssum : nullptr);
   else
     gather_dispatch(H, gl.cm + tc.cg * a.g.K2 * 64, gl.ko, gl.kvo, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane, nullptr,
                     nullptr, nullptr, true);
+  if (own_s) {
+    const float xs[1] = {h ? 0.0f : ssum};
+    gemm_small<1>(lds_upd + PackUpdInp::VC, lane, H, xs);
+  }
   frag_relu(H);
   if (tc.valid) frag_store_rows(H, a.mu, gc, h);
 }
