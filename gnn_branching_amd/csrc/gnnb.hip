@@ -122,6 +122,7 @@ struct gnnb_handle {
   gnnb_train::Trainer* trainer = nullptr;     // online learning (gnnb_online_create)
   float* d_pack[N_PACKS] = {nullptr};
   float* d_zero = nullptr;      // 64 zero floats: where masked gather loads point
+  float* d_s1 = nullptr;        // (N_1) bias sums of edge 1 forward over the (all live) input layer: sum of the weights that reach each node
   std::vector<int> proj;        // per graph layer: which Linear (LayerId) the rows of mu[k] still have to go through after
                                 // the last enqueued kernel (-1: the rows are final) -- the "deferred projection" of gnnb_pack.h
   std::vector<DevGather> gf, gb;   // gf[k]: edge k forward (dst = layer k); gb[k]: edge k transposed (dst = layer k-1)
@@ -286,6 +287,7 @@ extern "C" int gnnb_destroy(gnnb_t* h) {
   for (int i = 0; i < N_PACKS; ++i)
     if (h->d_pack[i]) (void)hipFree(h->d_pack[i]);
   if (h->d_zero) (void)hipFree(h->d_zero);
+  if (h->d_s1) (void)hipFree(h->d_s1);
   free_trainer(h);
   for (auto& ev : h->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
   for (auto& ev : h->pool) (void)hipEventDestroy(ev);
@@ -375,6 +377,35 @@ extern "C" int gnnb_bind_network(gnnb_t* h, const gnnb_layer_desc* L, int n, int
     const Edge& e = h->edges[k];
     DevEdge& d = h->dev[k];
     if (int rc = upload(&d.bias, e.b.data(), e.b.size())) return rc;
+    if (k == 1) {                       // row sums of edge 1 (for a conv: of the taps inside the image) -- k_livesum's job for this edge
+      std::vector<float> s1(h->N[1], 0.0f);
+      if (e.kind == 0) {
+        for (int co = 0; co < e.c_out; ++co)
+          for (int oy = 0; oy < e.h_out; ++oy)
+            for (int ox = 0; ox < e.w_out; ++ox) {
+              float acc = 0.0f;
+              for (int ci = 0; ci < e.c_in; ++ci)
+                for (int ky = 0; ky < e.kh; ++ky) {
+                  const int iy = oy * e.stride - e.pad + ky;
+                  if (iy < 0 || iy >= e.h_in) continue;
+                  for (int kx = 0; kx < e.kw; ++kx) {
+                    const int ix = ox * e.stride - e.pad + kx;
+                    if (ix < 0 || ix >= e.w_in) continue;
+                    acc += e.w[(((size_t)co * e.c_in + ci) * e.kh + ky) * e.kw + kx];
+                  }
+                }
+              s1[((size_t)co * e.h_out + oy) * e.w_out + ox] = acc;
+            }
+      } else {
+        for (int i = 0; i < e.n_out; ++i) {
+          float acc = 0.0f;
+          for (int q = 0; q < e.n_in; ++q) acc += e.w[(size_t)i * e.n_in + q];
+          s1[i] = acc;
+        }
+      }
+      if (h->d_s1) { (void)hipFree(h->d_s1); h->d_s1 = nullptr; }
+      if (int rc = upload(&h->d_s1, s1.data(), s1.size())) return rc;
+    }
     if (e.kind == 0) {
       std::vector<float> t(e.w.size());
       pack_conv_fwd(t.data(), e);
@@ -728,6 +759,12 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     if (transposed && e == 1) return (h->gather_sparse & 4) != 0;
     return (h->gather_sparse & (d.g.lanes == 16 ? 1 : 2)) != 0;
   };
+  // k_top's Linear edges walk live rows only (when their lists fit, top_sample `compact` / `keep`), so they produce the bias sums
+  // of edge L in both directions themselves and k_livesum skips those jobs
+  const bool s1_table = h->s_in_gather && L >= 2 && h->d_s1 != nullptr;      // bias sums of edge 1 forward: bind-time table
+  const int topK = L >= 1 && h->edges[L].kind == 1 ? h->edges[L].n_in : 0;
+  const bool top_s_fwd = top_fused && h->s_in_gather && (topK + 96 <= (int)TOP_LIST_INTS || topK + 96 <= (int)PackProp::FLOATS);
+  const bool top_s_bwd = top_fused && h->s_in_gather && topK + 96 <= (int)TOP_LIST_INTS && limit >= 2;
   auto zero_dead_rows = [&](int k) {
     if (debug_full || h->zero_dead) return true;
     if (k == L) return !top_fused;                                // k_top writes every row of layer L itself
@@ -769,7 +806,9 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     auto gather_has_s = [&](const DevGather& d, int bit) { return h->s_in_gather && d.ok && (h->gather_sparse & bit) != 0; };
     for (int k = 1; k <= L; ++k) {            // forward edge k: source layer k-1 (the input layer is all live)
       const Edge& e = h->edges[k];
+      if (k == 1 && s1_table) continue;
       if (k >= 2 && gather_has_s(h->gf[k], h->gf[k].g.lanes == 16 ? 1 : 2)) continue;
+      if (k == L && top_s_fwd) continue;
       push(e.kind == 0 ? 0 : 1, e, e.kind == 0 ? h->dev[k].w_fwd : h->dev[k].w_bwd, h->dev[k].ld_bwd, k > 1 ? ws + w.lf[k - 1] : nullptr,
            ws + w.sf[k], h->N[k], h->N[k - 1], 0);
     }
@@ -777,10 +816,12 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       for (int k = 0; k < L; ++k) {           // edge k+1 transposed: source layer k+1
         const Edge& e = h->edges[k + 1];
         if (k == 0 ? gather_has_s(h->gb[1], 4) : gather_has_s(h->gb[k + 1], h->gb[k + 1].g.lanes == 16 ? 1 : 2)) continue;
+        if (k == L - 1 && top_s_bwd) continue;
         push(e.kind == 0 ? 2 : 3, e, h->dev[k + 1].w_bwd, h->dev[k + 1].ld_bwd, ws + w.lf[k + 1], ws + w.sb[k], h->N[k], h->N[k + 1],
              k >= 1 ? 1 : 0);
       }
     a.njobs = q;
+    if (q > 0) {
     if (const char* e = getenv("GNNB_LS_ONLY")) {       // dev: time one job (results are wrong)
       const int only = atoi(e);
       if (only >= 0 && only < q) { a.job[0] = a.job[only]; q = 1; a.njobs = 1; }
@@ -794,6 +835,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     }
     // (running this and k_pre on a side stream under k_embed / the first aggregation was measured: 1.72 ms vs 1.59 ms in-line)
     lz.run(PC_LIVESUM, [&] { hipLaunchKernelGGL(k_livesum, dim3((unsigned)B, (unsigned)q), dim3(256), (size_t)(a.lv_floats + maxw) * sizeof(float), st, a); });
+    }                                   // (q == 0: every edge's bias sums come from its gather, k_top or the bind-time table)
   }
   {
     const long G = (long)B * h->N[0];
@@ -927,9 +969,11 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     const int src_proj = fwd ? h->proj[k - 1] : (k < L ? h->proj[k + 1] : -1);
     int pack = PK_UPD_BWD;
     const float* sarr = nullptr;
+    int smod = 0;
     if (fwd) {
       pack = src_proj == L_INP_F_1 ? PK_UPD_FWD_E : (src_proj == L_INP_B2_2 ? PK_UPD_FWD_I : PK_UPD_FWD_F);
       sarr = ws + w.sf[k];
+      if (k == 1 && s1_table) { sarr = h->d_s1; smod = h->N[1]; }      // the input layer is all live: one table for every sample
     } else if (k < L) {
       pack = PK_UPD_BWD_B;
       sarr = ws + w.sb[k];
@@ -937,7 +981,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     const bool deferred = sarr != nullptr;
     // normal: list0 = live non-ambiguous nodes (short chain), list1 = ambiguous nodes; restricted: the scored nodes, general chain
     UpdArgs a{h->d_pack[pack], in->lb[k], in->ub[k], nb, ws + (fwd ? w.Pf[k] : w.Pb[k]), (post_input && !debug_full) ? nullptr : mu(k), status,
-              ilist(w.live[k]), cnt + 4 * k + (scored ? 3 : 0), ilist(scored ? w.score[k] : w.amb[k]), cnt + 4 * k + (scored ? 2 : 1), sarr,
+              ilist(w.live[k]), cnt + 4 * k + (scored ? 3 : 0), ilist(scored ? w.score[k] : w.amb[k]), cnt + 4 * k + (scored ? 2 : 1), sarr, smod,
               post_input ? rows1_for_input : nullptr, nullptr};
     const int wv = h->nu_waves;  // waves per workgroup (one workgroup per CU shares the LDS weights)
     const bool bf3 = h->bf3 && wv == 12;
@@ -997,7 +1041,9 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     a.df = DenseLArgs{de.w_fwd, mu(L - 1), nullptr, B, e.n_in, e.n_out, de.ld_fwd, de.mt_fwd, de.kpad_fwd};
     a.db = DenseLArgs{de.w_bwd, nullptr, nb, B, e.n_out, e.n_in, de.ld_bwd, de.mt_bwd, de.kpad_bwd};
     a.pack_f = h->d_pack[PK_UPD_FWD_F]; a.pack_b = h->d_pack[PK_UPD_BWD]; a.pack_p = h->d_pack[PK_PROP];
-    a.Pf = ws + w.Pf[L]; a.Pb = ws + w.Pb[L]; a.sf = ws + w.sf[L];
+    a.Pf = ws + w.Pf[L]; a.Pb = ws + w.Pb[L];
+    a.sf = top_s_fwd ? nullptr : ws + w.sf[L];              // null: F1 walks exactly the live rows of layer L-1 and sums its weights itself
+    a.sb_out = top_s_bwd ? ws + w.sb[L - 1] : nullptr;
     a.lb = in->lb[L]; a.ub = in->ub[L];
     a.lbm = in->lb[L - 1]; a.ubm = in->ub[L - 1];
     a.prop_w = in->prop_w; a.prop_b = in->prop_b; a.lbK = in->lb[K]; a.ubK = in->ub[K]; a.z_out = in->primal[in->n_primal - 1];

@@ -185,8 +185,11 @@ struct DenseLArgs {
 // klist (LDS) != nullptr: only the K_eff source rows klist[0..K_eff) are walked (the caller dropped the all-zero rows of dead
 // nodes); klist must be padded with a.Kpad (a zero row of At) up to round_up(K_eff, 64) + 32 entries.
 template <class Store>
+// s_ret (only with klist, i.e. when exactly the live source rows are walked): the wave that stores row tile mt also returns, in
+// lane j, s[row mt*32 + j] = sum over the walked rows of W[row][k] = sum_k W[row][k] live_k -- the bias sum of this edge
+// (gnnb_pack.h "deferred projection"); needs 256 more floats of scratch behind the 16384 of the tiles
 __device__ __forceinline__ void dense_fwd_sample(const DenseLArgs& a, int b, float* scratch, Store store, const int* klist = nullptr,
-                                                 int K_eff = 0) {
+                                                 int K_eff = 0, float* s_ret = nullptr) {
   float (*xs)[2][32][64] = reinterpret_cast<float (*)[2][32][64]>(scratch);                 // [buffer][K-half][row][channel]  32 KB
   float (*red)[32][64] = reinterpret_cast<float (*)[32][64]>(scratch + 2 * 2 * 32 * 64);    // 32 KB
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
@@ -230,10 +233,12 @@ __device__ __forceinline__ void dense_fwd_sample(const DenseLArgs& a, int b, flo
 #pragma unroll
     for (int u = 0; u < 16; ++u) A[u] = At[(long)(kl ? kl[c * 32 + 2 * u + h] : c * 32 + 2 * u + h) * a.ldA];
   };
+  float sacc = 0.0f;
   auto mma = [&](const float (&A)[16], int buf) {
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const float2 bv = *reinterpret_cast<const float2*>(&xs[buf][kh][2 * u + h][2 * j]);
+      if (s_ret) sacc += A[u];               // (list padding points at a zero row of At)
       acc0 = mfma32(A[u], bv.x, acc0);
       acc1 = mfma32(A[u], bv.y, acc1);
     }
@@ -261,11 +266,15 @@ __device__ __forceinline__ void dense_fwd_sample(const DenseLArgs& a, int b, flo
     if (more2) lstore(0);
     __syncthreads();
   }
+  float (*sred)[64] = reinterpret_cast<float (*)[64]>(scratch + 2 * 2 * 32 * 64 + 4 * 32 * 64);
+  if (s_ret) sacc += __shfl_xor(sacc, 32);
   if (kh == 1) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { red[mt][r][lane] = acc0[r]; red[mt][16 + r][lane] = acc1[r]; }
+    if (s_ret) sred[mt][lane] = sacc;
   }
   __syncthreads();
+  if (s_ret && kh == 0) *s_ret = sacc + sred[mt][lane];
   if (kh == 0 && mt < a.MT) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -288,8 +297,9 @@ __global__ __launch_bounds__(512, 2) void k_dense_fwd_lds(DenseLArgs a) {
 // below; the others are never read); `klist` / K_eff -- only these source rows are walked (the live nodes of this layer; the
 // rows of dead ones are zero), padded with a.Kpad (a zero row of At and of xs) up to round_up(K_eff, 16) + 32 entries.
 template <class Store>
+// sout (only with klist): also writes sout[row] = sum over the walked k of W[k][row] = the bias sum of the transposed edge
 __device__ __forceinline__ void dense_bwd_sample(const DenseLArgs& a, const float* xs_raw, Store store, const int* rlist = nullptr,
-                                                 int n_rows = 0, const int* klist = nullptr, int K_eff = 0) {
+                                                 int n_rows = 0, const int* klist = nullptr, int K_eff = 0, float* sout = nullptr) {
   const float (*xs)[64] = reinterpret_cast<const float (*)[64]>(xs_raw);
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -308,10 +318,12 @@ __device__ __forceinline__ void dense_bwd_sample(const DenseLArgs& a, const floa
 #pragma unroll
       for (int u = 0; u < DL_CH; ++u) A[u] = At[(long)(klist ? klist[c * 16 + 2 * u + h] : c * 16 + 2 * u + h) * a.ldA];
     };
+    float sacc = 0.0f;
     auto mma = [&](const float (&A)[DL_CH], int c) {
 #pragma unroll
       for (int u = 0; u < DL_CH; ++u) {
         const float2 bv = *reinterpret_cast<const float2*>(&xs[klist ? klist[c * 16 + 2 * u + h] : c * 16 + 2 * u + h][2 * j]);
+        if (sout) sacc += A[u];
         acc0 = mfma32(A[u], bv.x, acc0);
         acc1 = mfma32(A[u], bv.y, acc1);
       }
@@ -338,6 +350,10 @@ __device__ __forceinline__ void dense_bwd_sample(const DenseLArgs& a, const floa
     for (int r = 0; r < 16; ++r) {
       const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       if (row < M) store(rlist ? rlist[row] : row, j, make_float2(acc0[r], acc1[r]));
+    }
+    if (sout) {
+      sacc += __shfl_xor(sacc, 32);
+      if (h == 0 && mt * 32 + j < M) sout[arow] = sacc;
     }
   }
 }
@@ -447,7 +463,8 @@ struct TopArgs {
   DenseLArgs db;            // transposed edge L (X unused: the rows come from LDS), out = aggregate rows of layer L-1
   const float *pack_f, *pack_b, *pack_p;
   const float *Pf, *Pb;     // cached P' rows of layer L (by node id), forward / backward
-  const float* sf;          // bias-sum scalars of the forward edge (B, N)
+  const float* sf;          // bias-sum scalars of the forward edge (B, N); null: computed here (live-row walk of F1)
+  float* sb_out;            // (B, K) bias-sum scalars of the transposed edge written by B2 (its live-row walk), or null (k_livesum has them)
   const float *lb, *ub;     // bounds of layer L, flat (B*N)
   const float *lbm, *ubm;   // bounds of layer L-1, flat (B*K): its dead rows (all zero) are skipped by the forward edge
   const float *prop_w, *prop_b, *lbK, *ubK, *z_out;
@@ -526,8 +543,9 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
   __syncthreads();
 
   // ---- F1: rows of C <- W_L . mu_{L-1}
+  float s_own = 0.0f;                                    // waves 0..3, lane j: bias sum of node wave*32 + j (when a.sf is null)
   dense_fwd_sample(a.df, b, A, [&](int row, int jj, float2 v) { *reinterpret_cast<float2*>(Cr + row * 64 + 2 * jj) = v; },
-                   compact ? klist : nullptr, K_eff);
+                   compact ? klist : nullptr, K_eff, (compact && !a.sf) ? &s_own : nullptr);
   __syncthreads();
   copy_to_lds(Bp, a.pack_p, PackProp::FLOATS);            // (read from F3 on, behind two more barriers)
 
@@ -580,7 +598,7 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
   if (upd_wave) {
     Frag X, E;
     load_row(X, valid ? n : 0);
-    chain(X, r.amb != 0.0f ? a.Pf + g * 64 : a.pack_f + PackUpd::BCBROW, true, (h ? r.r1 : r.r0) * a.sf[g], E);
+    chain(X, r.amb != 0.0f ? a.Pf + g * 64 : a.pack_f + PackUpd::BCBROW, true, (h ? r.r1 : r.r0) * (a.sf ? a.sf[g] : s_own), E);
     if (valid) {
       if (frag_has_nan(E)) atomicOr(a.status, 1);
       store_row(E, Cr + n * 64);
@@ -669,7 +687,7 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
   }
   float* out = a.db.out + (long)b * a.db.M * 64;
   auto put = [&](int row, int jj, float2 v) { *reinterpret_cast<float2*>(out + (long)row * 64 + 2 * jj) = v; };
-  if (keep) dense_bwd_sample(a.db, Cr, put, klist, K_eff, k2list, K2);
+  if (keep) dense_bwd_sample(a.db, Cr, put, klist, K_eff, k2list, K2, a.sb_out ? a.sb_out + (long)b * a.db.M : nullptr);
   else dense_bwd_sample(a.db, Cr, put);
 }
 

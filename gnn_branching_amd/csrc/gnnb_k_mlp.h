@@ -302,6 +302,7 @@ struct UpdArgs {
   const int *list0, *cnt0;  // nodes with r0 == r1 and no relaxation term (live, not ambiguous): short chain
   const int *list1, *cnt1;  // general nodes (ambiguous; or the scored nodes for the last backward step of layer 1)
   const float* sarr;        // DEFERRED: s[g] = sum over the edge of live_src (k_livesum), the bias term of the source rows' projection
+  int smod;                 // > 0: sarr is one (N) table shared by all samples (source layer all live: the input layer), index g % smod
   // POST (layer 1, backward, an input-layer update follows): the consumer's 64x64 map inp_b2[:, 64:].bc4_1.W is applied here,
   // on the ~3x fewer producer nodes: F = WP.E goes to `post` (rows by node id), and `mu` may be null (nothing else reads E)
   float* post;
@@ -340,7 +341,7 @@ __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, i
     g_ = (k0 ? a.list0 : a.list1)[v_ ? idx : 0];
     l_ = a.lb[g_];
     u_ = a.ub[g_];
-    if (deferred) s_ = a.sarr[g_];
+    if (deferred) s_ = a.sarr[a.smod > 0 ? g_ % a.smod : g_];
     frag_load_rows(x_, a.nb, g_, h);
   };
   if (tile < ntiles) fetch(tile, gc, valid, lb, ub, sw, X);
