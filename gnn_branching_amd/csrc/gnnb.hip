@@ -20,7 +20,7 @@
 //
 // One translation unit: gnnb_dev.h (fragments, GEMM blocks, tile maps), gnnb_k_mlp.h (setup + node-MLP kernels),
 // gnnb_k_gather.h (conv-edge message passing + score head), gnnb_k_edges.h (other edges, k_top), gnnb_k_misc.h (k_livesum,
-// k_babsr, k_argmax), gnnb_train.h (online learning) are included below; this file holds the host side and the C-ABI.
+// k_babsr, k_reset), gnnb_train.h (online learning) are included below; this file holds the host side and the C-ABI.
 //
 // gfx950 only.  No HIP call at load time.
 #include <hip/hip_runtime.h>
@@ -568,7 +568,7 @@ struct WsLayout {
   std::vector<size_t> lf;       // live flags (B, N_k) as floats
   std::vector<size_t> sf, sb;   // k_livesum outputs: sf[k] (B, N_k) over edge k, sb[k] (B, N_k) over edge k+1 transposed
   size_t F1 = 0;                // rows of layer 1 after the producer-side map of the input update (PackPostInp)
-  size_t cnt = 0, nb = 0, Q = 0, total = 0;
+  size_t cnt = 0, best = 0, nb = 0, Q = 0, total = 0;     // best: B 64-bit decision keys + the finished-workgroup counter of k_score
 };
 static size_t align64(size_t nfloats) { return (nfloats + 63) & ~(size_t)63; }
 static WsLayout ws_layout(const gnnb_t* h, int B) {
@@ -576,6 +576,7 @@ static WsLayout ws_layout(const gnnb_t* h, int B) {
   const int K = (int)h->N.size() - 1;
   size_t off = 0;
   w.cnt = off; off += 64;                      // int counters: 4 per ReLU layer (live, amb, score, pad), zeroed every forward
+  w.best = off; off += align64((size_t)2 * B + 2);
   w.mu.resize(K + 1);
   for (int k = 0; k <= K; ++k) { w.mu[k] = off; off += align64((size_t)B * h->N[k] * 64); }
   size_t maxn = 0;
@@ -731,7 +732,9 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   auto mu = [&](int k) { return ws + w.mu[k]; };
   float* nb = ws + w.nb;
 
-  hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, st, status, reinterpret_cast<int*>(ws + w.cnt));
+  unsigned long long* best = reinterpret_cast<unsigned long long*>(ws + w.best);
+  int* done_ctr = reinterpret_cast<int*>(ws + w.best + 2 * (size_t)B);
+  hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, st, status, reinterpret_cast<int*>(ws + w.cnt), best, done_ctr, B);
   int* cnt = reinterpret_cast<int*>(ws + w.cnt);
   auto ilist = [&](size_t off) { return reinterpret_cast<int*>(ws + off); };
   std::vector<int> roff(L + 2, 0);          // offset of layer k inside the flat ReLU index
@@ -1095,9 +1098,9 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   }
 
   // scores (graph_conv.py:442-450) and decision (graph_score.py:41-47)
-  ArgmaxArgs am{scores, decisions, B, h->R, L, {0}};
   {
     ScoreArgs a{};
+    a.best = best; a.done = done_ctr; a.dec = decisions; a.B = B; a.n_relu = L;
     a.pack = h->d_pack[h->proj[1] == L_FC4_2 ? PK_SCORE_F : PK_SCORE_B]; a.scores = scores; a.L = L; a.R = h->R; a.cnt = cnt + 4;
     long nt = 0;
     for (int k = 1; k <= L; ++k) {
@@ -1105,11 +1108,10 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       a.mu[i] = mu(k); a.list[i] = ilist(w.score[k]); a.N[i] = h->N[k]; a.off[i] = roff[k];
       a.lb[i] = in->lb[k]; a.ub[i] = in->ub[k];
       nt += ((long)B * h->N[k] + 31) / 32;
-      am.cum[k - 1] = roff[k] + h->N[k];
+      a.cum[k - 1] = roff[k] + h->N[k];
     }
     lz.run(PC_SCORE, [&] { hipLaunchKernelGGL(k_score, dim3(mlp_grid(h, nt / 4)), dim3(WG_MLP), PackScore::FLOATS * 4, st, a); });
   }
-  lz.run(PC_ARGMAX, [&] { hipLaunchKernelGGL(k_argmax, dim3(B), dim3(256), 0, st, am); });
   return lz.rc;
 }
 

@@ -827,6 +827,10 @@ struct ScoreArgs {        // every ReLU layer in one launch
   const float* lb[MAXL]; const float* ub[MAXL];
   const int* cnt;         // cnt[4k + 2] = number of scored nodes of layer k
   int N[MAXL], off[MAXL]; // nodes per sample in layer k, offset of layer k in the flat ReLU index
+  // the decision (graph_score.py:41-47: first maximal score -> [layer, idx]) in the same launch: every tile folds its scores into
+  // best[b] = max over (order-preserving score bits << 32 | ~flat index) -- ties go to the lower index -- and the workgroup that
+  // finishes last turns the B keys into decisions.  best / done are zeroed by k_reset.
+  unsigned long long* best; int* done; int* dec; int B, n_relu; int cum[16];
 };
 
 // score = fscore(relu(fnode(mu_g))) for the nodes g whose BaB mask is -1 (the rest stays -inf)    graph_conv.py:445-450
@@ -865,7 +869,26 @@ __device__ __forceinline__ void score_tile(const ScoreArgs& a, const float* lds,
       for (int c = 0; c < 4; ++c) part = fmaf(FRAG_AT(H, 4 * q + c), w[c], part);
     }
     part += __shfl_xor(part, 32);
-    if (valid && h == 0) a.scores[b * a.R + a.off[k] + (gc - b * N)] = part + bs;
+    const int flat = a.off[k] + (int)(gc - b * N);
+    if (valid && h == 0) a.scores[b * a.R + flat] = part + bs;
+    // fold into the per-sample best key: lanes of one sample are reduced in the wave first (a tile spans at most a few samples)
+    const unsigned u = __float_as_uint(part + bs);
+    const unsigned ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    unsigned long long key = (valid && h == 0) ? (((unsigned long long)ord << 32) | (0xffffffffu - (unsigned)flat)) : 0ull;
+    unsigned long long todo = __ballot(key != 0ull);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const long bl = __shfl((int)b, leader);                 // (B < 2^31)
+      const bool mine = key != 0ull && b == bl;
+      unsigned long long m = mine ? key : 0ull;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = ((unsigned long long)__shfl_xor((unsigned)(m >> 32), o) << 32) | (unsigned)__shfl_xor((unsigned)m, o);
+        m = other > m ? other : m;
+      }
+      if (lane == leader) atomicMax(a.best + bl, m);
+      todo &= ~__ballot(mine);
+    }
   }
 }
 
@@ -885,5 +908,27 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_score(ScoreArgs a) {
       t -= tk;
     }
     score_tile(a, lds, k, a.list[k], count, t, lane);
+  }
+  // the workgroup that finishes last converts the keys
+  __shared__ int last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    last = atomicAdd(a.done, 1) == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  for (int b = threadIdx.x; b < a.B; b += blockDim.x) {
+    const unsigned long long key = __hip_atomic_load(a.best + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int lay = -1, idx = -1;
+    if (key != 0ull) {
+      const int flat = (int)(0xffffffffu - (unsigned)key);
+      lay = 0;
+      while (lay < a.n_relu - 1 && a.cum[lay] <= flat) ++lay;
+      idx = lay == 0 ? flat : flat - a.cum[lay - 1];
+    }
+    a.dec[b * 2] = lay;
+    a.dec[b * 2 + 1] = idx;
   }
 }

@@ -1,5 +1,5 @@
 // gnnb_k_misc.h -- part of libgnnb.so, included by gnnb.hip (one translation unit; see its header comment).
-// k_livesum (bias sums of the deferred projections), k_babsr (BaBSR heuristic), k_argmax.
+// k_livesum (bias sums of the deferred projections), k_babsr (BaBSR heuristic), k_reset (the decision itself: k_score).
 #pragma once
 
 // ------------------------------------------------------------------------------------------
@@ -271,51 +271,9 @@ __global__ __launch_bounds__(256) void k_babsr(BabsrArgs a) {
   }
 }
 
-struct ArgmaxArgs { const float* scores; int* dec; int B, R, n_relu; int cum[16]; };
-
-// torch.max(scores, 0) -> first maximal index; flat index -> [layer, idx]      graph_score.py:41-47
-// first maximum of the sample's score row -> [layer, idx]; NT threads (a power of two), sv / si: NT floats / ints of LDS
-template <int NT>
-__device__ __forceinline__ void argmax_sample(const ArgmaxArgs& a, int b, float* sv, int* si) {
-  float best = -INFINITY;
-  int bi = 0x7fffffff;
-  const float* s = a.scores + (long)b * a.R;
-  for (int i = threadIdx.x; i < a.R; i += NT) {
-    const float v = s[i];
-    if (v > best) { best = v; bi = i; }     // strided ascending: keeps the first index per thread
-  }
-  sv[threadIdx.x] = best;
-  si[threadIdx.x] = bi;
-  __syncthreads();
-  for (int st = NT / 2; st > 0; st >>= 1) {
-    if ((int)threadIdx.x < st) {
-      const float v = sv[threadIdx.x + st];
-      const int i = si[threadIdx.x + st];
-      if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && i < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = i; }
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    int lay = -1, idx = -1;
-    if (si[0] != 0x7fffffff) {
-      const int flat = si[0];
-      lay = 0;
-      while (lay < a.n_relu - 1 && a.cum[lay] <= flat) ++lay;
-      idx = lay == 0 ? flat : flat - a.cum[lay - 1];
-    }
-    a.dec[b * 2] = lay;
-    a.dec[b * 2 + 1] = idx;
-  }
-}
-
-__global__ __launch_bounds__(256) void k_argmax(ArgmaxArgs a) {
-  __shared__ float sv[256];
-  __shared__ int si[256];
-  argmax_sample<256>(a, blockIdx.x, sv, si);
-}
-
-// start of a forward: the status word and the list counters back to zero (one launch instead of two memset nodes)
-__global__ __launch_bounds__(64) void k_reset(int32_t* status, int* cnt) {
+// start of a forward: the status word, the list counters and the decision keys back to zero (one launch instead of memset nodes)
+__global__ __launch_bounds__(64) void k_reset(int32_t* status, int* cnt, unsigned long long* best, int* done, int B) {
   cnt[threadIdx.x] = 0;
-  if (threadIdx.x == 0) *status = 0;
+  for (int b = threadIdx.x; b < B; b += 64) best[b] = 0ull;        // per-sample best score key of k_score
+  if (threadIdx.x == 0) { *status = 0; *done = 0; }
 }
