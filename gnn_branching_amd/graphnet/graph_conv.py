@@ -68,10 +68,21 @@ class GraphNet(nn.Module):
         self._engine = None
         self._engine_key = None
 
+    def _apply(self, fn, *a, **k):            # .cuda() / .to() / .float(): parameters may be replaced
+        self._plist = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._plist = None
+        return super().load_state_dict(*a, **k)
+
     def engine(self):
         """The HIP engine for the current parameters; re-packed whenever one changed
-        (load_state_dict, an optimizer step, .cuda())."""
-        key = tuple((q.data_ptr(), q._version) for q in self.parameters())
+        (load_state_dict, an optimizer step, .cuda()).  The Parameter objects are listed once: walking the module tree on
+        every call cost 0.12 ms of a 0.65 ms decision."""
+        if getattr(self, "_plist", None) is None:
+            self._plist = list(self.parameters())
+        key = tuple((q.data_ptr(), q._version) for q in self._plist)
         if self._engine is None or key != self._engine_key:
             self._engine = ScorerEngine(self.state_dict(), T=self.T, p=self.p)
             self._engine_key = key
@@ -87,7 +98,8 @@ class GraphNet(nn.Module):
                 q.copy_(torch.from_numpy(np.asarray(blob[off:off + n], dtype=np.float32)).reshape(q.shape))
                 off += n
         if self._engine is not None:
-            self._engine_key = tuple((q.data_ptr(), q._version) for q in self.parameters())
+            self._plist = list(self.parameters())
+            self._engine_key = tuple((q.data_ptr(), q._version) for q in self._plist)
 
     def forward_device(self, lower_bounds_all, upper_bounds_all, dual_vars, primals, primal_inputs, layers, masks):
         """Batched forward; returns the device-resident ForwardResult (padded scores, decisions,
