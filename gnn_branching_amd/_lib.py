@@ -40,6 +40,7 @@ SYMBOLS = [
     ("gnnb_workspace_bytes", C.c_size_t, [C.c_void_p, C.c_int]),
     ("gnnb_forward", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("gnnb_forward_host", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("gnnb_babsr", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p,
                              C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("gnnb_mu_projection", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),

@@ -122,6 +122,11 @@ struct gnnb_handle {
   gnnb_train::Trainer* trainer = nullptr;     // online learning (gnnb_online_create)
   float* d_pack[N_PACKS] = {nullptr};
   float* d_zero = nullptr;      // 64 zero floats: where masked gather loads point
+  // gnnb_forward_host: pinned staging of the host inputs, their device image, workspace and outputs (grown on demand)
+  float* hs_pinned = nullptr; float* hs_dev = nullptr; size_t hs_floats = 0;
+  void* hs_ws = nullptr; size_t hs_ws_bytes = 0;
+  float* hs_scores = nullptr; int32_t* hs_dec = nullptr; size_t hs_out_B = 0;
+  float* hs_out_pinned = nullptr;
   float* d_s1 = nullptr;        // (N_1) bias sums of edge 1 forward over the (all live) input layer: sum of the weights that reach each node
   std::vector<int> proj;        // per graph layer: which Linear (LayerId) the rows of mu[k] still have to go through after
                                 // the last enqueued kernel (-1: the rows are final) -- the "deferred projection" of gnnb_pack.h
@@ -288,6 +293,12 @@ extern "C" int gnnb_destroy(gnnb_t* h) {
     if (h->d_pack[i]) (void)hipFree(h->d_pack[i]);
   if (h->d_zero) (void)hipFree(h->d_zero);
   if (h->d_s1) (void)hipFree(h->d_s1);
+  if (h->hs_pinned) (void)hipHostFree(h->hs_pinned);
+  if (h->hs_out_pinned) (void)hipHostFree(h->hs_out_pinned);
+  if (h->hs_dev) (void)hipFree(h->hs_dev);
+  if (h->hs_ws) (void)hipFree(h->hs_ws);
+  if (h->hs_scores) (void)hipFree(h->hs_scores);
+  if (h->hs_dec) (void)hipFree(h->hs_dec);
   free_trainer(h);
   for (auto& ev : h->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
   for (auto& ev : h->pool) (void)hipEventDestroy(ev);
@@ -1113,6 +1124,83 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     lz.run(PC_SCORE, [&] { hipLaunchKernelGGL(k_score, dim3(mlp_grid(h, nt / 4)), dim3(WG_MLP), PackScore::FLOATS * 4, st, a); });
   }
   return lz.rc;
+}
+
+// gnnb_forward for HOST inputs -- the reference's own call pattern: one or two subproblems per decision, every tensor a CPU
+// tensor (graph_score.py:26-30 moves them with ~14 .cuda() calls).  All inputs the forward reads are packed into one pinned
+// buffer (256-B aligned slots) and cross PCIe as ONE copy; the forward runs on `stream`; decisions, status and (optionally) the
+// padded scores come back in one pinned block; the call returns after synchronising the stream.  Buffers live in the handle.
+extern "C" int gnnb_forward_host(gnnb_t* h, const gnnb_batch* in, int B, float* scores, int32_t* decisions, int32_t* status, void* stream) {
+  if (!h || !in || !decisions || !status) return fail(GNNB_E_INVALID, "gnnb_forward_host: null argument");
+  if (!h->bound) return fail(GNNB_E_STATE, "gnnb_forward_host: call gnnb_bind_network first");
+  const int K = (int)h->N.size() - 1, L = K - 1, R = h->R;
+  if (B < 1 || in->n_graph != K + 1 || in->n_relu != L || in->n_primal != h->n_fixed + 1)
+    return fail(GNNB_E_INVALID, "gnnb_forward_host: batch does not match the bound network");
+  hipStream_t st = (hipStream_t)stream;
+  // ---- slots: (host pointer, floats); primals the forward never reads are not transferred
+  struct Slot { const float* src; size_t n, off; };
+  std::vector<Slot> slots;
+  size_t total = 0;
+  auto add = [&](const float* p, size_t n) { slots.push_back(Slot{p, n, total}); total += (n + 63) & ~(size_t)63; return slots.size() - 1; };
+  std::vector<size_t> i_lb(K + 1), i_ub(K + 1), i_dual(L), i_prim(in->n_primal, (size_t)-1);
+  for (int k = 0; k <= K; ++k) { i_lb[k] = add(in->lb[k], (size_t)B * h->N[k]); i_ub[k] = add(in->ub[k], (size_t)B * h->N[k]); }
+  for (int k = 0; k < L; ++k) i_dual[k] = add(in->dual[k], (size_t)B * h->N[k + 1] * 3);
+  for (int k = 1; k <= L; ++k) {
+    const int q = h->relu_q[k];
+    for (int m : {q - 1, q})
+      if (i_prim[m] == (size_t)-1) i_prim[m] = add(in->primal[m], (size_t)B * h->N[k]);
+  }
+  if (i_prim[in->n_primal - 1] == (size_t)-1) i_prim[in->n_primal - 1] = add(in->primal[in->n_primal - 1], (size_t)B);
+  const size_t i_x = add(in->x_lp, (size_t)B * h->N[0]), i_pw = add(in->prop_w, (size_t)B * h->N[L]), i_pb = add(in->prop_b, (size_t)B);
+  const size_t i_mask = add(in->mask, (size_t)B * R);
+  for (const Slot& sl : slots)
+    if (!sl.src) return fail(GNNB_E_INVALID, "gnnb_forward_host: null input pointer");
+  // ---- buffers
+  if (h->hs_floats < total) {
+    if (h->hs_pinned) (void)hipHostFree(h->hs_pinned);
+    if (h->hs_dev) (void)hipFree(h->hs_dev);
+    h->hs_pinned = nullptr; h->hs_dev = nullptr; h->hs_floats = 0;
+    HIPCHK(hipHostMalloc((void**)&h->hs_pinned, total * sizeof(float), hipHostMallocDefault));
+    HIPCHK(hipMalloc((void**)&h->hs_dev, total * sizeof(float)));
+    h->hs_floats = total;
+  }
+  const size_t wsb = gnnb_workspace_bytes(h, B);
+  if (h->hs_ws_bytes < wsb) {
+    if (h->hs_ws) (void)hipFree(h->hs_ws);
+    h->hs_ws = nullptr; h->hs_ws_bytes = 0;
+    HIPCHK(hipMalloc(&h->hs_ws, wsb));
+    h->hs_ws_bytes = wsb;
+  }
+  if (h->hs_out_B < (size_t)B) {
+    if (h->hs_scores) (void)hipFree(h->hs_scores);
+    if (h->hs_dec) (void)hipFree(h->hs_dec);
+    if (h->hs_out_pinned) (void)hipHostFree(h->hs_out_pinned);
+    h->hs_scores = nullptr; h->hs_dec = nullptr; h->hs_out_pinned = nullptr; h->hs_out_B = 0;
+    HIPCHK(hipMalloc((void**)&h->hs_scores, (size_t)B * R * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&h->hs_dec, ((size_t)B * 2 + 1) * sizeof(int32_t)));          // decisions, then the status word
+    HIPCHK(hipHostMalloc((void**)&h->hs_out_pinned, ((size_t)B * R + (size_t)B * 2 + 1) * sizeof(float), hipHostMallocDefault));
+    h->hs_out_B = B;
+  }
+  // ---- stage, one transfer, forward
+  for (const Slot& sl : slots) memcpy(h->hs_pinned + sl.off, sl.src, sl.n * sizeof(float));
+  HIPCHK(hipMemcpyAsync(h->hs_dev, h->hs_pinned, total * sizeof(float), hipMemcpyHostToDevice, st));
+  std::vector<const float*> lb(K + 1), ub(K + 1), dual(L), prim(in->n_primal);
+  for (int k = 0; k <= K; ++k) { lb[k] = h->hs_dev + slots[i_lb[k]].off; ub[k] = h->hs_dev + slots[i_ub[k]].off; }
+  for (int k = 0; k < L; ++k) dual[k] = h->hs_dev + slots[i_dual[k]].off;
+  for (int m = 0; m < in->n_primal; ++m) prim[m] = i_prim[m] == (size_t)-1 ? h->hs_dev : h->hs_dev + slots[i_prim[m]].off;   // (unread ones: any valid pointer)
+  gnnb_batch dv{lb.data(), ub.data(), dual.data(), prim.data(), h->hs_dev + slots[i_x].off, h->hs_dev + slots[i_pw].off,
+                h->hs_dev + slots[i_pb].off, h->hs_dev + slots[i_mask].off, in->n_graph, in->n_relu, in->n_primal};
+  int32_t* d_status = h->hs_dec + (size_t)B * 2;
+  if (int rc = gnnb_forward(h, &dv, B, h->hs_scores, h->hs_dec, d_status, h->hs_ws, h->hs_ws_bytes, stream)) return rc;
+  int32_t* out_i = reinterpret_cast<int32_t*>(h->hs_out_pinned);
+  HIPCHK(hipMemcpyAsync(out_i, h->hs_dec, ((size_t)B * 2 + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  float* out_s = h->hs_out_pinned + (size_t)B * 2 + 1;
+  if (scores) HIPCHK(hipMemcpyAsync(out_s, h->hs_scores, (size_t)B * R * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  memcpy(decisions, out_i, (size_t)B * 2 * sizeof(int32_t));
+  *status = out_i[(size_t)B * 2];
+  if (scores) memcpy(scores, out_s, (size_t)B * R * sizeof(float));
+  return GNNB_OK;
 }
 
 // BaBSR scores of a batch (reference plnn/kw_score_conv.py choose_node_conv :41-113; the decision rule :115-156 stays

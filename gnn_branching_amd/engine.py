@@ -260,6 +260,66 @@ class ScorerEngine:
                     cur.wait_stream(self._streams[c])
         return ForwardResult(scores, dec, status, mask2)
 
+    # ---- the reference's own call pattern: host tensors, one or two subproblems ---------------------------------
+    @staticmethod
+    def _host(t):
+        """float32 C-contiguous numpy view / copy of a CPU tensor, python list or array."""
+        if torch.is_tensor(t):
+            t = t.detach()
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                t = t.to(torch.float32).contiguous()
+            return t.numpy()
+        return np.ascontiguousarray(t, dtype=np.float32)
+
+    def forward_host(self, lower_bounds_all, upper_bounds_all, dual_vars, primals, primal_inputs, layers, masks, want_scores=False):
+        """``forward`` for CPU inputs through ``gnnb_forward_host``: every input the kernels read is packed into ONE pinned
+        transfer by the library, and decisions / status (/ scores) come back in one block -- no torch device tensors, no
+        per-tensor ``.cuda()`` (graph_score.py:26-30).  Synchronous.  Returns (decisions (B, 2) int32 array, scores (B, R)
+        float32 array or None); raises FloatingPointError like ``ForwardResult.check``."""
+        fixed = layers["fixed_layers"]
+        self.bind(fixed, tuple(lower_bounds_all[0].shape[1:]))
+        B = int(lower_bounds_all[0].shape[0])
+        if len(layers["prop_layers"]) != B:
+            raise ValueError(f"{len(layers['prop_layers'])} property layers for a batch of {B}")
+        lbs = [self._host(t) for t in lower_bounds_all]
+        ubs = [self._host(t) for t in upper_bounds_all]
+        duals = [self._host(t) for t in dual_vars]
+        prim = [self._host(t) for t in primals]
+        x_lp, mask = self._host(primal_inputs), self._host(masks)
+        ng = len(self.sizes)
+        if len(lbs) != ng or len(ubs) != ng:
+            raise ValueError(f"{len(lbs)} bound tensors, layer graph has {ng} layers")
+        for k, (l, u) in enumerate(zip(lbs, ubs)):
+            if l.size != B * self.sizes[k] or u.size != B * self.sizes[k]:
+                raise ValueError(f"bounds of graph layer {k}: {l.shape} does not hold {B}x{self.sizes[k]} values")
+        for k, d in enumerate(duals):
+            if d.size != B * self.sizes[k + 1] * 3:
+                raise ValueError(f"dual_vars[{k}] has {d.shape}, expected ({B * self.sizes[k + 1]}, 3)")
+        if mask.size != B * self.R:
+            raise ValueError(f"masks has {mask.shape}, expected ({B}, {self.R})")
+        if x_lp.size != B * self.sizes[0]:
+            raise ValueError("primal_inputs has the wrong size")
+        self._check_primals(fixed, prim, B)
+        props = layers["prop_layers"]
+        pw = np.ascontiguousarray(np.stack([self._host(l.weight)[0] for l in props]))
+        pb = np.ascontiguousarray(np.array([float(l.bias.detach()[0]) for l in props], dtype=np.float32))
+        tabs = [(C.c_void_p * len(g))(*[a.ctypes.data for a in g]) for g in (lbs, ubs, duals, prim)]
+        batch = _lib.Batch(tabs[0], tabs[1], tabs[2], tabs[3], x_lp.ctypes.data, pw.ctypes.data, pb.ctypes.data, mask.ctypes.data,
+                           len(lbs), len(duals), len(prim))
+        dec = np.empty((B, 2), dtype=np.int32)
+        status = np.zeros(1, dtype=np.int32)
+        scores = np.empty((B, self.R), dtype=np.float32) if want_scores else None
+        with torch.cuda.device(self.device):
+            st = torch.cuda.current_stream().cuda_stream
+            rc = self.lib.gnnb_forward_host(self.h, C.byref(batch), B, scores.ctypes.data if want_scores else None, dec.ctypes.data,
+                                            status.ctypes.data, C.c_void_p(st))
+        _lib.check(rc, "gnnb_forward_host")
+        if int(status[0]) & 1:
+            msg = "mu contains nan"
+            print(f"[gnn_branching_amd] {msg}", flush=True)
+            raise FloatingPointError(msg)
+        return dec, scores
+
     # ---- online learning (SURVEY 8(f) N4) --------------------------------------------------------
     def get_weights(self):
         """The GNN parameters as a flat float32 array in checkpoint order (see state_blob)."""
@@ -344,6 +404,8 @@ class ScorerEngine:
         return BabsrResult(scores, icp, mask.view(B, self.R), self.sizes[1:-1])
 
     def _check_primals(self, fixed, prim, B):
+        def count(t):
+            return t.numel() if torch.is_tensor(t) else t.size
         if len(prim) != len(fixed) + 1:
             raise ValueError(f"{len(prim)} primal tensors for {len(fixed) + 1} network layers")
         k = 0
@@ -351,9 +413,9 @@ class ScorerEngine:
             if type(l) is nn.ReLU:
                 k += 1
                 n = B * self.sizes[k]
-                if prim[q - 1].numel() != n or prim[q].numel() != n:
+                if count(prim[q - 1]) != n or count(prim[q]) != n:
                     raise ValueError(f"primals[{q - 1}], primals[{q}] must hold {n} values each")
-        if prim[-1].numel() != B:
+        if count(prim[-1]) != B:
             raise ValueError("primals[-1] must hold one value per subproblem")
 
     # ---- inspection (tests / bench) ---------------------------------------------------------

@@ -45,11 +45,18 @@ class GraphChoice:
         ``primal_input, primals`` -- reference graph_score.py:21)."""
         mask_1d = self._mask_1d(mask).unsqueeze(0)
         start = time.time()
+        host = not any(torch.is_tensor(t) and t.is_cuda for grp in (lower_bounds_all, upper_bounds_all, dual_vars, primals) for t in grp) \
+            and not (torch.is_tensor(primal_input) and primal_input.is_cuda)
         with torch.no_grad():
-            res = self.model.forward_device(lower_bounds_all, upper_bounds_all, dual_vars, primals, primal_input,
-                                            layers, mask_1d)
-            res.check()
-            dec = res.decisions[0].tolist()
+            if host:                                              # the reference's pattern: CPU tensors -> one pinned transfer
+                d, _ = self.model.engine().forward_host(lower_bounds_all, upper_bounds_all, dual_vars, primals, primal_input,
+                                                        layers, mask_1d)
+                dec = d[0].tolist()
+            else:
+                res = self.model.forward_device(lower_bounds_all, upper_bounds_all, dual_vars, primals, primal_input,
+                                                layers, mask_1d)
+                res.check()
+                dec = res.decisions[0].tolist()
         end = time.time()
         if self.verbose:
             print(f'graph requires: {end-start}')                 # :36

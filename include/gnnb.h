@@ -91,6 +91,13 @@ size_t gnnb_workspace_bytes(const gnnb_t* h, int B);
 int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* scores_padded, int32_t* decisions,
                  int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
 
+/* gnnb_forward for HOST inputs -- the reference's own call pattern (relu_conv_gnnkwthreshold.py:117, :230, :239: one
+ * subproblem per graph.decision call, every argument a CPU tensor that graph_score.py:26-30 moves with ~14 .cuda() calls).
+ * `in` holds HOST pointers laid out exactly as for gnnb_forward.  The inputs cross PCIe as ONE pinned copy, the forward runs
+ * on `stream`, and decisions (B, 2), status (1) and -- if scores is not NULL -- the padded scores (B, R) are written to HOST
+ * memory; the call returns after synchronising `stream`.  Staging buffers and the workspace belong to the handle. */
+int gnnb_forward_host(gnnb_t* h, const gnnb_batch* in, int B, float* scores, int32_t* decisions, int32_t* status, void* stream);
+
 /* BaBSR ("KW") branching heuristic for a batch -- the fallback scorer of the BaB loop (reference
  * plnn/kw_score_conv.py choose_node_conv :41-113, called at plnn/relu_conv_gnnkwthreshold.py:157).  lb/ub: HOST tables of
  * n_graph DEVICE pointers laid out like struct gnnb_batch.lb, .ub -- only the ReLU layers 1..L are read; prop_w (B, N_L); mask (B, R) 1.0 where the

@@ -230,6 +230,29 @@ def test_nothing_reads_unwritten_workspace(case):
             assert res.decisions.cpu().tolist() == g["random_decisions"].tolist()
 
 
+@pytest.mark.parametrize("case", ["cifar_base_kw_B3", "cifar_deep_kw_B2"])
+def test_host_entry_point_matches(case):
+    """gnnb_forward_host (CPU inputs, one pinned transfer, results back on the host -- what GraphChoice.decision uses): same
+    scores as the device-pointer entry point bit for bit, decisions of the reference; python-list primals and B = 1 slices too."""
+    g, batch = load_golden(case)
+    model = make_model("random")
+    eng = model.engine()
+    with torch.no_grad():
+        ref = model.forward_device(*batch.forward_args()).check()
+    dec, scores = eng.forward_host(*batch.forward_args(), want_scores=True)
+    assert np.array_equal(scores, ref.scores.cpu().numpy())
+    assert dec.tolist() == g["random_decisions"].tolist()
+    for b in range(batch.batch_size):
+        one = batch.slice(b, b + 1)
+        args = list(one.forward_args())
+        args[3] = [p.tolist() for p in one.primals]                     # LP primals as python lists (graph_score.py:30)
+        d1, s1 = eng.forward_host(*args, want_scores=True)
+        assert d1[0].tolist() == g["random_decisions"][b].tolist()
+        assert np.array_equal(s1[0], scores[b])
+    with pytest.raises(ValueError):
+        eng.forward_host(batch.lower_bounds_all[:-1], *batch.forward_args()[1:])
+
+
 def test_small_batch_latency_path_matches(monkeypatch):
     """GNNB_PER_SAMPLE_MIN_B=96: batches below 96 take the per-tile dense kernel and separate top kernels (18 % lower
     latency at B = 2): same scores within the budget, same decisions."""
