@@ -71,8 +71,11 @@ class BatchedGraphChoice(GraphChoice):
         """[dec_lay, dec_idx] for every subproblem, one batched forward, one device->host copy."""
         args, _ = collate(subs, layers)
         with torch.no_grad():
-            res = self.model.forward_device(*args).check()
-            dec = res.decisions.cpu().tolist()
+            if len(subs) <= 16:          # a branch's children / a small frontier: host pointers in, decisions out (gnnb_forward_host)
+                dec = self.model.engine().forward_host(*args)[0].tolist()
+            else:                        # a large frontier: per-tensor copies overlap better than one staged 36 MB block
+                res = self.model.forward_device(*args).check()
+                dec = res.decisions.cpu().tolist()
         for b, d in enumerate(dec):
             if d[0] < 0:
                 raise RuntimeError(f"decision_many: subproblem {b} has no undecided ReLU in its mask")
