@@ -46,9 +46,17 @@ class GraphChoice:
         self.mask_1d = mask_1d
         start = time.time()
         args = (lower_bounds_all, upper_bounds_all, dual_vars, primals, primal_input, layers, mask_1d)
+        host = not any(torch.is_tensor(t) and t.is_cuda for grp in (lower_bounds_all, upper_bounds_all, dual_vars, primals) for t in grp) \
+            and not (torch.is_tensor(primal_input) and primal_input.is_cuda)
         with torch.no_grad():
-            res = self._eng().forward(*args).check()
-            dec = res.decisions[0].tolist()
+            if host:                                              # CPU tensors (the reference's pattern): one pinned transfer
+                d, sc = self._eng().forward_host(*args, want_scores=True)
+                dec = d[0].tolist()
+                ragged = [torch.from_numpy(sc[0][mask_1d[0].numpy() != 0])]
+            else:
+                res = self._eng().forward(*args).check()
+                dec = res.decisions[0].tolist()
+                ragged = res.ragged()
         end = time.time()
         if self.verbose:
             print(f'graph requires: {end-start}')                 # :36
@@ -56,7 +64,7 @@ class GraphChoice:
             print("[gnn_branching_amd] GraphChoice.decision: no undecided ReLU in the mask", file=sys.stderr)
             raise RuntimeError("GraphChoice.decision: no undecided ReLU in the mask")
         self._last = args
-        self.scores = res.ragged()                                # :34 (values only: the tape is rebuilt by online_learning)
+        self.scores = ragged                                      # :34 (values only: the tape is rebuilt by online_learning)
         self.gnn_score = self.scores[0].max() if self.scores[0].numel() else None
         return [int(dec[0]), int(dec[1])]
 
