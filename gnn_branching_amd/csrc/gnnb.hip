@@ -128,8 +128,9 @@ struct gnnb_handle {
   float* hs_scores = nullptr; int32_t* hs_dec = nullptr; size_t hs_out_B = 0;
   float* hs_out_pinned = nullptr;
   float* d_s1 = nullptr;        // (N_1) bias sums of edge 1 forward over the (all live) input layer: sum of the weights that reach each node
-  std::vector<int> proj;        // per graph layer: which Linear (LayerId) the rows of mu[k] still have to go through after
-                                // the last enqueued kernel (-1: the rows are final) -- the "deferred projection" of gnnb_pack.h
+  int last_proj[MAXL + 2];      // per graph layer: which Linear (LayerId) the rows of mu[k] written by the LAST forward still have to
+                                // go through (-1: final) -- the "deferred projection" of gnnb_pack.h; inspection only (gnnb_mu_projection),
+                                // gnnb_forward itself keeps this state on its stack
   std::vector<DevGather> gf, gb;   // gf[k]: edge k forward (dst = layer k); gb[k]: edge k transposed (dst = layer k-1)
   bool bound = false;
   std::vector<Edge> edges;       // edges[k], k = 1..L (edges[0] unused)
@@ -212,23 +213,41 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpdL3::FLOATS + 6144) * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpdL3::FLOATS + 6144) * 4));
   if (const char* e = getenv("GNNB_BF3")) h->bf3 = e[0] == '1';
+#ifdef GNNB_DEV
   if (const char* e = getenv("GNNB_ZERO_DEAD")) h->zero_dead = e[0] == '1';
+#endif
+#ifdef GNNB_DEV
   if (const char* e = getenv("GNNB_S_IN_GATHER")) h->s_in_gather = e[0] != '0';
+#endif
+#ifdef GNNB_DEV
   if (const char* e = getenv("GNNB_GIU_OCC")) h->giu_occ = atoi(e) < 1 ? 1 : atoi(e);
+#endif
+#ifdef GNNB_DEV
   if (const char* e = getenv("GNNB_NU_WAVES")) h->nu_waves = atoi(e) == 8 ? 8 : 12;
+#endif
+#ifdef GNNB_DEV
   if (const char* e = getenv("GNNB_GATHER_OCC")) h->gather_occ = atoi(e) < 1 ? 1 : atoi(e);
+#endif
   HIPCHK(hipFuncSetAttribute((const void*)k_input_update, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpdInp::FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_score, hipFuncAttributeMaxDynamicSharedMemorySize, PackScore::FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_gather<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_gather<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_gather16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_gather16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+#ifdef GNNB_DEV
   if (const char* e = getenv("GNNB_NO_GATHER16")) h->gather16 = !(e[0] == '1');
+#endif
+#ifdef GNNB_DEV
   if (const char* e = getenv("GNNB_SPARSE")) h->gather_sparse = atoi(e);
+#endif
   HIPCHK(hipFuncSetAttribute((const void*)k_gather16<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+#ifdef GNNB_DEV
   if (const char* e = getenv("GNNB_NO_EMBED_FUSE")) h->embed_fuse = !(e[0] == '1');
+#endif
   HIPCHK(hipFuncSetAttribute((const void*)k_livesum, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#ifdef GNNB_DEV
   if (const char* e = getenv("GNNB_NO_RESTRICT")) h->restrict_last = !(e[0] == '1');
+#endif
   if (const char* e = getenv("GNNB_NO_DENSE_LDS")) h->dense_lds = !(e[0] == '1');
   HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -381,7 +400,7 @@ extern "C" int gnnb_bind_network(gnnb_t* h, const gnnb_layer_desc* L, int n, int
   h->R = 0;
   for (int k = 1; k <= Lr; ++k) h->R += h->N[k];
   h->dev.resize(Lr + 1);
-  h->proj.assign(Lr + 2, -1);
+  for (int k = 0; k < MAXL + 2; ++k) h->last_proj[k] = -1;
   for (int k = 0; k <= Lr; ++k)
     if (h->N[k] > LIVESUM_MAXSRC) return fail(GNNB_E_INVALID, "graph layer %d has %d nodes, more than the %d k_livesum holds in LDS", k, h->N[k], LIVESUM_MAXSRC);
   for (int k = 1; k <= Lr; ++k) {
@@ -574,26 +593,25 @@ extern "C" int gnnb_describe(const gnnb_t* h, char* buf, size_t cap) {
 }
 
 // ---- workspace layout (float offsets, every region 256-B aligned) ----
-struct WsLayout {
-  std::vector<size_t> mu, Pf, Pb, live, amb, score;
-  std::vector<size_t> lf;       // live flags (B, N_k) as floats
-  std::vector<size_t> sf, sb;   // k_livesum outputs: sf[k] (B, N_k) over edge k, sb[k] (B, N_k) over edge k+1 transposed
+struct WsLayout {                // plain arrays: gnnb_forward computes it on its stack (no allocation in the call)
+  size_t mu[MAXL + 2], Pf[MAXL + 2], Pb[MAXL + 2], live[MAXL + 2], amb[MAXL + 2], score[MAXL + 2];
+  size_t lf[MAXL + 2];          // live flags (B, N_k) as floats
+  size_t sf[MAXL + 2], sb[MAXL + 2];   // k_livesum outputs: sf[k] (B, N_k) over edge k, sb[k] (B, N_k) over edge k+1 transposed
   size_t F1 = 0;                // rows of layer 1 after the producer-side map of the input update (PackPostInp)
   size_t cnt = 0, best = 0, nb = 0, Q = 0, total = 0;     // best: B 64-bit decision keys + the finished-workgroup counter of k_score
 };
 static size_t align64(size_t nfloats) { return (nfloats + 63) & ~(size_t)63; }
 static WsLayout ws_layout(const gnnb_t* h, int B) {
   WsLayout w;
+  for (int k = 0; k < MAXL + 2; ++k) w.mu[k] = w.Pf[k] = w.Pb[k] = w.live[k] = w.amb[k] = w.score[k] = w.lf[k] = w.sf[k] = w.sb[k] = 0;
   const int K = (int)h->N.size() - 1;
   size_t off = 0;
   w.cnt = off; off += 64;                      // int counters: 4 per ReLU layer (live, amb, score, pad), zeroed every forward
   w.best = off; off += align64((size_t)2 * B + 2);
-  w.mu.resize(K + 1);
   for (int k = 0; k <= K; ++k) { w.mu[k] = off; off += align64((size_t)B * h->N[k] * 64); }
   size_t maxn = 0;
   for (int k = 0; k < K; ++k) maxn = std::max(maxn, (size_t)h->N[k]);
   w.nb = off; off += align64((size_t)B * maxn * 64);
-  w.Pf.resize(K); w.Pb.resize(K); w.live.resize(K); w.amb.resize(K); w.score.resize(K);
   for (int k = 1; k < K; ++k) { w.Pf[k] = off; off += align64((size_t)B * h->N[k] * 64); }
   for (int k = 1; k < K; ++k) { w.Pb[k] = off; off += align64((size_t)B * h->N[k] * 64); }
   for (int k = 1; k < K; ++k) {
@@ -601,7 +619,6 @@ static WsLayout ws_layout(const gnnb_t* h, int B) {
     w.amb[k] = off; off += align64((size_t)B * h->N[k]);
     w.score[k] = off; off += align64((size_t)B * h->N[k]);
   }
-  w.sf.assign(K, 0); w.sb.assign(K, 0); w.lf.assign(K, 0);
   for (int k = 1; k < K; ++k) { w.lf[k] = off; off += align64((size_t)B * h->N[k]); }
   for (int k = 1; k < K; ++k) { w.sf[k] = off; off += align64((size_t)B * h->N[k]); }
   for (int k = 0; k < K - 1; ++k) { w.sb[k] = off; off += align64((size_t)B * h->N[k]); }
@@ -630,7 +647,7 @@ extern "C" int gnnb_mu_location(const gnnb_t* h, int B, int k, size_t* offset_by
 extern "C" int gnnb_mu_projection(const gnnb_t* h, int k, int* linear_id) {
   if (!h || !linear_id) return fail(GNNB_E_INVALID, "gnnb_mu_projection: null argument");
   if (k < 0 || k >= (int)h->N.size()) return fail(GNNB_E_INVALID, "gnnb_mu_projection: bad layer");
-  *linear_id = k < (int)h->proj.size() ? h->proj[k] : -1;
+  *linear_id = k < MAXL + 2 ? h->last_proj[k] : -1;
   return GNNB_OK;
 }
 
@@ -748,8 +765,10 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, st, status, reinterpret_cast<int*>(ws + w.cnt), best, done_ctr, B);
   int* cnt = reinterpret_cast<int*>(ws + w.cnt);
   auto ilist = [&](size_t off) { return reinterpret_cast<int*>(ws + off); };
-  std::vector<int> roff(L + 2, 0);          // offset of layer k inside the flat ReLU index
+  int roff[MAXL + 2] = {0};                 // offset of layer k inside the flat ReLU index
   for (int k = 2; k <= L + 1; ++k) roff[k] = roff[k - 1] + h->N[k - 1];
+  int proj[MAXL + 2];                       // deferred projection of the rows of mu[k] after the kernels enqueued so far (call-local)
+  for (int k = 0; k < MAXL + 2; ++k) proj[k] = -1;
 
   const int total_halfpasses = 2 * h->T;
   const int limit = h->halfpass_limit > 0 ? std::min(h->halfpass_limit, total_halfpasses) : total_halfpasses;
@@ -836,10 +855,6 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       }
     a.njobs = q;
     if (q > 0) {
-    if (const char* e = getenv("GNNB_LS_ONLY")) {       // dev: time one job (results are wrong)
-      const int only = atoi(e);
-      if (only >= 0 && only < q) { a.job[0] = a.job[only]; q = 1; a.njobs = 1; }
-    }
     int maxn = 0;
     for (int k = 0; k <= L; ++k) maxn = std::max(maxn, h->N[k]);
     a.lv_floats = (maxn + 3) & ~3;
@@ -859,8 +874,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     // with the MFMA gather on the first edge, round 0 computes the embedding inside that gather (k_gather<true>): nothing
     // else reads mu[0] before the input-layer update overwrites it.  Inspection runs keep the rows.
     if (!embed_in_gather) lz.run(PC_EMBED, [&] { hipLaunchKernelGGL(k_embed, dim3((unsigned)grid), dim3(256), 0, st, a); });
-    for (auto& pj : h->proj) pj = -1;
-    h->proj[0] = L_INP_F_1;
+    proj[0] = L_INP_F_1;
   }
   {
     PreAllArgs a{};
@@ -917,7 +931,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   // phase A: nb <- A_k mu[k-1]
   auto agg_fwd = [&](int k) {
     const Edge& e = h->edges[k];
-    if (h->gf[k].ok) { gather(h->gf[k], k, mu(k - 1), false, k == 1 && embed_in_gather && h->proj[0] == L_INP_F_1, k - 1, ws + w.sf[k]); return; }
+    if (h->gf[k].ok) { gather(h->gf[k], k, mu(k - 1), false, k == 1 && embed_in_gather && proj[0] == L_INP_F_1, k - 1, ws + w.sf[k]); return; }
     if (e.kind == 0) {
       ConvArgs a = conv_args(e, mu(k - 1), nb, h->dev[k].w_fwd, 0);
       lz.run(PC_CONV_FWD, [&] {
@@ -980,7 +994,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   auto node_update = [&](int k, bool fwd, bool scored, bool post_input = false) {
     const long nt = ((long)B * h->N[k] + 31) / 32;
     // the aggregate in `nb` was built from rows whose last Linear is deferred (gnnb_pack.h), except the one k_prop writes
-    const int src_proj = fwd ? h->proj[k - 1] : (k < L ? h->proj[k + 1] : -1);
+    const int src_proj = fwd ? proj[k - 1] : (k < L ? proj[k + 1] : -1);
     int pack = PK_UPD_BWD;
     const float* sarr = nullptr;
     int smod = 0;
@@ -1020,10 +1034,10 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       else if (deferred) hipLaunchKernelGGL((k_node_update<8, true>), g, b8, ldsb, st, a);
       else hipLaunchKernelGGL((k_node_update<8, false>), g, b8, ldsb, st, a);
     });
-    h->proj[k] = fwd ? L_FC4_2 : L_BC4_1;
+    proj[k] = fwd ? L_FC4_2 : L_BC4_1;
   };
   auto update_input = [&]() {
-    h->proj[0] = L_INP_B2_2;
+    proj[0] = L_INP_B2_2;
     if (h->gb[1].ok) {
       const DevGather& d = h->gb[1];
       const long nt = map_tiles(d.g.tm, B);
@@ -1063,7 +1077,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     a.prop_w = in->prop_w; a.prop_b = in->prop_b; a.lbK = in->lb[K]; a.ubK = in->ub[K]; a.z_out = in->primal[in->n_primal - 1];
     a.mu_prop = mu(K); a.mu = mu(L); a.status = status; a.N = h->N[L];
     lz.run(PC_TOP, [&] { hipLaunchKernelGGL(k_top, dim3(B), dim3(512), TOP_LDS_FLOATS * 4, st, a); });
-    h->proj[L] = L_BC4_1;
+    proj[L] = L_BC4_1;
   };
 
   int done = 0;
@@ -1112,7 +1126,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   {
     ScoreArgs a{};
     a.best = best; a.done = done_ctr; a.dec = decisions; a.B = B; a.n_relu = L;
-    a.pack = h->d_pack[h->proj[1] == L_FC4_2 ? PK_SCORE_F : PK_SCORE_B]; a.scores = scores; a.L = L; a.R = h->R; a.cnt = cnt + 4;
+    a.pack = h->d_pack[proj[1] == L_FC4_2 ? PK_SCORE_F : PK_SCORE_B]; a.scores = scores; a.L = L; a.R = h->R; a.cnt = cnt + 4;
     long nt = 0;
     for (int k = 1; k <= L; ++k) {
       const int i = k - 1;
@@ -1123,6 +1137,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     }
     lz.run(PC_SCORE, [&] { hipLaunchKernelGGL(k_score, dim3(mlp_grid(h, nt / 4)), dim3(WG_MLP), PackScore::FLOATS * 4, st, a); });
   }
+  for (int k = 0; k < MAXL + 2; ++k) h->last_proj[k] = proj[k];      // inspection (gnnb_mu_projection); one handle per thread
   return lz.rc;
 }
 
@@ -1269,8 +1284,7 @@ extern "C" int gnnb_online_create(gnnb_t* h, float lr, float weight_decay) {
   }
   HIPCHK(hipMemcpy(t->d_w, h->blob.data(), n * sizeof(float), hipMemcpyHostToDevice));
   HIPCHK(hipFuncSetAttribute((const void*)gnnb_train::k_tlin_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-  if (!(getenv("GNNB_ONLINE_ONE_STREAM") && getenv("GNNB_ONLINE_ONE_STREAM")[0] == '1'))
-    HIPCHK(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));      // weight-gradient kernels run beside the rest of the backward pass
   return GNNB_OK;
 }
 
