@@ -7,13 +7,21 @@ per-subproblem argmax) over a batch of synthetic subproblems already resident in
 ranks each rank scores its own shard of the live subproblems and ONE RCCL all-gather collects the
 padded scores for the branch selector (weak scaling: per-GPU batch fixed).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--net cifar_base_kw] [--batch 256]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4] [--net cifar_base_kw] [--batch 256]
+
+`--gpus N` with N > 1 and no torchrun environment starts the N ranks itself (fresh child processes of
+`python -m torch.distributed.run`, spawned before this process touches the GPU) and exits with their code; under
+torchrun (RANK / WORLD_SIZE set) it is one of the ranks.  A world size that does not match --gpus is an error -- it never
+silently benchmarks one rank.
 
 Prints ONE JSON line (rank 0).  The CPU oracle is imported only for the `cpu_baseline` leg.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -23,6 +31,13 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
+
+# BASELINE.json `configs` that are bench lines (config 1 is the CPU plumbing case, config 5 needs Gurobi + CIFAR-10)
+CONFIGS = {
+    2: {"net": "cifar_base_kw", "batch": 256},      # the headline config: 1 x MI355X, 256 synthetic subproblems
+    3: {"net": "cifar_wide_kw", "batch": 256},
+    4: {"net": "cifar_deep_kw", "batch": 128},      # 1024 subproblems over 8 ranks = 128 per rank (run with --gpus 8)
+}
 
 PEAK_HBM_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6.3 TB/s achievable)
 PEAK_F32_MFMA_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32, same guide
@@ -83,7 +98,9 @@ def plan_flops(plan, B, stats, restrict_last=True):
             n_upd = stats[k]["scored"] if restricted else stats[k]["live"]
             add(alg, upd, 2.0 * MLP_MACS_PER_NODE * n_upd)
             # message passing of this half-pass: every source row read once, every updated row written once
-            add(agg_bytes, agg, 4.0 * 64 * (B * u["n_src"] + n_upd))
+            # (round 0 with the embedding fused into the first gather reads three scalars per source node, not a 256-B row)
+            src_row_bytes = 12.0 if (plan.get("embed_fused") and u["update"] == "fwd" and k == 1 and t == 0) else 4.0 * 64
+            add(agg_bytes, agg, src_row_bytes * B * u["n_src"] + 4.0 * 64 * n_upd)
             # folded chains, last layer deferred: 128 (+2) MFMAs per tile of live non-ambiguous nodes, 192 (+2) per tile of general nodes
             if u["update"] == "bwd" and k == 1 and t < T - 1 and upd == "k_node_update":
                 add(issued, upd, MFMA_FLOP * tiles(stats[k]["live"]) * W64)     # the input update's 64x64 map, applied on the producer side
@@ -120,22 +137,99 @@ def message_passing_bytes(sizes, B, T):
     return 4.0 * p * B * (T * (fwd + bwd) + (T - 1) * inp)
 
 
-def main():
+class StepLoop:
+    """One bench step = one forward of this rank's shard + (N > 1) the one exchange step: ONE all-gather per scored batch
+    (scores -> branch selector), launched behind the scores on the communication stream.  The compute stream only waits for
+    the PREVIOUS batch's gather, so the collective of batch i overlaps the forward of batch i + 1; `drain()` completes the
+    last one, so every one of the K gathers finishes inside the timed region.  `forward_fn()` returns an object with a
+    `.scores` (B_local, R) tensor; tests/test_parallel_gloo.py drives this class with a CPU stand-in under gloo."""
+
+    def __init__(self, forward_fn, use_dist, total_batch):
+        self.forward_fn, self.use_dist, self.total_batch = forward_fn, use_dist, total_batch
+        self.pending = None
+        self.last_gathered = None
+        self.gathers_completed = 0
+
+    def step(self):
+        res = self.forward_fn()
+        if self.use_dist:
+            from gnn_branching_amd import parallel
+            nxt = parallel.gather_scores_async(res.scores, self.total_batch)
+            if self.pending is not None:
+                self.last_gathered = self.pending.wait()
+                self.gathers_completed += 1
+            self.pending = nxt
+        return res
+
+    def drain(self):
+        if self.pending is not None:
+            self.last_gathered = self.pending.wait()
+            self.gathers_completed += 1
+            self.pending = None
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_command(n, argv, port):
+    """The documented N-rank launch: one process per GPU over RCCL, rendezvous on 127.0.0.1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def spawn_ranks(n, argv):
+    """`bench.py --gpus N` outside torchrun: start the N ranks as fresh child processes (this process has not touched the
+    GPU: torch.cuda.device_count() does not initialise it) and exit with their code."""
+    ndev = torch.cuda.device_count()
+    if ndev < n:
+        print(f"bench.py: --gpus {n} requested but only {ndev} GPU(s) are visible; refusing to run fewer ranks than asked for",
+              file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    return subprocess.call(launch_command(n, argv, free_port()), env=env)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--net", default="cifar_base_kw")
-    ap.add_argument("--batch", type=int, default=256, help="subproblems per GPU")
+    ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=None,
+                    help="BASELINE.json config: 2 = cifar_base_kw B=256 (default), 3 = cifar_wide_kw B=256, 4 = cifar_deep_kw 128 per rank "
+                         "(1024 subproblems at --gpus 8)")
+    ap.add_argument("--net", default=None)
+    ap.add_argument("--batch", type=int, default=None, help="subproblems per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=16)
-    args = ap.parse_args()
+    ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds of CPU work for the cpu_baseline leg")
+    args = ap.parse_args(argv)
+    cfg = CONFIGS[args.config if args.config is not None else 2]
+    if args.net is None:
+        args.net = cfg["net"]
+    if args.batch is None:
+        args.batch = cfg["batch"]
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    return args
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+def main():
+    args = parse_args()
+    in_torchrun = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not in_torchrun:
+        if args.gpus > 1:
+            sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+        rank, local_rank, world = 0, 0, 1
+    else:
+        rank = int(os.environ["RANK"])
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        world = int(os.environ["WORLD_SIZE"])
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     from gnn_branching_amd import _lib, synth
@@ -146,7 +240,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    use_dist = world > 1 or "RANK" in os.environ          # under torchrun the collective path runs even with one rank
+    use_dist = in_torchrun                                 # under torchrun the collective path runs even with one rank
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -168,26 +262,8 @@ def main():
         return [t.to(dev).float().contiguous() for t in ts]
     d_args = (dev_list(batch.lower_bounds_all), dev_list(batch.upper_bounds_all), dev_list(batch.dual_vars),
               dev_list(batch.primals), batch.primal_inputs.to(dev), batch.layers, batch.masks.to(dev))
-    from gnn_branching_amd import parallel
-
-    pending = [None]
-
-    def step():
-        res = eng.forward(*d_args)
-        if use_dist:
-            # the one exchange step: ONE all-gather per scored batch (scores -> branch selector), launched behind the scores on
-            # the communication stream; this stream only waits for the PREVIOUS batch's gather, so the collective of batch i
-            # overlaps the forward of batch i + 1.  Every one of the K gathers completes inside the timed region (sync()).
-            nxt = parallel.gather_scores_async(res.scores, world * B)
-            if pending[0] is not None:
-                pending[0].wait()
-            pending[0] = nxt
-        return res
-
-    def drain():
-        if pending[0] is not None:
-            pending[0].wait()
-            pending[0] = None
+    loop = StepLoop(lambda: eng.forward(*d_args), use_dist, world * B)
+    step, drain = loop.step, loop.drain
 
     # Untimed pre-warm (allocator, clocks, caches), then the W warm-up steps the contract asks for.
     for _ in range(int(os.environ.get("BENCH_PREWARM", "32"))):
@@ -261,8 +337,11 @@ def main():
         # HBM traffic of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
         # (tools/pmc.sh + tools/pmc_table.py: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, gfx950 correction applied)
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc_path) and args.net == "cifar_base_kw" and B == 256:
+        pmc = None
+        pmc_path = os.path.join(ROOT, "profiles", f"pmc_latest_{args.net}_B{B}.json")
+        if not os.path.exists(pmc_path) and args.net == "cifar_base_kw" and B == 256:
+            pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc_path):
             # a profile class may cover several kernel templates (k_gather, k_gather16): launch-weighted mean
             pmc = json.load(open(pmc_path))
             rows = [v for k, v in pmc.items() if (k == dom or (k.startswith(dom) and k[len(dom):].isdigit())) and "hbm_bytes_per_launch" in v]
@@ -292,24 +371,44 @@ def main():
         if nu_s > 0:
             nu_tf = alg.get("k_node_update", 0.0) / nu_s / 1e12
             nu_iss = issued.get("k_node_update", 0.0) / nu_s / 1e12
-            roofline_nu = {"kernel": "k_node_update", "bound": "mfma", "achieved": round(nu_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                           "unit": "TFLOP/s", "frac": round(nu_tf / PEAK_F32_MFMA_TFLOPS, 4),
-                           "issued_mfma_tflops": round(nu_iss, 2), "issued_mfma_frac": round(nu_iss / PEAK_F32_MFMA_TFLOPS, 4),
-                           "note": "achieved = the reference's MACs for the updated nodes / time; issued = matrix-pipe time after the folds in "
-                                   "fp32-MFMA equivalents (a 32-cycle bf16 MFMA of the three-piece blocks counts half)"}
+            # frac = matrix-pipe time actually issued (after the folds; a 32-cycle bf16 MFMA of a three-piece block counts as half
+            # an fp32 MFMA) over the kernel time: <= 1 by construction.  The reference's MACs for the same nodes / time is kept
+            # beside it as `reference_equivalent_tflops`: it exceeds the fp32 peak because the folds remove 40-60 % of those MACs.
+            roofline_nu = {"kernel": "k_node_update", "bound": "mfma", "achieved": round(nu_iss, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                           "unit": "TFLOP/s (issued, fp32-MFMA equivalents)", "frac": round(nu_iss / PEAK_F32_MFMA_TFLOPS, 4),
+                           "reference_equivalent_tflops": round(nu_tf, 2)}
         # message passing is fused into the update kernels (the aggregate never reaches HBM): its algorithmic bytes
         # 4*p*(N_src+N_dst) per half-pass over the time of every kernel that performs an update
-        mp_names = ("k_gather", "k_gather_input_update", "k_conv_fwd", "k_convT_bwd", "k_dense_agg", "k_prop", "k_top",
+        mp_names = ("k_gather", "k_gather_update", "k_gather_input_update", "k_conv_fwd", "k_convT_bwd", "k_dense_agg", "k_prop", "k_top",
                     "k_node_update", "k_input_update")
         mp_ms = sum(prof[k][0] for k in mp_names if k in prof)
         mp_bytes = message_passing_bytes(sizes, B, T) * args.steps
         mp_gbs = mp_bytes / (mp_ms * 1e-3) / 1e9 if mp_ms > 0 else 0.0
+        # counter-based: HBM bytes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 correction) of the same kernels per forward
+        mp_traffic = None
+        if pmc is not None:
+            tot, ok = 0.0, True
+            for k in mp_names:
+                if k in kern:
+                    rows = [v for kk, v in pmc.items() if (kk == k or (kk.startswith(k) and kk[len(k):].isdigit())) and "hbm_bytes_per_launch" in v]
+                    n = sum(v.get("launches_sampled", 1) for v in rows)
+                    if not n:
+                        ok = False
+                        break
+                    tot += sum(v["hbm_bytes_per_launch"] * v.get("launches_sampled", 1) for v in rows) / n * (kern[k]["launches"] // args.steps)
+            mp_traffic = round(tot) if ok else None
+        mp_s = mp_ms * 1e-3 / args.steps
         roofline_mp = {"kernels": "all half-pass kernels (edge aggregation + node update)", "bound": "hbm",
                        "achieved": round(mp_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(mp_gbs / PEAK_HBM_GBS, 4),
-                       "traffic": None, "bytes_per_subproblem": message_passing_bytes(sizes, 1, T)}
+                       "traffic": mp_traffic,
+                       "frac_counter": round(mp_traffic / mp_s / 1e9 / PEAK_HBM_GBS, 4) if (mp_traffic and mp_s > 0) else None,
+                       "us_per_step": round(1e3 * mp_ms / args.steps, 1),
+                       "bytes_per_subproblem": message_passing_bytes(sizes, 1, T),
+                       "note": "achieved = SURVEY 8(d) algorithmic bytes 4*p*(N_src + N_dst) per half-pass / time of all half-pass kernels; "
+                               "frac_counter = HBM bytes the counters saw (dead rows are skipped, round 0 computes its source rows) / the same time"}
         cpu = None
         if not args.no_cpu_baseline:
-            cpu = cpu_baseline(sd, args.net, args.cpu_batch)
+            cpu = cpu_baseline(sd, args.net, args.cpu_budget)
         out = {
             "metric": "ReLU branching scores/sec (subproblems x ambiguous-ReLUs/s)",
             "value": round(total_amb * args.steps / elapsed, 1),
@@ -317,7 +416,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32 (bf16x3-split 64x64 blocks)" if plan.get("bf3") else "f32", "data": "synthetic",
             "config": {"workload": f"{args.net}, batch={B} synthetic subproblems per GPU, T=2, p=64, shipped cifar_trained_gnn weights",
                        "subproblems_per_s": round(world * B * args.steps / elapsed, 1),
                        "ambiguous_per_subproblem": round(total_amb / (world * B), 1),
@@ -337,51 +436,92 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(sd, net, cpu_batch):
-    """The CPU oracle (a torch-CPU port with the reference's op sequence) on a bounded sample of the same workload.
-    The small per-layer ops of this path do not scale with threads (128 threads are SLOWER than 16), so a few thread
-    counts are tried for <= 4 s each and the best one is then timed for ~12 s -- that is the baseline; the reference's own deployment point -- one core, one
-    subproblem per call (scripts/bab_mip.sh:3-5 pins with taskset) -- is reported next to it, as SURVEY 8(d) asks."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sd, net, budget_s=60.0):
+    """The CPU oracle (oracle/gnn_oracle.py: a torch-CPU port with the reference's aten op sequence, pinned by the reference's
+    own outputs) timed on this box's host cores, by the protocol of SURVEY 8(d): batch sizes 1 / 16 / 256 (or the largest
+    that fits the time budget), all host threads and ONE thread (the reference's own deployment pins one core with taskset,
+    scripts/bab_mip.sh:3-5,40), each with torch's default denormal handling (flush-to-zero off: the shipped
+    checkpoint holds 21 all-subnormal tensors, which put x86 cores on their slow path) and with torch.set_flush_denormal(True)
+    (scores are identical: those tensors contribute nothing at fp32).  Every cell: 2 warm-up forwards, then the median of 5
+    timed ones where the budget allows (cells that would not fit run fewer repetitions and say so).  `value` is the best cell.
+    A bounded sample: about `budget_s` seconds of CPU work in all."""
     from gnn_branching_amd import synth
     from oracle import gnn_oracle
     state = {k: v.numpy() for k, v in sd.items()}
-    batch = synth.make_batch(net, cpu_batch, seed=1234)
-    n_amb = int(batch.masks.sum().item())
-    nthreads = torch.get_num_threads()
+    all_threads = torch.get_num_threads()
+    ftz_default = False            # torch never enables flush-to-zero by itself (this torch has no getter; set_flush_denormal is the only switch)
+    batches = {}
 
-    def timed(b, budget_s, max_reps=20):
+    def get_batch(b):
+        if b not in batches:
+            big = synth.make_batch(net, b, seed=1234)
+            batches[b] = (big, int(big.masks.sum().item()))
+        return batches[b]
+
+    def one(b):
+        t0 = time.perf_counter()
         with torch.no_grad():
-            gnn_oracle.oracle_forward(state, *b.forward_args())      # warm-up
-            reps, t0 = 0, time.perf_counter()
-            while True:
-                gnn_oracle.oracle_forward(state, *b.forward_args())
-                reps += 1
-                if time.perf_counter() - t0 > budget_s or reps >= max_reps:
-                    break
-            return reps, time.perf_counter() - t0
+            gnn_oracle.oracle_forward(state, *b.forward_args())
+        return time.perf_counter() - t0
+
+    cells, skipped = [], []
+    thread_sets = [all_threads, 1] if all_threads > 1 else [1]
+    n_cells = 2 * len(thread_sets) * 3
+    per_cell = budget_s / n_cells
+    t_start = time.perf_counter()
     try:
-        tried = {}
-        for nt in sorted({nthreads, min(nthreads, 16), 1}, reverse=True):
-            torch.set_num_threads(nt)
-            reps, dt = timed(batch, 4.0)
-            tried[nt] = (n_amb * reps / dt, reps, dt)
-        best = max(tried, key=lambda k: tried[k][0])
-        torch.set_num_threads(best)                       # the reported value: ~12 s of CPU work at the best thread count
-        reps, dt = timed(batch, 12.0, max_reps=400)
-        rate = n_amb * reps / dt
-        out = {"value": round(rate, 1), "unit": "scores/s", "cores": best, "kind": "port",
-               "sample": f"{reps} forwards of {cpu_batch} {net} subproblems (seed 1234), oracle/gnn_oracle.py, {dt:.1f}s, best of "
-                         f"{len(tried)} thread counts", "subproblems_per_s": round(cpu_batch * reps / dt, 2),
-               "by_threads": {str(k): round(v[0], 1) for k, v in tried.items()}}
-        torch.set_num_threads(1)
-        one = batch.slice(0, 1)
-        n1 = int(one.masks.sum().item())
-        reps1, dt1 = timed(one, 4.0)
-        out["one_core_batch1"] = {"value": round(n1 * reps1 / dt1, 1), "unit": "scores/s", "cores": 1,
-                                  "sample": f"{reps1} forwards of 1 subproblem, {dt1:.1f}s", "ms_per_decision": round(1e3 * dt1 / reps1, 1)}
+        for ftz in (False, True):
+            if not torch.set_flush_denormal(ftz) and ftz:
+                continue                                   # this CPU has no flush-to-zero mode
+            for nt in thread_sets:
+                torch.set_num_threads(nt)
+                per_sub = None                             # seconds per subproblem, from the previous (smaller) batch size
+                for want_b in (1, 16, 256):
+                    b = want_b
+                    while per_sub is not None and b > 16 and per_sub * b * 3 > per_cell:
+                        b //= 2                            # "256 or the largest that fits"
+                    if b != want_b and b <= 16:
+                        skipped.append({"batch": want_b, "threads": nt, "flush_denormal": ftz,
+                                        "why": f"a forward of {want_b} would take ~{per_sub * want_b:.1f}s of a {per_cell:.1f}s cell"})
+                        continue
+                    batch, n_amb = get_batch(b)
+                    t_first = one(batch)                   # warm-up 1
+                    runs, warm = [], 1
+                    if t_first * 3 <= per_cell:
+                        one(batch)                         # warm-up 2
+                        warm = 2
+                        reps = int(max(1, min(5, (per_cell - 2 * t_first) // max(t_first, 1e-6))))
+                        runs = [one(batch) for _ in range(reps)]
+                    else:
+                        runs = [t_first]                   # over budget: the single (cold) forward is the sample
+                        warm = 0
+                    med = statistics.median(runs)
+                    per_sub = med / b
+                    cells.append({"batch": b, "threads": nt, "flush_denormal": ftz, "ms_per_forward": round(1e3 * med, 2),
+                                  "scores_per_s": round(n_amb / med, 1), "subproblems_per_s": round(b / med, 2),
+                                  "warmups": warm, "timed_runs": len(runs)})
     finally:
-        torch.set_num_threads(nthreads)
-    return out
+        torch.set_flush_denormal(ftz_default)
+        torch.set_num_threads(all_threads)
+    best = max(cells, key=lambda c: c["scores_per_s"])
+    dep = [c for c in cells if c["batch"] == 1 and c["threads"] == 1 and not c["flush_denormal"]]
+    return {"value": best["scores_per_s"], "unit": "scores/s", "cores": best["threads"], "kind": "port",
+            "sample": f"best of {len(cells)} cells: {net}, batch {best['batch']} (seed 1234), {best['threads']} thread(s), "
+                      f"flush_denormal={best['flush_denormal']}, median of {best['timed_runs']} forwards after {best['warmups']} warm-ups; "
+                      f"oracle/gnn_oracle.py; {time.perf_counter() - t_start:.0f}s of CPU work in all",
+            "host_cpu": cpu_model_name(), "host_threads": all_threads, "torch_default_flush_denormal": ftz_default,
+            "reference_deployment_1core_batch1_ms": dep[0]["ms_per_forward"] if dep else None,
+            "cells": cells, "cells_skipped": skipped}
 
 
 if __name__ == "__main__":

@@ -546,7 +546,7 @@ extern "C" int gnnb_graph_info(const gnnb_t* h, int* n_graph, int* sizes, int* n
 extern "C" int gnnb_describe(const gnnb_t* h, char* buf, size_t cap) {
   if (!h || !h->bound || !buf || cap < 64) return fail(GNNB_E_INVALID, "gnnb_describe: bad arguments");
   const int L = (int)h->N.size() - 2;
-  std::string o = "{\"T\": " + std::to_string(h->T) + ", \"bf3\": " + std::to_string(h->bf3 && h->nu_waves == 12 ? 1 : 0) + ", \"sizes\": [";
+  std::string o = "{\"T\": " + std::to_string(h->T) + ", \"bf3\": " + std::to_string(h->bf3 && h->nu_waves == 12 ? 1 : 0) + ", \"embed_fused\": " + std::to_string(h->embed_fuse && h->gf.size() > 1 && h->gf[1].ok ? 1 : 0) + ", \"sizes\": [";
   for (size_t k = 0; k < h->N.size(); ++k) o += (k ? ", " : "") + std::to_string(h->N[k]);
   o += "], \"updates\": [";
   auto nnz = [&](int e) -> long {     // edges of the layer graph between layer e-1 and e (no-padding upper bound)

@@ -419,36 +419,45 @@ class ScorerEngine:
             raise ValueError("primals[-1] must hold one value per subproblem")
 
     # ---- inspection (tests / bench) ---------------------------------------------------------
-    def mu(self, B, k):
-        """View of embedding mu[k] (B, N_k, p) inside the workspace of the last forward at batch B."""
+    def mu_rows(self, B, k):
+        """(rows, linear_id): the raw rows of graph layer k as the last forward at batch B left them in the workspace -- a
+        (B, N_k, p) view -- and the index (state-dict order) of the Linear they still have to go through: producers leave
+        their last Linear to the consumer, mu = (W.rows + b).[r0 != 0]; -1: the rows are final.
+        Rows of dead nodes, and after a default (restricted) forward the rows of layer 1 that are not scored, hold
+        whatever was there before."""
         off, n = C.c_size_t(), C.c_size_t()
         _lib.check(self.lib.gnnb_mu_location(self.h, B, k, C.byref(off), C.byref(n)), "gnnb_mu_location")
         if self.n_streams > 1 and B >= self.n_streams * self.min_chunk:
             raise RuntimeError("mu() inspects a single-chunk forward: set engine.n_streams = 1 first")
         ws = self.workspace(B)
         rows = ws[off.value:off.value + 4 * n.value].view(torch.float32).view(B, self.sizes[k], self.p)
-        # producers leave their last Linear to the consumer (DESIGN.md section 4): mu = (W.E + b).[r0 != 0]; apply it here,
-        # for inspection only
         lid = C.c_int(-1)
         _lib.check(self.lib.gnnb_mu_projection(self.h, k, C.byref(lid)), "gnnb_mu_projection")
-        if lid.value < 0:
-            return rows
-        W, b = self._linear(lid.value)
-        out = rows @ W.t() + b
-        if 1 <= k < len(self.sizes) - 1:
-            lb, ub = (t.reshape(B, -1) for t in self._last_bounds[k])
-            lower_temp, upper_temp = lb - torch.relu(lb), torch.relu(ub)
-            live = (upper_temp / (upper_temp - lower_temp)) != 0          # graph_conv.py:178 / :347
-            out = out * live.unsqueeze(-1)
-        return out
+        return rows, lid.value
 
-    def _linear(self, idx):
-        """(weight, bias) of the idx-th Linear of the checkpoint (state-dict order) as device tensors."""
+    def linear_host(self, idx):
+        """(weight (out, in), bias (out)) of the idx-th Linear of the checkpoint as float64 numpy arrays."""
         off = sum(o * i + o for o, i in GNN_LINEARS[:idx])
         o, i = GNN_LINEARS[idx]
-        W = torch.from_numpy(self._blob[off:off + o * i].reshape(o, i).copy()).to(self.device)
-        b = torch.from_numpy(self._blob[off + o * i:off + o * i + o].copy()).to(self.device)
-        return W, b
+        return (self._blob[off:off + o * i].reshape(o, i).astype(np.float64), self._blob[off + o * i:off + o * i + o].astype(np.float64))
+
+    def mu(self, B, k):
+        """Embedding mu[k] (B, N_k, p) of the last forward at batch B, for inspection: the deferred projection is applied
+        on the HOST in float64 (numpy), nothing of it runs through torch on the GPU.  Returns a float32 CPU tensor."""
+        rows, lid = self.mu_rows(B, k)
+        rows = rows.cpu().numpy()
+        if lid < 0:
+            return torch.from_numpy(rows.copy())
+        W, b = self.linear_host(lid)
+        live = np.ones(rows.shape[:2], dtype=bool)
+        if 1 <= k < len(self.sizes) - 1:
+            lb, ub = (t.reshape(B, -1).cpu().numpy() for t in self._last_bounds[k])
+            lower_temp, upper_temp = lb - np.maximum(lb, 0), np.maximum(ub, 0)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                live = (upper_temp / (upper_temp - lower_temp)) != 0      # graph_conv.py:178 / :347
+        safe = np.where(live[..., None], rows, 0.0).astype(np.float64)     # dead rows may never have been written
+        out = (safe @ W.T + b) * live[..., None]
+        return torch.from_numpy(out.astype(np.float32))
 
     def describe(self):
         """The launch plan of one forward on the bound network (dict parsed from gnnb_describe's JSON)."""

@@ -12,8 +12,21 @@ GOLDEN_CASES = ["cifar_base_kw_B3", "cifar_wide_kw_B2", "cifar_deep_kw_B2"]
 FAMILIES = ["shipped", "random"]
 STAGES = ["r0_fwd", "r0_bwd", "r1_fwd", "r1_bwd"]
 
-# north_star: scores within 1e-4 (fp32, absolute) of the reference CPU forward
+# north_star: scores within 1e-4 (fp32, absolute) of the reference CPU forward.  The shipped checkpoint produces scores of
+# magnitude 5..50 (the reference's own fp32-vs-fp64 noise there is ~1e-5), so 1e-4 is its bar.
 SCORE_ATOL = 1e-4
+# The seeded random weight set is the one that exercises the forward half-pass (the shipped checkpoint's forward weights are
+# all subnormal); its scores lie in about [-1, 0.05] and the reference's own fp32 noise is 2..4e-7 there, so it gets a bar
+# 20x tighter: 5e-6 absolute, or 1e-5 of the score range where scores are larger (other networks).
+RANDOM_ATOL = 5e-6
+
+
+def score_tol(fam, want=None):
+    """Absolute tolerance for a weight family; `want`: the finite reference scores (for the range rule)."""
+    if fam == "shipped":
+        return SCORE_ATOL
+    rng = float(np.max(want) - np.min(want)) if want is not None and np.size(want) else 0.0
+    return max(RANDOM_ATOL, 1e-5 * rng)
 
 
 @lru_cache(None)

@@ -30,7 +30,8 @@ def first_argmax_decisions(scores, sizes):
     return out
 
 
-@pytest.mark.parametrize("net,B", [("cifar_base_kw", 256), ("cifar_wide_kw", 256), ("cifar_deep_kw", 128)])
+# BASELINE.json configs 2, 3, 4: deep at its per-rank shard (128) and at the config's whole batch (1024) on one GPU
+@pytest.mark.parametrize("net,B", [("cifar_base_kw", 256), ("cifar_wide_kw", 256), ("cifar_deep_kw", 128), ("cifar_deep_kw", 1024)])
 def test_full_size_batch_properties(net, B):
     from gnn_branching_amd import synth
     from oracle import gnn_oracle

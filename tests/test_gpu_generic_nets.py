@@ -8,7 +8,7 @@ import torch
 
 from gnn_branching_amd import nets, synth
 from gnn_branching_amd.graphnet.graph_conv import GraphNet
-from tests.common import SCORE_ATOL
+from tests.common import SCORE_ATOL, score_tol
 
 pytestmark = pytest.mark.gpu
 
@@ -53,8 +53,9 @@ def test_scores_match_oracle(name):
     fin = np.isfinite(want)
     assert fin.any()
     err = np.abs(got[fin] - want[fin]).max()
-    print(f"{name}: max|score - oracle| = {err:.3e} over {int(fin.sum())} scores")
-    assert err <= SCORE_ATOL
+    tol = score_tol("random", want[fin])
+    print(f"{name}: max|score - oracle| = {err:.3e} over {int(fin.sum())} scores (bar {tol:.1e})")
+    assert err <= tol
     # nothing may depend on scratch the call did not write itself (rows of dead nodes are only written where a consumer
     # reads them): poison the workspace and run again
     model.engine().workspace(batch.batch_size).view(torch.float32).fill_(float("nan"))
@@ -83,7 +84,7 @@ def test_other_round_counts_match_oracle(T):
     got = res.scores.cpu().numpy()
     fin = np.isfinite(want)
     assert np.array_equal(np.isinf(got), ~fin)
-    assert np.abs(got[fin] - want[fin]).max() <= SCORE_ATOL
+    assert np.abs(got[fin] - want[fin]).max() <= score_tol("random", want[fin])
 
 
 @pytest.mark.parametrize("B", [1, 5, 67])

@@ -7,7 +7,7 @@ import torch
 
 from gnn_branching_amd import synth
 from gnn_branching_amd.graphnet.graph_conv import GraphNet
-from tests.common import SCORE_ATOL, state_of
+from tests.common import SCORE_ATOL, score_tol, state_of
 
 pytestmark = pytest.mark.gpu
 
@@ -21,7 +21,7 @@ def test_random_batches_masks_and_weights(net):
         m = GraphNet(2, 64)
         m.load_state_dict({k: torch.as_tensor(v) for k, v in state_of(fam).items()})
         models[fam] = m
-    worst, n = 0.0, 0
+    worst, n = {"shipped": 0.0, "random": 0.0}, 0
     for B in (1, 3, 8, 17):
         for seed in (100, 101, 102):
             batch = synth.make_batch(net, B, seed=seed + B)
@@ -42,11 +42,12 @@ def test_random_batches_masks_and_weights(net):
                 fin = np.isfinite(want)
                 assert np.array_equal(np.isfinite(got), fin), (net, B, seed, fam)
                 if fin.any():
-                    worst = max(worst, float(np.abs(got[fin] - want[fin]).max()))
-                assert worst <= SCORE_ATOL, (net, B, seed, fam, worst)
+                    err = float(np.abs(got[fin] - want[fin]).max())
+                    worst[fam] = max(worst[fam], err)
+                    assert err <= score_tol(fam, want[fin]), (net, B, seed, fam, err)
                 dec = res.decisions.cpu().tolist()
                 for b in range(B):
                     if not fin[b].any():
                         assert dec[b] == [-1, -1]
                 n += 1
-    print(f"{net}: {n} cases, worst |score - oracle| = {worst:.3e}")
+    print(f"{net}: {n} cases, worst |score - oracle| shipped {worst['shipped']:.3e}, random {worst['random']:.3e}")

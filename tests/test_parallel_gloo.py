@@ -77,3 +77,83 @@ def test_sharded_scoring_equals_single_process(tmp_path, world):
     a = np.load(os.path.join(tmp_path, "rank0.npz"))["scores"]
     for r in range(1, world):
         assert np.array_equal(a, np.load(os.path.join(tmp_path, f"rank{r}.npz"))["scores"])
+
+
+# ---- bench.py's N-rank loop (StepLoop) and launcher ------------------------------------------------------------------
+class _Scores:
+    def __init__(self, scores):
+        self.scores = scores
+
+
+def _bench_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        B, R, K = 4, 37, 5                     # per-rank shard, padded score width, steps
+        calls = [0]
+
+        def forward():                         # stand-in scorer: shard `rank` of step i holds i*1000 + global row + column/100
+            i = calls[0]
+            calls[0] += 1
+            rows = torch.arange(rank * B, (rank + 1) * B, dtype=torch.float32).unsqueeze(1)
+            s = i * 1000.0 + rows + torch.arange(R, dtype=torch.float32).unsqueeze(0) / 100.0
+            s[:, ::5] = float("-inf")          # non-ambiguous columns
+            return _Scores(s)
+        loop = bench.StepLoop(forward, True, world * B)
+        seen = []
+        for i in range(K):
+            loop.step()
+            if loop.last_gathered is not None:
+                seen.append(loop.last_gathered.clone())
+        assert loop.gathers_completed == K - 1 and loop.pending is not None     # one collective still in flight
+        loop.drain()
+        seen.append(loop.last_gathered.clone())
+        assert loop.gathers_completed == K and loop.pending is None
+        # every gather holds ALL ranks' shards of ITS step, in rank order
+        step_of = [int(t[0, 1].item() // 1000) for t in seen]
+        for t, i in zip(seen, step_of):
+            rows = torch.arange(world * B, dtype=torch.float32).unsqueeze(1)
+            want = i * 1000.0 + rows + torch.arange(R, dtype=torch.float32).unsqueeze(0) / 100.0
+            want[:, ::5] = float("-inf")
+            assert torch.equal(t, want), (rank, i)
+        assert step_of[-1] == K - 1
+        torch.save(seen[-1], os.path.join(out_dir, f"bench_rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_step_loop_under_gloo(tmp_path):
+    """bench.py's step()/drain() with world size 2: one all-gather per step, pipelined one step deep, all K completed by
+    drain(), every rank ends with the whole batch's scores."""
+    world = 2
+    mp.spawn(_bench_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a = torch.load(os.path.join(tmp_path, "bench_rank0.pt"))
+    b = torch.load(os.path.join(tmp_path, "bench_rank1.pt"))
+    assert torch.equal(a, b) and a.shape == (8, 37)
+
+
+def test_bench_launcher_never_runs_fewer_ranks_than_asked(tmp_path):
+    """`bench.py --gpus 2` without torchrun starts the ranks itself; on a box with fewer GPUs it must fail, not run 1 rank.
+    Under a torchrun environment with the wrong world size it must fail too."""
+    import subprocess
+    import sys
+    import bench
+    cmd = bench.launch_command(2, ["--gpus", "2", "--steps", "3"], 29999)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "2", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    a = bench.parse_args(["--config", "4", "--gpus", "8"])
+    assert (a.net, a.batch, a.gpus) == ("cifar_deep_kw", 128, 8)
+    a = bench.parse_args([])
+    assert (a.net, a.batch, a.gpus) == ("cifar_base_kw", 256, 1)
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box could actually run two ranks")
+    root = os.path.dirname(os.path.abspath(bench.__file__))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "only" in r.stderr and not r.stdout.strip()
+    env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()
