@@ -205,7 +205,7 @@ def parse_args(argv=None):
     ap.add_argument("--net", default=None)
     ap.add_argument("--batch", type=int, default=None, help="subproblems per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds of CPU work for the cpu_baseline leg")
+    ap.add_argument("--cpu-budget", type=float, default=75.0, help="seconds of CPU work for the cpu_baseline leg")
     args = ap.parse_args(argv)
     cfg = CONFIGS[args.config if args.config is not None else 2]
     if args.net is None:
@@ -446,10 +446,10 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(sd, net, budget_s=60.0):
+def cpu_baseline(sd, net, budget_s=75.0):
     """The CPU oracle (oracle/gnn_oracle.py: a torch-CPU port with the reference's aten op sequence, pinned by the reference's
     own outputs) timed on this box's host cores, by the protocol of SURVEY 8(d): batch sizes 1 / 16 / 256 (or the largest
-    that fits the time budget), all host threads and ONE thread (the reference's own deployment pins one core with taskset,
+    that fits the time budget), all host threads, 16 threads and ONE thread (the reference's own deployment pins one core with taskset,
     scripts/bab_mip.sh:3-5,40), each with torch's default denormal handling (flush-to-zero off: the shipped
     checkpoint holds 21 all-subnormal tensors, which put x86 cores on their slow path) and with torch.set_flush_denormal(True)
     (scores are identical: those tensors contribute nothing at fp32).  Every cell: 2 warm-up forwards, then the median of 5
@@ -475,7 +475,9 @@ def cpu_baseline(sd, net, budget_s=60.0):
         return time.perf_counter() - t0
 
     cells, skipped = [], []
-    thread_sets = [all_threads, 1] if all_threads > 1 else [1]
+    # all host threads, 16 (the small per-layer ops of this path stop scaling there: on a 128-thread host all threads are
+    # 5-10x SLOWER than 16), and one
+    thread_sets = sorted({all_threads, min(16, all_threads), 1}, reverse=True)
     n_cells = 2 * len(thread_sets) * 3
     per_cell = budget_s / n_cells
     t_start = time.perf_counter()

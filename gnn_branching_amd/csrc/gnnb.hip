@@ -97,7 +97,8 @@ struct DevGather {          // one conv edge in one direction, as MFMA gather ta
 struct gnnb_handle {
   int T = 2, p = 64, device = 0, n_cu = 256;
   bool use_gather = true;       // MFMA gather for conv edges (false: VALU gather kernels)
-  int nu_waves = 12;            // waves per workgroup of k_node_update: 3 per SIMD at 168 VGPRs, measured 6 % faster
+  // (k_node_update: 12 waves per workgroup = 3 per SIMD with the bf16x3 blocks (142-152 VGPRs, no scratch); the fp32-MFMA-only
+  // form (GNNB_BF3=0) needs 167-181 VGPRs and runs 8 waves per workgroup)
                                 // than 8 (16 waves: 27 % slower); k_gather_input_update prefers 8, k_gather 8 x 2 workgroups
   int gather_occ = 2;           // workgroups per CU for k_gather (its LDS footprint is only the tap matrix)
   bool dense_lds = true;        // Linear edges: one workgroup per sample with the source rows in LDS (false: per-tile kernel)
@@ -201,13 +202,9 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   HIPCHK(hipFuncSetAttribute((const void*)k_pre<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackPreFwdL3::FLOATS + PackPreBwdL3::FLOATS) * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_pre_inp, hipFuncAttributeMaxDynamicSharedMemorySize, PackPreInp::FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_node_update<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpd::FLOATS + 4096) * 4));
-  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpd::FLOATS + 4096) * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_node_update<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpd::FLOATS + 4096) * 4));
-  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpd::FLOATS + 4096) * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_node_update<8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpd::FLOATS + 4096) * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_node_update<8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpd::FLOATS + 4096) * 4));
-  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpd::FLOATS + 4096) * 4));
-  HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpd::FLOATS + 4096) * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpdL3::FLOATS + 6144) * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpdL3::FLOATS + 6144) * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpdL3::FLOATS + 6144) * 4));
@@ -221,9 +218,6 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
 #endif
 #ifdef GNNB_DEV
   if (const char* e = getenv("GNNB_GIU_OCC")) h->giu_occ = atoi(e) < 1 ? 1 : atoi(e);
-#endif
-#ifdef GNNB_DEV
-  if (const char* e = getenv("GNNB_NU_WAVES")) h->nu_waves = atoi(e) == 8 ? 8 : 12;
 #endif
 #ifdef GNNB_DEV
   if (const char* e = getenv("GNNB_GATHER_OCC")) h->gather_occ = atoi(e) < 1 ? 1 : atoi(e);
@@ -546,7 +540,7 @@ extern "C" int gnnb_graph_info(const gnnb_t* h, int* n_graph, int* sizes, int* n
 extern "C" int gnnb_describe(const gnnb_t* h, char* buf, size_t cap) {
   if (!h || !h->bound || !buf || cap < 64) return fail(GNNB_E_INVALID, "gnnb_describe: bad arguments");
   const int L = (int)h->N.size() - 2;
-  std::string o = "{\"T\": " + std::to_string(h->T) + ", \"bf3\": " + std::to_string(h->bf3 && h->nu_waves == 12 ? 1 : 0) + ", \"embed_fused\": " + std::to_string(h->embed_fuse && h->gf.size() > 1 && h->gf[1].ok ? 1 : 0) + ", \"sizes\": [";
+  std::string o = "{\"T\": " + std::to_string(h->T) + ", \"bf3\": " + std::to_string(h->bf3 ? 1 : 0) + ", \"embed_fused\": " + std::to_string(h->embed_fuse && h->gf.size() > 1 && h->gf[1].ok ? 1 : 0) + ", \"sizes\": [";
   for (size_t k = 0; k < h->N.size(); ++k) o += (k ? ", " : "") + std::to_string(h->N[k]);
   o += "], \"updates\": [";
   auto nnz = [&](int e) -> long {     // edges of the layer graph between layer e-1 and e (no-padding upper bound)
@@ -1011,8 +1005,8 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     UpdArgs a{h->d_pack[pack], in->lb[k], in->ub[k], nb, ws + (fwd ? w.Pf[k] : w.Pb[k]), (post_input && !debug_full) ? nullptr : mu(k), status,
               ilist(w.live[k]), cnt + 4 * k + (scored ? 3 : 0), ilist(scored ? w.score[k] : w.amb[k]), cnt + 4 * k + (scored ? 2 : 1), sarr, smod,
               post_input ? rows1_for_input : nullptr, nullptr};
-    const int wv = h->nu_waves;  // waves per workgroup (one workgroup per CU shares the LDS weights)
-    const bool bf3 = h->bf3 && wv == 12;
+    const bool bf3 = h->bf3;
+    const int wv = bf3 ? 12 : 8;  // waves per workgroup (one workgroup per CU shares the LDS weights)
     a.wp = h->d_pack[PK_POST_INP] + (bf3 ? (h->gb[1].ok ? PackPostInp::WPG3 : PackPostInp::WPN3) : (h->gb[1].ok ? PackPostInp::WPG : PackPostInp::WPN));
     const size_t ldsb = bf3 ? (size_t)(PackUpdL3::FLOATS + (post_input ? 6144 : 0)) * 4 : (size_t)(PackUpd::FLOATS + (post_input ? 4096 : 0)) * 4;
     long grid = (nt + wv - 1) / wv;
@@ -1025,13 +1019,9 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
         else if (deferred) hipLaunchKernelGGL((k_node_update<12, true, false, true>), g, b12, ldsb, st, a);
         else hipLaunchKernelGGL((k_node_update<12, false, false, true>), g, b12, ldsb, st, a);
       } else if (post_input) {
-        if (wv == 12 && deferred) hipLaunchKernelGGL((k_node_update<12, true, true>), g, b12, ldsb, st, a);
-        else if (wv == 12) hipLaunchKernelGGL((k_node_update<12, false, true>), g, b12, ldsb, st, a);
-        else if (deferred) hipLaunchKernelGGL((k_node_update<8, true, true>), g, b8, ldsb, st, a);
+        if (deferred) hipLaunchKernelGGL((k_node_update<8, true, true>), g, b8, ldsb, st, a);
         else hipLaunchKernelGGL((k_node_update<8, false, true>), g, b8, ldsb, st, a);
-      } else if (wv == 12 && deferred) hipLaunchKernelGGL((k_node_update<12, true>), g, b12, ldsb, st, a);
-      else if (wv == 12) hipLaunchKernelGGL((k_node_update<12, false>), g, b12, ldsb, st, a);
-      else if (deferred) hipLaunchKernelGGL((k_node_update<8, true>), g, b8, ldsb, st, a);
+      } else if (deferred) hipLaunchKernelGGL((k_node_update<8, true>), g, b8, ldsb, st, a);
       else hipLaunchKernelGGL((k_node_update<8, false>), g, b8, ldsb, st, a);
     });
     proj[k] = fwd ? L_FC4_2 : L_BC4_1;

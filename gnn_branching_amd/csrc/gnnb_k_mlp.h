@@ -332,9 +332,14 @@ __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, i
   long gc = 0, gc_n = 0;
   bool valid = false, valid_n = false;
   float lb = 0.0f, ub = 0.0f, lb_n = 0.0f, ub_n = 0.0f, sw = 0.0f, sw_n = 0.0f;
-  Frag X, Xn;
+  Frag X;
   constexpr bool deferred = DEFERRED;            // the aggregate is built from rows with a deferred projection (gnnb_pack.h)
-  auto fetch = [&](long tl, long& g_, bool& v_, float& l_, float& u_, float& s_, Frag& x_) {
+  // The inputs of the next tile are fetched under this tile's chain in two stages: the list entry and the per-node scalars at
+  // the top (a handful of registers), the 32-register aggregate row only once the first GEMM has consumed X -- it lands in X
+  // itself, so no second fragment is alive across the chain (a separate prefetch fragment put every bf16x3 instantiation
+  // 2-14 VGPRs over the 168 of three waves per SIMD: scratch spills) and the two dependent round trips (list -> row) are
+  // split over the two stages.
+  auto fetch_scalars = [&](long tl, long& g_, bool& v_, float& l_, float& u_, float& s_) {
     const bool k0 = tl >= n1;
     const long idx = (k0 ? tl - n1 : tl) * 32 + j;
     v_ = idx < (k0 ? c0 : c1);
@@ -342,9 +347,11 @@ __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, i
     l_ = a.lb[g_];
     u_ = a.ub[g_];
     if (deferred) s_ = a.sarr[a.smod > 0 ? g_ % a.smod : g_];
-    frag_load_rows(x_, a.nb, g_, h);
   };
-  if (tile < ntiles) fetch(tile, gc, valid, lb, ub, sw, X);
+  if (tile < ntiles) {
+    fetch_scalars(tile, gc, valid, lb, ub, sw);
+    frag_load_rows(X, a.nb, gc, h);
+  }
   constexpr bool post = POST;
   if (post) copy_to_lds(lds + O_END, a.wp, BF3 ? 6144 : 4096);
   if (BF3) {
@@ -359,10 +366,10 @@ __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, i
     const bool kind0 = tile >= n1;             // wave-uniform
     const long next = tile + stride;
     const bool has_next = next < ntiles;
+    if (has_next) fetch_scalars(next, gc_n, valid_n, lb_n, ub_n, sw_n);
     Frag H, H2;
     frag_bias(H, lds + O_BA, h);
     if (kind0) {
-      if (has_next) fetch(next, gc_n, valid_n, lb_n, ub_n, sw_n, Xn);
       const float r0 = r.r0;
       if (deferred) {                        // + s.(r0 Wa0.bp + r1 Wa1.bp), r0 == r1: one small k-step
         const float x[1] = {r0 * sw};
@@ -374,7 +381,6 @@ __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, i
     } else {
       // nodes without a relaxation term (amb = 0) read the bias row instead of their (never written) P' row
       frag_load_rowptr(H2, r.amb != 0.0f ? a.P + gc * 64 : bias_row, h);
-      if (has_next) fetch(next, gc_n, valid_n, lb_n, ub_n, sw_n, Xn);
       const float r0 = r.r0, r1 = r.r1;
       if (deferred) {
         const float x[1] = {(h ? r1 : r0) * sw};
@@ -382,6 +388,9 @@ __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, i
       }
       gemm_w64<64>(lds + O_WA, lane, H, [&](int s) { return FRAG_AT(X, s & 31) * (s < 32 ? r0 : r1); });
     }
+    __builtin_amdgcn_sched_barrier(0);         // X is dead from here: the next tile's row loads go into it, under the second GEMM
+    if (has_next) frag_load_rows(X, a.nb, gc_n, h);
+    __builtin_amdgcn_sched_barrier(0);
     frag_relu(H);
     if (BF3) gemm_w64_bf3<1>(lds + PackUpdL3::WCB3, lane, H2, [&](int s) { return FRAG_AT(H, s); });
     else gemm_w64<32>(lds + PackUpd::WCB, lane, H2, [&](int s) { return FRAG_AT(H, s); });
@@ -403,8 +412,6 @@ __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, i
     }
     if (!has_next) break;
     tile = next; gc = gc_n; valid = valid_n; lb = lb_n; ub = ub_n; sw = sw_n;
-#pragma unroll
-    for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = FRAG_AT(Xn, R);
   }
 }
 

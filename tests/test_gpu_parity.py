@@ -77,8 +77,9 @@ def test_default_path_embeddings_after_the_last_sweep(case, fam):
     eng = model.engine()
     stride = int(g["sample_stride"])
     B = batch.batch_size
-    eng.workspace(B).view(torch.float32).fill_(float("nan"))          # what the forward does not write stays NaN
     with torch.no_grad():
+        model.forward_device(*batch.forward_args()).check()           # (binds the network, allocates the workspace)
+        eng.workspace(B).view(torch.float32).fill_(float("nan"))      # what the forward does not write stays NaN
         model.forward_device(*batch.forward_args()).check()
     L = len(batch.lower_bounds_all) - 2
     sizes = relu_sizes(batch)
