@@ -19,7 +19,7 @@
 //     round's input-layer update (:360-385), whose result nothing reads.
 //
 // One translation unit: gnnb_dev.h (fragments, GEMM blocks, tile maps), gnnb_k_mlp.h (setup + node-MLP kernels),
-// gnnb_k_gather.h (conv-edge message passing + score head), gnnb_k_edges.h (other edges, k_top), gnnb_k_misc.h (k_livesum,
+// gnnb_k_gather.h (conv-edge message passing + score head), gnnb_k_fused.h (gather + node update in one kernel), gnnb_k_edges.h (other edges, k_top), gnnb_k_misc.h (k_livesum,
 // k_babsr, k_reset), gnnb_train.h (online learning) are included below; this file holds the host side and the C-ABI.
 //
 // gfx950 only.  No HIP call at load time.
@@ -45,6 +45,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #include "gnnb_dev.h"
 #include "gnnb_k_mlp.h"
 #include "gnnb_k_gather.h"
+#include "gnnb_k_fused.h"
 #include "gnnb_k_edges.h"
 #include "gnnb_k_misc.h"
 
@@ -75,11 +76,11 @@ static int fail(int code, const char* fmt, ...) {
 
 enum ProfClass {
   PC_EMBED, PC_PRE, PC_PRE_INP, PC_CONV_FWD, PC_CONVT_BWD, PC_DENSE_AGG, PC_PROP_FWD,
-  PC_NODE_UPDATE, PC_INPUT_UPDATE, PC_SCORE, PC_ARGMAX, PC_GATHER, PC_GATHER_INPUT, PC_CLASSIFY, PC_LIVESUM, PC_TOP, PC_COUNT
+  PC_NODE_UPDATE, PC_INPUT_UPDATE, PC_SCORE, PC_ARGMAX, PC_GATHER, PC_GATHER_INPUT, PC_CLASSIFY, PC_LIVESUM, PC_TOP, PC_GATHER_UPDATE, PC_COUNT
 };
 static const char* kProfNames[PC_COUNT] = {
     "k_embed", "k_pre", "k_pre_inp", "k_conv_fwd", "k_convT_bwd", "k_dense_agg", "k_prop",
-    "k_node_update", "k_input_update", "k_score", "k_argmax", "k_gather", "k_gather_input_update", "k_classify", "k_livesum", "k_top"};
+    "k_node_update", "k_input_update", "k_score", "k_argmax", "k_gather", "k_gather_input_update", "k_classify", "k_livesum", "k_top", "k_gather_update"};
 
 struct DevEdge {
   float *w_fwd = nullptr, *w_bwd = nullptr, *bias = nullptr;   // conv: tap-major copies; linear: W^T / W, zero-padded
@@ -111,6 +112,7 @@ struct gnnb_handle {
                                 // gathers, bit 1 = 32-node gathers, bit 2 = the input-layer gather
   bool gather16 = true;         // forward conv edges: 16-node tiles on the 16x16x4 MFMA when their window is smaller
   bool embed_fuse = true;       // round 0: the first forward gather computes the input embedding itself (no k_embed, no mu[0] rows)
+  bool fuse = true;             // conv edges: gather + node update in one kernel (k_gather_update); GNNB_NO_FUSE=1: two kernels
   bool use_top = true;          // fuse the top of the network (last Linear edge, last ReLU layer, property node) into k_top
   bool top_ok = false;          // ... which the bound network allows (set by gnnb_bind_network)
   int per_sample_min_b = 0;     // GNNB_PER_SAMPLE_MIN_B: batches below it take the per-tile dense kernel + separate launches
@@ -250,6 +252,12 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   HIPCHK(hipFuncSetAttribute((const void*)k_gather<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   if (const char* e = getenv("GNNB_NO_GATHER")) h->use_gather = !(e[0] == '1');
   if (const char* e = getenv("GNNB_NO_TOP")) h->use_top = !(e[0] == '1');
+  if (const char* e = getenv("GNNB_NO_FUSE")) h->fuse = !(e[0] == '1');
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather_update<16, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_MAX_LDS));
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather_update<16, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_MAX_LDS));
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather_update<16, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_MAX_LDS));
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather_update<32, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_MAX_LDS));
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather_update<32, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_MAX_LDS));
   if (const char* e = getenv("GNNB_PER_SAMPLE_MIN_B")) h->per_sample_min_b = atoi(e);
   HIPCHK(hipFuncSetAttribute((const void*)k_top, hipFuncAttributeMaxDynamicSharedMemorySize, TOP_LDS_FLOATS * 4));
   *out = h;
@@ -526,6 +534,19 @@ static size_t sparse_tab_bytes(const DevGather& d) {
   return 8 + (size_t)WAVES_MLP * ((d.g.lanes == 16 ? 4 : 2) * d.g.K2 + 32) * 8;
 }
 
+// k_gather_update over one conv edge at batch B: grid, ints per tail-list segment, dynamic LDS bytes
+struct FusedGeom { long grid; int seg; size_t lds; };
+static FusedGeom fused_geom(const gnnb_t* h, const DevGather& d, int B, bool sparse, bool post) {
+  FusedGeom f;
+  const long nt = map_tiles(d.g.tm, B), nrounds = (nt + FUSED_WAVES - 1) / FUSED_WAVES;
+  f.grid = std::max<long>(1, std::min<long>(nrounds, h->n_cu));
+  f.seg = (int)((nrounds + f.grid - 1) / f.grid) * FUSED_WAVES * d.g.lanes;
+  const size_t tables = (size_t)d.g.tm.NCG * d.g.K2 * 64 * 4 + (size_t)gather_slots(d.g.K2, d.g.lanes) * 8 + (size_t)((d.g.tm.TPS + 3) & ~3) * 4 +
+                        (size_t)((gather_slots(d.g.K2, d.g.lanes) + 3) & ~3) * 4;
+  f.lds = (size_t)(PackUpdL3::FLOATS + (post ? 6144 : 0)) * 4 + tables + FUSED_WAVES * fused_wave_bytes(d.g.K2, d.g.lanes, sparse);
+  return f;
+}
+
 extern "C" int gnnb_graph_info(const gnnb_t* h, int* n_graph, int* sizes, int* n_relu_total) {
   if (!h || !h->bound) return fail(GNNB_E_STATE, "gnnb_graph_info: no network bound");
   if (n_graph) *n_graph = (int)h->N.size();
@@ -592,7 +613,7 @@ struct WsLayout {                // plain arrays: gnnb_forward computes it on it
   size_t lf[MAXL + 2];          // live flags (B, N_k) as floats
   size_t sf[MAXL + 2], sb[MAXL + 2];   // k_livesum outputs: sf[k] (B, N_k) over edge k, sb[k] (B, N_k) over edge k+1 transposed
   size_t F1 = 0;                // rows of layer 1 after the producer-side map of the input update (PackPostInp)
-  size_t cnt = 0, best = 0, nb = 0, Q = 0, total = 0;     // best: B 64-bit decision keys + the finished-workgroup counter of k_score
+  size_t cnt = 0, best = 0, nb = 0, Q = 0, tail = 0, total = 0;     // tail: the per-workgroup node lists of k_gather_update     // best: B 64-bit decision keys + the finished-workgroup counter of k_score
 };
 static size_t align64(size_t nfloats) { return (nfloats + 63) & ~(size_t)63; }
 static WsLayout ws_layout(const gnnb_t* h, int B) {
@@ -618,6 +639,14 @@ static WsLayout ws_layout(const gnnb_t* h, int B) {
   for (int k = 0; k < K - 1; ++k) { w.sb[k] = off; off += align64((size_t)B * h->N[k]); }
   w.F1 = off; off += align64((size_t)B * h->N[1] * 64);
   w.Q = off; off += (size_t)map_tiles(bwd_map(h, 0), B) * 2048;
+  size_t tail_ints = 0;
+  for (auto* v : {&h->gf, &h->gb})
+    for (const DevGather& d : *v)
+      if (d.ok) {
+        const FusedGeom f = fused_geom(h, d, B, true, false);
+        tail_ints = std::max(tail_ints, (size_t)f.grid * 2 * f.seg);
+      }
+  w.tail = off; off += align64(tail_ints);
   w.total = off;
   return w;
 }
@@ -985,8 +1014,8 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   // phase B: node MLP over a compacted list of nodes
   // post_input: this is the backward update of layer 1 and an input-layer update follows -- the kernel also applies the input
   // update's 64x64 map to its rows (PackPostInp) and writes them to F1; only inspection runs still need the plain rows
-  auto node_update = [&](int k, bool fwd, bool scored, bool post_input = false) {
-    const long nt = ((long)B * h->N[k] + 31) / 32;
+  // the arguments of the node update of layer k (shared by k_node_update and the fused k_gather_update)
+  auto upd_args = [&](int k, bool fwd, bool scored, bool post_input) {
     // the aggregate in `nb` was built from rows whose last Linear is deferred (gnnb_pack.h), except the one k_prop writes
     const int src_proj = fwd ? proj[k - 1] : (k < L ? proj[k + 1] : -1);
     int pack = PK_UPD_BWD;
@@ -1000,14 +1029,22 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       pack = PK_UPD_BWD_B;
       sarr = ws + w.sb[k];
     }
-    const bool deferred = sarr != nullptr;
     // normal: list0 = live non-ambiguous nodes (short chain), list1 = ambiguous nodes; restricted: the scored nodes, general chain
     UpdArgs a{h->d_pack[pack], in->lb[k], in->ub[k], nb, ws + (fwd ? w.Pf[k] : w.Pb[k]), (post_input && !debug_full) ? nullptr : mu(k), status,
               ilist(w.live[k]), cnt + 4 * k + (scored ? 3 : 0), ilist(scored ? w.score[k] : w.amb[k]), cnt + 4 * k + (scored ? 2 : 1), sarr, smod,
               post_input ? rows1_for_input : nullptr, nullptr};
+    a.wp = h->d_pack[PK_POST_INP] + (h->bf3 ? (h->gb[1].ok ? PackPostInp::WPG3 : PackPostInp::WPN3) : (h->gb[1].ok ? PackPostInp::WPG : PackPostInp::WPN));
+    return a;
+  };
+  // phase B: node MLP over a compacted list of nodes
+  // post_input: this is the backward update of layer 1 and an input-layer update follows -- the kernel also applies the input
+  // update's 64x64 map to its rows (PackPostInp) and writes them to F1; only inspection runs still need the plain rows
+  auto node_update = [&](int k, bool fwd, bool scored, bool post_input = false) {
+    const long nt = ((long)B * h->N[k] + 31) / 32;
+    const UpdArgs a = upd_args(k, fwd, scored, post_input);
+    const bool deferred = a.sarr != nullptr;
     const bool bf3 = h->bf3;
     const int wv = bf3 ? 12 : 8;  // waves per workgroup (one workgroup per CU shares the LDS weights)
-    a.wp = h->d_pack[PK_POST_INP] + (bf3 ? (h->gb[1].ok ? PackPostInp::WPG3 : PackPostInp::WPN3) : (h->gb[1].ok ? PackPostInp::WPG : PackPostInp::WPN));
     const size_t ldsb = bf3 ? (size_t)(PackUpdL3::FLOATS + (post_input ? 6144 : 0)) * 4 : (size_t)(PackUpd::FLOATS + (post_input ? 4096 : 0)) * 4;
     long grid = (nt + wv - 1) / wv;
     if (grid > h->n_cu) grid = h->n_cu;
@@ -1025,6 +1062,45 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       else hipLaunchKernelGGL((k_node_update<8, false>), g, b8, ldsb, st, a);
     });
     proj[k] = fwd ? L_FC4_2 : L_BC4_1;
+  };
+  // One half-pass over a conv edge as ONE kernel (k_gather_update): the gather of edge k (forward) / k + 1 (transposed) and the
+  // node update of layer k, the aggregate staying in registers.  Returns false where the two-kernel path has to run: inspection
+  // runs, the restricted last step (every node it updates takes the general chain), gathers without the sparse walk behind a
+  // ReLU layer, tile forms the fused kernel is not built for, tables that do not fit beside the weights in LDS.
+  auto fused_halfpass = [&](int k, bool fwd, bool post_input) -> bool {
+    if (!h->fuse || !h->bf3 || debug_full) return false;
+    const DevGather& d = fwd ? h->gf[k] : h->gb[k + 1];
+    if (!d.ok) return false;
+    const int src_layer = fwd ? k - 1 : k + 1;
+    const bool embed_src = fwd && k == 1 && embed_in_gather && proj[0] == L_INP_F_1;
+    const bool sparse = (h->gather_sparse & (d.g.lanes == 16 ? 1 : 2)) && !embed_src && src_layer >= 1;
+    if (src_layer >= 1 && !sparse) return false;
+    if (d.g.lanes == 32 && !sparse) return false;
+    if (d.g.lanes == 16 && post_input) return false;
+    if (!fwd && k >= L) return false;
+    const FusedGeom fg = fused_geom(h, d, B, sparse, post_input);
+    if (fg.lds > FUSED_MAX_LDS) return false;
+    const long nt = map_tiles(d.g.tm, B);
+    FArgs a{};
+    float* sout = fwd ? ws + w.sf[k] : ws + w.sb[k];
+    a.sw_from_gather = sparse && h->s_in_gather ? 1 : 0;
+    a.g = GArgs{in->lb[k], in->ub[k], in->mask, fwd ? mu(k - 1) : mu(k + 1), nb, nt, 0, h->R, roff[k], to_dtm(d.g.tm), to_dg(d, h->d_zero),
+                EmbedSrc{in->lb[0], in->x_lp, in->ub[0], h->d_pack[PK_EMBED]}, sparse ? in->lb[src_layer] : nullptr, sparse ? in->ub[src_layer] : nullptr,
+                a.sw_from_gather ? sout : nullptr};
+    a.u = upd_args(k, fwd, false, post_input);
+    a.tail = reinterpret_cast<int*>(ws + w.tail);
+    a.seg = fg.seg;
+    const dim3 g((unsigned)fg.grid), b(FUSED_WAVES * 64);
+    lz.run(PC_GATHER_UPDATE, [&] {
+      if (d.g.lanes == 16) {
+        if (embed_src) hipLaunchKernelGGL((k_gather_update<16, 2, false>), g, b, fg.lds, st, a);
+        else if (sparse) hipLaunchKernelGGL((k_gather_update<16, 1, false>), g, b, fg.lds, st, a);
+        else hipLaunchKernelGGL((k_gather_update<16, 0, false>), g, b, fg.lds, st, a);
+      } else if (post_input) hipLaunchKernelGGL((k_gather_update<32, 1, true>), g, b, fg.lds, st, a);
+      else hipLaunchKernelGGL((k_gather_update<32, 1, false>), g, b, fg.lds, st, a);
+    });
+    proj[k] = fwd ? L_FC4_2 : L_BC4_1;
+    return true;
   };
   auto update_input = [&]() {
     proj[0] = L_INP_B2_2;
@@ -1074,12 +1150,14 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   for (int t = 0; t < h->T && done < limit; ++t) {
     if (top_fused) {
       for (int k = 1; k < L; ++k) {
+        if (fused_halfpass(k, true, false)) continue;
         agg_fwd(k);
         node_update(k, true, false);
       }
       top();                                     // F1 .. B2: both half-passes of layer L, aggregate of layer L-1 in `nb`
       for (int k = L - 1; k >= 1; --k) {
         const bool scored = h->restrict_last && t == h->T - 1 && k == 1;
+        if (k < L - 1 && !scored && fused_halfpass(k, false, k == 1 && t < h->T - 1)) continue;
         if (k < L - 1) agg_bwd(k, 1, scored);
         node_update(k, false, scored, k == 1 && t < h->T - 1);
       }
@@ -1089,6 +1167,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     }
     // forward sweep (graph_conv.py:107-192) + property node (:194-210)
     for (int k = 1; k <= L; ++k) {
+      if (fused_halfpass(k, true, false)) continue;
       agg_fwd(k);
       node_update(k, true, false);
     }
@@ -1104,6 +1183,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     for (int k = L; k >= 1; --k) {
       // after the last backward step mu[1] is only read by the score head, i.e. at the scored nodes
       const bool scored = h->restrict_last && !debug_full && t == h->T - 1 && k == 1;
+      if (k < L && !scored && fused_halfpass(k, false, k == 1 && t < h->T - 1)) continue;
       if (k < L) agg_bwd(k, 1, scored);          // (k == L: k_prop already wrote the aggregate from the property node)
       node_update(k, false, scored, k == 1 && (t < h->T - 1 || debug_full));
     }

@@ -524,19 +524,14 @@ __device__ __forceinline__ EmbedLane embed_lane(const GArgs& a, int j) {
   return e;
 }
 
-// one tile of phase A: the aggregate rows of the tile's dst nodes that will be updated
+// the aggregate of one 32-node tile into X (gather channel map), tap-count division included; ssum: the bias-sum scalar of the
+// sparse walk (see gather_tile_sparse), normalised like the aggregate
 template <bool EMBED, bool SPARSE>
-__device__ __forceinline__ void gather_process_tile(const GArgs& a, const TileCtx& tc, int sample, const float* lds_cm, const int2* lds_ko,
-                                                    const unsigned* lds_kvo, uint2* tab, const EmbedLane& el, int lane) {
-  const int h = lane >> 5, j = lane & 31;
-  const long gc = tc.sample * a.tm.N + tc.n;
-  float ssum = 0.0f;
-  bool need;
-  if (a.need_scored) need = tc.valid && a.mask[tc.sample * a.R + a.off + tc.n] != 0.0f;
-  else need = tc.valid && node_is_live(a.lb[gc], a.ub[gc]);    // (one load of k_classify's live flag instead: measured 1.7 % slower)
-  if (!__any(need)) return;
+__device__ __forceinline__ void gather_compute_tile(const GArgs& a, const TileCtx& tc, int sample, const float* lds_cm, const int2* lds_ko,
+                                                    const unsigned* lds_kvo, uint2* tab, const EmbedLane& el, int lane, Frag& X, float& ssum) {
+  const int j = lane & 31;
+  ssum = 0.0f;
   const int wy0 = tc.by * a.g.ystep + a.g.ybase, wx0 = tc.bx * a.g.xstep + a.g.xbase;
-  Frag X;
   if (EMBED) {
     const int uy = __builtin_amdgcn_readfirstlane(wy0), ux = __builtin_amdgcn_readfirstlane(wx0);
     const long sb = (long)sample * a.g.Ns;
@@ -570,6 +565,21 @@ __device__ __forceinline__ void gather_process_tile(const GArgs& a, const TileCt
     }
     ssum = ssum / freq;                      // the bias sum of a transposed conv edge is normalised like its aggregate
   }
+}
+
+// one tile of phase A: the aggregate rows of the tile's dst nodes that will be updated
+template <bool EMBED, bool SPARSE>
+__device__ __forceinline__ void gather_process_tile(const GArgs& a, const TileCtx& tc, int sample, const float* lds_cm, const int2* lds_ko,
+                                                    const unsigned* lds_kvo, uint2* tab, const EmbedLane& el, int lane) {
+  const int h = lane >> 5;
+  const long gc = tc.sample * a.tm.N + tc.n;
+  float ssum = 0.0f;
+  bool need;
+  if (a.need_scored) need = tc.valid && a.mask[tc.sample * a.R + a.off + tc.n] != 0.0f;
+  else need = tc.valid && node_is_live(a.lb[gc], a.ub[gc]);    // (one load of k_classify's live flag instead: measured 1.7 % slower)
+  if (!__any(need)) return;
+  Frag X;
+  gather_compute_tile<EMBED, SPARSE>(a, tc, sample, lds_cm, lds_ko, lds_kvo, tab, el, lane, X, ssum);
   if (need) frag_store_rows_gathered(X, a.nb, gc, h);
   if (SPARSE && need && h == 0 && a.sout) a.sout[gc] = ssum;
 }
@@ -623,22 +633,16 @@ __device__ __forceinline__ void gather_tile16_embed_mfma(f32x4 (&acc)[4], const 
   }
 }
 
-// one 16-node tile of phase A (forward edges only: no tap-count division)
+// the aggregate of one 16-node tile (forward edges only: no tap-count division): acc[t][r] of lane (j, g') = channel 16 g' + 4 r + t
 template <bool EMBED, bool SPARSE>
-__device__ __forceinline__ void gather_process_tile16(const GArgs& a, const TileCtx& tc, int sample, const float* lds_cm, const int2* lds_ko,
-                                                      const unsigned* lds_kvo, uint2* tab, const float (&ew)[4][3], const float (&eb)[4], int lane) {
-  const int gq = lane >> 4;
-  const long gc = tc.sample * a.tm.N + tc.n;
-  float ssum = 0.0f;
-  bool need;
-  if (a.need_scored) need = tc.valid && a.mask[tc.sample * a.R + a.off + tc.n] != 0.0f;
-  else need = tc.valid && node_is_live(a.lb[gc], a.ub[gc]);
-  if (!__any(need)) return;
+__device__ __forceinline__ void gather_compute_tile16(const GArgs& a, const TileCtx& tc, int sample, const float* lds_cm, const int2* lds_ko,
+                                                      const unsigned* lds_kvo, uint2* tab, const float (&ew)[4][3], const float (&eb)[4], int lane,
+                                                      f32x4 (&acc)[4], float& ssum) {
+  ssum = 0.0f;
   const int wy0 = tc.by * a.g.ystep + a.g.ybase, wx0 = tc.bx * a.g.xstep + a.g.xbase;
   const int uy = __builtin_amdgcn_readfirstlane(wy0), ux = __builtin_amdgcn_readfirstlane(wx0);
   const bool interior = uy >= 0 && ux >= 0 && uy + a.g.WY <= a.g.Hs && ux + a.g.WX <= a.g.Ws;
   const float* cmt = lds_cm + tc.cg * a.g.K2 * 64;
-  f32x4 acc[4];
   if (EMBED) {
     const long sb = (long)sample * a.g.Ns;
     const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(a.es.lb + sb), 0, a.g.Ns * 4, 0x00020000);
@@ -663,6 +667,21 @@ __device__ __forceinline__ void gather_process_tile16(const GArgs& a, const Tile
     } else if (interior) gather_tile16<true>(acc, cmt, lds_ko, lds_kvo, a.g.K2, rsrc, uy, ux, a.g.Hs, a.g.Ws, lane);
     else gather_tile16<false>(acc, cmt, lds_ko, lds_kvo, a.g.K2, rsrc, uy, ux, a.g.Hs, a.g.Ws, lane);
   }
+}
+
+// one 16-node tile of phase A
+template <bool EMBED, bool SPARSE>
+__device__ __forceinline__ void gather_process_tile16(const GArgs& a, const TileCtx& tc, int sample, const float* lds_cm, const int2* lds_ko,
+                                                      const unsigned* lds_kvo, uint2* tab, const float (&ew)[4][3], const float (&eb)[4], int lane) {
+  const int gq = lane >> 4;
+  const long gc = tc.sample * a.tm.N + tc.n;
+  float ssum = 0.0f;
+  bool need;
+  if (a.need_scored) need = tc.valid && a.mask[tc.sample * a.R + a.off + tc.n] != 0.0f;
+  else need = tc.valid && node_is_live(a.lb[gc], a.ub[gc]);
+  if (!__any(need)) return;
+  f32x4 acc[4];
+  gather_compute_tile16<EMBED, SPARSE>(a, tc, sample, lds_cm, lds_ko, lds_kvo, tab, ew, eb, lane, acc, ssum);
   if (need) {                                  // lane (j, g'): channels 16g' + 4r + t of its node
     f32x4* p = reinterpret_cast<f32x4*>(a.nb + gc * 64 + 16 * gq);
 #pragma unroll

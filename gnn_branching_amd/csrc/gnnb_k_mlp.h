@@ -320,7 +320,8 @@ struct UpdArgs {
 // pack is staged into `lds` here (the first fetch overlaps it).
 // BF3: the 64x64 blocks of the short chain (WAS, WCB) and of POST run on the bf16 matrix rate with three-piece operands
 // (gemm_w64_bf3; LDS image PackUpdL3); the general chain's 128-wide first layer stays on the fp32 MFMA (6-11 % of the tiles).
-template <bool DEFERRED, bool POST = false, bool BF3 = false>
+// STAGE = false: the caller (k_gather_update) has the LDS image in place already
+template <bool DEFERRED, bool POST = false, bool BF3 = false, bool STAGE = true>
 __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, int c0, int c1, long tile, long stride, int lane) {
   constexpr int O_WA = BF3 ? (int)PackUpdL3::WA : (int)PackUpd::WA, O_BA = BF3 ? (int)PackUpdL3::BA : (int)PackUpd::BA;
   constexpr int O_BCB = BF3 ? (int)PackUpdL3::BCB : (int)PackUpd::BCB, O_VAW = BF3 ? (int)PackUpdL3::VAW : (int)PackUpd::VAW;
@@ -353,13 +354,15 @@ __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, i
     frag_load_rows(X, a.nb, gc, h);
   }
   constexpr bool post = POST;
-  if (post) copy_to_lds(lds + O_END, a.wp, BF3 ? 6144 : 4096);
-  if (BF3) {
-    copy_to_lds(lds + PackUpdL3::WA, a.pack + PackUpd::WA, 8192);
-    copy_to_lds(lds + PackUpdL3::BA, a.pack + PackUpd::BA, 64);
-    copy_to_lds(lds + PackUpdL3::BCB, a.pack + PackUpd::BCB, 64 + 64 + 128);          // BCB, BCBROW, VAW
-    stage_pack(lds + PackUpdL3::WAS3, a.pack + PackUpd::WAS3, 2 * 6144);               // WAS3, WCB3
-  } else stage_pack(lds, a.pack, PackUpd::FLOATS);
+  if (STAGE) {
+    if (post) copy_to_lds(lds + O_END, a.wp, BF3 ? 6144 : 4096);
+    if (BF3) {
+      copy_to_lds(lds + PackUpdL3::WA, a.pack + PackUpd::WA, 8192);
+      copy_to_lds(lds + PackUpdL3::BA, a.pack + PackUpd::BA, 64);
+      copy_to_lds(lds + PackUpdL3::BCB, a.pack + PackUpd::BCB, 64 + 64 + 128);          // BCB, BCBROW, VAW
+      stage_pack(lds + PackUpdL3::WAS3, a.pack + PackUpd::WAS3, 2 * 6144);               // WAS3, WCB3
+    } else stage_pack(lds, a.pack, PackUpd::FLOATS);
+  }
   if (tile >= ntiles) return;
   for (;;) {
     const Ratio r = compute_ratio(lb, ub);

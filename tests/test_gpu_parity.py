@@ -199,6 +199,28 @@ def test_unfused_valu_gather_path_matches(monkeypatch):
     assert res.decisions.cpu().tolist() == g["random_decisions"].tolist()
 
 
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+@pytest.mark.parametrize("fam", FAMILIES)
+def test_two_kernel_halfpass_path_matches(monkeypatch, case, fam):
+    """GNNB_NO_FUSE=1: every conv half-pass as k_gather + k_node_update (the aggregate goes through HBM) instead of the fused
+    k_gather_update -- the path inspection runs, the restricted last step and tile forms without a fused kernel take.  Both
+    sit inside the parity bar, agree with each other to fp32 rounding and take the same decisions."""
+    g, batch = load_golden(case)
+    want = g[f"{fam}_scores"]
+    fin = np.isfinite(want)
+    out = {}
+    for nofuse in ("0", "1"):
+        monkeypatch.setenv("GNNB_NO_FUSE", nofuse)
+        model = make_model(fam)                      # a new engine: the knob is read by gnnb_create
+        with torch.no_grad():
+            res = model.forward_device(*batch.forward_args()).check()
+        out[nofuse] = res.scores.cpu().numpy()
+        assert np.abs(out[nofuse][fin] - want[fin]).max() <= score_tol(fam, want[fin])
+        assert res.decisions.cpu().tolist() == g[f"{fam}_decisions"].tolist()
+    scale = np.abs(want[fin]).max()
+    assert np.abs(out["1"][fin] - out["0"][fin]).max() <= 2e-6 * max(scale, 1.0)
+
+
 def test_per_tile_dense_kernel_path_matches(monkeypatch):
     """GNNB_NO_DENSE_LDS=1 selects the per-tile dense edge kernels (the fallback for Linear layers whose source does
     not fit the LDS-staged kernels): same scores."""
