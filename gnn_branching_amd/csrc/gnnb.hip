@@ -112,7 +112,8 @@ struct gnnb_handle {
                                 // gathers, bit 1 = 32-node gathers, bit 2 = the input-layer gather
   bool gather16 = true;         // forward conv edges: 16-node tiles on the 16x16x4 MFMA when their window is smaller
   bool embed_fuse = true;       // round 0: the first forward gather computes the input embedding itself (no k_embed, no mu[0] rows)
-  bool fuse = true;             // conv edges: gather + node update in one kernel (k_gather_update); GNNB_NO_FUSE=1: two kernels
+  bool fuse = false;            // GNNB_FUSE=1: conv edges as ONE kernel per half-pass (k_gather_update: the aggregate never reaches HBM).
+                                // Off by default: parity-green and 33 % less HBM traffic, but 5-20 % slower than the two kernels
   bool use_top = true;          // fuse the top of the network (last Linear edge, last ReLU layer, property node) into k_top
   bool top_ok = false;          // ... which the bound network allows (set by gnnb_bind_network)
   int per_sample_min_b = 0;     // GNNB_PER_SAMPLE_MIN_B: batches below it take the per-tile dense kernel + separate launches
@@ -252,12 +253,14 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   HIPCHK(hipFuncSetAttribute((const void*)k_gather<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   if (const char* e = getenv("GNNB_NO_GATHER")) h->use_gather = !(e[0] == '1');
   if (const char* e = getenv("GNNB_NO_TOP")) h->use_top = !(e[0] == '1');
-  if (const char* e = getenv("GNNB_NO_FUSE")) h->fuse = !(e[0] == '1');
-  HIPCHK(hipFuncSetAttribute((const void*)k_gather_update<16, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_MAX_LDS));
-  HIPCHK(hipFuncSetAttribute((const void*)k_gather_update<16, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_MAX_LDS));
-  HIPCHK(hipFuncSetAttribute((const void*)k_gather_update<16, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_MAX_LDS));
-  HIPCHK(hipFuncSetAttribute((const void*)k_gather_update<32, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_MAX_LDS));
-  HIPCHK(hipFuncSetAttribute((const void*)k_gather_update<32, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_MAX_LDS));
+  if (const char* e = getenv("GNNB_FUSE")) h->fuse = e[0] == '1';
+#define FUSED_ATTR(L, S, P, N) HIPCHK(hipFuncSetAttribute((const void*)k_gather_update<L, S, P, N>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_MAX_LDS))
+  FUSED_ATTR(16, 2, false, 1);
+  FUSED_ATTR(16, 0, false, 1); FUSED_ATTR(16, 0, false, 2); FUSED_ATTR(16, 0, false, 4);
+  FUSED_ATTR(16, 1, false, 1); FUSED_ATTR(16, 1, false, 2); FUSED_ATTR(16, 1, false, 4);
+  FUSED_ATTR(32, 1, false, 1); FUSED_ATTR(32, 1, false, 2); FUSED_ATTR(32, 1, false, 4);
+  FUSED_ATTR(32, 1, true, 1); FUSED_ATTR(32, 1, true, 2); FUSED_ATTR(32, 1, true, 4);
+#undef FUSED_ATTR
   if (const char* e = getenv("GNNB_PER_SAMPLE_MIN_B")) h->per_sample_min_b = atoi(e);
   HIPCHK(hipFuncSetAttribute((const void*)k_top, hipFuncAttributeMaxDynamicSharedMemorySize, TOP_LDS_FLOATS * 4));
   *out = h;
@@ -534,18 +537,27 @@ static size_t sparse_tab_bytes(const DevGather& d) {
   return 8 + (size_t)WAVES_MLP * ((d.g.lanes == 16 ? 4 : 2) * d.g.K2 + 32) * 8;
 }
 
-// k_gather_update over one conv edge at batch B: grid, ints per tail-list segment, dynamic LDS bytes
-struct FusedGeom { long grid; int seg; size_t lds; };
+// k_gather_update over one conv edge at batch B: grid, dynamic LDS bytes
+struct FusedGeom { long grid; size_t lds; };
 static FusedGeom fused_geom(const gnnb_t* h, const DevGather& d, int B, bool sparse, bool post) {
   FusedGeom f;
   const long nt = map_tiles(d.g.tm, B), nrounds = (nt + FUSED_WAVES - 1) / FUSED_WAVES;
   f.grid = std::max<long>(1, std::min<long>(nrounds, h->n_cu));
-  f.seg = (int)((nrounds + f.grid - 1) / f.grid) * FUSED_WAVES * d.g.lanes;
   const size_t tables = (size_t)d.g.tm.NCG * d.g.K2 * 64 * 4 + (size_t)gather_slots(d.g.K2, d.g.lanes) * 8 + (size_t)((d.g.tm.TPS + 3) & ~3) * 4 +
                         (size_t)((gather_slots(d.g.K2, d.g.lanes) + 3) & ~3) * 4;
-  f.lds = (size_t)(PackUpdL3::FLOATS + (post ? 6144 : 0)) * 4 + tables + FUSED_WAVES * fused_wave_bytes(d.g.K2, d.g.lanes, sparse);
+  f.lds = (size_t)(PackUpdF3::FLOATS + (post ? 6144 : 0)) * 4 + tables + FUSED_WAVES * fused_wave_bytes(d.g.K2, d.g.lanes, sparse);
   return f;
 }
+
+#ifdef FUSED_TIMING
+// dev: cycle sums of k_gather_update's phases over every wave since the last reset (index 15: number of waves)
+extern "C" int gnnb_debug_read(unsigned long long* out, int reset) {
+  unsigned long long z[16] = {0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_t), sizeof z) != hipSuccess) return -1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_fused_t), z, sizeof z) != hipSuccess) return -1;
+  return 0;
+}
+#endif
 
 extern "C" int gnnb_graph_info(const gnnb_t* h, int* n_graph, int* sizes, int* n_relu_total) {
   if (!h || !h->bound) return fail(GNNB_E_STATE, "gnnb_graph_info: no network bound");
@@ -613,7 +625,7 @@ struct WsLayout {                // plain arrays: gnnb_forward computes it on it
   size_t lf[MAXL + 2];          // live flags (B, N_k) as floats
   size_t sf[MAXL + 2], sb[MAXL + 2];   // k_livesum outputs: sf[k] (B, N_k) over edge k, sb[k] (B, N_k) over edge k+1 transposed
   size_t F1 = 0;                // rows of layer 1 after the producer-side map of the input update (PackPostInp)
-  size_t cnt = 0, best = 0, nb = 0, Q = 0, tail = 0, total = 0;     // tail: the per-workgroup node lists of k_gather_update     // best: B 64-bit decision keys + the finished-workgroup counter of k_score
+  size_t cnt = 0, best = 0, nb = 0, Q = 0, total = 0;     // best: B 64-bit decision keys + the finished-workgroup counter of k_score
 };
 static size_t align64(size_t nfloats) { return (nfloats + 63) & ~(size_t)63; }
 static WsLayout ws_layout(const gnnb_t* h, int B) {
@@ -639,14 +651,6 @@ static WsLayout ws_layout(const gnnb_t* h, int B) {
   for (int k = 0; k < K - 1; ++k) { w.sb[k] = off; off += align64((size_t)B * h->N[k]); }
   w.F1 = off; off += align64((size_t)B * h->N[1] * 64);
   w.Q = off; off += (size_t)map_tiles(bwd_map(h, 0), B) * 2048;
-  size_t tail_ints = 0;
-  for (auto* v : {&h->gf, &h->gb})
-    for (const DevGather& d : *v)
-      if (d.ok) {
-        const FusedGeom f = fused_geom(h, d, B, true, false);
-        tail_ints = std::max(tail_ints, (size_t)f.grid * 2 * f.seg);
-      }
-  w.tail = off; off += align64(tail_ints);
   w.total = off;
   return w;
 }
@@ -1079,7 +1083,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     if (d.g.lanes == 16 && post_input) return false;
     if (!fwd && k >= L) return false;
     const FusedGeom fg = fused_geom(h, d, B, sparse, post_input);
-    if (fg.lds > FUSED_MAX_LDS) return false;
+    if (fg.lds > FUSED_MAX_LDS || (d.g.lanes == 16 ? 4 : 2) * d.g.K2 > 64 * FW_MAXIT) return false;
     const long nt = map_tiles(d.g.tm, B);
     FArgs a{};
     float* sout = fwd ? ws + w.sf[k] : ws + w.sb[k];
@@ -1088,16 +1092,22 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
                 EmbedSrc{in->lb[0], in->x_lp, in->ub[0], h->d_pack[PK_EMBED]}, sparse ? in->lb[src_layer] : nullptr, sparse ? in->ub[src_layer] : nullptr,
                 a.sw_from_gather ? sout : nullptr};
     a.u = upd_args(k, fwd, false, post_input);
-    a.tail = reinterpret_cast<int*>(ws + w.tail);
-    a.seg = fg.seg;
     const dim3 g((unsigned)fg.grid), b(FUSED_WAVES * 64);
+    const int nslots = (d.g.lanes == 16 ? 4 : 2) * d.g.K2, nit = nslots <= 64 ? 1 : (nslots <= 128 ? 2 : 4);      // 64-slot sweeps per window
     lz.run(PC_GATHER_UPDATE, [&] {
+#define FUSED_LAUNCH(L, S, P)                                                                       \
+  do {                                                                                              \
+    if (nit == 1) hipLaunchKernelGGL((k_gather_update<L, S, P, 1>), g, b, fg.lds, st, a);           \
+    else if (nit == 2) hipLaunchKernelGGL((k_gather_update<L, S, P, 2>), g, b, fg.lds, st, a);      \
+    else hipLaunchKernelGGL((k_gather_update<L, S, P, 4>), g, b, fg.lds, st, a);                    \
+  } while (0)
       if (d.g.lanes == 16) {
-        if (embed_src) hipLaunchKernelGGL((k_gather_update<16, 2, false>), g, b, fg.lds, st, a);
-        else if (sparse) hipLaunchKernelGGL((k_gather_update<16, 1, false>), g, b, fg.lds, st, a);
-        else hipLaunchKernelGGL((k_gather_update<16, 0, false>), g, b, fg.lds, st, a);
-      } else if (post_input) hipLaunchKernelGGL((k_gather_update<32, 1, true>), g, b, fg.lds, st, a);
-      else hipLaunchKernelGGL((k_gather_update<32, 1, false>), g, b, fg.lds, st, a);
+        if (embed_src) hipLaunchKernelGGL((k_gather_update<16, 2, false, 1>), g, b, fg.lds, st, a);
+        else if (sparse) FUSED_LAUNCH(16, 1, false);
+        else FUSED_LAUNCH(16, 0, false);
+      } else if (post_input) FUSED_LAUNCH(32, 1, true);
+      else FUSED_LAUNCH(32, 1, false);
+#undef FUSED_LAUNCH
     });
     proj[k] = fwd ? L_FC4_2 : L_BC4_1;
     return true;

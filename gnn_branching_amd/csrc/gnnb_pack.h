@@ -131,18 +131,9 @@ inline int gather_feature(int R, int h) {           // channel held by register 
 // register, out of the gather's accumulators; which channel register R of lane half h holds depends on the gather form:
 //   32-node tiles (32x32x2 MFMA): gather_feature(R, h)            16-node tiles (16x16x4 MFMA): 32 h + R
 // (16-node form: accumulator (t, r) of lane group g' holds channel 16 g' + 4 r + t; P[16 q + 4 r + t] of half h comes from group
-// g' = 2 h + q).  pack_w64_map / pack_w64_bf3_map are pack_w64 / pack_w64_bf3 for an arbitrary such map.
+// g' = 2 h + q).  pack_w64_bf3_map is pack_w64_bf3 for an arbitrary such map.
 typedef int (*FeatMap)(int R, int h);
 inline int gather16_feature(int R, int h) { return 32 * h + R; }
-inline void pack_w64_map(float* dst, const float* W, int ldw, int col0, int nfrag, FeatMap fm) {
-  for (int s = 0; s < 32 * nfrag; ++s)
-    for (int it = 0; it < 2; ++it)
-      for (int lane = 0; lane < 64; ++lane) {
-        int out = 32 * it + (lane & 31);
-        int in = col0 + 64 * (s >> 5) + fm(s & 31, lane >> 5);
-        dst[(((size_t)(s >> 2) * 2 + it) * 64 + lane) * 4 + (s & 3)] = W[(size_t)out * ldw + in];
-      }
-}
 inline void pack_w64_bf3_map(float* dst, const float* W, int ldw, int col0, int nfrag, FeatMap fm) {
   unsigned short* d = reinterpret_cast<unsigned short*>(dst);
   for (int f = 0; f < nfrag; ++f)
@@ -194,10 +185,15 @@ struct PackUpd { enum { WA = 0, WAS = WA + 8192, BA = WAS + 4096, WCB = BA + 64,
                         VAW = BCBROW + 64, FLOATS = VAW + 128,
                         // bf16 x 3 forms of WAS and WCB (pack_w64_bf3) behind the fp32 image
                         WAS3 = FLOATS, WCB3 = WAS3 + 6144, FLOATS3 = WCB3 + 6144,
-                        // k_gather_update: WA (fp32) and WAS (bf16 x 3) for an input fragment in the channel map of the 32-node
-                        // and of the 16-node gather (pack_w64_map / pack_w64_bf3_map); everything behind the first layer is shared
-                        WA_G32 = FLOATS3, WAS3_G32 = WA_G32 + 8192, WA_G16 = WAS3_G32 + 6144, WAS3_G16 = WA_G16 + 8192,
-                        FLOATS_ALL = WAS3_G16 + 6144 }; };
+                        // k_gather_update: the first layer for an input fragment in the channel map of the 32-node and of the 16-node
+                        // gather (pack_w64_bf3_map), all bf16 x 3: WAS, and the second half of Wa alone -- ambiguous nodes ride in the
+                        // same tiles as the others there, Wa.[r0 x, r1 x] = WAS.(r0 x) + Wa[:, 64:].((r1 - r0) x), the second term
+                        // being exactly zero for r0 == r1.  Everything behind the first layer is shared.
+                        WAS3_G32 = FLOATS3, WAS3_G16 = WAS3_G32 + 6144, WA1S3_G32 = WAS3_G16 + 6144, WA1S3_G16 = WA1S3_G32 + 6144,
+                        FLOATS_ALL = WA1S3_G16 + 6144 }; };
+// LDS image of k_gather_update: no 128-wide fp32 first layer, three bf16 x 3 blocks
+struct PackUpdF3 { enum { BA = 0, BCB = BA + 64, BCBROW = BCB + 64, VAW = BCBROW + 64, WAS3 = VAW + 128, WCB3 = WAS3 + 6144, WA1S3 = WCB3 + 6144,
+                          FLOATS = WA1S3 + 6144 }; };
 // LDS image of the bf16 x 3 node update: WAS / WCB in three bf16 pieces; the general chain's 128-wide WA stays fp32 (its
 // tiles are 6-11 % of the work; as bf16 x 3 it costs 16 KB more staging and register spills, measured slower)
 struct PackUpdL3 { enum { WA = 0, BA = WA + 8192, BCB = BA + 64, BCBROW = BCB + 64, VAW = BCBROW + 64, WAS3 = VAW + 128,
@@ -322,10 +318,10 @@ inline void build_packs(const float* blob, Packs& pk) {
     pack_w64_bf3(&v[PackUpd::WAS3], was.data(), 64, 0, 1);
     pack_w64_bf3(&v[PackUpd::WCB3], wcb.data(), 64, 0, 1);
     if (with_gather_maps) {
-      pack_w64_map(&v[PackUpd::WA_G32], wa.data(), 128, 0, 2, gather_feature);
       pack_w64_bf3_map(&v[PackUpd::WAS3_G32], was.data(), 64, 0, 1, gather_feature);
-      pack_w64_map(&v[PackUpd::WA_G16], wa.data(), 128, 0, 2, gather16_feature);
       pack_w64_bf3_map(&v[PackUpd::WAS3_G16], was.data(), 64, 0, 1, gather16_feature);
+      pack_w64_bf3_map(&v[PackUpd::WA1S3_G32], wa.data(), 128, 64, 1, gather_feature);
+      pack_w64_bf3_map(&v[PackUpd::WA1S3_G16], wa.data(), 128, 64, 1, gather16_feature);
     }
     pack_vec64(&v[PackUpd::BCB], bcb);
     (void)d;   // the last layer is folded into the consumers of the rows
@@ -469,7 +465,7 @@ inline void pack_conv_bwd(float* dst, const Edge& e) {
 // B operand is the translation-invariant tap matrix Cmat[k][j] (weight of src window node k for dst
 // lane j, 0 where no tap connects them), held in LDS in operand order [cg][s][lane].
 // The result lands in fragment layout with the channel map  (it, r, h) -> 2*((r&3)+8*(r>>2)+4*h) + it,
-// which the first layer of the node MLP absorbs through pack_w64_map(.., gather_feature) when it is fed from registers.
+// which the first layer of the node MLP absorbs through pack_w64_bf3_map(.., gather_feature) when it is fed from registers.
 // ------------------------------------------------------------------------------------------
 struct TileMap {        // lane j of tile t <-> node of the dst layer
   int mode = 0;         // 0: flat, tile = 32 consecutive rows of the (B*N) layer; 1: block

@@ -201,22 +201,29 @@ def test_unfused_valu_gather_path_matches(monkeypatch):
 
 @pytest.mark.parametrize("case", GOLDEN_CASES)
 @pytest.mark.parametrize("fam", FAMILIES)
-def test_two_kernel_halfpass_path_matches(monkeypatch, case, fam):
-    """GNNB_NO_FUSE=1: every conv half-pass as k_gather + k_node_update (the aggregate goes through HBM) instead of the fused
-    k_gather_update -- the path inspection runs, the restricted last step and tile forms without a fused kernel take.  Both
-    sit inside the parity bar, agree with each other to fp32 rounding and take the same decisions."""
+def test_fused_halfpass_kernel_matches(monkeypatch, case, fam):
+    """GNNB_FUSE=1: every conv half-pass as ONE kernel, k_gather_update (the aggregate stays in registers: live nodes are
+    compacted into the chain's tile with ds_bpermute, ambiguous nodes ride in the same tiles) instead of k_gather +
+    k_node_update.  Both paths sit inside the parity bar, agree with each other to fp32 rounding and take the same decisions."""
     g, batch = load_golden(case)
     want = g[f"{fam}_scores"]
     fin = np.isfinite(want)
     out = {}
-    for nofuse in ("0", "1"):
-        monkeypatch.setenv("GNNB_NO_FUSE", nofuse)
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("GNNB_FUSE", fuse)
         model = make_model(fam)                      # a new engine: the knob is read by gnnb_create
         with torch.no_grad():
             res = model.forward_device(*batch.forward_args()).check()
-        out[nofuse] = res.scores.cpu().numpy()
-        assert np.abs(out[nofuse][fin] - want[fin]).max() <= score_tol(fam, want[fin])
+        out[fuse] = res.scores.cpu().numpy()
+        assert np.abs(out[fuse][fin] - want[fin]).max() <= score_tol(fam, want[fin])
         assert res.decisions.cpu().tolist() == g[f"{fam}_decisions"].tolist()
+        # batched == per-sample bit for bit on this path too (a node's result must not depend on what shares its tile)
+        if fuse == "1":
+            one = model.forward_device(*batch.slice(1, 2).forward_args()).check().scores.cpu().numpy()
+            assert np.array_equal(one[0], out[fuse][1])
+            model.engine().workspace(batch.batch_size).view(torch.float32).fill_(float("nan"))
+            again = model.forward_device(*batch.forward_args()).check().scores.cpu().numpy()
+            assert np.array_equal(again, out[fuse], equal_nan=True)
     scale = np.abs(want[fin]).max()
     assert np.abs(out["1"][fin] - out["0"][fin]).max() <= 2e-6 * max(scale, 1.0)
 
