@@ -7,17 +7,22 @@ read the primal point, the per-layer primal values and the constraint duals ``Pi
 ``GraphChoice.decision`` takes.  Gurobi is not available here, so this module restates that producer on
 ``scipy.optimize.linprog(method="highs")``:
 
-* intermediate bounds: interval arithmetic through the fixed layers (the reference intersects them with Wong-Kolter
-  bounds, dual_network_linear_approximation.py:205-451, which are tighter; interval bounds are valid, only looser),
-  honouring the split mask (a node forced passing gets ``pre >= 0``, forced blocking ``pre <= 0``);
+* intermediate bounds: Wong-Kolter bounds (``kw_bounds``: the dual-network backward pass of
+  convex_adversarial/dual_network.py:15-121 for every pre-ReLU layer, as init_kw_bounds / update_kw_bounds use it,
+  dual_network_linear_approximation.py:205-451) intersected with interval arithmetic and, for a child domain, with its
+  parent's bounds; below the split layer the parent's bounds are kept (incremental update), honouring the split mask (a
+  node forced passing gets ``pre >= 0``, forced blocking ``pre <= 0``).  ``bounds="interval"`` selects plain interval
+  arithmetic (the looser relaxation round 1 used);
 * the LP: one variable block per network layer, affine layers as equalities with their scipy.sparse matrix, decided
   ReLUs as equalities / fixed bounds, undecided ones as the two inequality rows (``v >= 0`` is the variable bound);
 * duals in Gurobi's sign convention: ``Pi(v >= pre) = -marginal(pre - v <= 0)``, ``Pi(v <= slope pre + bias) =
   marginal(v - slope pre <= bias)``; the column of ``v >= 0`` stays 0 (graph_conv.py reads columns 1 and 2 only).
 
-Parity with the reference's Gurobi numbers cannot be pinned here (no Gurobi to compare with; LP duals are not unique
-anyway): ``tests/test_lp_producer.py`` checks what can be checked without it -- soundness of the bound, primal
-feasibility, complementary slackness of the reported duals, monotonicity under branching.
+PARITY UNPINNED: neither the LP (no Gurobi to compare with; LP duals are not unique anyway) nor the Wong-Kolter bounds (the
+reference module imports ``plnn.model`` -> ``gurobipy`` and cannot be imported here) can be pinned against the reference's
+numbers.  ``tests/test_lp_producer.py`` checks what can be checked without it -- soundness of every bound on sampled
+points, KW within interval, LP bound with KW >= LP bound with interval, primal feasibility, complementary slackness of the
+reported duals, monotonicity under branching, incremental == inherited below the split.
 Host-side CPU code, like the reference's; the GPU only scores.
 """
 from dataclasses import dataclass
@@ -68,6 +73,7 @@ class Subproblem:
     dual_vars: List[torch.Tensor]    # per ReLU layer (N, 3)
     primals: List[list]              # per network layer after the input
     mask: List[torch.Tensor]         # per ReLU layer, {-1, 0, 1}
+    bounds64: tuple = None           # (lbs, ubs) in float64 as computed: what a child's bounds are intersected with
 
     def graph_bounds(self, pre_relu_indices, n_layers):
         idx = [0] + list(pre_relu_indices) + [n_layers]
@@ -77,7 +83,10 @@ class Subproblem:
 class LayerGraphLP:
     """LP relaxation of ``layers`` (net.layers with the folded Linear(., 1) property layer last) over an input box."""
 
-    def __init__(self, layers, input_lb, input_ub):
+    def __init__(self, layers, input_lb, input_ub, bounds="kw"):
+        if bounds not in ("kw", "interval"):
+            raise ValueError(bounds)
+        self.bound_mode = bounds
         self.layers = list(layers)
         self.input_lb, self.input_ub = input_lb.detach().double(), input_ub.detach().double()
         self.shapes = [tuple(input_lb.shape)]
@@ -135,11 +144,115 @@ class LayerGraphLP:
             ubs.append(nu)
         return lbs, ubs
 
+    def _interval_step(self, l, lo, up):
+        """Interval image of [lo, up] under one affine layer."""
+        if type(l) is nn.Conv2d:
+            wp, wn = l.weight.double().clamp(min=0), l.weight.double().clamp(max=0)
+            nl = F.conv2d(lo[None], wp, l.bias.double(), l.stride, l.padding) + F.conv2d(up[None], wn, None, l.stride, l.padding)
+            nu = F.conv2d(up[None], wp, l.bias.double(), l.stride, l.padding) + F.conv2d(lo[None], wn, None, l.stride, l.padding)
+            return nl[0], nu[0]
+        wp, wn = l.weight.double().clamp(min=0), l.weight.double().clamp(max=0)
+        return wp @ lo + wn @ up + l.bias.double(), wp @ up + wn @ lo + l.bias.double()
+
+    def _kw_layer(self, q, lbs, ubs):
+        """Wong-Kolter bounds on the output of the affine layer ``self.layers[q]`` given pre-activation bounds ``lbs`` /
+        ``ubs`` (bounds-list indexing: entry i = output of layer i - 1) of every ReLU below it.
+
+        One backward pass of the dual network for all N_q output coordinates at once (the identity as a batch of N_q
+        directions, convex_adversarial/dual_network.py:51-102 builds the same pass layer by layer): through an affine layer
+        nu_hat = W^T nu and the constant gains nu.b; through a ReLU with pre-activation bounds (l, u) nu = d * nu_hat with
+        d = 1 (l >= 0), 0 (u <= 0), u / (u - l) (ambiguous, the set I), and the lower / upper bound gain
+        sum_I (-d l) min(nu_hat, 0) / sum_I (-d l) max(nu_hat, 0) (DualReLU.objective, dual_layers.py: the l [nu]_+ term); at the
+        input the box [x_lo, x_hi] contributes nu_hat^+ x_lo + nu_hat^- x_hi (lower) and nu_hat^+ x_hi + nu_hat^- x_lo (upper) (InfBallBounded)."""
+        n = int(np.prod(self.shapes[q + 1]))
+        nu = torch.eye(n, dtype=torch.float64).reshape((n,) + tuple(self.shapes[q + 1]))
+        lo = torch.zeros(n, dtype=torch.float64)
+        up = torch.zeros(n, dtype=torch.float64)
+        for i in range(q, -1, -1):
+            l = self.layers[i]
+            if type(l) is nn.Conv2d:
+                bias = l.bias.double()
+                c = (nu.sum((2, 3)) * bias[None]).sum(1)
+                lo, up = lo + c, up + c
+                hin, win = self.shapes[i][1], self.shapes[i][2]
+                hout, wout = self.shapes[i + 1][1], self.shapes[i + 1][2]
+                opad = (hin - ((hout - 1) * l.stride[0] - 2 * l.padding[0] + l.kernel_size[0]),
+                        win - ((wout - 1) * l.stride[1] - 2 * l.padding[1] + l.kernel_size[1]))
+                nu = F.conv_transpose2d(nu, l.weight.double(), None, l.stride, l.padding, output_padding=opad)
+            elif type(l) is nn.Linear:
+                c = nu @ l.bias.double()
+                lo, up = lo + c, up + c
+                nu = nu @ l.weight.double()
+            elif type(l) is nn.ReLU:
+                pl, pu = lbs[i].reshape(-1), ubs[i].reshape(-1)
+                amb = (pl < 0) & (pu > 0)
+                d = torch.where(pl >= 0, torch.ones_like(pl), torch.zeros_like(pl))
+                d = torch.where(amb, pu / (pu - pl).clamp(min=1e-300), d)
+                flat = nu.reshape(n, -1)
+                gain = torch.where(amb, -d * pl, torch.zeros_like(pl))          # >= 0
+                lo = lo + (flat.clamp(max=0) * gain[None]).sum(1)
+                up = up + (flat.clamp(min=0) * gain[None]).sum(1)
+                nu = (flat * d[None]).reshape(nu.shape)
+            else:                                                               # Flatten
+                nu = nu.reshape((n,) + tuple(self.shapes[i]))
+        flat = nu.reshape(n, -1)
+        xl, xu = self.input_lb.reshape(-1), self.input_ub.reshape(-1)
+        lo = lo + flat.clamp(min=0) @ xl + flat.clamp(max=0) @ xu
+        up = up + flat.clamp(min=0) @ xu + flat.clamp(max=0) @ xl
+        return lo.reshape(self.shapes[q + 1]), up.reshape(self.shapes[q + 1])
+
+    def kw_bounds(self, mask, parent=None, split_layer=None):
+        """Intermediate bounds of the domain ``mask``: for every affine layer the Wong-Kolter bounds (``_kw_layer``, built on the
+        tightened bounds of the layers below, as the reference's DualNetwork does with zl / zu) intersected with interval
+        arithmetic, then the split mask applied to the pre-activation bounds.
+
+        ``parent`` = (lbs, ubs) of the parent domain and ``split_layer`` = index of the ReLU layer the child was split on: the
+        incremental form of update_kw_bounds (dual_network_linear_approximation.py:296-451) -- every bound up to and including
+        that layer's pre-activation is the parent's (only the split node is clamped, :311-318), later layers are recomputed and
+        intersected with the parent's bounds (:398-399).  Returns (lbs, ubs) like ``interval_bounds``."""
+        lbs, ubs = [self.input_lb.clone()], [self.input_ub.clone()]
+        keep_upto = self.pre_relu_indices[split_layer] if (parent is not None and split_layer is not None) else -1
+        r = 0
+        first_affine = True
+        for q, l in enumerate(self.layers):
+            lo, up = lbs[-1], ubs[-1]
+            if type(l) in (nn.Conv2d, nn.Linear):
+                if q + 1 <= keep_upto:
+                    nl, nu = parent[0][q + 1].double().clone(), parent[1][q + 1].double().clone()
+                else:
+                    nl, nu = self._interval_step(l, lo, up)
+                    if not first_affine:                       # the first affine layer's interval image of the box is exact
+                        kl, ku = self._kw_layer(q, lbs + [None], ubs + [None])
+                        nl, nu = torch.maximum(nl, kl), torch.minimum(nu, ku)
+                    if parent is not None:
+                        nl, nu = torch.maximum(nl, parent[0][q + 1].double()), torch.minimum(nu, parent[1][q + 1].double())
+                first_affine = False
+            elif type(l) is nn.ReLU:
+                m = mask[r].reshape(lo.shape)
+                lo = torch.where(m == 1, lo.clamp(min=0), lo)
+                up = torch.where(m == 0, up.clamp(max=0), up)
+                lbs[-1], ubs[-1] = lo, up
+                nl, nu = lo.clamp(min=0), up.clamp(min=0)
+                r += 1
+            else:
+                nl, nu = lo.reshape(-1), up.reshape(-1)
+            lbs.append(nl)
+            ubs.append(nu)
+        return lbs, ubs
+
+    def bounds(self, mask, parent=None, split_layer=None):
+        if self.bound_mode == "interval":
+            return self.interval_bounds(mask)
+        return self.kw_bounds(mask, parent, split_layer)
+
     # ---- the LP -----------------------------------------------------------------------------
-    def solve(self, mask):
-        """Bounds + LP for the domain described by ``mask``; returns a Subproblem, or None when the domain is infeasible."""
+    def solve(self, mask, parent=None, split_layer=None):
+        """Bounds + LP for the domain described by ``mask``; returns a Subproblem, or None when the domain is infeasible.
+        ``parent`` (a Subproblem) and ``split_layer`` (the ReLU layer of the split that made this child): bounds below the
+        split are inherited, bounds above it recomputed and intersected with the parent's (update_kw_bounds)."""
         mask = [m.clone() for m in mask]
-        lbs, ubs = self.interval_bounds(mask)
+        pb = None if parent is None else parent.bounds64
+        lbs, ubs = self.bounds(mask, pb, split_layer)
         for lo, up in zip(lbs, ubs):
             if bool((lo > up + 1e-9).any()):
                 return None
@@ -224,7 +337,7 @@ class LayerGraphLP:
         lower_all = [t.float() for t in lbs]
         upper_all = [t.float() for t in ubs]
         lower_all[-1] = torch.tensor([float(res.fun)])
-        return Subproblem(float(res.fun), float(act.reshape(-1)[0]), x0[None], lower_all, upper_all, duals, primals, mask)
+        return Subproblem(float(res.fun), float(act.reshape(-1)[0]), x0[None], lower_all, upper_all, duals, primals, mask, (lbs, ubs))
 
 
 def branch_and_bound(lp, scorer, layers, eps=1e-4, max_nodes=200, decision_bound=None, log=print):
@@ -255,7 +368,7 @@ def branch_and_bound(lp, scorer, layers, eps=1e-4, max_nodes=200, decision_bound
         for choice in (0, 1):
             m = [t.clone() for t in dom.mask]
             m[decision[0]][decision[1]] = choice
-            child = lp.solve(m)
+            child = lp.solve(m, parent=dom, split_layer=decision[0])
             visited += 1
             if child is None:
                 continue
@@ -296,7 +409,7 @@ def branch_and_bound_online(lp, graph, layers, eps=1e-4, max_nodes=200, decision
         for choice in (0, 1):
             m = [t.clone() for t in dom.mask]
             m[decision[0]][decision[1]] = choice
-            out.append(lp.solve(m))
+            out.append(lp.solve(m, parent=dom, split_layer=decision[0]))
         return out
 
     def child_lb(c):                          # an infeasible child cannot contain a counter-example

@@ -137,3 +137,96 @@ def test_online_bab_learns_on_the_device(problem):
     kw_lines = sum(1 for l in lines if l.split(" decision ")[1].split(" gnn:")[0] == l.rsplit(" decision ", 1)[1])
     assert 1 <= steps <= kw_lines
     assert np.abs(after - before).max() > 0 and np.abs(after - before).max() <= 1.05e-4 * steps + 1e-7
+
+
+# ---- Wong-Kolter intermediate bounds (reference: plnn/dual_network_linear_approximation.py:205-451) -------------------------
+KW_SPEC = [("conv", 3, 4, 4, 2, 1), ("relu",), ("conv", 4, 4, 4, 2, 1), ("relu",), ("flatten",), ("linear", 4 * 8 * 8, 24), ("relu",),
+           ("linear", 24, 10)]
+
+
+@pytest.fixture(scope="module")
+def kw_problem():
+    nets.register_arch("toy_kw", KW_SPEC, seed=77)
+    layers = nets.load_verified_net("toy_kw", 2, 6)
+    rng = np.random.RandomState(9)
+    x = torch.from_numpy(rng.standard_normal((3, 32, 32)).astype(np.float32))
+    eps = 0.04
+    lp = lp_producer.LayerGraphLP(layers, x - eps, x + eps)
+    mask = [torch.full((int(np.prod(lp.shapes[i + 1])),), -1, dtype=torch.long) for i in lp.pre_relu_indices]
+    return layers, x, eps, lp, mask
+
+
+def test_kw_bounds_are_sound_and_within_interval(kw_problem):
+    """Every activation of 10^4 points sampled in the box lies inside the KW bounds; the bounds lie inside the interval
+    bounds and are strictly tighter on the layers behind the second affine map."""
+    layers, x, eps, lp, mask = kw_problem
+    kl, ku = lp.kw_bounds(mask)
+    il, iu = lp.interval_bounds(mask)
+    rng = np.random.RandomState(1)
+    pts = x[None] + eps * torch.from_numpy(rng.uniform(-1, 1, (10000,) + tuple(x.shape)).astype(np.float32))
+    pts[:64] = x[None] + eps * torch.from_numpy(np.sign(rng.standard_normal((64,) + tuple(x.shape))).astype(np.float32))   # box corners
+    a = pts.double()
+    with torch.no_grad():
+        for i, l in enumerate(layers):
+            a = l.double()(a) if isinstance(l, (nn.Conv2d, nn.Linear)) else l(a)
+            lo, up = kl[i + 1].reshape(a.shape[1:]), ku[i + 1].reshape(a.shape[1:])
+            assert bool((a >= lo[None] - 1e-6).all()) and bool((a <= up[None] + 1e-6).all()), i
+    for l in layers:
+        l.float()
+    tighter = 0.0
+    for i in range(len(kl)):
+        assert bool((kl[i] >= il[i] - 1e-9).all()) and bool((ku[i] <= iu[i] + 1e-9).all())
+        assert bool((kl[i] <= ku[i] + 1e-9).all())
+        if i >= 3:
+            tighter += float(((iu[i] - il[i]) - (ku[i] - kl[i])).sum())
+    assert tighter > 0
+    # the raw dual-network pass alone (no interval intersection) is sound too, and it is what tightens the last layers
+    q = max(i for i, l in enumerate(layers[:-1]) if isinstance(l, nn.Linear))
+    rl, ru = lp._kw_layer(q, kl, ku)
+    with torch.no_grad():
+        a = pts[:2000].double()
+        for i, l in enumerate(layers[:q + 1]):
+            a = l.double()(a) if isinstance(l, (nn.Conv2d, nn.Linear)) else l(a)
+    for l in layers:
+        l.float()
+    assert bool((a >= rl[None] - 1e-6).all()) and bool((a <= ru[None] + 1e-6).all())
+    assert float((ru - rl).sum()) < float((iu[q + 1] - il[q + 1]).sum())
+
+
+def test_kw_lp_bound_is_at_least_the_interval_lp_bound(kw_problem):
+    layers, x, eps, lp, mask = kw_problem
+    sub_kw = lp.solve(mask)
+    lp_int = lp_producer.LayerGraphLP(layers, x - eps, x + eps, bounds="interval")
+    sub_int = lp_int.solve(mask)
+    assert sub_kw.lb >= sub_int.lb - 1e-7                   # a tighter relaxation cannot give a lower bound
+    outs = [run(layers, x + eps * torch.from_numpy(np.random.RandomState(s).uniform(-1, 1, x.shape).astype(np.float32)))[-1].item() for s in range(200)]
+    assert sub_kw.lb <= min(outs) + 1e-6
+
+
+def test_kw_bounds_are_monotone_and_incremental_under_branching(kw_problem):
+    """A child's bounds lie inside its parent's; below the split layer they ARE the parent's (only the split node clamped);
+    the incremental form lies inside the from-scratch bounds of the same mask."""
+    layers, x, eps, lp, mask = kw_problem
+    root = lp.solve(mask)
+    rl = 1                                                   # split on the second ReLU layer
+    amb = torch.nonzero(root.mask[rl] == -1).reshape(-1)
+    node = int(amb[len(amb) // 2])
+    for choice in (0, 1):
+        m = [t.clone() for t in root.mask]
+        m[rl][node] = choice
+        child = lp.solve(m, parent=root, split_layer=rl)
+        assert child is not None
+        cl, cu = child.bounds64
+        pl, pu = root.bounds64
+        sl, su = lp.kw_bounds(m)                             # from scratch, no parent
+        cut = lp.pre_relu_indices[rl]
+        for i in range(len(cl) - 1):
+            assert bool((cl[i] >= pl[i] - 1e-9).all()) and bool((cu[i] <= pu[i] + 1e-9).all())
+            assert bool((cl[i] >= sl[i] - 1e-9).all()) and bool((cu[i] <= su[i] + 1e-9).all())
+            if i < cut:
+                assert torch.equal(cl[i], pl[i]) and torch.equal(cu[i], pu[i])
+        same = torch.ones_like(cl[cut].reshape(-1), dtype=torch.bool)
+        same[node] = False
+        assert torch.equal(cl[cut].reshape(-1)[same], pl[cut].reshape(-1)[same])
+        assert (cu[cut].reshape(-1)[node] <= 0) if choice == 0 else (cl[cut].reshape(-1)[node] >= 0)
+        assert child.lb >= root.lb - 1e-7
