@@ -227,10 +227,10 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
 #endif
   HIPCHK(hipFuncSetAttribute((const void*)k_input_update, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpdInp::FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_score, hipFuncAttributeMaxDynamicSharedMemorySize, PackScore::FLOATS * 4));
-  HIPCHK(hipFuncSetAttribute((const void*)k_gather<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void*)k_gather<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void*)k_gather16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void*)k_gather16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
 #ifdef GNNB_DEV
   if (const char* e = getenv("GNNB_NO_GATHER16")) h->gather16 = !(e[0] == '1');
 #endif
@@ -942,7 +942,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     GArgs a{in->lb[k], in->ub[k], in->mask, src, nb, nt, scored ? 1 : 0, h->R, roff[k], to_dtm(d.g.tm), to_dg(d, h->d_zero),
             EmbedSrc{in->lb[0], in->x_lp, in->ub[0], h->d_pack[PK_EMBED]}, sparse ? in->lb[src_layer] : nullptr, sparse ? in->ub[src_layer] : nullptr,
             sparse && h->s_in_gather ? sout : nullptr};
-    const size_t lds = gather_lds_bytes(d, 0) + (sparse ? sparse_tab_bytes(d) : 0);
+    const size_t lds = gather_lds_bytes(d, 0) + (sparse ? sparse_tab_bytes(d) : 0) + (d.g.lanes == 16 ? 16 + (size_t)WAVES_MLP * STAGE16_FLOATS * 4 : 0);
     long grid = (nt + WAVES_MLP - 1) / WAVES_MLP;
     if (grid > (long)h->n_cu * h->gather_occ) grid = (long)h->n_cu * h->gather_occ;
     lz.run(PC_GATHER, [&] {

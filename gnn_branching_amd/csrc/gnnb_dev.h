@@ -282,5 +282,19 @@ __device__ __forceinline__ void tile_range(long ntiles, int waves, long& begin, 
   end = begin + base + (wg < rem ? 1 : 0);
 }
 
+// dev instrumentation (-DFUSED_TIMING): cycle sums per kernel phase, read back through gnnb_debug_read (tools/fused_timing.py)
+#ifdef FUSED_TIMING      // dev: per-phase cycle sums over all waves (tools/fused_timing.py reads them through gnnb_debug_read)
+__device__ unsigned long long g_fused_t[16];
+#define FUSED_TIMING_ON 1
+#define FT_DECL unsigned long long ft_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ft_last = __builtin_readcyclecounter()
+#define FT_MARK(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); ft_[i] += n_ - ft_last; ft_last = n_; } while (0)
+#define FT_FLUSH() do { if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&g_fused_t[i_], ft_[i_]); atomicAdd(&g_fused_t[15], 1ull); } } while (0)
+#else
+#define FUSED_TIMING_ON 0
+#define FT_DECL
+#define FT_MARK(i)
+#define FT_FLUSH()
+#endif
+
 #define WG_MLP 512       // 8 waves: 2 per SIMD share one LDS copy of the weights
 #define WAVES_MLP 8

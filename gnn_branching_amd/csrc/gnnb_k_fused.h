@@ -19,17 +19,6 @@
 // barrier -- 45 % of the kernel's time for a few tiles per workgroup.)
 #pragma once
 
-#ifdef FUSED_TIMING      // dev: per-phase cycle sums over all waves (tools/fused_timing.py reads them through gnnb_debug_read)
-__device__ unsigned long long g_fused_t[16];
-#define FT_DECL unsigned long long ft_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ft_last = __builtin_readcyclecounter()
-#define FT_MARK(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); ft_[i] += n_ - ft_last; ft_last = n_; } while (0)
-#define FT_FLUSH() do { if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&g_fused_t[i_], ft_[i_]); atomicAdd(&g_fused_t[15], 1ull); } } while (0)
-#else
-#define FT_DECL
-#define FT_MARK(i)
-#define FT_FLUSH()
-#endif
-
 struct FArgs {
   GArgs g;             // the gather (k_gather / k_gather16 arguments; g.nb is unused; g.sout != null: the sparse walk computes the bias sums)
   UpdArgs u;           // the node update (k_node_update arguments; list0 / list1 / cnt0 / cnt1, nb are unused)
@@ -504,5 +493,5 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, FUSED_WAVES / 4) void k_gather_up
     fused_chain<POST>(a, lds, P, valid ? gcP : 0, valid ? r0P : 0.0f, valid ? r1P : 0.0f, sw, valid, lane);
   }
   FT_MARK(6);        // last, partly filled tile
-  FT_FLUSH();
+  if (FUSED_TIMING_ON) FT_FLUSH();
 }

@@ -18,6 +18,7 @@ struct DGather {
   int lanes;             // dst nodes per tile: 32 (32x32x2 MFMA, 2 window slots per k-step) or 16 (16x16x4, 4 slots per k-step)
 };
 
+#define STAGE16_FLOATS (16 * 68 + 16)      // per-wave LDS image of the gathers' row stores (store_tile16 / frag_store_rows_*_staged<16>)
 #define GATHER_CH 8   // k-steps per prefetch chunk
 #define KOFF_PAD (2 * GATHER_CH)   // always-masked koff entries behind the table (one chunk is loaded past the end)
 // window slots in the koff / kvo tables, padding included (gnnb_pack.h fill_gather_tables)
@@ -670,9 +671,39 @@ __device__ __forceinline__ void gather_compute_tile16(const GArgs& a, const Tile
 }
 
 // one 16-node tile of phase A
+// The aggregate rows of a 16-node tile -> HBM.  Lane (j, g') holds channels 16 g' + 4 r + t of node j; stored straight from
+// there one wave instruction writes 16-B pieces at a 64-B stride (every 64-B sector a quarter full, four times).  Through a
+// 4.3 KB per-wave LDS image (rows padded to 68 floats) each instruction writes four whole 256-B rows instead.
+__device__ __forceinline__ void store_tile16(const f32x4 (&acc)[4], float* stage, float* nb, long gc, bool need, int lane) {
+  const int j = lane & 15, gq = lane >> 4;
+  if (!stage) {
+    if (need) {
+      f32x4* p = reinterpret_cast<f32x4*>(nb + gc * 64 + 16 * gq);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[r] = f32x4{acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+    }
+    return;
+  }
+  f32x4* srow = reinterpret_cast<f32x4*>(stage + j * 68 + 16 * gq);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) srow[r] = f32x4{acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+  int* sgc = reinterpret_cast<int*>(stage + 16 * 68);
+  if (gq == 0) sgc[j] = need ? (int)gc : -1;
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 4 * i + gq;
+    const int g = sgc[row];
+    const f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * 68 + 4 * j);
+    if (g >= 0) *reinterpret_cast<f32x4*>(nb + (long)g * 64 + 4 * j) = v;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 template <bool EMBED, bool SPARSE>
 __device__ __forceinline__ void gather_process_tile16(const GArgs& a, const TileCtx& tc, int sample, const float* lds_cm, const int2* lds_ko,
-                                                      const unsigned* lds_kvo, uint2* tab, const float (&ew)[4][3], const float (&eb)[4], int lane) {
+                                                      const unsigned* lds_kvo, uint2* tab, const float (&ew)[4][3], const float (&eb)[4], int lane,
+                                                      float* stage = nullptr) {
   const int gq = lane >> 4;
   const long gc = tc.sample * a.tm.N + tc.n;
   float ssum = 0.0f;
@@ -682,12 +713,8 @@ __device__ __forceinline__ void gather_process_tile16(const GArgs& a, const Tile
   if (!__any(need)) return;
   f32x4 acc[4];
   gather_compute_tile16<EMBED, SPARSE>(a, tc, sample, lds_cm, lds_ko, lds_kvo, tab, ew, eb, lane, acc, ssum);
-  if (need) {                                  // lane (j, g'): channels 16g' + 4r + t of its node
-    f32x4* p = reinterpret_cast<f32x4*>(a.nb + gc * 64 + 16 * gq);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) p[r] = f32x4{acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-    if (SPARSE && gq == 0 && a.sout) a.sout[gc] = ssum;
-  }
+  if (SPARSE && need && gq == 0 && a.sout) a.sout[gc] = ssum;
+  store_tile16(acc, stage, a.nb, gc, need, lane);
 }
 
 // LDS image of a gather's tables: tap matrix, window offsets (two forms), tile table
@@ -734,8 +761,13 @@ __global__ __launch_bounds__(WG_MLP, 4) void k_gather16(GArgs a) {
   stage_gather(gl.cm, gl.ko, gl.tt, gl.kvo, a.g, a.tm.TPS);
   __syncthreads();
   const int lane = threadIdx.x & 63, j = lane & 15, wave = threadIdx.x >> 6;
-  // SPARSE: per-wave table of the live window slots, behind the shared tables
-  uint2* tab = reinterpret_cast<uint2*>(gl.kvo + ((gather_slots(a.g.K2, 16) + 1) & ~1)) + wave * (4 * a.g.K2 + 32);
+#ifdef GATHER_STAGGER      // dev: start the waves of a workgroup GATHER_STAGGER x 64 cycles apart (they otherwise run their phases in lockstep)
+  for (int w_ = 0; w_ < __builtin_amdgcn_readfirstlane(wave); ++w_) __builtin_amdgcn_s_sleep(GATHER_STAGGER);
+#endif
+  // per wave, behind the shared tables: the staging image of store_tile16, then (SPARSE) the table of the live window slots
+  float* wsc = reinterpret_cast<float*>(gl.kvo + ((gather_slots(a.g.K2, 16) + 3) & ~3));
+  float* stage = wsc + wave * STAGE16_FLOATS;
+  uint2* tab = reinterpret_cast<uint2*>(wsc + WAVES_MLP * STAGE16_FLOATS) + wave * (4 * a.g.K2 + 32);
   float ew[4][3] = {}, eb[4] = {};               // EMBED: inp_f rows of this lane's channels 4i .. 4i+3
   if (EMBED) {
 #pragma unroll
@@ -753,14 +785,46 @@ __global__ __launch_bounds__(WG_MLP, 4) void k_gather16(GArgs a) {
   const int nwg = gridDim.x;
   if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
   const long nrounds = (a.ntiles + WAVES_MLP - 1) / WAVES_MLP;
+  FT_DECL;
   for (long r = wg; r < nrounds; r += nwg) {
     const long tile = r * WAVES_MLP + wave;
     if (tile >= a.ntiles) break;
     const int sample = __builtin_amdgcn_readfirstlane((int)(tile / a.tm.TPS));
     const int t = __builtin_amdgcn_readfirstlane((int)(tile - (long)sample * a.tm.TPS));
     const TileCtx tc = block_decode(a.tm, gl.tt, sample, t, j);
-    gather_process_tile16<EMBED, SPARSE>(a, tc, sample, gl.cm, gl.ko, gl.kvo, tab, ew, eb, lane);
+#ifdef FUSED_TIMING
+    {
+      FT_MARK(0);                               // loop overhead + decode
+      const int gq = lane >> 4;
+      const long gc = tc.sample * a.tm.N + tc.n;
+      float ssum = 0.0f;
+      const bool need = tc.valid && node_is_live(a.lb[gc], a.ub[gc]);
+      if (!__any(need)) { FT_MARK(1); continue; }
+      FT_MARK(1);                               // bounds of the dst nodes (one memory round trip)
+      f32x4 acc[4];
+      gather_compute_tile16<EMBED, SPARSE>(a, tc, sample, gl.cm, gl.ko, gl.kvo, tab, ew, eb, lane, acc, ssum);
+      FT_MARK(2);                               // walk
+      if (need) {
+        f32x4* p = reinterpret_cast<f32x4*>(a.nb + gc * 64 + 16 * gq);
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) p[r4] = f32x4{acc[0][r4], acc[1][r4], acc[2][r4], acc[3][r4]};
+        if (SPARSE && gq == 0 && a.sout) a.sout[gc] = ssum;
+      }
+      FT_MARK(3);                               // store issue
+#if FUSED_TIMING > 1
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      FT_MARK(4);                               // store completion (perturbs: the next tile's loads wait for it anyway)
+#endif
+    }
+#else
+    gather_process_tile16<EMBED, SPARSE>(a, tc, sample, gl.cm, gl.ko, gl.kvo, tab, ew, eb, lane, stage);
+#endif
   }
+#ifdef FUSED_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  FT_MARK(5);
+  if (FUSED_TIMING < 3 && !EMBED && !SPARSE) FT_FLUSH();       // (the dense layer-1 gather only)
+#endif
 }
 
 struct GIArgs {

@@ -364,7 +364,9 @@ __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, i
     } else stage_pack(lds, a.pack, PackUpd::FLOATS);
   }
   if (tile >= ntiles) return;
+  FT_DECL;
   for (;;) {
+    FT_MARK(0);                                // loop overhead
     const Ratio r = compute_ratio(lb, ub);
     const bool kind0 = tile >= n1;             // wave-uniform
     const long next = tile + stride;
@@ -391,21 +393,23 @@ __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, i
       }
       gemm_w64<64>(lds + O_WA, lane, H, [&](int s) { return FRAG_AT(X, s & 31) * (s < 32 ? r0 : r1); });
     }
+    FT_MARK(1);                                // wait for this tile's rows + first GEMM
     __builtin_amdgcn_sched_barrier(0);         // X is dead from here: the next tile's row loads go into it, under the second GEMM
     if (has_next) frag_load_rows(X, a.nb, gc_n, h);
     __builtin_amdgcn_sched_barrier(0);
+    FT_MARK(2);                                // wait for the next tile's list entry / scalars + issue of its row loads
     frag_relu(H);
     if (BF3) gemm_w64_bf3<1>(lds + PackUpdL3::WCB3, lane, H2, [&](int s) { return FRAG_AT(H, s); });
     else gemm_w64<32>(lds + PackUpd::WCB, lane, H2, [&](int s) { return FRAG_AT(H, s); });
     frag_relu(H2);
+    FT_MARK(3);                                // second GEMM
     if (r.live == 0.0f) {                      // a dead node's row is zero whatever its (possibly never written) aggregate held
 #pragma unroll
       for (int R = 0; R < 32; ++R) FRAG_AT(H2, R) = 0.0f;
     }
-    if (valid) {
-      if (frag_has_nan(H2)) atomicOr(a.status, 1);      // a NaN here is a NaN in mu = Wd.E + bd (:184-186, :339-341)
-      if (a.mu) frag_store_rows(H2, a.mu, gc, h);
-    }
+    // (row stores through an LDS image, whole 256-B rows per instruction instead of 32-B pieces: measured, no gain here)
+    if (valid && frag_has_nan(H2)) atomicOr(a.status, 1);      // a NaN here is a NaN in mu = Wd.E + bd (:184-186, :339-341)
+    if (valid && a.mu) frag_store_rows(H2, a.mu, gc, h);
     if (post) {
 #pragma unroll
       for (int R = 0; R < 32; ++R) FRAG_AT(H, R) = 0.0f;
@@ -413,9 +417,13 @@ __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, i
       else gemm_w64<32>(lds + O_END, lane, H, [&](int s) { return FRAG_AT(H2, s); });
       if (valid) frag_store_rows(H, a.post, gc, h);
     }
+    FT_MARK(4);                                // stores (+ POST block)
     if (!has_next) break;
     tile = next; gc = gc_n; valid = valid_n; lb = lb_n; ub = ub_n; sw = sw_n;
   }
+#ifdef FUSED_TIMING
+  if (FUSED_TIMING == 3 && !POST) FT_FLUSH();
+#endif
 }
 
 template <int WAVES, bool DEFERRED, bool POST = false, bool BF3 = false>
