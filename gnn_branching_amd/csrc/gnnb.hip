@@ -19,7 +19,7 @@
 //     round's input-layer update (:360-385), whose result nothing reads.
 //
 // One translation unit: gnnb_dev.h (fragments, GEMM blocks, tile maps), gnnb_k_mlp.h (setup + node-MLP kernels),
-// gnnb_k_gather.h (conv-edge message passing + score head), gnnb_k_fused.h (gather + node update in one kernel), gnnb_k_edges.h (other edges, k_top), gnnb_k_misc.h (k_livesum,
+// gnnb_k_gather.h (conv-edge message passing + score head), gnnb_k_fusedq.h (gather + node update in one kernel), gnnb_k_edges.h (other edges, k_top), gnnb_k_misc.h (k_livesum,
 // k_babsr, k_reset), gnnb_train.h (online learning) are included below; this file holds the host side and the C-ABI.
 //
 // gfx950 only.  No HIP call at load time.
@@ -45,7 +45,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #include "gnnb_dev.h"
 #include "gnnb_k_mlp.h"
 #include "gnnb_k_gather.h"
-#include "gnnb_k_fused.h"
+#include "gnnb_k_fusedq.h"
 #include "gnnb_k_edges.h"
 #include "gnnb_k_misc.h"
 
@@ -112,8 +112,9 @@ struct gnnb_handle {
                                 // gathers, bit 1 = 32-node gathers, bit 2 = the input-layer gather
   bool gather16 = true;         // forward conv edges: 16-node tiles on the 16x16x4 MFMA when their window is smaller
   bool embed_fuse = true;       // round 0: the first forward gather computes the input embedding itself (no k_embed, no mu[0] rows)
-  bool fuse = false;            // GNNB_FUSE=1: conv edges as ONE kernel per half-pass (k_gather_update: the aggregate never reaches HBM).
-                                // Off by default: parity-green and 33 % less HBM traffic, but 5-20 % slower than the two kernels
+  int fuse = 1;                 // conv half-passes as ONE kernel (k_gather_update_q: the aggregate never reaches HBM): 0 never, 2 wherever
+                                // the kernel exists, 1 (default) where it is the faster form (fuse_edge below).  Both forms compute
+                                // the same arithmetic per node -- results are bit-identical -- so this is a pure scheduling choice.  GNNB_FUSE
   bool use_top = true;          // fuse the top of the network (last Linear edge, last ReLU layer, property node) into k_top
   bool top_ok = false;          // ... which the bound network allows (set by gnnb_bind_network)
   int per_sample_min_b = 0;     // GNNB_PER_SAMPLE_MIN_B: batches below it take the per-tile dense kernel + separate launches
@@ -253,14 +254,10 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   HIPCHK(hipFuncSetAttribute((const void*)k_gather<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   if (const char* e = getenv("GNNB_NO_GATHER")) h->use_gather = !(e[0] == '1');
   if (const char* e = getenv("GNNB_NO_TOP")) h->use_top = !(e[0] == '1');
-  if (const char* e = getenv("GNNB_FUSE")) h->fuse = e[0] == '1';
-#define FUSED_ATTR(L, S, P, N) HIPCHK(hipFuncSetAttribute((const void*)k_gather_update<L, S, P, N>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_MAX_LDS))
-  FUSED_ATTR(16, 2, false, 1);
-  FUSED_ATTR(16, 0, false, 1); FUSED_ATTR(16, 0, false, 2); FUSED_ATTR(16, 0, false, 4);
-  FUSED_ATTR(16, 1, false, 1); FUSED_ATTR(16, 1, false, 2); FUSED_ATTR(16, 1, false, 4);
-  FUSED_ATTR(32, 1, false, 1); FUSED_ATTR(32, 1, false, 2); FUSED_ATTR(32, 1, false, 4);
-  FUSED_ATTR(32, 1, true, 1); FUSED_ATTR(32, 1, true, 2); FUSED_ATTR(32, 1, true, 4);
-#undef FUSED_ATTR
+  if (const char* e = getenv("GNNB_FUSE")) h->fuse = e[0] - '0';
+#define FUSEDQ_ATTR(L, S, P) HIPCHK(hipFuncSetAttribute((const void*)k_gather_update_q<L, S, P>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+  FUSEDQ_ATTR(16, 0, false); FUSEDQ_ATTR(16, 1, false); FUSEDQ_ATTR(16, 2, false); FUSEDQ_ATTR(32, 1, false); FUSEDQ_ATTR(32, 1, true);
+#undef FUSEDQ_ATTR
   if (const char* e = getenv("GNNB_PER_SAMPLE_MIN_B")) h->per_sample_min_b = atoi(e);
   HIPCHK(hipFuncSetAttribute((const void*)k_top, hipFuncAttributeMaxDynamicSharedMemorySize, TOP_LDS_FLOATS * 4));
   *out = h;
@@ -535,18 +532,6 @@ static size_t gather_lds_bytes(const DevGather& d, size_t pack_floats) {
 // per-wave live-slot tables of the sparse gathers (behind the shared tables, 8-byte aligned)
 static size_t sparse_tab_bytes(const DevGather& d) {
   return 8 + (size_t)WAVES_MLP * ((d.g.lanes == 16 ? 4 : 2) * d.g.K2 + 32) * 8;
-}
-
-// k_gather_update over one conv edge at batch B: grid, dynamic LDS bytes
-struct FusedGeom { long grid; size_t lds; };
-static FusedGeom fused_geom(const gnnb_t* h, const DevGather& d, int B, bool sparse, bool post) {
-  FusedGeom f;
-  const long nt = map_tiles(d.g.tm, B), nrounds = (nt + FUSED_WAVES - 1) / FUSED_WAVES;
-  f.grid = std::max<long>(1, std::min<long>(nrounds, h->n_cu));
-  const size_t tables = (size_t)d.g.tm.NCG * d.g.K2 * 64 * 4 + (size_t)gather_slots(d.g.K2, d.g.lanes) * 8 + (size_t)((d.g.tm.TPS + 3) & ~3) * 4 +
-                        (size_t)((gather_slots(d.g.K2, d.g.lanes) + 3) & ~3) * 4;
-  f.lds = (size_t)(PackUpdF3::FLOATS + (post ? 6144 : 0)) * 4 + tables + FUSED_WAVES * fused_wave_bytes(d.g.K2, d.g.lanes, sparse);
-  return f;
 }
 
 #ifdef FUSED_TIMING
@@ -1072,7 +1057,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   // runs, the restricted last step (every node it updates takes the general chain), gathers without the sparse walk behind a
   // ReLU layer, tile forms the fused kernel is not built for, tables that do not fit beside the weights in LDS.
   auto fused_halfpass = [&](int k, bool fwd, bool post_input) -> bool {
-    if (!h->fuse || !h->bf3 || debug_full) return false;
+    if (h->fuse == 0 || !h->bf3 || debug_full) return false;
     const DevGather& d = fwd ? h->gf[k] : h->gb[k + 1];
     if (!d.ok) return false;
     const int src_layer = fwd ? k - 1 : k + 1;
@@ -1082,35 +1067,36 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     if (d.g.lanes == 32 && !sparse) return false;
     if (d.g.lanes == 16 && post_input) return false;
     if (!fwd && k >= L) return false;
-    const FusedGeom fg = fused_geom(h, d, B, sparse, post_input);
-    if (fg.lds > FUSED_MAX_LDS || (d.g.lanes == 16 ? 4 : 2) * d.g.K2 > 64 * FW_MAXIT) return false;
     const long nt = map_tiles(d.g.tm, B);
-    FArgs a{};
-    float* sout = fwd ? ws + w.sf[k] : ws + w.sb[k];
-    a.sw_from_gather = sparse && h->s_in_gather ? 1 : 0;
-    a.g = GArgs{in->lb[k], in->ub[k], in->mask, fwd ? mu(k - 1) : mu(k + 1), nb, nt, 0, h->R, roff[k], to_dtm(d.g.tm), to_dg(d, h->d_zero),
-                EmbedSrc{in->lb[0], in->x_lp, in->ub[0], h->d_pack[PK_EMBED]}, sparse ? in->lb[src_layer] : nullptr, sparse ? in->ub[src_layer] : nullptr,
-                a.sw_from_gather ? sout : nullptr};
-    a.u = upd_args(k, fwd, false, post_input);
-    const dim3 g((unsigned)fg.grid), b(FUSED_WAVES * 64);
-    const int nslots = (d.g.lanes == 16 ? 4 : 2) * d.g.K2, nit = nslots <= 64 ? 1 : (nslots <= 128 ? 2 : 4);      // 64-slot sweeps per window
-    lz.run(PC_GATHER_UPDATE, [&] {
-#define FUSED_LAUNCH(L, S, P)                                                                       \
-  do {                                                                                              \
-    if (nit == 1) hipLaunchKernelGGL((k_gather_update<L, S, P, 1>), g, b, fg.lds, st, a);           \
-    else if (nit == 2) hipLaunchKernelGGL((k_gather_update<L, S, P, 2>), g, b, fg.lds, st, a);      \
-    else hipLaunchKernelGGL((k_gather_update<L, S, P, 4>), g, b, fg.lds, st, a);                    \
-  } while (0)
-      if (d.g.lanes == 16) {
-        if (embed_src) hipLaunchKernelGGL((k_gather_update<16, 2, false, 1>), g, b, fg.lds, st, a);
-        else if (sparse) FUSED_LAUNCH(16, 1, false);
-        else FUSED_LAUNCH(16, 0, false);
-      } else if (post_input) FUSED_LAUNCH(32, 1, true);
-      else FUSED_LAUNCH(32, 1, false);
-#undef FUSED_LAUNCH
-    });
-    proj[k] = fwd ? L_FC4_2 : L_BC4_1;
-    return true;
+    // where the fused form wins (MI355X): every sparse 16-node forward gather (64 vs 71 us on base B = 256);
+    // everything when the launch count is what binds (few tiles per CU: small batches, the per-decision calls of the BaB loop)
+    if (h->fuse == 1 && !(d.g.lanes == 16 && sparse) && nt > (long)h->n_cu * 16) return false;
+    {
+      const size_t tables = (size_t)d.g.tm.NCG * d.g.K2 * 64 * 4 + (size_t)gather_slots(d.g.K2, d.g.lanes) * 8 + (size_t)((d.g.tm.TPS + 3) & ~3) * 4 +
+                            (size_t)((gather_slots(d.g.K2, d.g.lanes) + 3) & ~3) * 4;
+      const size_t ldsq = (size_t)(PackUpdL3::FLOATS + (post_input ? 6144 : 0) + fusedq_queue_floats()) * 4 + tables +
+                          (sparse ? (size_t)QG_WAVES * ((d.g.lanes == 16 ? 4 : 2) * d.g.K2 + 32) * 8 : 0);
+      if (ldsq > 160 * 1024) return false;
+      FArgs a{};
+      float* sout = fwd ? ws + w.sf[k] : ws + w.sb[k];
+      a.sw_from_gather = sparse && h->s_in_gather ? 1 : 0;
+      a.g = GArgs{in->lb[k], in->ub[k], in->mask, fwd ? mu(k - 1) : mu(k + 1), nb, nt, 0, h->R, roff[k], to_dtm(d.g.tm), to_dg(d, h->d_zero),
+                  EmbedSrc{in->lb[0], in->x_lp, in->ub[0], h->d_pack[PK_EMBED]}, sparse ? in->lb[src_layer] : nullptr, sparse ? in->ub[src_layer] : nullptr,
+                  a.sw_from_gather ? sout : nullptr};
+      a.u = upd_args(k, fwd, false, post_input);
+      const long nrounds = (nt + QG_WAVES - 1) / QG_WAVES;
+      const dim3 g((unsigned)std::max<long>(1, std::min<long>(nrounds, h->n_cu))), b((QG_WAVES + QC_WAVES) * 64);
+      lz.run(PC_GATHER_UPDATE, [&] {
+        if (d.g.lanes == 16) {
+          if (embed_src) hipLaunchKernelGGL((k_gather_update_q<16, 2, false>), g, b, ldsq, st, a);
+          else if (sparse) hipLaunchKernelGGL((k_gather_update_q<16, 1, false>), g, b, ldsq, st, a);
+          else hipLaunchKernelGGL((k_gather_update_q<16, 0, false>), g, b, ldsq, st, a);
+        } else if (post_input) hipLaunchKernelGGL((k_gather_update_q<32, 1, true>), g, b, ldsq, st, a);
+        else hipLaunchKernelGGL((k_gather_update_q<32, 1, false>), g, b, ldsq, st, a);
+      });
+      proj[k] = fwd ? L_FC4_2 : L_BC4_1;
+      return true;
+    }
   };
   auto update_input = [&]() {
     proj[0] = L_INP_B2_2;

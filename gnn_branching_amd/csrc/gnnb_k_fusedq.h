@@ -1,0 +1,236 @@
+// gnnb_k_fusedq.h -- part of libgnnb.so, included by gnnb.hip (one translation unit; see its header comment).
+// k_gather_update_q: one conv half-pass (gather of the neighbour aggregate + folded node update, reference graph_conv.py:110-181
+// forward, :299-349 backward) in ONE kernel with the waves of a workgroup SPECIALISED: QG_WAVES gather waves, the rest chain waves, and an
+// LDS row queue between them -- the aggregate rows never reach HBM.
+//
+// Why this shape (measured): the gather wants many light waves (72-104 registers; 16 per CU: 76 us, 8: 85 us),
+// the node update 150 registers per wave.  The first fused form -- every wave gathers a tile, compacts its live nodes into a
+// pending chain tile IN REGISTERS (ds_bpermute) and runs the chain when that is full -- had to run 8 waves of 240 registers and
+// serialised the two latency chains in each wave: parity-green, 33 % less HBM traffic, and 5-20 % SLOWER than the two kernels (12
+// waves spilled 30-90 registers and were slower still; a software-pipelined table walk for its gather bought nothing).  Here the
+// gather waves run the stand-alone gathers' code and only stop storing rows to HBM: the live nodes of a tile are ranked with a
+// ballot and written to consecutive rows of a ring of 4 x 32 rows in LDS.  A chain wave claims the next tile, waits for its 32
+// rows, copies them to registers, hands the ring slot back and runs the bf16x3 chain on them (the whole kernel fits 128 registers
+// = 4 waves per SIMD), stores the rows of mu.
+//
+// Queue protocol (all in LDS; `q` points at QHDR_INTS ints):
+//   reserve            rows handed out so far (atomic add by the gather waves: rows of a tile are consecutive)
+//   filled[s]          rows written into ring slot s for its current tile
+//   free_id[s]         the tile id slot s accepts (starts at s; the chain wave sets T + QTILES when it is done with tile T)
+//   done               gather waves that have finished
+// A gather wave writes its rows of tile T only after free_id[T % QTILES] == T, then adds their number to filled[.] (LDS executes
+// one wave's operations in order, so the count lands after the rows).  Tile T's rows were reserved before tile T + QTILES's, and a
+// wave publishes its part of T before it waits for T + 1: no cycle.  Chain wave c takes tiles c, c + 4, ...; it leaves when all
+// gather waves are done and `reserve` says there is no tile T (a last, partly filled tile runs with its missing lanes masked).
+// Every poll loop has an iteration cap that raises status bit 2 and leaves: a protocol bug must never hang the GPU.
+// Ambiguous nodes ride in the same tiles: every node goes through H = WAS.(r0 x) + Wa[:, 64:].((r1 - r0) x) (PackUpdL3), the second
+// block -- exact zeros for r0 == r1 -- only runs when the tile holds such a node.  k_node_update does the same arithmetic per node, so
+// the fused and the two-kernel half-pass are bit-identical and which one runs is a pure scheduling decision.
+#pragma once
+
+struct FArgs {
+  GArgs g;             // the gather (k_gather / k_gather16 arguments; g.nb is unused; g.sout != null: the sparse walk computes the bias sums)
+  UpdArgs u;           // the node update (k_node_update arguments; list0 / list1 / cnt0 / cnt1, nb are unused)
+  int sw_from_gather;  // 1: the bias-sum scalar of a node comes out of its (sparse) gather; 0: u.sarr holds it (table / k_livesum)
+};
+
+#ifndef QG_WAVES
+#define QG_WAVES 8            // gather waves (8 + 8 chain waves measured best on base B = 256; 10 + 6 and 12 + 4 are 2-8 % slower)
+#endif
+#define QC_WAVES (16 - QG_WAVES)      // chain waves
+#define QTILES 4              // ring slots of 32 rows
+#define QROW 72               // floats per ring row: 64 channels, {node id | ambiguous << 31, r0, r1, s}, 4 pad (16-B rows, <= 2-way bank conflicts)
+#define QHDR_INTS 16
+#define Q_POLL_CAP (1 << 22)
+__host__ __device__ constexpr size_t fusedq_queue_floats() { return (size_t)QTILES * 32 * QROW + QHDR_INTS; }
+
+struct QHdr { int reserve, done, claim, pad1, filled[QTILES], free_id[QTILES], pad2[4]; };
+static_assert(sizeof(QHdr) == QHDR_INTS * 4, "queue header");
+
+// (acquire / release at workgroup scope: LDS needs no cache maintenance, this only keeps compiler and wait counters honest)
+__device__ __forceinline__ int q_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// the folded node update (see node_update_loop) on ring slot `ring` (32 rows of QROW floats); `release` runs once the rows are in registers
+template <bool POST, class Release>
+__device__ __forceinline__ void q_chain(const FArgs& a, const float* lds, const float* ring, int nvalid, int lane, Release release) {
+  const int h = lane >> 5, j = lane & 31;
+  const bool valid = j < nvalid;
+  const float* row = ring + j * QROW;
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(row + 64);
+  const int gc_amb = __float_as_int(sc[0]);
+  const int gc = valid ? (gc_amb & 0x7fffffff) : 0;
+  const float r0 = valid ? sc[1] : 0.0f, r1 = valid ? sc[2] : 0.0f;
+  const bool amb = valid && gc_amb < 0;
+  const float sw = !valid ? 0.0f : (a.sw_from_gather ? sc[3] : a.u.sarr[a.u.smod > 0 ? gc % a.u.smod : gc]);
+  Frag X;                                    // fragment order: register 4 q + c = feature 8 q + 4 h + c
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(row + 8 * q + 4 * h);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) FRAG_AT(X, 4 * q + c) = v[c];
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the rows and scalars are in registers
+  release();
+  Frag H, H2;
+  frag_bias(H, lds + PackUpdL3::BA, h);
+  {
+    const float x[1] = {(h ? r1 : r0) * sw};            // + s.(r0 Wa0.bp + r1 Wa1.bp): the bias of the source rows' deferred projection
+    gemm_small<1>(lds + PackUpdL3::VAW, lane, H, x);
+  }
+  gemm_w64_bf3<1>(lds + PackUpdL3::WAS3, lane, H, [&](int s) { return FRAG_AT(X, s) * r0; });
+  if (__any(amb)) {
+    const float dr = r1 - r0;
+    gemm_w64_bf3<1>(lds + PackUpdL3::WA1S3, lane, H, [&](int s) { return FRAG_AT(X, s) * dr; });
+  }
+  // P' of an ambiguous node: its cached row (k_pre); of every other node: the bias row
+  frag_load_rowptr(H2, amb ? a.u.P + (long)gc * 64 : a.u.pack + PackUpd::BCBROW, h);
+  frag_relu(H);
+  gemm_w64_bf3<1>(lds + PackUpdL3::WCB3, lane, H2, [&](int s) { return FRAG_AT(H, s); });
+  frag_relu(H2);
+  if (valid) {
+    if (frag_has_nan(H2)) atomicOr(a.u.status, 1);
+    if (a.u.mu) frag_store_rows(H2, a.u.mu, gc, h);
+  }
+  if (POST) {
+#pragma unroll
+    for (int R = 0; R < 32; ++R) FRAG_AT(H, R) = 0.0f;
+    gemm_w64_bf3<1>(lds + PackUpdL3::FLOATS, lane, H, [&](int s) { return FRAG_AT(H2, s); });
+    if (valid) frag_store_rows(H, a.u.post, gc, h);
+  }
+}
+
+// LANES: dst nodes per gather tile (16: forward edges, 32: transposed edges).  SRC: 0 dense source rows, 1 sparse walk (the source
+// is a ReLU layer), 2 round-0 embedding computed in the gather (16-node tiles only).  POST: see UpdArgs.
+template <int LANES, int SRC, bool POST>
+__global__ __launch_bounds__((QG_WAVES + QC_WAVES) * 64, 4) void k_gather_update_q(FArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr bool SPARSE = SRC == 1, EMBED = SRC == 2;
+  float* qbase = lds + PackUpdL3::FLOATS + (POST ? 6144 : 0);
+  QHdr* q = reinterpret_cast<QHdr*>(qbase + (size_t)QTILES * 32 * QROW);
+  float* gbase = qbase + fusedq_queue_floats();
+  const GatherLds gl = gather_lds(gbase, a.g.g, a.g.tm.TPS);
+  stage_gather(gl.cm, gl.ko, gl.tt, gl.kvo, a.g.g, a.g.tm.TPS);
+  copy_to_lds(lds + PackUpdL3::BA, a.u.pack + PackUpd::BA, 64);
+  copy_to_lds(lds + PackUpdL3::BCB, a.u.pack + PackUpd::BCB, 64 + 64 + 128);          // BCB, BCBROW, VAW
+  copy_to_lds(lds + PackUpdL3::WAS3, a.u.pack + PackUpd::WAS3, 6144);
+  copy_to_lds(lds + PackUpdL3::WCB3, a.u.pack + PackUpd::WCB3, 6144);
+  copy_to_lds(lds + PackUpdL3::WA1S3, a.u.pack + PackUpd::WA1S3, 6144);
+  if (POST) copy_to_lds(lds + PackUpdL3::FLOATS, a.u.wp, 6144);
+  if (threadIdx.x < QHDR_INTS) reinterpret_cast<int*>(q)[threadIdx.x] = 0;
+  __syncthreads();
+  if (threadIdx.x < QTILES) q->free_id[threadIdx.x] = threadIdx.x;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+  if (wave >= QG_WAVES) {
+    // ---------------- chain wave: claims the next tile, copies it out of its ring slot, releases the slot, runs the chain ----------------
+    for (;;) {
+      int T = 0;
+      if (lane == 0) T = atomicAdd(&q->claim, 1);
+      T = __builtin_amdgcn_readfirstlane(T);
+      const int s = T % QTILES;
+      const float* ring = qbase + (size_t)s * 32 * QROW;
+      int nvalid = -1;
+      for (int it = 0; it < Q_POLL_CAP; ++it) {
+        if (q_ld(&q->free_id[s]) == T && q_ld(&q->filled[s]) == 32) { nvalid = 32; break; }
+        if (q_ld(&q->done) == QG_WAVES) {            // every row there will ever be has been published
+          const int rem = q_ld(&q->reserve) - 32 * T;
+          nvalid = rem <= 0 ? 0 : (rem < 32 ? rem : 32);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      if (nvalid < 0) { if (lane == 0) atomicOr(a.u.status, 2); return; }
+      if (nvalid == 0) return;
+      q_chain<POST>(a, lds, ring, nvalid, lane, [&]() {
+        // (called once the rows are in registers) hand the slot back before the chain runs: the ring only has to cover the
+        // time a tile takes to fill and to be copied out, not the ~10 us of its chain
+        if (nvalid == 32 && lane == 0) {
+          __hip_atomic_store(&q->filled[s], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_store(&q->free_id[s], T + QTILES, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      });
+      if (nvalid < 32) return;                       // the last, partly filled tile
+    }
+  }
+
+  // ---------------- gather wave ----------------
+  const int jn = LANES == 16 ? (lane & 15) : (lane & 31);
+  const int h = lane >> 5;
+  char* wsc = reinterpret_cast<char*>(gl.kvo + ((gather_slots(a.g.g.K2, LANES) + 3) & ~3));
+  uint2* tab = reinterpret_cast<uint2*>(wsc) + (size_t)wave * ((LANES == 16 ? 4 : 2) * a.g.g.K2 + 32);      // SPARSE: live window slots of this wave's tile
+  const EmbedLane el{};
+  float ew[4][3] = {}, eb[4] = {};
+  if (EMBED && !EMBED_MFMA) {
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      eb[cc] = a.g.es.wb[192 + 4 * jn + cc];
+#pragma unroll
+      for (int qq = 0; qq < 3; ++qq) ew[cc][qq] = a.g.es.wb[(4 * jn + cc) * 3 + qq];
+    }
+  }
+  int wg = blockIdx.x;
+  const int nwg = gridDim.x;
+  if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
+  const long nrounds = (a.g.ntiles + QG_WAVES - 1) / QG_WAVES;
+  bool stuck = false;
+  for (long r = wg; r < nrounds && !stuck; r += nwg) {
+    const long tile = r * QG_WAVES + wave;
+    if (tile >= a.g.ntiles) break;
+    const int sample = __builtin_amdgcn_readfirstlane((int)(tile / a.g.tm.TPS));
+    const int t = __builtin_amdgcn_readfirstlane((int)(tile - (long)sample * a.g.tm.TPS));
+    const TileCtx tc = block_decode(a.g.tm, gl.tt, sample, t, jn);
+    const int gc = (int)(tc.sample * a.g.tm.N + tc.n);
+    const float lb = a.g.lb[gc], ub = a.g.ub[gc];
+    const bool need = tc.valid && node_is_live(lb, ub);
+    if (!__any(need)) continue;
+    const Ratio rt = compute_ratio(lb, ub);
+    float ssum = 0.0f;
+    Frag X;
+    f32x4 acc[4];
+    if (LANES == 32) gather_compute_tile<false, SPARSE>(a.g, tc, sample, gl.cm, gl.ko, gl.kvo, tab, el, lane, X, ssum);
+    else gather_compute_tile16<EMBED, SPARSE>(a.g, tc, sample, gl.cm, gl.ko, gl.kvo, tab, ew, eb, lane, acc, ssum);
+
+    // ---- the live nodes of the tile -> consecutive rows of the ring ----
+    const unsigned long long bal = __ballot(need) & (LANES == 16 ? 0xffffull : 0xffffffffull);
+    const int n = __popcll(bal);
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&q->reserve, n);
+    base = __builtin_amdgcn_readfirstlane(base);
+    const int pos = base + __popcll(bal & ((1ull << jn) - 1ull));        // this lane's node (if needed) goes to row `pos`
+    const int T0 = base >> 5, T1 = (base + n - 1) >> 5;
+    for (int T = T0; T <= T1; ++T) {
+      const int s = T % QTILES;
+      bool ok = false;
+      for (int it = 0; it < Q_POLL_CAP; ++it) {
+        if (q_ld(&q->free_id[s]) == T) { ok = true; break; }
+        __builtin_amdgcn_s_sleep(4);
+      }
+      if (!ok) { if (lane == 0) atomicOr(a.u.status, 2); stuck = true; break; }
+      const bool mine = need && (pos >> 5) == T;
+      if (mine) {
+        float* row = qbase + ((size_t)s * 32 + (pos & 31)) * QROW;
+        if (LANES == 32) {
+          float* d = row + 8 * h;                   // gather channel map: x.t[0][r], x.t[1][r] = channels 2k, 2k + 1, k = (r & 3) + 8 (r >> 2) + 4 h
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr)
+            *reinterpret_cast<float2*>(d + 2 * (rr & 3) + 16 * (rr >> 2)) = make_float2(X.t[0][rr], X.t[1][rr]);
+          if (h == 0)
+            *reinterpret_cast<f32x4*>(row + 64) = f32x4{__int_as_float(gc | (rt.amb != 0.0f ? (int)0x80000000 : 0)), rt.r0, rt.r1, ssum};
+        } else {
+          const int gq = lane >> 4;                 // lane (j, g'): channels 16 g' + 4 r + t
+          f32x4* d = reinterpret_cast<f32x4*>(row + 16 * gq);
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) d[rr] = f32x4{acc[0][rr], acc[1][rr], acc[2][rr], acc[3][rr]};
+          if (gq == 0)
+            *reinterpret_cast<f32x4*>(row + 64) = f32x4{__int_as_float(gc | (rt.amb != 0.0f ? (int)0x80000000 : 0)), rt.r0, rt.r1, ssum};
+        }
+      }
+      const int lo = T * 32 > base ? T * 32 : base, hi = (T + 1) * 32 < base + n ? (T + 1) * 32 : base + n;
+      __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the rows are in LDS before their count is
+      if (lane == 0) __hip_atomic_fetch_add(&q->filled[s], hi - lo, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  if (lane == 0) __hip_atomic_fetch_add(&q->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}

@@ -319,11 +319,11 @@ struct UpdArgs {
 // The tile loop of the node update: tiles `tile`, `tile + stride`, ... of the lists in `a` (c0 / c1 entries); the weight
 // pack is staged into `lds` here (the first fetch overlaps it).
 // BF3: the 64x64 blocks of the short chain (WAS, WCB) and of POST run on the bf16 matrix rate with three-piece operands
-// (gemm_w64_bf3; LDS image PackUpdL3); the general chain's 128-wide first layer stays on the fp32 MFMA (6-11 % of the tiles).
+// (gemm_w64_bf3; LDS image PackUpdL3), and so does the general chain: its 128-wide first layer as WAS.(r0 x) + Wa[:, 64:].((r1 - r0) x).
 // STAGE = false: the caller (k_gather_update) has the LDS image in place already
 template <bool DEFERRED, bool POST = false, bool BF3 = false, bool STAGE = true>
 __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, int c0, int c1, long tile, long stride, int lane) {
-  constexpr int O_WA = BF3 ? (int)PackUpdL3::WA : (int)PackUpd::WA, O_BA = BF3 ? (int)PackUpdL3::BA : (int)PackUpd::BA;
+  constexpr int O_WA = (int)PackUpd::WA, O_BA = BF3 ? (int)PackUpdL3::BA : (int)PackUpd::BA;
   constexpr int O_BCB = BF3 ? (int)PackUpdL3::BCB : (int)PackUpd::BCB, O_VAW = BF3 ? (int)PackUpdL3::VAW : (int)PackUpd::VAW;
   constexpr int O_END = BF3 ? (int)PackUpdL3::FLOATS : (int)PackUpd::FLOATS;
   const int h = lane >> 5, j = lane & 31;
@@ -357,10 +357,9 @@ __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, i
   if (STAGE) {
     if (post) copy_to_lds(lds + O_END, a.wp, BF3 ? 6144 : 4096);
     if (BF3) {
-      copy_to_lds(lds + PackUpdL3::WA, a.pack + PackUpd::WA, 8192);
       copy_to_lds(lds + PackUpdL3::BA, a.pack + PackUpd::BA, 64);
       copy_to_lds(lds + PackUpdL3::BCB, a.pack + PackUpd::BCB, 64 + 64 + 128);          // BCB, BCBROW, VAW
-      stage_pack(lds + PackUpdL3::WAS3, a.pack + PackUpd::WAS3, 2 * 6144);               // WAS3, WCB3
+      stage_pack(lds + PackUpdL3::WAS3, a.pack + PackUpd::WAS3, 3 * 6144);               // WAS3, WCB3, WA1S3
     } else stage_pack(lds, a.pack, PackUpd::FLOATS);
   }
   if (tile >= ntiles) return;
@@ -391,7 +390,11 @@ __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, i
         const float x[1] = {(h ? r1 : r0) * sw};
         gemm_small<1>(lds + O_VAW, lane, H, x);
       }
-      gemm_w64<64>(lds + O_WA, lane, H, [&](int s) { return FRAG_AT(X, s & 31) * (s < 32 ? r0 : r1); });
+      if (BF3) {                             // Wa.[r0 x, r1 x] = WAS.(r0 x) + Wa[:, 64:].((r1 - r0) x), both blocks bf16 x 3 (PackUpdL3)
+        const float dr = r1 - r0;
+        gemm_w64_bf3<1>(lds + PackUpdL3::WAS3, lane, H, [&](int s) { return FRAG_AT(X, s) * r0; });
+        gemm_w64_bf3<1>(lds + PackUpdL3::WA1S3, lane, H, [&](int s) { return FRAG_AT(X, s) * dr; });
+      } else gemm_w64<64>(lds + O_WA, lane, H, [&](int s) { return FRAG_AT(X, s & 31) * (s < 32 ? r0 : r1); });
     }
     FT_MARK(1);                                // wait for this tile's rows + first GEMM
     __builtin_amdgcn_sched_barrier(0);         // X is dead from here: the next tile's row loads go into it, under the second GEMM

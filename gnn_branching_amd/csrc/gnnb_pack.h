@@ -127,29 +127,6 @@ inline int gather_feature(int R, int h) {           // channel held by register 
   const int it = R >> 4, r = R & 15;
   return 2 * ((r & 3) + 8 * (r >> 2) + 4 * h) + it;
 }
-// The fused gather + node-update kernel (k_gather_update) feeds the chain from a fragment P that was compacted, register for
-// register, out of the gather's accumulators; which channel register R of lane half h holds depends on the gather form:
-//   32-node tiles (32x32x2 MFMA): gather_feature(R, h)            16-node tiles (16x16x4 MFMA): 32 h + R
-// (16-node form: accumulator (t, r) of lane group g' holds channel 16 g' + 4 r + t; P[16 q + 4 r + t] of half h comes from group
-// g' = 2 h + q).  pack_w64_bf3_map is pack_w64_bf3 for an arbitrary such map.
-typedef int (*FeatMap)(int R, int h);
-inline int gather16_feature(int R, int h) { return 32 * h + R; }
-inline void pack_w64_bf3_map(float* dst, const float* W, int ldw, int col0, int nfrag, FeatMap fm) {
-  unsigned short* d = reinterpret_cast<unsigned short*>(dst);
-  for (int f = 0; f < nfrag; ++f)
-    for (int ks = 0; ks < 4; ++ks)
-      for (int ot = 0; ot < 2; ++ot)
-        for (int lane = 0; lane < 64; ++lane)
-          for (int j = 0; j < 8; ++j) {
-            float w = W[(size_t)(32 * ot + (lane & 31)) * ldw + col0 + 64 * f + fm(8 * ks + j, lane >> 5)];
-            for (int p = 0; p < 3; ++p) {
-              const unsigned short b = bf16_rne(w);
-              d[((((size_t)(f * 4 + ks) * 2 + ot) * 3 + p) * 64 + lane) * 8 + j] = b;
-              w -= bf16_f32(b);
-            }
-          }
-}
-
 // W (out x in, row-major) -> W^T (in x out): lane = out index reads consecutive floats.
 inline void pack_transposed(float* dst, const float* W, int out, int in) {
   for (int o = 0; o < out; ++o)
@@ -185,19 +162,15 @@ struct PackUpd { enum { WA = 0, WAS = WA + 8192, BA = WAS + 4096, WCB = BA + 64,
                         VAW = BCBROW + 64, FLOATS = VAW + 128,
                         // bf16 x 3 forms of WAS and WCB (pack_w64_bf3) behind the fp32 image
                         WAS3 = FLOATS, WCB3 = WAS3 + 6144, FLOATS3 = WCB3 + 6144,
-                        // k_gather_update: the first layer for an input fragment in the channel map of the 32-node and of the 16-node
-                        // gather (pack_w64_bf3_map), all bf16 x 3: WAS, and the second half of Wa alone -- ambiguous nodes ride in the
-                        // same tiles as the others there, Wa.[r0 x, r1 x] = WAS.(r0 x) + Wa[:, 64:].((r1 - r0) x), the second term
-                        // being exactly zero for r0 == r1.  Everything behind the first layer is shared.
-                        WAS3_G32 = FLOATS3, WAS3_G16 = WAS3_G32 + 6144, WA1S3_G32 = WAS3_G16 + 6144, WA1S3_G16 = WA1S3_G32 + 6144,
-                        FLOATS_ALL = WA1S3_G16 + 6144 }; };
-// LDS image of k_gather_update: no 128-wide fp32 first layer, three bf16 x 3 blocks
-struct PackUpdF3 { enum { BA = 0, BCB = BA + 64, BCBROW = BCB + 64, VAW = BCBROW + 64, WAS3 = VAW + 128, WCB3 = WAS3 + 6144, WA1S3 = WCB3 + 6144,
+                        // the second half of Wa alone (bf16 x 3): see PackUpdL3
+                        WA1S3 = FLOATS3, FLOATS_ALL = WA1S3 + 6144 }; };
+// LDS image of the bf16 x 3 node update (k_node_update, k_gather_update_q): three 64x64 blocks in three bf16 pieces each -- WAS
+// (nodes with r0 == r1), WCB, and the second half of Wa: a general node goes through
+//   Wa.[r0 x, r1 x] = WAS.(r0 x) + Wa[:, 64:].((r1 - r0) x)
+// (the 128-wide fp32 first layer it replaced cost 8192 matrix-pipe cycles per tile against 3072; and the same arithmetic per
+// node whether its tile holds ambiguous nodes or not is what makes the fused and the two-kernel half-pass bit-identical)
+struct PackUpdL3 { enum { BA = 0, BCB = BA + 64, BCBROW = BCB + 64, VAW = BCBROW + 64, WAS3 = VAW + 128, WCB3 = WAS3 + 6144, WA1S3 = WCB3 + 6144,
                           FLOATS = WA1S3 + 6144 }; };
-// LDS image of the bf16 x 3 node update: WAS / WCB in three bf16 pieces; the general chain's 128-wide WA stays fp32 (its
-// tiles are 6-11 % of the work; as bf16 x 3 it costs 16 KB more staging and register spills, measured slower)
-struct PackUpdL3 { enum { WA = 0, BA = WA + 8192, BCB = BA + 64, BCBROW = BCB + 64, VAW = BCBROW + 64, WAS3 = VAW + 128,
-                          WCB3 = WAS3 + 6144, FLOATS = WCB3 + 6144 }; };
 // k_pre_bwd: P = bc4[:, :64] (bc2_1(relu(bc2([s, -d2 s, d1 s]))) * amb) + bc4.bias,
 //            s = bc1_2(relu(bc1_1(relu(bc1 feat7'))))                      (:273-293, :344-345)
 // likewise W5 = bc4[:, :64].bc2_1.W, B5 = bc4[:, :64].bc2_1.b + bcb
@@ -276,8 +249,7 @@ inline void build_packs(const float* blob, Packs& pk) {
   // folded bias of the update chain: bcb = b_c + W_c[:, 64:].b_b  (also added to the P' the feature chains cache)
   auto bcb_of = [&](int b, int c, float* out) { matvec64(out, W(c), 128, 64, Bv(b), Bv(c)); };
   // proj >= 0: the aggregate this update reads is built from rows whose projection Linear `proj` is deferred
-  // with_gather_maps: also the first layer for the fused gather + update kernel (only edges whose aggregate is a conv gather)
-  auto upd = [&](std::vector<float>& v, int a, int b, int c, int d, bool with_gather_maps, int proj = -1) {
+  auto upd = [&](std::vector<float>& v, int a, int b, int c, int d, int proj = -1) {
     v.assign(PackUpd::FLOATS_ALL, 0.f);
     std::vector<float> was(64 * 64), wcb(64 * 64), wa(64 * 128);
     float bcb[64];
@@ -317,21 +289,16 @@ inline void build_packs(const float* blob, Packs& pk) {
     pack_w64(&v[PackUpd::WCB], wcb.data(), 64, 0, 1);
     pack_w64_bf3(&v[PackUpd::WAS3], was.data(), 64, 0, 1);
     pack_w64_bf3(&v[PackUpd::WCB3], wcb.data(), 64, 0, 1);
-    if (with_gather_maps) {
-      pack_w64_bf3_map(&v[PackUpd::WAS3_G32], was.data(), 64, 0, 1, gather_feature);
-      pack_w64_bf3_map(&v[PackUpd::WAS3_G16], was.data(), 64, 0, 1, gather16_feature);
-      pack_w64_bf3_map(&v[PackUpd::WA1S3_G32], wa.data(), 128, 64, 1, gather_feature);
-      pack_w64_bf3_map(&v[PackUpd::WA1S3_G16], wa.data(), 128, 64, 1, gather16_feature);
-    }
+    pack_w64_bf3(&v[PackUpd::WA1S3], wa.data(), 128, 64, 1);
     pack_vec64(&v[PackUpd::BCB], bcb);
     (void)d;   // the last layer is folded into the consumers of the rows
     std::memcpy(&v[PackUpd::BCBROW], bcb, 64 * sizeof(float));
   };
-  upd(pk.upd_fwd_e, L_FC3, L_FC3_2, L_FC4, L_FC4_2, true, L_INP_F_1);       // layer 1, round 0: mu0 comes from the embedding
-  upd(pk.upd_fwd_i, L_FC3, L_FC3_2, L_FC4, L_FC4_2, true, L_INP_B2_2);      // layer 1, later rounds: from the input-layer update
-  upd(pk.upd_fwd_f, L_FC3, L_FC3_2, L_FC4, L_FC4_2, true, L_FC4_2);         // layers >= 2: from the forward update below
-  upd(pk.upd_bwd, L_BC3, L_BC3_1, L_BC4, L_BC4_1, false);                   // top layer: final aggregate from the property node
-  upd(pk.upd_bwd_b, L_BC3, L_BC3_1, L_BC4, L_BC4_1, true, L_BC4_1);         // below: from the backward update above
+  upd(pk.upd_fwd_e, L_FC3, L_FC3_2, L_FC4, L_FC4_2, L_INP_F_1);      // layer 1, round 0: mu0 comes from the embedding
+  upd(pk.upd_fwd_i, L_FC3, L_FC3_2, L_FC4, L_FC4_2, L_INP_B2_2);     // layer 1, later rounds: from the input-layer update
+  upd(pk.upd_fwd_f, L_FC3, L_FC3_2, L_FC4, L_FC4_2, L_FC4_2);        // layers >= 2: from the forward update below
+  upd(pk.upd_bwd, L_BC3, L_BC3_1, L_BC4, L_BC4_1);                   // top layer: final aggregate from the property node
+  upd(pk.upd_bwd_b, L_BC3, L_BC3_1, L_BC4, L_BC4_1, L_BC4_1);        // below: from the backward update above
   {   // the feature chains cache P' = W4[:, :64].relax + bcb, relax = fc1_1(.) folded in
     float bcb[64], b2[64];
     std::vector<float> w2(64 * 64);
@@ -465,7 +432,7 @@ inline void pack_conv_bwd(float* dst, const Edge& e) {
 // B operand is the translation-invariant tap matrix Cmat[k][j] (weight of src window node k for dst
 // lane j, 0 where no tap connects them), held in LDS in operand order [cg][s][lane].
 // The result lands in fragment layout with the channel map  (it, r, h) -> 2*((r&3)+8*(r>>2)+4*h) + it,
-// which the first layer of the node MLP absorbs through pack_w64_bf3_map(.., gather_feature) when it is fed from registers.
+// which the first layer of the node MLP absorbs (the input update's producer-side map, PackPostInp::WPG, is packed for it).
 // ------------------------------------------------------------------------------------------
 struct TileMap {        // lane j of tile t <-> node of the dst layer
   int mode = 0;         // 0: flat, tile = 32 consecutive rows of the (B*N) layer; 1: block

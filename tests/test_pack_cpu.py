@@ -131,18 +131,8 @@ E = "EmbedUpdates.update."
 
 UPD = dict(WA=0, WAS=8192, BA=12288, WCB=12352, BCB=16448, BCBROW=16512, VAW=16576, WAS3=16704, WCB3=16704 + 6144,
            FLOATS3=16704 + 2 * 6144)
-# k_gather_update: first-layer weights for an input fragment in the channel order of the 32-node / 16-node gather
-UPD.update(WAS3_G32=UPD["FLOATS3"], WAS3_G16=UPD["FLOATS3"] + 6144, WA1S3_G32=UPD["FLOATS3"] + 2 * 6144,
-           WA1S3_G16=UPD["FLOATS3"] + 3 * 6144, FLOATS=UPD["FLOATS3"] + 4 * 6144)
-
-
-def gather32_feature(R, h):
-    it, r = R >> 4, R & 15
-    return 2 * ((r & 3) + 8 * (r >> 2) + 4 * h) + it
-
-
-def gather16_feature(R, h):
-    return 32 * h + R
+# the second half of Wa alone, bf16 x 3: general nodes go through WAS.(r0 x) + Wa[:, 64:].((r1 - r0) x) (PackUpdL3)
+UPD.update(WA1S3=UPD["FLOATS3"], FLOATS=UPD["FLOATS3"] + 6144)
 
 
 @pytest.mark.parametrize("pack,chain,proj", [
@@ -205,31 +195,23 @@ def test_node_update_chain(packs, pack, chain, proj):
     H2 = frag_bias(p[BCB:BCB + 64])
     gemm_w64_bf3(p[UPD["WCB3"]:], 1, H2, lambda s: Hf[:, s])
     np.testing.assert_allclose(rows_from_frag(np.maximum(H2, 0)), reference(nb, r0, r0, np.zeros_like(relax)), atol=2e-5)
-    # k_gather_update: the pending tile P holds the aggregate in the channel order of the gather's accumulators (register R of
-    # lane half h = channel map(R, h)); WAS3_G.. / WA1S3_G.. are the first layer for that order (all bf16 x 3), the rest of the
-    # chain is shared.  Every node of a tile -- ambiguous or not -- goes through H = WAS.(r0 x) + Wa[:, 64:].((r1 - r0) x).
-    if proj is not None:
-        amb = np.arange(32) % 3 == 0                      # a mixed tile: every third node ambiguous (r1 != r0, cached P' row)
-        r1m = np.where(amb, r1, r0)
-        relaxm = np.where(amb[:, None], relax, 0.0)
-        Ppm = relaxm @ w4[:, :64].T + bcb
-        for fmap, was_off, wa1_off in ((gather32_feature, UPD["WAS3_G32"], UPD["WA1S3_G32"]), (gather16_feature, UPD["WAS3_G16"], UPD["WA1S3_G16"])):
-            assert sorted(fmap(R, hh) for hh in range(2) for R in range(32)) == list(range(64))
-            Pm = np.zeros((64, 32))
-            for R in range(32):
-                Pm[:, R] = G[J, fmap(R, H)]
-            Hf = frag_bias(p[BA:BA + 64])
-            gemm_small(p[VAW:], 1, Hf, [np.where(H == 0, r0[J], r1m[J]) * sw[J]])
-            gemm_w64_bf3(p[was_off:], 1, Hf, lambda s: Pm[:, s] * r0[J])
-            before = Hf.copy()
-            gemm_w64_bf3(p[wa1_off:], 1, Hf, lambda s: Pm[:, s] * (r1m[J] - r0[J]))
-            assert np.array_equal(Hf[~amb[J]], before[~amb[J]])          # exact zeros for the nodes with r0 == r1
-            Hf = np.maximum(Hf, 0)
-            H2 = frag_from_rows(Ppm)
-            gemm_w64_bf3(p[UPD["WCB3"]:], 1, H2, lambda s: Hf[:, s])
-            np.testing.assert_allclose(rows_from_frag(np.maximum(H2, 0)), reference(nb, r0, r1m, relaxm), atol=2e-5)
-    else:
-        assert not p[UPD["FLOATS3"]:].any()          # the top layer's aggregate never comes from a conv gather
+    # the bf16 x 3 node update (k_node_update, k_gather_update_q): EVERY node -- ambiguous or not -- goes through
+    # H = WAS.(r0 x) + Wa[:, 64:].((r1 - r0) x); the second block adds exact zeros for r0 == r1, so a node's result does not depend on
+    # whether its tile ran it
+    amb = np.arange(32) % 3 == 0                      # a mixed tile: every third node ambiguous (r1 != r0, cached P' row)
+    r1m = np.where(amb, r1, r0)
+    relaxm = np.where(amb[:, None], relax, 0.0)
+    Ppm = relaxm @ w4[:, :64].T + bcb
+    Hf = frag_bias(p[BA:BA + 64])
+    gemm_small(p[VAW:], 1, Hf, [np.where(H == 0, r0[J], r1m[J]) * sw[J]])
+    gemm_w64_bf3(p[UPD["WAS3"]:], 1, Hf, lambda s: X[:, s] * r0[J])
+    before = Hf.copy()
+    gemm_w64_bf3(p[UPD["WA1S3"]:], 1, Hf, lambda s: X[:, s] * (r1m[J] - r0[J]))
+    assert np.array_equal(Hf[~amb[J]], before[~amb[J]])          # exact zeros for the nodes with r0 == r1
+    Hf = np.maximum(Hf, 0)
+    H2 = frag_from_rows(Ppm)
+    gemm_w64_bf3(p[UPD["WCB3"]:], 1, H2, lambda s: Hf[:, s])
+    np.testing.assert_allclose(rows_from_frag(np.maximum(H2, 0)), reference(nb, r0, r1m, relaxm), atol=2e-5)
 
 
 def test_input_update_packs(packs):
