@@ -45,7 +45,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32, same guide
 
 MFMA_FLOP = 2 * 32 * 32 * 2          # one v_mfma_f32_32x32x2_f32
 MLP_MACS_PER_NODE = 128 * 64 + 3 * 64 * 64   # fc3|bc3, fc3_2|bc3_1, 2nd half of fc4|bc4, fc4_2|bc4_1 (SURVEY 8(d) minus the hoisted feature chains)
-AGGREGATION_KERNELS = ("k_gather", "k_conv_fwd", "k_convT_bwd", "k_dense_agg")   # edge aggregation = message passing: HBM-bound
+AGGREGATION_KERNELS = ("k_gather", "k_gather_update", "k_conv_fwd", "k_convT_bwd", "k_dense_agg")   # edge aggregation = message passing: HBM-bound
 
 
 def node_stats(batch):
@@ -92,27 +92,40 @@ def plan_flops(plan, B, stats, restrict_last=True):
                 add(issued, upd, reps * MFMA_FLOP * tiles(nodes) * 66)
                 add(alg, agg, reps * 2.0 * nnz * 64)
             continue
-        agg, upd = u["kernel"].split("+")
+        fused = "+" not in u["kernel"]              # k_gather_update: gather + node update in one launch
         for t in range(T):
             restricted = restrict_last and u["update"] == "bwd" and k == 1 and t == T - 1
+            if fused and not restricted:
+                agg = upd = u["kernel"]
+            elif fused:                             # the restricted last step always runs as two kernels
+                agg, upd = "k_gather", "k_node_update"
+            else:
+                agg, upd = u["kernel"].split("+")
             n_upd = stats[k]["scored"] if restricted else stats[k]["live"]
             add(alg, upd, 2.0 * MLP_MACS_PER_NODE * n_upd)
             # message passing of this half-pass: every source row read once, every updated row written once
             # (round 0 with the embedding fused into the first gather reads three scalars per source node, not a 256-B row)
             src_row_bytes = 12.0 if (plan.get("embed_fused") and u["update"] == "fwd" and k == 1 and t == 0) else 4.0 * 64
             add(agg_bytes, agg, src_row_bytes * B * u["n_src"] + 4.0 * 64 * n_upd)
-            # folded chains, last layer deferred: 128 (+2) MFMAs per tile of live non-ambiguous nodes, 192 (+2) per tile of general nodes
-            if u["update"] == "bwd" and k == 1 and t < T - 1 and upd == "k_node_update":
-                add(issued, upd, MFMA_FLOP * tiles(stats[k]["live"]) * W64)     # the input update's 64x64 map, applied on the producer side
-            if upd == "k_top":                   # one workgroup per sample: every node of the layer through the general chain
+            # folded chains, last layer deferred.  bf16x3 (default): a tile of nodes with r0 == r1 runs 2 blocks of 48 bf16 MFMAs (+2 small),
+            # a tile that holds an ambiguous node 3; fp32 MFMA only (GNNB_BF3=0): 130 / 194 fp32 MFMAs
+            live, amb = stats[k]["live"], stats[k]["amb"]
+            post = u["update"] == "bwd" and k == 1 and t < T - 1 and upd in ("k_node_update", "k_gather_update")
+            if upd == "k_top":                   # one workgroup per sample: every node of the layer through the general fp32 chain
                 add(issued, upd, MFMA_FLOP * B * tiles(u["nodes"]) * 194)
+            elif not bf3:
+                gen = tiles(n_upd) if restricted else tiles(amb)
+                add(issued, upd, MFMA_FLOP * ((0 if restricted else tiles(live - amb)) * 130 + gen * 194 + (tiles(live) * 64 if post else 0)))
             elif restricted:
-                add(issued, upd, MFMA_FLOP * tiles(n_upd) * (130 + W64))
+                add(issued, upd, MFMA_FLOP * tiles(n_upd) * (2 + 3 * W64))
+            elif fused:                          # ambiguous nodes ride in the same tiles: share of 32-node tiles that hold at least one
+                p_amb = 1.0 - (1.0 - amb / max(live, 1)) ** 32
+                add(issued, upd, MFMA_FLOP * tiles(live) * (2 + (2 + p_amb) * W64 + (W64 if post else 0)))
             else:
-                add(issued, upd, MFMA_FLOP * (tiles(stats[k]["live"] - stats[k]["amb"]) * (2 + 2 * W64) + tiles(stats[k]["amb"]) * (130 + W64)))
+                add(issued, upd, MFMA_FLOP * (tiles(live - amb) * (2 + 2 * W64) + tiles(amb) * (2 + 3 * W64) + (tiles(live) * W64 if post else 0)))
             frac = n_upd / max(stats[k]["nodes"], 1)
             add(alg, agg, 2.0 * nnz * 64 * frac)
-            if agg == "k_gather":
+            if agg in ("k_gather", "k_gather_update"):
                 add(issued, agg, MFMA_FLOP * u["tiles_per_sample"] * B * 2 * u["gather_ksteps"])
             elif agg == "k_top" and u["n_src"] > 1:      # dense edge on the MFMA: row tiles x k-steps x 2 channel halves
                 add(issued, agg, MFMA_FLOP * B * tiles(u["nodes"]) * ((u["n_src"] + 1) // 2) * 2)

@@ -112,9 +112,10 @@ struct gnnb_handle {
                                 // gathers, bit 1 = 32-node gathers, bit 2 = the input-layer gather
   bool gather16 = true;         // forward conv edges: 16-node tiles on the 16x16x4 MFMA when their window is smaller
   bool embed_fuse = true;       // round 0: the first forward gather computes the input embedding itself (no k_embed, no mu[0] rows)
-  int fuse = 1;                 // conv half-passes as ONE kernel (k_gather_update_q: the aggregate never reaches HBM): 0 never, 2 wherever
-                                // the kernel exists, 1 (default) where it is the faster form (fuse_edge below).  Both forms compute
-                                // the same arithmetic per node -- results are bit-identical -- so this is a pure scheduling choice.  GNNB_FUSE
+  int fuse = 1;                 // conv half-passes as ONE kernel (k_gather_update_q: the aggregate never reaches HBM) wherever that kernel
+                                // exists (measured faster at every batch size and on all three networks: base B = 256 0.975 vs 1.014 ms,
+                                // deep B = 1024 6.59 vs 7.31 ms, B = 1 0.344 vs 0.359 ms); GNNB_FUSE=0: always two kernels.  Both forms
+                                // compute the same arithmetic per node -- bit-identical results -- so this is a pure scheduling choice.
   bool use_top = true;          // fuse the top of the network (last Linear edge, last ReLU layer, property node) into k_top
   bool top_ok = false;          // ... which the bound network allows (set by gnnb_bind_network)
   int per_sample_min_b = 0;     // GNNB_PER_SAMPLE_MIN_B: batches below it take the per-tile dense kernel + separate launches
@@ -254,6 +255,7 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   HIPCHK(hipFuncSetAttribute((const void*)k_gather<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   if (const char* e = getenv("GNNB_NO_GATHER")) h->use_gather = !(e[0] == '1');
   if (const char* e = getenv("GNNB_NO_TOP")) h->use_top = !(e[0] == '1');
+
   if (const char* e = getenv("GNNB_FUSE")) h->fuse = e[0] - '0';
 #define FUSEDQ_ATTR(L, S, P) HIPCHK(hipFuncSetAttribute((const void*)k_gather_update_q<L, S, P>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
   FUSEDQ_ATTR(16, 0, false); FUSEDQ_ATTR(16, 1, false); FUSEDQ_ATTR(16, 2, false); FUSEDQ_ATTR(32, 1, false); FUSEDQ_ATTR(32, 1, true);
@@ -553,6 +555,23 @@ extern "C" int gnnb_graph_info(const gnnb_t* h, int* n_graph, int* sizes, int* n
   return GNNB_OK;
 }
 
+// k_gather_update_q over conv edge `d`: dynamic LDS bytes (weights, row queue, gather tables, per-gather-wave slot tables), and
+// whether the edge can take it at all (a sparse walk behind a ReLU layer, 16-node tiles without POST, everything in 160 KB)
+static size_t fusedq_lds_bytes(const DevGather& d, bool sparse, bool post) {
+  const size_t tables = (size_t)d.g.tm.NCG * d.g.K2 * 64 * 4 + (size_t)gather_slots(d.g.K2, d.g.lanes) * 8 + (size_t)((d.g.tm.TPS + 3) & ~3) * 4 +
+                        (size_t)((gather_slots(d.g.K2, d.g.lanes) + 3) & ~3) * 4;
+  return (size_t)(PackUpdL3::FLOATS + (post ? 6144 : 0) + fusedq_queue_floats()) * 4 + tables +
+         (sparse ? (size_t)QG_WAVES * ((d.g.lanes == 16 ? 4 : 2) * d.g.K2 + 32) * 8 : 0);
+}
+static bool fusedq_ok(const gnnb_t* h, const DevGather& d, int src_layer, bool embed_src, bool post) {
+  if (h->fuse == 0 || !h->bf3 || !d.ok) return false;
+  const bool sparse = (h->gather_sparse & (d.g.lanes == 16 ? 1 : 2)) && !embed_src && src_layer >= 1;
+  if (src_layer >= 1 && !sparse) return false;
+  if (d.g.lanes == 32 && !sparse) return false;
+  if (d.g.lanes == 16 && post) return false;
+  return fusedq_lds_bytes(d, sparse, post) <= 160 * 1024;
+}
+
 // JSON description of the launch plan of one forward (per B=1): which kernel updates which layer, tile shapes and
 // MFMA counts.  bench.py derives the algorithmic flops per kernel class from it; DESIGN.md quotes it.
 extern "C" int gnnb_describe(const gnnb_t* h, char* buf, size_t cap) {
@@ -574,7 +593,8 @@ extern "C" int gnnb_describe(const gnnb_t* h, char* buf, size_t cap) {
       snprintf(t, sizeof t,
                "{\"update\": \"%s\", \"layer\": %d, \"kernel\": \"%s\", \"nodes\": %d, \"tiles_per_sample\": %d, \"tile_nodes\": %d, "
                "\"tile\": [%d, %d, %d], \"align\": [%d, %d], \"window\": [%d, %d], \"gather_ksteps\": %d, \"n_src\": %d, \"edge_nnz\": %ld}",
-               what, k, k == 0 ? "k_gather_input_update" : "k_gather+k_node_update", h->N[k], g.tm.TPS, g.lanes, g.tm.CT, g.tm.PY, g.tm.PX,
+               what, k, k == 0 ? "k_gather_input_update" : (fusedq_ok(h, *d, what[0] == 'f' ? k - 1 : k + 1, false, false) ? "k_gather_update" : "k_gather+k_node_update"),
+               h->N[k], g.tm.TPS, g.lanes, g.tm.CT, g.tm.PY, g.tm.PX,
                g.tm.ay, g.tm.ax, g.WY, g.WX, g.K2, n_src, ez);
     } else {
       snprintf(t, sizeof t, "{\"update\": \"%s\", \"layer\": %d, \"kernel\": \"%s\", \"nodes\": %d, \"n_src\": %d, \"edge_nnz\": %ld}",
@@ -1057,26 +1077,16 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   // runs, the restricted last step (every node it updates takes the general chain), gathers without the sparse walk behind a
   // ReLU layer, tile forms the fused kernel is not built for, tables that do not fit beside the weights in LDS.
   auto fused_halfpass = [&](int k, bool fwd, bool post_input) -> bool {
-    if (h->fuse == 0 || !h->bf3 || debug_full) return false;
+    if (debug_full) return false;
     const DevGather& d = fwd ? h->gf[k] : h->gb[k + 1];
-    if (!d.ok) return false;
+    if (!d.ok || (!fwd && k >= L)) return false;
     const int src_layer = fwd ? k - 1 : k + 1;
     const bool embed_src = fwd && k == 1 && embed_in_gather && proj[0] == L_INP_F_1;
+    if (!fusedq_ok(h, d, src_layer, embed_src, post_input)) return false;
     const bool sparse = (h->gather_sparse & (d.g.lanes == 16 ? 1 : 2)) && !embed_src && src_layer >= 1;
-    if (src_layer >= 1 && !sparse) return false;
-    if (d.g.lanes == 32 && !sparse) return false;
-    if (d.g.lanes == 16 && post_input) return false;
-    if (!fwd && k >= L) return false;
     const long nt = map_tiles(d.g.tm, B);
-    // where the fused form wins (MI355X): every sparse 16-node forward gather (64 vs 71 us on base B = 256);
-    // everything when the launch count is what binds (few tiles per CU: small batches, the per-decision calls of the BaB loop)
-    if (h->fuse == 1 && !(d.g.lanes == 16 && sparse) && nt > (long)h->n_cu * 16) return false;
     {
-      const size_t tables = (size_t)d.g.tm.NCG * d.g.K2 * 64 * 4 + (size_t)gather_slots(d.g.K2, d.g.lanes) * 8 + (size_t)((d.g.tm.TPS + 3) & ~3) * 4 +
-                            (size_t)((gather_slots(d.g.K2, d.g.lanes) + 3) & ~3) * 4;
-      const size_t ldsq = (size_t)(PackUpdL3::FLOATS + (post_input ? 6144 : 0) + fusedq_queue_floats()) * 4 + tables +
-                          (sparse ? (size_t)QG_WAVES * ((d.g.lanes == 16 ? 4 : 2) * d.g.K2 + 32) * 8 : 0);
-      if (ldsq > 160 * 1024) return false;
+      const size_t ldsq = fusedq_lds_bytes(d, sparse, post_input);
       FArgs a{};
       float* sout = fwd ? ws + w.sf[k] : ws + w.sb[k];
       a.sw_from_gather = sparse && h->s_in_gather ? 1 : 0;

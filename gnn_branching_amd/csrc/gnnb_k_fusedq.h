@@ -78,7 +78,11 @@ __device__ __forceinline__ void q_chain(const FArgs& a, const float* lds, const 
     gemm_small<1>(lds + PackUpdL3::VAW, lane, H, x);
   }
   gemm_w64_bf3<1>(lds + PackUpdL3::WAS3, lane, H, [&](int s) { return FRAG_AT(X, s) * r0; });
+#ifdef Q_ABL_NOAMB      // dev, timing only (wrong results): what the chain would cost if no tile held an ambiguous node
+  if (false) {
+#else
   if (__any(amb)) {
+#endif
     const float dr = r1 - r0;
     gemm_w64_bf3<1>(lds + PackUpdL3::WA1S3, lane, H, [&](int s) { return FRAG_AT(X, s) * dr; });
   }
