@@ -139,6 +139,15 @@ def plan_flops(plan, B, stats, restrict_last=True):
     return alg, issued, agg_bytes
 
 
+def pmc_rows(pmc, cls):
+    """Counter summaries of the kernel templates behind profile class `cls` (k_gather covers k_gather and k_gather16, k_gather_update
+    the kernel k_gather_update_q)."""
+    def same(name):
+        rest = name[len(cls):] if name.startswith(cls) else None
+        return rest is not None and (rest == "" or rest.isdigit() or rest == "_q")
+    return [v for k, v in pmc.items() if same(k) and "hbm_bytes_per_launch" in v]
+
+
 def message_passing_bytes(sizes, B, T):
     """4*p*(N_src + N_dst) bytes per half-pass update src->dst, summed over the
     live half-passes (the last round's input-layer update is dead)."""
@@ -357,7 +366,7 @@ def main():
         if os.path.exists(pmc_path):
             # a profile class may cover several kernel templates (k_gather, k_gather16): launch-weighted mean
             pmc = json.load(open(pmc_path))
-            rows = [v for k, v in pmc.items() if (k == dom or (k.startswith(dom) and k[len(dom):].isdigit())) and "hbm_bytes_per_launch" in v]
+            rows = pmc_rows(pmc, dom)
             n = sum(v.get("launches_sampled", 1) for v in rows)
             traffic = round(sum(v["hbm_bytes_per_launch"] * v.get("launches_sampled", 1) for v in rows) / n) if n else None
         ach_tf = alg.get(dom, 0.0) / dom_s / 1e12 if dom_s > 0 else 0.0
@@ -403,7 +412,7 @@ def main():
             tot, ok = 0.0, True
             for k in mp_names:
                 if k in kern:
-                    rows = [v for kk, v in pmc.items() if (kk == k or (kk.startswith(k) and kk[len(k):].isdigit())) and "hbm_bytes_per_launch" in v]
+                    rows = pmc_rows(pmc, k)
                     n = sum(v.get("launches_sampled", 1) for v in rows)
                     if not n:
                         ok = False

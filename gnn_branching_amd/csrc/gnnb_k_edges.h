@@ -510,6 +510,7 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int N = a.N;
+  FT_DECL;
   for (int i = tid; i < DENSE_BWD_ROWS * 16; i += 512) reinterpret_cast<f32x4*>(Cr)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   // live source rows of layer L-1 (the dead ones are all zero: ~45 % of the forward edge's k-steps), compacted in node order
   // into the region PackProp takes afterwards
@@ -541,12 +542,17 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
     for (int i = K_eff + tid; i < (K_eff + 63) / 64 * 64 + 32; i += 512) klist[i] = a.df.Kpad;     // a zero row of At
   }
   __syncthreads();
+  FT_MARK(0);        // zero C, live-row list of layer L-1
 
   // ---- F1: rows of C <- W_L . mu_{L-1}
   float s_own = 0.0f;                                    // waves 0..3, lane j: bias sum of node wave*32 + j (when a.sf is null)
+#if defined(TOP_ABL) && (TOP_ABL & 2)     // dev, timing only: no F1
+  if (K_eff < 0)
+#endif
   dense_fwd_sample(a.df, b, A, [&](int row, int jj, float2 v) { *reinterpret_cast<float2*>(Cr + row * 64 + 2 * jj) = v; },
                    compact ? klist : nullptr, K_eff, (compact && !a.sf) ? &s_own : nullptr);
   __syncthreads();
+  FT_MARK(1);        // F1 dense forward edge
   copy_to_lds(Bp, a.pack_p, PackProp::FLOATS);            // (read from F3 on, behind two more barriers)
 
   // per-lane node of the update phases (waves 0..3: one tile of 32 nodes each)
@@ -595,6 +601,7 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
 
   // ---- F2: forward node update of layer L (rows stay in C)
   stage_pack(A, a.pack_f, PackUpd::FLOATS);
+  FT_MARK(2);        // staging PackProp + forward pack
   if (upd_wave) {
     Frag X, E;
     load_row(X, valid ? n : 0);
@@ -605,6 +612,7 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
     }
   }
   __syncthreads();
+  FT_MARK(3);        // F2 chain
 
   // ---- F3: property node (k_prop) on the rows in C; meanwhile waves 1..7 stage the backward pack
   {
@@ -647,6 +655,7 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
     copy_to_lds_part(A, a.pack_b, PackUpd::FLOATS, tid - 64, 448);
   }
   __syncthreads();
+  FT_MARK(4);        // F3 property node + staging backward pack
 
   // ---- B1: backward node update of layer L; its aggregate is the rank-1 edge from the property node
   if (upd_wave) {
@@ -669,6 +678,7 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
     }
   }
   __syncthreads();
+  FT_MARK(5);        // B1 chain
 
   // ---- B2: aggregate rows of layer L-1 <- W_L^T . rows of C: only the live rows of layer L-1 (nothing reads the others), only
   // the live (non-zero) rows of layer L
@@ -686,9 +696,22 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
     __syncthreads();
   }
   float* out = a.db.out + (long)b * a.db.M * 64;
+#ifdef TOP_ABL_NOSTORE   // dev, timing only
+  auto put = [&](int row, int jj, float2 v) { if (v.x > 1e30f) *reinterpret_cast<float2*>(out + (long)row * 64 + 2 * jj) = v; };
+#else
   auto put = [&](int row, int jj, float2 v) { *reinterpret_cast<float2*>(out + (long)row * 64 + 2 * jj) = v; };
+#endif
+#if defined(TOP_ABL) && (TOP_ABL & 1)     // dev, timing only: no B2
+  if (K2 < 0) dense_bwd_sample(a.db, Cr, put);
+#else
   if (keep) dense_bwd_sample(a.db, Cr, put, klist, K_eff, k2list, K2, a.sb_out ? a.sb_out + (long)b * a.db.M : nullptr);
   else dense_bwd_sample(a.db, Cr, put);
+#endif
+#ifdef FUSED_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  FT_MARK(6);        // B2 dense transposed edge
+  if (FUSED_TIMING == 4) FT_FLUSH();
+#endif
 }
 
 __global__ __launch_bounds__(512, 1) void k_top(TopArgs a) {

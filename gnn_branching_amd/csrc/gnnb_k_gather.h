@@ -855,8 +855,11 @@ __device__ __forceinline__ void input_update_tile(const GIArgs& a, const TileCtx
   frag_relu(H0);
   Frag H;                                  // inp_b_1 and the first half of inp_b2 are folded into one 64x64 map
   frag_bias(H, lds_pre + PackPreInp::B2, h);
+#if defined(GIU_ABL) && (GIU_ABL & 2)      // dev, timing only: no feature chain
+#else
   if (BF3) gemm_w64_bf3<1>(lds_pre + PackPreInp::W23, lane, H, [&](int s) { return FRAG_AT(H0, s); });
   else gemm_w64<32>(lds_pre + PackPreInp::W2, lane, H, [&](int s) { return FRAG_AT(H0, s); });
+#endif
   float ssum = 0.0f;
   const bool own_s = SPARSE && a.s_from_gather;
   if (!own_s) {                              // bias term of the projection deferred in the rows of mu_1
@@ -865,6 +868,9 @@ __device__ __forceinline__ void input_update_tile(const GIArgs& a, const TileCtx
   }
   // The aggregate already went through inp_b2[:, 64:].bc4_1.W on the producer side, with its rows permuted to this fragment
   // layout (PackPostInp::WPG), register for register: the gather accumulates straight onto H (one fragment less alive).
+#if defined(GIU_ABL) && (GIU_ABL & 4)      // dev, timing only: no gather
+  if (wy0 > 100000)
+#endif
   if (SPARSE)
     gather_dispatch(H, gl.cm + tc.cg * a.g.K2 * 64, gl.ko, gl.kvo, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane, tab,
                     a.src_lb + (long)sample * a.g.Ns, a.src_ub + (long)sample * a.g.Ns, true, own_s ? &ssum : nullptr);
@@ -876,7 +882,11 @@ __device__ __forceinline__ void input_update_tile(const GIArgs& a, const TileCtx
     gemm_small<1>(lds_upd + PackUpdInp::VC, lane, H, xs);
   }
   frag_relu(H);
+#if defined(GIU_ABL) && (GIU_ABL & 1)      // dev, timing only: no row stores
+  if (tc.valid && FRAG_AT(H, 0) > 1e30f) frag_store_rows(H, a.mu, gc, h);
+#else
   if (tc.valid) frag_store_rows(H, a.mu, gc, h);
+#endif
 }
 
 template <bool SPARSE, bool BF3>

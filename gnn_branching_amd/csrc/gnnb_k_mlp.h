@@ -425,7 +425,7 @@ __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, i
     tile = next; gc = gc_n; valid = valid_n; lb = lb_n; ub = ub_n; sw = sw_n;
   }
 #ifdef FUSED_TIMING
-  if (FUSED_TIMING == 3 && !POST) FT_FLUSH();
+  if (FUSED_TIMING == 3 && !POST && STAGE) FT_FLUSH();
 #endif
 }
 
