@@ -557,11 +557,17 @@ extern "C" int gnnb_graph_info(const gnnb_t* h, int* n_graph, int* sizes, int* n
 
 // k_gather_update_q over conv edge `d`: dynamic LDS bytes (weights, row queue, gather tables, per-gather-wave slot tables), and
 // whether the edge can take it at all (a sparse walk behind a ReLU layer, 16-node tiles without POST, everything in 160 KB)
-static size_t fusedq_lds_bytes(const DevGather& d, bool sparse, bool post) {
+static size_t fusedq_lds_bytes(const DevGather& d, bool sparse, bool post, int qtiles) {
   const size_t tables = (size_t)d.g.tm.NCG * d.g.K2 * 64 * 4 + (size_t)gather_slots(d.g.K2, d.g.lanes) * 8 + (size_t)((d.g.tm.TPS + 3) & ~3) * 4 +
                         (size_t)((gather_slots(d.g.K2, d.g.lanes) + 3) & ~3) * 4;
-  return (size_t)(PackUpdL3::FLOATS + (post ? 6144 : 0) + fusedq_queue_floats()) * 4 + tables +
+  return (size_t)(PackUpdL3::FLOATS + (post ? 6144 : 0) + fusedq_queue_floats(qtiles)) * 4 + tables +
          (sparse ? (size_t)QG_WAVES * ((d.g.lanes == 16 ? 4 : 2) * d.g.K2 + 32) * 8 : 0);
+}
+// ring slots that fit (0: the kernel does not fit at all)
+static int fusedq_qtiles(const DevGather& d, bool sparse, bool post) {
+  for (int q = QTILES; q >= 2; --q)
+    if (fusedq_lds_bytes(d, sparse, post, q) <= 160 * 1024) return q;
+  return 0;
 }
 static bool fusedq_ok(const gnnb_t* h, const DevGather& d, int src_layer, bool embed_src, bool post) {
   if (h->fuse == 0 || !h->bf3 || !d.ok) return false;
@@ -569,7 +575,7 @@ static bool fusedq_ok(const gnnb_t* h, const DevGather& d, int src_layer, bool e
   if (src_layer >= 1 && !sparse) return false;
   if (d.g.lanes == 32 && !sparse) return false;
   if (d.g.lanes == 16 && post) return false;
-  return fusedq_lds_bytes(d, sparse, post) <= 160 * 1024;
+  return fusedq_qtiles(d, sparse, post) > 0;
 }
 
 // JSON description of the launch plan of one forward (per B=1): which kernel updates which layer, tile shapes and
@@ -1086,7 +1092,8 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     const bool sparse = (h->gather_sparse & (d.g.lanes == 16 ? 1 : 2)) && !embed_src && src_layer >= 1;
     const long nt = map_tiles(d.g.tm, B);
     {
-      const size_t ldsq = fusedq_lds_bytes(d, sparse, post_input);
+      const int nq = fusedq_qtiles(d, sparse, post_input);
+      const size_t ldsq = fusedq_lds_bytes(d, sparse, post_input, nq);
       FArgs a{};
       float* sout = fwd ? ws + w.sf[k] : ws + w.sb[k];
       a.sw_from_gather = sparse && h->s_in_gather ? 1 : 0;
@@ -1094,6 +1101,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
                   EmbedSrc{in->lb[0], in->x_lp, in->ub[0], h->d_pack[PK_EMBED]}, sparse ? in->lb[src_layer] : nullptr, sparse ? in->ub[src_layer] : nullptr,
                   a.sw_from_gather ? sout : nullptr};
       a.u = upd_args(k, fwd, false, post_input);
+      a.qtiles = nq;
       const long nrounds = (nt + QG_WAVES - 1) / QG_WAVES;
       const dim3 g((unsigned)std::max<long>(1, std::min<long>(nrounds, h->n_cu))), b((QG_WAVES + QC_WAVES) * 64);
       lz.run(PC_GATHER_UPDATE, [&] {

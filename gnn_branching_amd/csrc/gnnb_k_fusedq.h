@@ -32,17 +32,18 @@ struct FArgs {
   GArgs g;             // the gather (k_gather / k_gather16 arguments; g.nb is unused; g.sout != null: the sparse walk computes the bias sums)
   UpdArgs u;           // the node update (k_node_update arguments; list0 / list1 / cnt0 / cnt1, nb are unused)
   int sw_from_gather;  // 1: the bias-sum scalar of a node comes out of its (sparse) gather; 0: u.sarr holds it (table / k_livesum)
+  int qtiles;          // ring slots (2..QTILES): as many as fit beside the weights and the gather's tables in LDS
 };
 
 #ifndef QG_WAVES
 #define QG_WAVES 8            // gather waves (8 + 8 chain waves measured best on base B = 256; 10 + 6 and 12 + 4 are 2-8 % slower)
 #endif
 #define QC_WAVES (16 - QG_WAVES)      // chain waves
-#define QTILES 4              // ring slots of 32 rows
+#define QTILES 4              // ring slots of 32 rows at most; FArgs.qtiles (2..4) says how many this launch has room for
 #define QROW 72               // floats per ring row: 64 channels, {node id | ambiguous << 31, r0, r1, s}, 4 pad (16-B rows, <= 2-way bank conflicts)
 #define QHDR_INTS 16
 #define Q_POLL_CAP (1 << 22)
-__host__ __device__ constexpr size_t fusedq_queue_floats() { return (size_t)QTILES * 32 * QROW + QHDR_INTS; }
+__host__ __device__ constexpr size_t fusedq_queue_floats(int qtiles) { return (size_t)qtiles * 32 * QROW + QHDR_INTS; }
 
 struct QHdr { int reserve, done, claim, pad1, filled[QTILES], free_id[QTILES], pad2[4]; };
 static_assert(sizeof(QHdr) == QHDR_INTS * 4, "queue header");
@@ -110,8 +111,9 @@ __global__ __launch_bounds__((QG_WAVES + QC_WAVES) * 64, 4) void k_gather_update
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr bool SPARSE = SRC == 1, EMBED = SRC == 2;
   float* qbase = lds + PackUpdL3::FLOATS + (POST ? 6144 : 0);
-  QHdr* q = reinterpret_cast<QHdr*>(qbase + (size_t)QTILES * 32 * QROW);
-  float* gbase = qbase + fusedq_queue_floats();
+  const int NQ = a.qtiles;
+  QHdr* q = reinterpret_cast<QHdr*>(qbase + (size_t)NQ * 32 * QROW);
+  float* gbase = qbase + fusedq_queue_floats(NQ);
   const GatherLds gl = gather_lds(gbase, a.g.g, a.g.tm.TPS);
   stage_gather(gl.cm, gl.ko, gl.tt, gl.kvo, a.g.g, a.g.tm.TPS);
   copy_to_lds(lds + PackUpdL3::BA, a.u.pack + PackUpd::BA, 64);
@@ -132,7 +134,7 @@ __global__ __launch_bounds__((QG_WAVES + QC_WAVES) * 64, 4) void k_gather_update
       int T = 0;
       if (lane == 0) T = atomicAdd(&q->claim, 1);
       T = __builtin_amdgcn_readfirstlane(T);
-      const int s = T % QTILES;
+      const int s = T % NQ;
       const float* ring = qbase + (size_t)s * 32 * QROW;
       int nvalid = -1;
       for (int it = 0; it < Q_POLL_CAP; ++it) {
@@ -151,7 +153,7 @@ __global__ __launch_bounds__((QG_WAVES + QC_WAVES) * 64, 4) void k_gather_update
         // time a tile takes to fill and to be copied out, not the ~10 us of its chain
         if (nvalid == 32 && lane == 0) {
           __hip_atomic_store(&q->filled[s], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_store(&q->free_id[s], T + QTILES, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_store(&q->free_id[s], T + NQ, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       });
       if (nvalid < 32) return;                       // the last, partly filled tile
@@ -204,7 +206,7 @@ __global__ __launch_bounds__((QG_WAVES + QC_WAVES) * 64, 4) void k_gather_update
     const int pos = base + __popcll(bal & ((1ull << jn) - 1ull));        // this lane's node (if needed) goes to row `pos`
     const int T0 = base >> 5, T1 = (base + n - 1) >> 5;
     for (int T = T0; T <= T1; ++T) {
-      const int s = T % QTILES;
+      const int s = T % NQ;
       bool ok = false;
       for (int it = 0; it < Q_POLL_CAP; ++it) {
         if (q_ld(&q->free_id[s]) == T) { ok = true; break; }
