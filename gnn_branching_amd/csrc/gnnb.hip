@@ -116,6 +116,7 @@ struct gnnb_handle {
                                 // exists (measured faster at every batch size and on all three networks: base B = 256 0.975 vs 1.014 ms,
                                 // deep B = 1024 6.59 vs 7.31 ms, B = 1 0.344 vs 0.359 ms); GNNB_FUSE=0: always two kernels.  Both forms
                                 // compute the same arithmetic per node -- bit-identical results -- so this is a pure scheduling choice.
+  bool scored_gather = true;    // the restricted last step's aggregate one wave per scored node (k_gather_scored); GNNB_DEV: GNNB_NO_SCORED_GATHER=1
   bool use_top = true;          // fuse the top of the network (last Linear edge, last ReLU layer, property node) into k_top
   bool top_ok = false;          // ... which the bound network allows (set by gnnb_bind_network)
   int per_sample_min_b = 0;     // GNNB_PER_SAMPLE_MIN_B: batches below it take the per-tile dense kernel + separate launches
@@ -255,6 +256,9 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   HIPCHK(hipFuncSetAttribute((const void*)k_gather<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   if (const char* e = getenv("GNNB_NO_GATHER")) h->use_gather = !(e[0] == '1');
   if (const char* e = getenv("GNNB_NO_TOP")) h->use_top = !(e[0] == '1');
+#ifdef GNNB_DEV
+  if (const char* e = getenv("GNNB_NO_SCORED_GATHER")) h->scored_gather = !(e[0] == '1');
+#endif
 
   if (const char* e = getenv("GNNB_FUSE")) h->fuse = e[0] - '0';
 #define FUSEDQ_ATTR(L, S, P) HIPCHK(hipFuncSetAttribute((const void*)k_gather_update_q<L, S, P>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
@@ -1000,6 +1004,16 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     const Edge& e = h->edges[k + 1];
     // the input layer (k = 0) aggregates the rows of layer 1 that already went through its 64x64 map (PackPostInp)
     const float* srcb = k == 0 ? rows1_for_input : mu(k + 1);
+    if (k >= 1 && scored && h->gb[k + 1].ok && h->scored_gather && (h->gather_sparse & 2) &&
+        e.c_out * ((e.kh + e.stride - 1) / e.stride) * ((e.kw + e.stride - 1) / e.stride) <= 96) {
+      // the restricted last step: one wave per scored node instead of every tile that holds one (k_gather_scored).  Only for
+      // windows up to 96 source nodes: a scored node re-reads its whole window, a tile shares it among 32 nodes (base, 64 slots:
+      // 31 vs 38 us; deep 18 vs 38; wide, 128 slots: 116 vs 99 -> stays on the tile gather)
+      GSArgs a{ilist(w.score[k]), cnt + 4 * k + 2, mu(k + 1), h->dev[k + 1].w_bwd, in->lb[k + 1], in->ub[k + 1], nb, h->s_in_gather ? ws + w.sb[k] : nullptr,
+               h->N[k], e.c_in, e.h_in, e.w_in, e.c_out, e.h_out, e.w_out, e.kh, e.kw, e.stride, e.pad, normalise};
+      lz.run(PC_GATHER, [&] { hipLaunchKernelGGL(k_gather_scored, dim3((unsigned)h->n_cu * 4), dim3(GS_WAVES * 64), 0, st, a); });
+      return;
+    }
     if (k >= 1 && h->gb[k + 1].ok) { gather(h->gb[k + 1], k, mu(k + 1), scored, false, k + 1, ws + w.sb[k]); return; }
     if (e.kind == 0) {
       ConvArgs a = conv_args(e, srcb, nb, h->dev[k + 1].w_bwd, normalise);

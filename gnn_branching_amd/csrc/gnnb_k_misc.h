@@ -277,3 +277,90 @@ __global__ __launch_bounds__(64) void k_reset(int32_t* status, int* cnt, unsigne
   for (int b = threadIdx.x; b < B; b += 64) best[b] = 0ull;        // per-sample best score key of k_score
   if (threadIdx.x == 0) { *status = 0; *done = 0; }
 }
+
+
+// ------------------------------------------------------------------------------------------
+// k_gather_scored: the restricted last step's transposed conv aggregate (graph_conv.py:299-318), list-driven.
+// After the last backward sweep mu[1] is read by the score head only, i.e. at the scored nodes (3-6 % of layer 1), but 62 % of
+// the 32-node gather tiles hold one: the tile gather spent 38 us (base, deep) on them.  Here ONE WAVE PER SCORED NODE:
+// lane = embedding channel.  The node's window (C_out x (k/s)^2 source nodes of the layer above) is evaluated lane-parallel
+// first -- slot validity, liveness of the source node (a dead row is zero and need not be in memory), tap weight -- and
+// compacted into a per-wave LDS list; then one coalesced 256-B row load + one FMA per live slot, in slot order (deterministic).
+// Divided by the tap count like the tile gather (:306-312); also writes the bias-sum scalar of the deferred projection.
+// ------------------------------------------------------------------------------------------
+struct GSArgs {
+  const int* list; const int* cnt;          // scored nodes of the dst layer (flat ids b * N + n) and their number
+  const float* mu_src;                      // (B, Ns, 64) rows of the layer above
+  const float* w;                           // conv weight as [co][ky][kx][ci] (pack_conv_bwd)
+  const float *src_lb, *src_ub;             // bounds of the layer above (B, Ns)
+  float* nb; float* sout;                   // out: aggregate rows by node id; bias sums (or null)
+  int N, C, H, W, Co, Ho, Wo, kh, kw, stride, pad, normalise;
+};
+#define GS_WAVES 8
+#define GS_MAXSLOTS 104      // C_out x (k/s)^2 <= 96 window slots (the host's limit) + padding to a multiple of 8
+__global__ __launch_bounds__(GS_WAVES * 64) void k_gather_scored(GSArgs a) {
+  __shared__ int s_row[GS_WAVES][GS_MAXSLOTS];
+  __shared__ float s_w[GS_WAVES][GS_MAXSLOTS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int total = *a.cnt;
+  const int Ns = a.Co * a.Ho * a.Wo;
+  // window slots (co, dy, dx): the taps ky = (y + pad) % s + s dy that can hit a source pixel at all (k/s per axis, not k)
+  const int ty_n = (a.kh + a.stride - 1) / a.stride, tx_n = (a.kw + a.stride - 1) / a.stride;
+  const int nslots = a.Co * ty_n * tx_n;
+  for (int idx = blockIdx.x * GS_WAVES + wave; idx < total; idx += gridDim.x * GS_WAVES) {
+    const int gc = a.list[idx];
+    const int b = gc / a.N, n = gc - b * a.N;
+    const int ci = n / (a.H * a.W), y = (n / a.W) % a.H, x = n % a.W;
+    const float* slb = a.src_lb + (long)b * Ns;
+    const float* sub = a.src_ub + (long)b * Ns;
+    const int ky0 = (y + a.pad) % a.stride, kx0 = (x + a.pad) % a.stride;
+    int nlive = 0, freq = 0;
+    for (int s0 = 0; s0 < nslots; s0 += 64) {
+      const int sl = s0 + lane;
+      const int co = sl / (ty_n * tx_n), dy = (sl / tx_n) % ty_n, dx = sl % tx_n;
+      const int ky = ky0 + a.stride * dy, kx = kx0 + a.stride * dx;
+      const int ty = y + a.pad - ky, tx = x + a.pad - kx;              // multiples of the stride by construction
+      const int oy = ty / a.stride, ox = tx / a.stride;
+      const bool hit = sl < nslots && ky < a.kh && kx < a.kw && ty >= 0 && tx >= 0 && oy < a.Ho && ox < a.Wo;
+      const int row = hit ? (co * a.Ho + oy) * a.Wo + ox : 0;
+      if (s0 == 0) freq = __popcll(__ballot(hit && co == 0));           // taps that touch this pixel (the reference's `freq`)
+      const bool live = hit && node_is_live(slb[row], sub[row]);
+      const float wv = live ? a.w[((co * a.kh + ky) * a.kw + kx) * a.C + ci] : 0.0f;
+      const unsigned long long bal = __ballot(live);
+      if (live) {
+        const int p = nlive + __popcll(bal & ((1ull << lane) - 1ull));
+        s_row[wave][p] = row;
+        s_w[wave][p] = wv;
+      }
+      nlive += __popcll(bal);
+    }
+    // pad to a multiple of 8 with (row 0, weight 0): whole rounds of eight independent row loads, no remainder loop
+    const int npad = (nlive + 7) & ~7;
+    if (lane < npad - nlive) { s_row[wave][nlive + lane] = 0; s_w[wave][nlive + lane] = 0.0f; }
+    __builtin_amdgcn_wave_barrier();
+    const float* src = a.mu_src + (long)b * Ns * 64 + lane;
+    float acc = 0.0f, ssum = 0.0f;
+    for (int q = 0; q < npad; q += 8) {
+      float v[8], wq[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        wq[u] = s_w[wave][q + u];
+        v[u] = q + u < nlive ? src[(long)s_row[wave][q + u] * 64] : 0.0f;     // (wave-uniform; a padding slot must not touch memory:
+                                                                              //  row 0 may be a dead node's never-written row)
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        acc = fmaf(wq[u], v[u], acc);
+        ssum += wq[u];
+      }
+    }
+    if (a.normalise) {
+      const float f = (float)(freq > 0 ? freq : 1);
+      acc = acc / f;
+      ssum = ssum / f;
+    }
+    a.nb[(long)gc * 64 + lane] = acc;
+    if (lane == 0 && a.sout) a.sout[gc] = ssum;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
