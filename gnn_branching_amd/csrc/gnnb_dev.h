@@ -282,8 +282,8 @@ __device__ __forceinline__ void tile_range(long ntiles, int waves, long& begin, 
   end = begin + base + (wg < rem ? 1 : 0);
 }
 
-// dev instrumentation (-DFUSED_TIMING): cycle sums per kernel phase, read back through gnnb_debug_read (tools/fused_timing.py)
-#ifdef FUSED_TIMING      // dev: per-phase cycle sums over all waves (tools/fused_timing.py reads them through gnnb_debug_read)
+// dev instrumentation (-DFUSED_TIMING): cycle sums per kernel phase, read back through gnnb_debug_read (tools/gather_timing.py)
+#ifdef FUSED_TIMING      // dev: per-phase cycle sums over all waves (tools/gather_timing.py reads them through gnnb_debug_read)
 __device__ unsigned long long g_fused_t[16];
 #define FUSED_TIMING_ON 1
 #define FT_DECL unsigned long long ft_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ft_last = __builtin_readcyclecounter()
