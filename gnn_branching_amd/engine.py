@@ -47,6 +47,26 @@ class BabsrResult:
         return tuple(list(torch.split(t[b], self.relu_sizes)) for t in (self.scores, self.intercepts, self.masks))
 
 
+def _or_reduce(status):
+    v = 0
+    for x in status.cpu().tolist():
+        v |= int(x)
+    return v
+
+
+def _raise_for_status(st):
+    """status word of gnnb_forward: bit 0 = an embedding was NaN (the reference enters pdb there, graph_conv.py:184-186, :339-341);
+    bit 1 = a wait inside k_gather_update_q ran into its iteration cap (a protocol bug or a wedged GPU: results are invalid)."""
+    if st & 2:
+        msg = "k_gather_update_q: internal wait timed out (status bit 1); results are invalid"
+        print(f"[gnn_branching_amd] {msg}", flush=True)
+        raise RuntimeError(msg)
+    if st & 1:
+        msg = "mu contains nan"
+        print(f"[gnn_branching_amd] {msg}", flush=True)
+        raise FloatingPointError(msg)
+
+
 class ForwardResult:
     """Device outputs of one batched forward."""
     __slots__ = ("scores", "decisions", "status", "masks")
@@ -57,10 +77,7 @@ class ForwardResult:
     def check(self):
         """Synchronises.  Raises like the reference would stop (it enters pdb on NaN embeddings,
         graph_conv.py:184-186, :339-341)."""
-        if int(self.status.max().item()) & 1:
-            msg = "mu contains nan"
-            print(f"[gnn_branching_amd] {msg}", flush=True)
-            raise FloatingPointError(msg)
+        _raise_for_status(_or_reduce(self.status))
         return self
 
     def ragged(self):
@@ -314,10 +331,7 @@ class ScorerEngine:
             rc = self.lib.gnnb_forward_host(self.h, C.byref(batch), B, scores.ctypes.data if want_scores else None, dec.ctypes.data,
                                             status.ctypes.data, C.c_void_p(st))
         _lib.check(rc, "gnnb_forward_host")
-        if int(status[0]) & 1:
-            msg = "mu contains nan"
-            print(f"[gnn_branching_amd] {msg}", flush=True)
-            raise FloatingPointError(msg)
+        _raise_for_status(int(status[0]))
         return dec, scores
 
     # ---- online learning --------------------------------------------------------
