@@ -828,7 +828,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   // are written (k_classify) only for a layer with a consumer that reads every row: VALU / non-sparse gathers, the
   // per-sample / per-tile dense kernels, k_prop, inspection runs.
   auto reads_live_rows_only = [&](int e, bool transposed) {      // edge e between layers e-1 and e; transposed: reads layer e
-    if (e == L && top_fused) return transposed || h->edges[L].n_in + 96 <= (int)TOP_LIST_INTS || h->edges[L].n_in + 96 <= (int)PackProp::FLOATS;
+    if (e == L && top_fused) return transposed || TOP_LIST_OK(h->edges[L].n_in);
     const DevGather& d = transposed ? h->gb[e] : h->gf[e];
     if (!d.ok) return false;
     if (transposed && e == 1) return (h->gather_sparse & 4) != 0;
@@ -838,8 +838,8 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   // of edge L in both directions themselves and k_livesum skips those jobs
   const bool s1_table = h->s_in_gather && L >= 2 && h->d_s1 != nullptr;      // bias sums of edge 1 forward: bind-time table
   const int topK = L >= 1 && h->edges[L].kind == 1 ? h->edges[L].n_in : 0;
-  const bool top_s_fwd = top_fused && h->s_in_gather && (topK + 96 <= (int)TOP_LIST_INTS || topK + 96 <= (int)PackProp::FLOATS);
-  const bool top_s_bwd = top_fused && h->s_in_gather && topK + 96 <= (int)TOP_LIST_INTS && limit >= 2;
+  const bool top_s_fwd = top_fused && h->s_in_gather && TOP_LIST_OK(topK);
+  const bool top_s_bwd = top_fused && h->s_in_gather && TOP_LIST_KEEP_OK(topK) && limit >= 2;
   auto zero_dead_rows = [&](int k) {
     if (debug_full || h->zero_dead) return true;
     if (k == L) return !top_fused;                                // k_top writes every row of layer L itself

@@ -305,6 +305,8 @@ __device__ __forceinline__ void dense_bwd_sample(const DenseLArgs& a, const floa
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nch = (klist ? (K_eff + 15) / 16 * 16 : a.Kpad) / 16;      // chunks of 8 k-steps
   const int M = rlist ? n_rows : a.M, MT = rlist ? (n_rows + 31) / 32 : a.MT;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.At, 0, 0x7fffffff, 0x00020000);
+  const unsigned ldb = (unsigned)a.ldA * 4u;
   for (int mt = wave; mt < MT; mt += 8) {
     const int arow = rlist ? rlist[mt * 32 + j < M ? mt * 32 + j : 0] : mt * 32 + j;
     const float* At = a.At + arow;
@@ -371,6 +373,271 @@ __global__ __launch_bounds__(512, 2) void k_dense_bwd_lds(DenseLArgs a) {
   __syncthreads();
   float* out = a.out + (long)b * a.M * 64;
   dense_bwd_sample(a, &xs[0][0], [&](int row, int j, float2 v) { *reinterpret_cast<float2*>(out + (long)row * 64 + 2 * j) = v; });
+}
+
+// ---- the two Linear edges of k_top on the bf16 matrix rate ----------------------------------------------------------------------
+// Both operands in three bf16 pieces, six products per k-step (gemm_w64_bf3's arithmetic: fp32-grade sums, 2.7x fewer matrix-pipe
+// cycles than v_mfma_f32_32x32x2_f32).  The weights stay fp32 in memory and are split in registers next to the MFMAs (a
+// pre-split image would double the bytes every sample pulls out of L2).  v_mfma_f32_32x32x16_bf16 operands: lane (i = l & 31,
+// kg = l >> 5) holds k = 8 kg .. 8 kg + 7 of row / column i; WHICH source rows a k-step's 16 slots stand for is free, so a lane
+// simply takes 8 consecutive entries of the live-row list.
+struct Split3 { unsigned u1, u2, u3; };
+__device__ __forceinline__ Split3 split3(float a, float b) {
+  Split3 r;
+  r.u1 = pk_bf16(a, b);
+  const float ra = a - __uint_as_float(r.u1 << 16), rb = b - __uint_as_float(r.u1 & 0xffff0000u);
+  r.u2 = pk_bf16(ra, rb);
+  const float sa = ra - __uint_as_float(r.u2 << 16), sb = rb - __uint_as_float(r.u2 & 0xffff0000u);
+  r.u3 = pk_bf16(sa, sb);
+  return r;
+}
+__device__ __forceinline__ void split3_to(u32x4 (&d)[3], int q, float a, float b) {
+  const Split3 r = split3(a, b);
+  d[0][q] = r.u1; d[1][q] = r.u2; d[2][q] = r.u3;
+}
+__device__ __forceinline__ f32x16 mfma6(const u32x4 (&w)[3], const u32x4 (&x)[3], f32x16 acc) {
+  const bf16x8 w1 = __builtin_bit_cast(bf16x8, w[0]), w2 = __builtin_bit_cast(bf16x8, w[1]), w3 = __builtin_bit_cast(bf16x8, w[2]);
+  const bf16x8 x1 = __builtin_bit_cast(bf16x8, x[0]), x2 = __builtin_bit_cast(bf16x8, x[1]), x3 = __builtin_bit_cast(bf16x8, x[2]);
+  acc = mfma_bf16(w3, x1, acc);
+  acc = mfma_bf16(w2, x2, acc);
+  acc = mfma_bf16(w1, x3, acc);
+  acc = mfma_bf16(w2, x1, acc);
+  acc = mfma_bf16(w1, x2, acc);
+  return mfma_bf16(w1, x1, acc);
+}
+typedef unsigned short top_idx_t;      // live-row lists of k_top: 16-bit (layers up to 65535 nodes), so that they fit beside the weights
+
+// forward edge (long K) of sample b: out[m][c] = sum_k W[m][k] X[k][c], m < 128 (a.ldA <= 128 columns of At), c < 64.
+// 8 waves split K: wave w takes k-steps (16 list entries each) w, w + 8, ... for ALL rows and channels (8 accumulator tiles), so
+// every X row and every weight is loaded and split by exactly one wave -- no staging, no barrier in the loop.
+// Row tile t holds rows 4 i + t (i < 32) and channel tile nt channels 2 j + nt: one 16-B load per lane and list entry brings the
+// weights of all four row tiles (a whole 512-B row of At per half-wave; as 4-B loads -- 32 instead of 8 per k-step -- the
+// loop was bound by the address rate of the texture path, 23 us of loads for 460 KB), one 8-B load both channel tiles of X.
+// The 8 partial sums meet in LDS in wave order (4 phases of 2 tiles, `scratch`: 16384 floats; every wave adds up a quarter tile).
+// klist (LDS, or null: all a.K rows): the K_eff live source rows, padded with a.Kpad (a zero row of At) up to K_eff + 1.
+// s_fin (LDS, 128 floats) != null: s_fin[m] = sum over the walked rows of W[m][k] (the bias sum of this edge); spart: 256 floats.
+// store(row, channel, value).  Requires 512 threads.
+template <class Store1>
+__device__ __forceinline__ void dense_fwd_sample_bf3(const DenseLArgs& a, int b, float* scratch, float* spart, Store1 store,
+                                                     const top_idx_t* klist, int K_eff, float* s_fin) {
+  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int Kw = klist ? K_eff : a.K;
+  const int nsteps = (Kw + 15) >> 4;
+  // buffer loads: a row's address is one 32-bit multiply, and a slot past the end of the list (row Kpad >= K) is out of range
+  // of this sample's X -> reads zero, while At has a zero row there
+  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + (long)b * a.K * 64), 0, a.K * 256, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.At, 0, 0x7fffffff, 0x00020000);
+  const unsigned ldb = (unsigned)a.ldA * 4u;
+  const unsigned acol = 4 * j < a.ldA ? 16u * (unsigned)j : 0u;       // (rows 4 j + t >= ldA do not exist: any finite weights will do)
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[t][0][r] = 0.0f; acc[t][1][r] = 0.0f; }
+  float sacc[4] = {0.f, 0.f, 0.f, 0.f};
+  // One set of raw registers: they are free as soon as they are split, and the loads of the wave's next k-step go out right
+  // there, under this step's MFMAs (8 accumulator tiles leave no room for a second buffer).
+  float2 x[8];
+  f32x4 A[8];
+  auto rowof = [&](int s, int q) {
+    const int i = s * 16 + 8 * h + q;
+    const bool v = i < Kw;
+    return (unsigned)(klist ? (int)klist[v ? i : Kw] : (v ? i : a.Kpad));      // (list entry Kw is padding = Kpad)
+  };
+  auto issueX = [&](int s) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const auto v = __builtin_amdgcn_raw_buffer_load_b64(rX, rowof(s, q) * 256u + 8u * (unsigned)j, 0, 0);
+      x[q] = make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
+    }
+  };
+  auto issueA = [&](int s) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const auto v = __builtin_amdgcn_raw_buffer_load_b128(rA, rowof(s, q) * ldb + acol, 0, 0);
+      A[q] = f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+    }
+  };
+  auto splitA = [&](u32x4 (&wa)[3], int t) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      split3_to(wa, q, A[2 * q][t], A[2 * q + 1][t]);
+      sacc[t] += A[2 * q][t] + A[2 * q + 1][t];
+    }
+  };
+  int s = wave;
+  if (s < nsteps) {
+    issueX(s);
+    issueA(s);
+  }
+  for (; s < nsteps; s += 8) {
+    u32x4 xb0[3], xb1[3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      split3_to(xb0, q, x[2 * q].x, x[2 * q + 1].x);
+      split3_to(xb1, q, x[2 * q].y, x[2 * q + 1].y);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    issueX(s + 8);                             // (past the end: padding entries -> zeros)
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      u32x4 wa[3];
+      splitA(wa, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0][0] = mfma6(wa, xb0, acc[0][0]);
+      acc[0][1] = mfma6(wa, xb1, acc[0][1]);
+      __builtin_amdgcn_sched_barrier(0);
+      splitA(wa, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[1][0] = mfma6(wa, xb0, acc[1][0]);
+      acc[1][1] = mfma6(wa, xb1, acc[1][1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {
+      u32x4 wa[3], wb[3];
+      splitA(wa, 2);
+      splitA(wb, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      issueA(s + 8);                           // all four tiles' weights are split: their registers take the next step's
+      __builtin_amdgcn_sched_barrier(0);
+      acc[2][0] = mfma6(wa, xb0, acc[2][0]);
+      acc[2][1] = mfma6(wa, xb1, acc[2][1]);
+      acc[3][0] = mfma6(wb, xb0, acc[3][0]);
+      acc[3][1] = mfma6(wb, xb1, acc[3][1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // ---- the 8 partial sums of every tile meet in LDS, two tiles per phase; every wave adds up a quarter of a tile in wave order
+  float (*sc)[2][16][64] = reinterpret_cast<float (*)[2][16][64]>(scratch);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int id = 2 * p + u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[wave][u][r][lane] = acc[id & 3][id >> 2][r];
+    }
+    if (s_fin) {
+      const float sp = sacc[p] + __shfl_xor(sacc[p], 32);
+      if (h == 0) spart[wave * 32 + j] = sp;
+    }
+    __syncthreads();
+    {
+      const int u = wave & 1, rq = wave >> 1, id = 2 * p + u, t = id & 3, nt = id >> 2;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        float tot = sc[0][u][4 * rq + rr][lane];
+#pragma unroll
+        for (int w8 = 1; w8 < 8; ++w8) tot += sc[w8][u][4 * rq + rr][lane];
+        const int row = 4 * (rr + 8 * rq + 4 * h) + t;
+        if (row < a.M) store(row, 2 * j + nt, tot);
+      }
+      if (s_fin && wave == 0 && h == 0) {
+        float tot = spart[j];
+#pragma unroll
+        for (int w8 = 1; w8 < 8; ++w8) tot += spart[w8 * 32 + j];
+        s_fin[4 * j + p] = tot;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// transposed edge (short K <= 128) of one sample: out[row][c] = sum_k W[k][row] C[k][c], the rows of C (layer L) in LDS (`Cr`,
+// fp32, rows >= K zero).  First the walked rows of C are split into three bf16 pieces and laid down as the B operands of
+// every k-step (`img`: 12288 floats; one ds_read_b128 per operand and lane afterwards); then 8 waves walk the row tiles, the
+// weights from L2 two k-steps ahead, split in registers.
+// rlist / n_rows (LDS): only these output rows (the live nodes of the layer below); klist / K_eff: only these source rows,
+// padded with a.Kpad (a zero row of At and of C) up to round_up(K_eff, 16) + 32 entries.  sout as in dense_bwd_sample.
+// (Measured against this: 64 consecutive rows per wave with 8-B weight loads for two row tiles at once, every row computed and
+// the live ones stored -- equal on cifar_base, 11 us slower on cifar_wide, whose 40 % dead rows it cannot skip.)
+template <class Store>
+__device__ __forceinline__ void dense_bwd_sample_bf3(const DenseLArgs& a, const float* Cr, float* img, Store store, const top_idx_t* rlist,
+                                                     int n_rows, const int* klist, int K_eff, float* sout) {
+  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nst = (klist ? (K_eff + 15) / 16 * 16 : a.Kpad) / 16;
+  unsigned* im = reinterpret_cast<unsigned*>(img);
+  for (int e = threadIdx.x; e < nst * 256; e += 512) {
+    const int q = e & 3, n = (e >> 2) & 31, kg = (e >> 7) & 1, st = e >> 8;
+    const int i0 = st * 16 + kg * 8 + 2 * q;
+    const int k0 = klist ? klist[i0] : i0, k1 = klist ? klist[i0 + 1] : i0 + 1;
+    const float2 v0 = *reinterpret_cast<const float2*>(Cr + k0 * 64 + 2 * n), v1 = *reinterpret_cast<const float2*>(Cr + k1 * 64 + 2 * n);
+    const Split3 sx = split3(v0.x, v1.x), sy = split3(v0.y, v1.y);
+    const unsigned u[2][3] = {{sx.u1, sx.u2, sx.u3}, {sy.u1, sy.u2, sy.u3}};
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) im[((((st * 2 + nt) * 3 + p) * 64) + kg * 32 + n) * 4 + q] = u[nt][p];
+  }
+  __syncthreads();
+  const u32x4* im4 = reinterpret_cast<const u32x4*>(img) + lane;
+  const int M = rlist ? n_rows : a.M, MT = rlist ? (n_rows + 31) / 32 : a.MT;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.At, 0, 0x7fffffff, 0x00020000);
+  const unsigned ldb = (unsigned)a.ldA * 4u;
+  for (int mt = wave; mt < MT; mt += 8) {
+    const int arow = rlist ? (int)rlist[mt * 32 + j < M ? mt * 32 + j : 0] : mt * 32 + j;
+    const unsigned acol = 4u * (unsigned)arow;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+    // Software pipeline: while the 12 MFMAs of k-step st run, the wave splits the weights of st + 1 (5 vector instructions fit
+    // under each MFMA's 32 cycles: MI355X_MICROARCH.md, vector-instruction issue cost) and the loads of st + 3 go out into
+    // the registers just split.
+    float A0[8], A1[8];
+    auto loadA = [&](float (&A)[8], int st) {
+      const int sc = st < nst ? st : nst;          // (past the end: the padding entries / zero rows behind the walked ones)
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        A[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rA, (unsigned)(klist ? klist[sc * 16 + 8 * h + q] : sc * 16 + 8 * h + q) * ldb + acol, 0, 0));
+    };
+    float sacc = 0.0f;
+    auto split = [&](u32x4 (&w)[3], const float (&A)[8]) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        split3_to(w, q, A[2 * q], A[2 * q + 1]);
+        if (sout) sacc += A[2 * q] + A[2 * q + 1];
+      }
+    };
+    auto body = [&](const u32x4 (&cur)[3], int st, u32x4 (&nxt)[3], const float (&Araw)[8]) {
+      __builtin_amdgcn_sched_barrier(0);
+      const u32x4 xa[3] = {im4[((st * 2 + 0) * 3 + 0) * 64], im4[((st * 2 + 0) * 3 + 1) * 64], im4[((st * 2 + 0) * 3 + 2) * 64]};
+      const u32x4 xb[3] = {im4[((st * 2 + 1) * 3 + 0) * 64], im4[((st * 2 + 1) * 3 + 1) * 64], im4[((st * 2 + 1) * 3 + 2) * 64]};
+      split(nxt, Araw);
+      acc0 = mfma6(cur, xa, acc0);
+      acc1 = mfma6(cur, xb, acc1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);       // the six operand reads first
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);     // five vector instructions under it
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    u32x4 wa[3], wb[3];
+    loadA(A0, 0);
+    loadA(A1, 1);
+    split(wa, A0);
+    __builtin_amdgcn_sched_barrier(0);
+    loadA(A0, 2);
+    for (int st = 0; st < nst; st += 2) {
+      body(wa, st, wb, A1);
+      loadA(A1, st + 3);
+      if (st + 1 >= nst) break;
+      body(wb, st + 1, wa, A0);
+      loadA(A0, st + 4);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < M) store(rlist ? (int)rlist[row] : row, j, make_float2(acc0[r], acc1[r]));
+    }
+    if (sout) {
+      sacc += __shfl_xor(sacc, 32);
+      if (h == 0 && mt * 32 + j < M) sout[arow] = sacc;
+    }
+  }
 }
 
 struct PropArgs {
@@ -478,6 +745,11 @@ struct TopArgs {
 #define TOP_LDS_FLOATS 40960                   // all 160 KB: what the fixed regions leave holds the live-row lists
 #define TOP_K2_INTS (128 + 48)                  // live rows of layer L, padded for the chunks read ahead
 #define TOP_LIST_INTS (TOP_LDS_FLOATS - TOP_FIXED_FLOATS - TOP_K2_INTS)
+// the live-row list of layer L-1 (16-bit entries): behind the fixed regions when it fits (then the transposed edge walks only
+// live rows too), else in the region PackProp takes after F1, else the edge walks every row
+#define TOP_LIST_KEEP_OK(K) ((K) + 96 <= 2 * (int)TOP_LIST_INTS && (K) < 65535)
+#define TOP_LIST_OK(K) (TOP_LIST_KEEP_OK(K) || ((K) + 96 <= 2 * (int)PackProp::FLOATS && (K) < 65535))
+static_assert(TOP_A_FLOATS >= 16384 && TOP_A_FLOATS >= 12288, "k_top: F1's reduction scratch and B2's operand image live in region A");
 
 __device__ __forceinline__ void copy_to_lds_part(float* lds, const float* src, int nfloats, int tid, int nthr) {
   const f32x4* g = reinterpret_cast<const f32x4*>(src);
@@ -518,10 +790,10 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
   // live rows of layer L-1), else into the region PackProp takes after F1.
   int* k2list = reinterpret_cast<int*>(spart + 8);        // live rows of layer L (B2)
   int* tail = k2list + TOP_K2_INTS;
-  const bool keep = a.df.K + 96 <= TOP_LIST_INTS;
-  int* klist = keep ? tail : reinterpret_cast<int*>(Bp);
+  const bool keep = TOP_LIST_KEEP_OK(a.df.K);
+  top_idx_t* klist = reinterpret_cast<top_idx_t*>(keep ? tail : reinterpret_cast<int*>(Bp));
   int K_eff = 0;
-  const bool compact = keep || a.df.K + 96 <= PackProp::FLOATS;
+  const bool compact = TOP_LIST_OK(a.df.K);
   if (compact) {
     int* wc = reinterpret_cast<int*>(part);              // per-wave counts
     const int K = a.df.K;
@@ -535,23 +807,28 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
       int before = 0, total = 0;
 #pragma unroll
       for (int w8 = 0; w8 < 8; ++w8) { before += w8 < wave ? wc[w8] : 0; total += wc[w8]; }
-      if (live) klist[K_eff + before + __popcll(bal & ((1ull << lane) - 1ull))] = n;
+      if (live) klist[K_eff + before + __popcll(bal & ((1ull << lane) - 1ull))] = (top_idx_t)n;
       K_eff += total;
       __syncthreads();
     }
-    for (int i = K_eff + tid; i < (K_eff + 63) / 64 * 64 + 32; i += 512) klist[i] = a.df.Kpad;     // a zero row of At
+    for (int i = K_eff + tid; i < (K_eff + 63) / 64 * 64 + 32; i += 512) klist[i] = (top_idx_t)a.df.Kpad;     // a zero row of At
   }
   __syncthreads();
   FT_MARK(0);        // zero C, live-row list of layer L-1
 
+#if defined(TOP_STOP) && TOP_STOP == 1     // dev, timing only (TOP_STOP = 1 / 2 / 3: leave before F1 / after F1 / before B2)
+  if (a.N > 0) return;
+#endif
   // ---- F1: rows of C <- W_L . mu_{L-1}
-  float s_own = 0.0f;                                    // waves 0..3, lane j: bias sum of node wave*32 + j (when a.sf is null)
+  const bool own_s = compact && !a.sf;                    // the bias sums of the forward edge come out of F1's own walk (-> xs)
 #if defined(TOP_ABL) && (TOP_ABL & 2)     // dev, timing only: no F1
   if (K_eff < 0)
 #endif
-  dense_fwd_sample(a.df, b, A, [&](int row, int jj, float2 v) { *reinterpret_cast<float2*>(Cr + row * 64 + 2 * jj) = v; },
-                   compact ? klist : nullptr, K_eff, (compact && !a.sf) ? &s_own : nullptr);
-  __syncthreads();
+  dense_fwd_sample_bf3(a.df, b, A, part, [&](int row, int ch, float v) { Cr[row * 64 + ch] = v; }, compact ? klist : nullptr, K_eff,
+                       own_s ? xs : nullptr);
+#if defined(TOP_STOP) && TOP_STOP == 2
+  if (a.N > 0) { if (Cr[tid] == 12345.0f) a.mu_prop[0] = 1.0f; return; }
+#endif
   FT_MARK(1);        // F1 dense forward edge
   copy_to_lds(Bp, a.pack_p, PackProp::FLOATS);            // (read from F3 on, behind two more barriers)
 
@@ -561,6 +838,7 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
   const bool valid = n < N;
   const long g = (long)b * N + (valid ? n : 0);
   const float* pw = a.prop_w + (long)b * N;
+  const float s_own = (own_s && upd_wave) ? xs[wave * 32 + j] : 0.0f;      // (xs is rewritten in F3, behind a barrier)
   Ratio r{};
   if (upd_wave) r = compute_ratio(a.lb[g], a.ub[g]);
   auto load_row = [&](Frag& x_, int row) {       // fragment <- LDS row (row-major 64 floats)
@@ -695,6 +973,9 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
     for (int i = K2 + tid; i < TOP_K2_INTS; i += 512) k2list[i] = a.db.Kpad;   // zero row of At and of C
     __syncthreads();
   }
+#if defined(TOP_STOP) && TOP_STOP == 3
+  if (a.N > 0) return;
+#endif
   float* out = a.db.out + (long)b * a.db.M * 64;
 #ifdef TOP_ABL_NOSTORE   // dev, timing only
   auto put = [&](int row, int jj, float2 v) { if (v.x > 1e30f) *reinterpret_cast<float2*>(out + (long)row * 64 + 2 * jj) = v; };
@@ -702,10 +983,10 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
   auto put = [&](int row, int jj, float2 v) { *reinterpret_cast<float2*>(out + (long)row * 64 + 2 * jj) = v; };
 #endif
 #if defined(TOP_ABL) && (TOP_ABL & 1)     // dev, timing only: no B2
-  if (K2 < 0) dense_bwd_sample(a.db, Cr, put);
+  if (K2 < 0) dense_bwd_sample_bf3(a.db, Cr, A, put, nullptr, 0, nullptr, 0, nullptr);
 #else
-  if (keep) dense_bwd_sample(a.db, Cr, put, klist, K_eff, k2list, K2, a.sb_out ? a.sb_out + (long)b * a.db.M : nullptr);
-  else dense_bwd_sample(a.db, Cr, put);
+  if (keep) dense_bwd_sample_bf3(a.db, Cr, A, put, klist, K_eff, k2list, K2, a.sb_out ? a.sb_out + (long)b * a.db.M : nullptr);
+  else dense_bwd_sample_bf3(a.db, Cr, A, put, nullptr, 0, nullptr, 0, nullptr);
 #endif
 #ifdef FUSED_TIMING
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
