@@ -26,6 +26,8 @@ ARCHS = {
     # kernel sizes / strides without a compile-time stencil in the bias-sum pass: 5x5 stride 1 pad 2, 2x2 stride 2 pad 0
     "toy_k5": [("conv", 3, 8, 5, 1, 2), ("relu",), ("conv", 8, 8, 2, 2, 0), ("relu",), ("flatten",), ("linear", 8 * 16 * 16, 40),
                ("relu",), ("linear", 40, 10)],
+    # a 32768-node layer under the Linear head: too long for k_top's live-row list (LDS), so its forward edge walks every row
+    "toy_longk": [("conv", 3, 32, 3, 1, 1), ("relu",), ("flatten",), ("linear", 32 * 32 * 32, 72), ("relu",), ("linear", 72, 10)],
     # a single ReLU layer (L = 1)
     "toy_single": [("conv", 3, 8, 4, 2, 1), ("relu",), ("flatten",), ("linear", 8 * 16 * 16, 10)],
 }

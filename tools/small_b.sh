@@ -1,4 +1,12 @@
-for b in 1 2 16 64; do
-  python bench.py --batch $b --no-cpu-baseline --steps 50 --warmup 10 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('B=$b', d['ms_per_step'], 'ms', round(d['value']/1e6,2), 'M scores/s', 'instrumented', d['instrumented_ms_per_step'])"
+#!/bin/bash
+# dev helper (GPU box): per-kernel durations of one forward at small batch sizes -> gpurun_out/smallb/
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/smallb; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+for B in ${SMALL_B:-1 8}; do
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/s$B -- python3 $R/bench.py --no-cpu-baseline --net ${SMALL_NET:-cifar_base_kw} --batch $B --steps 200 --warmup 20 > $O/bench$B.json 2> $O/s$B.log || { echo "failed"; tail -5 $O/s$B.log; exit 1; }
+cp $(ls $O/s$B/*/*kernel_stats.csv | head -1) $O/kernel_stats$B.csv; rm -rf $O/s$B
+python3 -c "
+import json,sys
+d=json.loads(open('$O/bench$B.json').read().strip().splitlines()[-1]); print('B=$B ms_per_step', d['ms_per_step'])"
+cut -d, -f1,2,4 $O/kernel_stats$B.csv | head -16
 done
-python bench.py --batch 2 --no-cpu-baseline --steps 50 --warmup 10 > gpurun_out/b2.json 2>/dev/null; python tools/kern_table.py gpurun_out/b2.json
