@@ -141,10 +141,10 @@ def plan_flops(plan, B, stats, restrict_last=True):
 
 def pmc_rows(pmc, cls):
     """Counter summaries of the kernel templates behind profile class `cls` (k_gather covers k_gather and k_gather16, k_gather_update
-    the kernel k_gather_update_q)."""
+    the kernel k_gather_update_q; k_gather_scored runs under class k_gather)."""
     def same(name):
         rest = name[len(cls):] if name.startswith(cls) else None
-        return rest is not None and (rest == "" or rest.isdigit() or rest == "_q")
+        return rest is not None and (rest == "" or rest.isdigit() or rest == "_q" or (cls == "k_gather" and rest == "_scored"))
     return [v for k, v in pmc.items() if same(k) and "hbm_bytes_per_launch" in v]
 
 

@@ -592,31 +592,30 @@ __device__ __forceinline__ void gather_process_tile(const GArgs& a, const TileCt
 // lane (lane group 0 / 1 / 2 reads l / x / u of its row's slot, group 3 supplies the 1 of the bias), 4 embedding MFMAs (one
 // per 16-channel tile), 16 v_max, 16 tap MFMAs -- instead of 64 FMAs + 16 v_max + 12 loads per lane.  An out-of-range slot
 // feeds zeros (including its "1"), so its embedding is relu(0) = 0.
-__device__ __forceinline__ void gather_tile16_embed_mfma(f32x4 (&acc)[4], const float* cm, const int2* ko, int K2, __amdgpu_buffer_rsrc_t rl,
-                                                         __amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t ru, const float (&bw)[4],
+// The scalars: every lane needs ONE of l / x / u (its k-index) per group, so it loads just that one through its own pointer,
+// and a window of up to EMB_PRE groups (the 4x4 and 5x5 first convolutions: 3 and 5) is loaded whole before the first MFMA: one
+// memory round trip per tile.  (Three buffer loads per lane and group, each prefetched one group = 20 MFMAs ahead, left the
+// gather waves waiting on memory half of their time: SQ_WAIT_INST_ANY 50 %, profiles/r02c.)
+#define EMB_PRE 6
+__device__ __forceinline__ void gather_tile16_embed_mfma(f32x4 (&acc)[4], const float* cm, const int2* ko, int K2, const float* pl,
+                                                         const float* px, const float* pu, const float (&bw)[4],
                                                          int wy0, int wx0, int Hs, int Ws, int lane) {
   const int m = lane & 15, kq = lane >> 4;
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int origin = wy0 * Ws + wx0;
   const int sl = 4 * (m & 3) + (m >> 2);            // slot of embedding row m inside a group of 16
+  const float* src = kq == 0 ? pl : kq == 1 ? px : pu;
   auto load = [&](int grp) -> float {
     const unsigned long long ev = reinterpret_cast<const unsigned long long*>(ko)[16 * grp + sl];
     const int ex = (int)(unsigned)ev, ey = (int)(unsigned)(ev >> 32);
     const int wy = wy0 + (ey & 0xffff), wx = wx0 + (ey >> 16);
     const bool inb = (unsigned)wy < (unsigned)Hs && (unsigned)wx < (unsigned)Ws;      // (table padding: 0x7fff, never in range)
-    const unsigned o = inb ? (unsigned)(origin + ex) * 4u : BUF_OOB;
-    const float vl = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rl, o, 0, 0));
-    const float vx = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, 0));
-    const float vu = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, o, 0, 0));
-    return kq == 0 ? vl : kq == 1 ? vx : kq == 2 ? vu : (inb ? 1.0f : 0.0f);
+    float v = inb ? 1.0f : 0.0f;                    // k-index 3: the 1 of the bias; an out-of-range slot feeds zeros
+    if (inb && kq < 3) v = src[origin + ex];
+    return v;
   };
-  const int ngrp = K2 / 4;
-  float ain = load(0);
-  for (int grp = 0; grp < ngrp; ++grp) {
-    const float cur = ain;
-    if (grp + 1 < ngrp) ain = load(grp + 1);
-    __builtin_amdgcn_sched_barrier(0);
+  auto group = [&](float cur, int grp) {
     f32x4 e[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -630,6 +629,26 @@ __device__ __forceinline__ void gather_tile16_embed_mfma(f32x4 (&acc)[4], const 
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[t] = mfma16(e[t][r], b, acc[t]);
     }
+  };
+  const int ngrp = K2 / 4;
+  if (ngrp <= EMB_PRE) {
+    float ain[EMB_PRE];
+#pragma unroll
+    for (int g = 0; g < EMB_PRE; ++g) ain[g] = g < ngrp ? load(g) : 0.0f;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < EMB_PRE; ++g) {
+      if (g < ngrp) group(ain[g], g);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
+  }
+  float ain = load(0);
+  for (int grp = 0; grp < ngrp; ++grp) {
+    const float cur = ain;
+    if (grp + 1 < ngrp) ain = load(grp + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    group(cur, grp);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -655,7 +674,7 @@ __device__ __forceinline__ void gather_compute_tile16(const GArgs& a, const Tile
       float bw[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) bw[t] = k < 3 ? a.es.wb[(4 * n + t) * 3 + k] : a.es.wb[192 + 4 * n + t];
-      gather_tile16_embed_mfma(acc, cmt, lds_ko, a.g.K2, rl, rx, ru, bw, uy, ux, a.g.Hs, a.g.Ws, lane);
+      gather_tile16_embed_mfma(acc, cmt, lds_ko, a.g.K2, a.es.lb + sb, a.es.x + sb, a.es.ub + sb, bw, uy, ux, a.g.Hs, a.g.Ws, lane);
     } else if (interior) gather_tile16_embed<true>(acc, cmt, lds_ko, lds_kvo, a.g.K2, rl, rx, ru, ew, eb, uy, ux, a.g.Hs, a.g.Ws, lane);
     else gather_tile16_embed<false>(acc, cmt, lds_ko, lds_kvo, a.g.K2, rl, rx, ru, ew, eb, uy, ux, a.g.Hs, a.g.Ws, lane);
   } else {

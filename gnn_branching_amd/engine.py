@@ -107,7 +107,7 @@ class ScorerEngine:
         self._prop_cache = {}
         # batch pipelining: a large batch is cut into `n_streams` contiguous chunks that run on separate HIP streams,
         # so the launch ramps and tails of one chunk's ~40 dependent kernels overlap the other chunk's work
-        self.n_streams = int(os.environ.get("GNNB_STREAMS", "1"))   # measured on base B=256: 2 streams 1.89 ms vs 1 stream 1.83 ms
+        self.n_streams = int(os.environ.get("GNNB_STREAMS", "1"))   # measured on base B=256 (round 2): 1 stream 0.92 ms, 2 streams 0.97, 3 streams 1.10
         self.min_chunk = 64
         self._streams = []
 
