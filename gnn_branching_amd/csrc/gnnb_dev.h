@@ -80,18 +80,24 @@ __device__ __forceinline__ void gemm_w64_bf3(const float* wl, int lane, Frag& ac
       p1[q] = u1; p2[q] = u2; p3[q] = pk_bf16(sa, sb);
     }
     const bf16x8 x1 = __builtin_bit_cast(bf16x8, p1), x2 = __builtin_bit_cast(bf16x8, p2), x3 = __builtin_bit_cast(bf16x8, p3);
-#pragma unroll
-    for (int ot = 0; ot < 2; ++ot) {
-      const bf16x8 w1 = __builtin_bit_cast(bf16x8, w[((fk * 2 + ot) * 3 + 0) * 64]);
-      const bf16x8 w2 = __builtin_bit_cast(bf16x8, w[((fk * 2 + ot) * 3 + 1) * 64]);
-      const bf16x8 w3 = __builtin_bit_cast(bf16x8, w[((fk * 2 + ot) * 3 + 2) * 64]);
-      acc.t[ot] = mfma_bf16(w3, x1, acc.t[ot]);
-      acc.t[ot] = mfma_bf16(w2, x2, acc.t[ot]);
-      acc.t[ot] = mfma_bf16(w1, x3, acc.t[ot]);
-      acc.t[ot] = mfma_bf16(w2, x1, acc.t[ot]);
-      acc.t[ot] = mfma_bf16(w1, x2, acc.t[ot]);
-      acc.t[ot] = mfma_bf16(w1, x1, acc.t[ot]);
-    }
+    // the two output tiles' product chains alternate: an MFMA's accumulator was written two instructions earlier, not one
+    // (back to back, each of the six waits out its predecessor's result latency); each accumulator still sees its six
+    // products in the same order
+    const bf16x8 w1a = __builtin_bit_cast(bf16x8, w[((fk * 2 + 0) * 3 + 0) * 64]), w1b = __builtin_bit_cast(bf16x8, w[((fk * 2 + 1) * 3 + 0) * 64]);
+    const bf16x8 w2a = __builtin_bit_cast(bf16x8, w[((fk * 2 + 0) * 3 + 1) * 64]), w2b = __builtin_bit_cast(bf16x8, w[((fk * 2 + 1) * 3 + 1) * 64]);
+    const bf16x8 w3a = __builtin_bit_cast(bf16x8, w[((fk * 2 + 0) * 3 + 2) * 64]), w3b = __builtin_bit_cast(bf16x8, w[((fk * 2 + 1) * 3 + 2) * 64]);
+    acc.t[0] = mfma_bf16(w3a, x1, acc.t[0]);
+    acc.t[1] = mfma_bf16(w3b, x1, acc.t[1]);
+    acc.t[0] = mfma_bf16(w2a, x2, acc.t[0]);
+    acc.t[1] = mfma_bf16(w2b, x2, acc.t[1]);
+    acc.t[0] = mfma_bf16(w1a, x3, acc.t[0]);
+    acc.t[1] = mfma_bf16(w1b, x3, acc.t[1]);
+    acc.t[0] = mfma_bf16(w2a, x1, acc.t[0]);
+    acc.t[1] = mfma_bf16(w2b, x1, acc.t[1]);
+    acc.t[0] = mfma_bf16(w1a, x2, acc.t[0]);
+    acc.t[1] = mfma_bf16(w1b, x2, acc.t[1]);
+    acc.t[0] = mfma_bf16(w1a, x1, acc.t[0]);
+    acc.t[1] = mfma_bf16(w1b, x1, acc.t[1]);
     __builtin_amdgcn_sched_barrier(0);      // one k-step's pieces and weight fragments at a time (else hipcc hoists them all and spills)
   }
 }

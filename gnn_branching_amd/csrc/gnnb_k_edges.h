@@ -722,8 +722,9 @@ __global__ __launch_bounds__(256) void k_prop(PropArgs a) {
 //   B1  mu_L   <- backward node update                 (:253-350)
 //   B2  nb_{L-1} = W_L^T . mu_L                        (dense transposed edge, :320-322)
 // As five launches these cost ~160 us of mostly launch ramps, weight staging and latency; here the layer's rows never
-// leave LDS.  LDS map (floats): A = weight pack of the running phase (first the dense-forward staging buffers),
-// Bp = PackProp, C = the rows of layer L (DENSE_BWD_ROWS x 64, rows >= N zero), sm = small vectors.
+// leave LDS.  LDS map (floats): W = A + Bp (29568) = what the running phase needs: F1's reduction scratch (and, in Bp, a live-row
+// list too long for the tail), then the bf16 x 3 image of the forward / backward node-update pack (PackUpdL3), then B2's operand
+// image; C = the rows of layer L (DENSE_BWD_ROWS x 64, rows >= N zero), sm = small vectors, the lists.
 // ------------------------------------------------------------------------------------------
 struct TopArgs {
   DenseLArgs df;            // forward edge L (out unused)
@@ -750,6 +751,7 @@ struct TopArgs {
 #define TOP_LIST_KEEP_OK(K) ((K) + 96 <= 2 * (int)TOP_LIST_INTS && (K) < 65535)
 #define TOP_LIST_OK(K) (TOP_LIST_KEEP_OK(K) || ((K) + 96 <= 2 * (int)PackProp::FLOATS && (K) < 65535))
 static_assert(TOP_A_FLOATS >= 16384 && TOP_A_FLOATS >= 12288, "k_top: F1's reduction scratch and B2's operand image live in region A");
+static_assert(TOP_A_FLOATS + PackProp::FLOATS >= PackUpdL3::FLOATS, "k_top: the bf16 x 3 node-update image spans regions A and Bp");
 
 __device__ __forceinline__ void copy_to_lds_part(float* lds, const float* src, int nfloats, int tid, int nthr) {
   const f32x4* g = reinterpret_cast<const f32x4*>(src);
@@ -830,7 +832,6 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
   if (a.N > 0) { if (Cr[tid] == 12345.0f) a.mu_prop[0] = 1.0f; return; }
 #endif
   FT_MARK(1);        // F1 dense forward edge
-  copy_to_lds(Bp, a.pack_p, PackProp::FLOATS);            // (read from F3 on, behind two more barriers)
 
   // per-lane node of the update phases (waves 0..3: one tile of 32 nodes each)
   const int n = wave * 32 + j;
@@ -860,26 +861,41 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
       p[2 * q] = v;
     }
   };
-  // general folded node chain on fragment X (k_node_update, kind 1); `sx`: small k-step input of a deferred projection
+  // general folded node chain on fragment X, the arithmetic of k_node_update / k_gather_update_q (bf16 x 3 blocks, LDS image
+  // PackUpdL3 in W: Wa.[r0 x, r1 x] = WAS.(r0 x) + Wa[:, 64:].((r1 - r0) x)); `sx`: small k-step input of a deferred projection.
+  // (As fp32 MFMAs a chain of 4 tiles took 5 us of this one-CU kernel, twice per call.)
   auto chain = [&](const Frag& X, const float* Prow, bool deferred, float sx, Frag& H2) {
     Frag H;
-    frag_bias(H, A + PackUpd::BA, h);
+    frag_load_rowptr(H2, Prow, h);             // P' row (global): requested before the first block, wanted after it
+    frag_bias(H, A + PackUpdL3::BA, h);
     if (deferred) {
       const float x1[1] = {sx};
-      gemm_small<1>(A + PackUpd::VAW, lane, H, x1);
+      gemm_small<1>(A + PackUpdL3::VAW, lane, H, x1);
     }
-    const float r0 = r.r0, r1 = r.r1;
-    gemm_w64<64>(A + PackUpd::WA, lane, H, [&](int s) { return FRAG_AT(X, s & 31) * (s < 32 ? r0 : r1); });
+    const float r0 = r.r0, dr = r.r1 - r.r0;
+    gemm_w64_bf3<1>(A + PackUpdL3::WAS3, lane, H, [&](int s) { return FRAG_AT(X, s) * r0; });
+    if (__any(r.amb != 0.0f)) gemm_w64_bf3<1>(A + PackUpdL3::WA1S3, lane, H, [&](int s) { return FRAG_AT(X, s) * dr; });
     frag_relu(H);
-    frag_load_rowptr(H2, Prow, h);
-    gemm_w64<32>(A + PackUpd::WCB, lane, H2, [&](int s) { return FRAG_AT(H, s); });
+    gemm_w64_bf3<1>(A + PackUpdL3::WCB3, lane, H2, [&](int s) { return FRAG_AT(H, s); });
     frag_relu(H2);
     frag_scale(H2, r.live);
   };
+  // the bf16 x 3 image of a node-update pack -> W, by threads t0 .. t0 + nthr - 1 (no barrier)
+  auto stage_l3 = [&](const float* pack, int t0, int nthr) {
+    copy_to_lds_part(A + PackUpdL3::BA, pack + PackUpd::BA, 64, tid - t0, nthr);
+    copy_to_lds_part(A + PackUpdL3::BCB, pack + PackUpd::BCB, 64 + 64 + 128, tid - t0, nthr);        // BCB, BCBROW, VAW
+    copy_to_lds_part(A + PackUpdL3::WAS3, pack + PackUpd::WAS3, 6144, tid - t0, nthr);
+    copy_to_lds_part(A + PackUpdL3::WCB3, pack + PackUpd::WCB3, 6144, tid - t0, nthr);
+    copy_to_lds_part(A + PackUpdL3::WA1S3, pack + PackUpd::WA1S3, 6144, tid - t0, nthr);
+  };
 
   // ---- F2: forward node update of layer L (rows stay in C)
-  stage_pack(A, a.pack_f, PackUpd::FLOATS);
-  FT_MARK(2);        // staging PackProp + forward pack
+  stage_l3(a.pack_f, 0, 512);
+  __syncthreads();
+#if defined(TOP_STOP) && TOP_STOP == 5
+  if (a.N > 0) return;
+#endif
+  FT_MARK(2);        // staging the forward pack
   if (upd_wave) {
     Frag X, E;
     load_row(X, valid ? n : 0);
@@ -890,6 +906,9 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
     }
   }
   __syncthreads();
+#if defined(TOP_STOP) && TOP_STOP == 6
+  if (a.N > 0) return;
+#endif
   FT_MARK(3);        // F2 chain
 
   // ---- F3: property node (k_prop) on the rows in C; meanwhile waves 1..7 stage the backward pack
@@ -911,28 +930,37 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
     float nbv = 0.0f, spt = 0.0f;
 #pragma unroll
     for (int w8 = 0; w8 < 8; ++w8) { nbv += part[w8 * 64 + lane]; spt += spart[w8]; }
+    // The property node's weights (PackProp, 51 KB) come straight from L2, 16 coalesced 256-B rows in flight: one wave reads
+    // them once, so staging them in LDS first bought nothing and its region now belongs to the node-update image W.
+    const float* Pp = a.pack_p;
     const float f[4] = {a.lbK[b], a.ubK[b], a.z_out[b], a.prop_b[b]};
-    float h1 = Bp[PackProp::B1 + lane];
+    float h1 = Pp[PackProp::B1 + lane];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) h1 = fmaf(Bp[PackProp::W1T + k * 64 + lane], f[k], h1);
+    for (int k = 0; k < 4; ++k) h1 = fmaf(Pp[PackProp::W1T + k * 64 + lane], f[k], h1);
     xs[lane] = relu_nan(h1);
     xs[64 + lane] = nbv;
     __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): this wave's LDS writes are visible to its own reads
-    float h2 = fmaf(spt, Bp[PackProp::V2 + lane], Bp[PackProp::B2 + lane]);
-#pragma unroll 8
-    for (int k = 0; k < 128; ++k) h2 = fmaf(Bp[PackProp::W2T + k * 64 + lane], xs[k], h2);
+    float w3[64];                                     // the last layer's weights do not wait for the hidden layer
+#pragma unroll
+    for (int k = 0; k < 64; ++k) w3[k] = Pp[PackProp::W3T + k * 64 + lane];
+    float h2 = fmaf(spt, Pp[PackProp::V2 + lane], Pp[PackProp::B2 + lane]);
+#pragma unroll 32
+    for (int k = 0; k < 128; ++k) h2 = fmaf(Pp[PackProp::W2T + k * 64 + lane], xs[k], h2);
     __builtin_amdgcn_s_waitcnt(0xc07f);
     xs[lane] = relu_nan(h2);
     __builtin_amdgcn_s_waitcnt(0xc07f);
-    float o = Bp[PackProp::B3 + lane];
-#pragma unroll 8
-    for (int k = 0; k < 64; ++k) o = fmaf(Bp[PackProp::W3T + k * 64 + lane], xs[k], o);
+    float o = Pp[PackProp::B3 + lane];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) o = fmaf(w3[k], xs[k], o);
     a.mu_prop[(long)b * 64 + lane] = o;
     outv[lane] = o;
   } else {
-    copy_to_lds_part(A, a.pack_b, PackUpd::FLOATS, tid - 64, 448);
+    stage_l3(a.pack_b, 64, 448);
   }
   __syncthreads();
+#if defined(TOP_STOP) && TOP_STOP == 7
+  if (a.N > 0) return;
+#endif
   FT_MARK(4);        // F3 property node + staging backward pack
 
   // ---- B1: backward node update of layer L; its aggregate is the rank-1 edge from the property node
@@ -956,6 +984,9 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
     }
   }
   __syncthreads();
+#if defined(TOP_STOP) && TOP_STOP == 8
+  if (a.N > 0) return;
+#endif
   FT_MARK(5);        // B1 chain
 
   // ---- B2: aggregate rows of layer L-1 <- W_L^T . rows of C: only the live rows of layer L-1 (nothing reads the others), only
