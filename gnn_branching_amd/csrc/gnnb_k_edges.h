@@ -553,8 +553,13 @@ __device__ __forceinline__ void dense_fwd_sample_bf3(const DenseLArgs& a, int b,
 // (Measured against this: 64 consecutive rows per wave with 8-B weight loads for two row tiles at once, every row computed and
 // the live ones stored -- equal on cifar_base, 11 us slower on cifar_wide, whose 40 % dead rows it cannot skip.)
 template <class Store>
+// Wk != null (then klist must be null): the weights are read from the FORWARD edge's image Wk[row][k] (ldK floats per row) --
+// a lane's 8 k of a k-step are 32 contiguous bytes of its row, two 16-B loads instead of eight 4-B ones (this edge is bound by
+// load instructions, not bytes: without its loads it runs 10 / 39 us faster on base / wide).  Every k < a.Kpad is walked then
+// (the rows of dead layer-L nodes are zero in C), and livek[k] (LDS, 0 / 1) says which k count for sout.
 __device__ __forceinline__ void dense_bwd_sample_bf3(const DenseLArgs& a, const float* Cr, float* img, Store store, const top_idx_t* rlist,
-                                                     int n_rows, const int* klist, int K_eff, float* sout) {
+                                                     int n_rows, const int* klist, int K_eff, float* sout, const float* Wk = nullptr,
+                                                     int ldK = 0, const float* livek = nullptr) {
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nst = (klist ? (K_eff + 15) / 16 * 16 : a.Kpad) / 16;
@@ -574,11 +579,11 @@ __device__ __forceinline__ void dense_bwd_sample_bf3(const DenseLArgs& a, const 
   __syncthreads();
   const u32x4* im4 = reinterpret_cast<const u32x4*>(img) + lane;
   const int M = rlist ? n_rows : a.M, MT = rlist ? (n_rows + 31) / 32 : a.MT;
-  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.At, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)(Wk ? Wk : a.At), 0, 0x7fffffff, 0x00020000);
   const unsigned ldb = (unsigned)a.ldA * 4u;
   for (int mt = wave; mt < MT; mt += 8) {
     const int arow = rlist ? (int)rlist[mt * 32 + j < M ? mt * 32 + j : 0] : mt * 32 + j;
-    const unsigned acol = 4u * (unsigned)arow;
+    const unsigned acol = Wk ? (unsigned)arow * (unsigned)ldK * 4u + 32u * (unsigned)h : 4u * (unsigned)arow;
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
@@ -587,24 +592,40 @@ __device__ __forceinline__ void dense_bwd_sample_bf3(const DenseLArgs& a, const 
     // the registers just split.
     float A0[8], A1[8];
     auto loadA = [&](float (&A)[8], int st) {
+      if (Wk) {
+        const unsigned off = st < nst ? acol + 64u * (unsigned)st : 0x80000000u;      // (past the end: out of range -> zeros)
+        const auto v0 = __builtin_amdgcn_raw_buffer_load_b128(rA, off, 0, 0), v1 = __builtin_amdgcn_raw_buffer_load_b128(rA, off, 16, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { A[q] = __uint_as_float(v0[q]); A[4 + q] = __uint_as_float(v1[q]); }
+        return;
+      }
       const int sc = st < nst ? st : nst;          // (past the end: the padding entries / zero rows behind the walked ones)
 #pragma unroll
       for (int q = 0; q < 8; ++q)
         A[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rA, (unsigned)(klist ? klist[sc * 16 + 8 * h + q] : sc * 16 + 8 * h + q) * ldb + acol, 0, 0));
     };
     float sacc = 0.0f;
-    auto split = [&](u32x4 (&w)[3], const float (&A)[8]) {
+    auto split = [&](u32x4 (&w)[3], const float (&A)[8], int st) {         // st: the k-step these weights belong to
+      float lk[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) lk[q] = 1.0f;
+      if (sout && livek) {
+        const f32x4* l4 = reinterpret_cast<const f32x4*>(livek + 16 * (st < nst ? st : nst - 1) + 8 * h);
+        const f32x4 u0 = l4[0], u1 = l4[1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { lk[q] = u0[q]; lk[4 + q] = u1[q]; }
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         split3_to(w, q, A[2 * q], A[2 * q + 1]);
-        if (sout) sacc += A[2 * q] + A[2 * q + 1];
+        if (sout) sacc += A[2 * q] * lk[2 * q] + A[2 * q + 1] * lk[2 * q + 1];
       }
     };
     auto body = [&](const u32x4 (&cur)[3], int st, u32x4 (&nxt)[3], const float (&Araw)[8]) {
       __builtin_amdgcn_sched_barrier(0);
       const u32x4 xa[3] = {im4[((st * 2 + 0) * 3 + 0) * 64], im4[((st * 2 + 0) * 3 + 1) * 64], im4[((st * 2 + 0) * 3 + 2) * 64]};
       const u32x4 xb[3] = {im4[((st * 2 + 1) * 3 + 0) * 64], im4[((st * 2 + 1) * 3 + 1) * 64], im4[((st * 2 + 1) * 3 + 2) * 64]};
-      split(nxt, Araw);
+      split(nxt, Araw, st + 1);
       acc0 = mfma6(cur, xa, acc0);
       acc1 = mfma6(cur, xb, acc1);
       __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);       // the six operand reads first
@@ -618,7 +639,7 @@ __device__ __forceinline__ void dense_bwd_sample_bf3(const DenseLArgs& a, const 
     u32x4 wa[3], wb[3];
     loadA(A0, 0);
     loadA(A1, 1);
-    split(wa, A0);
+    split(wa, A0, 0);
     __builtin_amdgcn_sched_barrier(0);
     loadA(A0, 2);
     for (int st = 0; st < nst; st += 2) {
@@ -790,8 +811,7 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
   // into the region PackProp takes afterwards
   // The list goes behind the fixed regions when it fits there (then the transposed edge B2 also uses it, to compute only the
   // live rows of layer L-1), else into the region PackProp takes after F1.
-  int* k2list = reinterpret_cast<int*>(spart + 8);        // live rows of layer L (B2)
-  int* tail = k2list + TOP_K2_INTS;
+  int* tail = reinterpret_cast<int*>(spart + 8) + TOP_K2_INTS;       // (TOP_K2_INTS: spare, once the list of layer L's live rows)
   const bool keep = TOP_LIST_KEEP_OK(a.df.K);
   top_idx_t* klist = reinterpret_cast<top_idx_t*>(keep ? tail : reinterpret_cast<int*>(Bp));
   int K_eff = 0;
@@ -982,6 +1002,9 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
       store_row(E, Cr + n * 64);
       store_row(E, a.mu + g * 64);
     }
+    if (h == 0) xs[n] = valid ? r.live : 0.0f;        // which rows of C count for B2's bias sums (xs: free since F3)
+  } else if (wave < 4 && h == 0) {
+    xs[n] = 0.0f;
   }
   __syncthreads();
 #if defined(TOP_STOP) && TOP_STOP == 8
@@ -989,21 +1012,8 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
 #endif
   FT_MARK(5);        // B1 chain
 
-  // ---- B2: aggregate rows of layer L-1 <- W_L^T . rows of C: only the live rows of layer L-1 (nothing reads the others), only
-  // the live (non-zero) rows of layer L
-  int K2 = 0;
-  if (keep) {
-    int* wc = reinterpret_cast<int*>(part);
-    const unsigned long long bal = __ballot(upd_wave && valid && r.live != 0.0f && (lane < 32));
-    if (lane == 0) wc[wave] = __popcll(bal);
-    __syncthreads();
-    int before = 0;
-#pragma unroll
-    for (int w8 = 0; w8 < 8; ++w8) { before += w8 < wave ? wc[w8] : 0; K2 += wc[w8]; }
-    if (upd_wave && valid && r.live != 0.0f && lane < 32) k2list[before + __popcll(bal & ((1ull << lane) - 1ull))] = n;
-    for (int i = K2 + tid; i < TOP_K2_INTS; i += 512) k2list[i] = a.db.Kpad;   // zero row of At and of C
-    __syncthreads();
-  }
+  // ---- B2: aggregate rows of layer L-1 <- W_L^T . rows of C: only the live rows of layer L-1 (nothing reads the others); every
+  // row of C is walked (the dead ones are zero), the weights come k-contiguous out of the forward edge's image
 #if defined(TOP_STOP) && TOP_STOP == 3
   if (a.N > 0) return;
 #endif
@@ -1014,10 +1024,10 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
   auto put = [&](int row, int jj, float2 v) { *reinterpret_cast<float2*>(out + (long)row * 64 + 2 * jj) = v; };
 #endif
 #if defined(TOP_ABL) && (TOP_ABL & 1)     // dev, timing only: no B2
-  if (K2 < 0) dense_bwd_sample_bf3(a.db, Cr, A, put, nullptr, 0, nullptr, 0, nullptr);
+  if (N < 0) dense_bwd_sample_bf3(a.db, Cr, A, put, nullptr, 0, nullptr, 0, nullptr);
 #else
-  if (keep) dense_bwd_sample_bf3(a.db, Cr, A, put, klist, K_eff, k2list, K2, a.sb_out ? a.sb_out + (long)b * a.db.M : nullptr);
-  else dense_bwd_sample_bf3(a.db, Cr, A, put, nullptr, 0, nullptr, 0, nullptr);
+  if (keep) dense_bwd_sample_bf3(a.db, Cr, A, put, klist, K_eff, nullptr, 0, a.sb_out ? a.sb_out + (long)b * a.db.M : nullptr, a.df.At, a.df.ldA, xs);
+  else dense_bwd_sample_bf3(a.db, Cr, A, put, nullptr, 0, nullptr, 0, nullptr, a.df.At, a.df.ldA, xs);
 #endif
 #ifdef FUSED_TIMING
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
