@@ -216,6 +216,26 @@ __device__ __forceinline__ void copy_to_lds(float* lds, const float* src, int nf
     }
   }
 }
+// the same by threads tid = 0 .. nthr - 1 of a subset of the workgroup (the caller passes its index in the subset)
+__device__ __forceinline__ void copy_to_lds_part(float* lds, const float* src, int nfloats, int tid, int nthr) {
+  const f32x4* g = reinterpret_cast<const f32x4*>(src);
+  f32x4* l = reinterpret_cast<f32x4*>(lds);
+  const int n4 = nfloats / 4;
+  for (int i0 = tid; i0 < n4; i0 += 8 * nthr) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * nthr;
+      v[u] = g[i < n4 ? i : i0];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * nthr;
+      if (i < n4) l[i] = v[u];
+    }
+  }
+}
+
 __device__ __forceinline__ void stage_pack(float* lds, const float* pack, int nfloats) {
   copy_to_lds(lds, pack, nfloats);
   __syncthreads();

@@ -774,25 +774,6 @@ struct TopArgs {
 static_assert(TOP_A_FLOATS >= 16384 && TOP_A_FLOATS >= 12288, "k_top: F1's reduction scratch and B2's operand image live in region A");
 static_assert(TOP_A_FLOATS + PackProp::FLOATS >= PackUpdL3::FLOATS, "k_top: the bf16 x 3 node-update image spans regions A and Bp");
 
-__device__ __forceinline__ void copy_to_lds_part(float* lds, const float* src, int nfloats, int tid, int nthr) {
-  const f32x4* g = reinterpret_cast<const f32x4*>(src);
-  f32x4* l = reinterpret_cast<f32x4*>(lds);
-  const int n4 = nfloats / 4;
-  for (int i0 = tid; i0 < n4; i0 += 8 * nthr) {
-    f32x4 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = i0 + u * nthr;
-      v[u] = g[i < n4 ? i : i0];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = i0 + u * nthr;
-      if (i < n4) l[i] = v[u];
-    }
-  }
-}
-
 // needs 512 threads (threads beyond that idle) and TOP_LDS_FLOATS of LDS
 __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float* lds) {
   float* A = lds;

@@ -18,6 +18,7 @@
 //   filled[s]          rows written into ring slot s for its current tile
 //   free_id[s]         the tile id slot s accepts (starts at s; the chain wave sets T + QTILES when it is done with tile T)
 //   done               gather waves that have finished
+//   staged             chain waves whose share of the node-update weights is in LDS (the chain waves wait for all of them)
 // A gather wave writes its rows of tile T only after free_id[T % QTILES] == T, then adds their number to filled[.] (LDS executes
 // one wave's operations in order, so the count lands after the rows).  Tile T's rows were reserved before tile T + QTILES's, and a
 // wave publishes its part of T before it waits for T + 1: no cycle.  Chain wave c takes tiles c, c + 4, ...; it leaves when all
@@ -45,7 +46,7 @@ struct FArgs {
 #define Q_POLL_CAP (1 << 22)
 __host__ __device__ constexpr size_t fusedq_queue_floats(int qtiles) { return (size_t)qtiles * 32 * QROW + QHDR_INTS; }
 
-struct QHdr { int reserve, done, claim, pad1, filled[QTILES], free_id[QTILES], pad2[4]; };
+struct QHdr { int reserve, done, claim, staged, filled[QTILES], free_id[QTILES], pad2[4]; };
 static_assert(sizeof(QHdr) == QHDR_INTS * 4, "queue header");
 
 // (acquire / release at workgroup scope: LDS needs no cache maintenance, this only keeps compiler and wait counters honest)
@@ -116,12 +117,6 @@ __global__ __launch_bounds__((QG_WAVES + QC_WAVES) * 64, 4) void k_gather_update
   float* gbase = qbase + fusedq_queue_floats(NQ);
   const GatherLds gl = gather_lds(gbase, a.g.g, a.g.tm.TPS);
   stage_gather(gl.cm, gl.ko, gl.tt, gl.kvo, a.g.g, a.g.tm.TPS);
-  copy_to_lds(lds + PackUpdL3::BA, a.u.pack + PackUpd::BA, 64);
-  copy_to_lds(lds + PackUpdL3::BCB, a.u.pack + PackUpd::BCB, 64 + 64 + 128);          // BCB, BCBROW, VAW
-  copy_to_lds(lds + PackUpdL3::WAS3, a.u.pack + PackUpd::WAS3, 6144);
-  copy_to_lds(lds + PackUpdL3::WCB3, a.u.pack + PackUpd::WCB3, 6144);
-  copy_to_lds(lds + PackUpdL3::WA1S3, a.u.pack + PackUpd::WA1S3, 6144);
-  if (POST) copy_to_lds(lds + PackUpdL3::FLOATS, a.u.wp, 6144);
   if (threadIdx.x < QHDR_INTS) reinterpret_cast<int*>(q)[threadIdx.x] = 0;
   __syncthreads();
   if (threadIdx.x < QTILES) q->free_id[threadIdx.x] = threadIdx.x;
@@ -129,7 +124,27 @@ __global__ __launch_bounds__((QG_WAVES + QC_WAVES) * 64, 4) void k_gather_update
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
   if (wave >= QG_WAVES) {
-    // ---------------- chain wave: claims the next tile, copies it out of its ring slot, releases the slot, runs the chain ----------------
+    // ---------------- chain wave ----------------
+    // The node-update weights (74 KB + 24 KB of POST) are staged by the chain waves alone while the gather waves, which only need the
+    // gather's tables, already walk their first tiles; `staged` counts the chain waves whose part is in LDS.
+    {
+      const int ct = threadIdx.x - QG_WAVES * 64, cn = QC_WAVES * 64;
+      copy_to_lds_part(lds + PackUpdL3::BA, a.u.pack + PackUpd::BA, 64, ct, cn);
+      copy_to_lds_part(lds + PackUpdL3::BCB, a.u.pack + PackUpd::BCB, 64 + 64 + 128, ct, cn);          // BCB, BCBROW, VAW
+      copy_to_lds_part(lds + PackUpdL3::WAS3, a.u.pack + PackUpd::WAS3, 6144, ct, cn);
+      copy_to_lds_part(lds + PackUpdL3::WCB3, a.u.pack + PackUpd::WCB3, 6144, ct, cn);
+      copy_to_lds_part(lds + PackUpdL3::WA1S3, a.u.pack + PackUpd::WA1S3, 6144, ct, cn);
+      if (POST) copy_to_lds_part(lds + PackUpdL3::FLOATS, a.u.wp, 6144, ct, cn);
+      __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): this wave's part is in LDS before it is counted
+      if (lane == 0) __hip_atomic_fetch_add(&q->staged, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      bool ok = false;
+      for (int it = 0; it < Q_POLL_CAP; ++it) {
+        if (q_ld(&q->staged) == QC_WAVES) { ok = true; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (!ok) { if (lane == 0) atomicOr(a.u.status, 2); return; }
+    }
+    // claims the next tile, copies it out of its ring slot, releases the slot, runs the chain
     for (;;) {
       int T = 0;
       if (lane == 0) T = atomicAdd(&q->claim, 1);
