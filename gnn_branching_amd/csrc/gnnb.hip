@@ -205,7 +205,7 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   HIPCHK(hipMemset(h->d_zero, 0, 256 * sizeof(float)));
   // > 64 KiB of dynamic LDS needs the attribute
   HIPCHK(hipFuncSetAttribute((const void*)k_pre<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackPreFwd::FLOATS + PackPreBwd::FLOATS) * 4));
-  HIPCHK(hipFuncSetAttribute((const void*)k_pre<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackPreFwdL3::FLOATS + PackPreBwdL3::FLOATS) * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_pre<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PackPreBwdL3::FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_pre_inp, hipFuncAttributeMaxDynamicSharedMemorySize, PackPreInp::FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_node_update<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpd::FLOATS + 4096) * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_node_update<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpd::FLOATS + 4096) * 4));
@@ -931,10 +931,10 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       a.N[i] = h->N[k]; a.hw[i] = h->hw[k];
       nt += (((long)B * h->N[k] + 31) / 32) * 2;
     }
-    const size_t lds = (h->bf3 ? (size_t)PackPreFwdL3::FLOATS + PackPreBwdL3::FLOATS : (size_t)PackPreFwd::FLOATS + PackPreBwd::FLOATS) * 4;
+    const size_t lds = (h->bf3 ? (size_t)PackPreBwdL3::FLOATS : (size_t)PackPreFwd::FLOATS + PackPreBwd::FLOATS) * 4;
     lz.run(PC_PRE, [&] {
-      if (h->bf3) hipLaunchKernelGGL(k_pre<true>, dim3(mlp_grid(h, nt / 8)), dim3(WG_MLP), lds, st, a);
-      else hipLaunchKernelGGL(k_pre<false>, dim3(mlp_grid(h, nt / 8)), dim3(WG_MLP), lds, st, a);
+      if (h->bf3) hipLaunchKernelGGL(k_pre<true>, dim3(mlp_grid(h, nt / 8)), dim3(PRE_WAVES * 64), lds, st, a);
+      else hipLaunchKernelGGL(k_pre<false>, dim3(mlp_grid(h, nt / 8)), dim3(PRE_WAVES * 64), lds, st, a);
     });
   }
   const bool need_inp = (limit >= 2) && (h->T > 1 || debug_full) && !h->gb[1].ok;    // the fused input kernel computes Q itself

@@ -168,7 +168,7 @@ __device__ __forceinline__ void pre_tile(const PreAllArgs& a, const float* lds, 
   constexpr int F_B2 = BF3 ? (int)PackPreFwdL3::B2 : (int)PackPreFwd::B2;
   constexpr int B_W1 = BF3 ? (int)PackPreBwdL3::W1 : (int)PackPreBwd::W1, B_B1 = BF3 ? (int)PackPreBwdL3::B1 : (int)PackPreBwd::B1;
   constexpr int B_B2 = BF3 ? (int)PackPreBwdL3::B2 : (int)PackPreBwd::B2, B_B3 = BF3 ? (int)PackPreBwdL3::B3 : (int)PackPreBwd::B3;
-  constexpr int B_W4 = BF3 ? (int)PackPreBwdL3::W4 : (int)PackPreBwd::W4, B_B4 = BF3 ? (int)PackPreBwdL3::B4 : (int)PackPreBwd::B4;
+  constexpr int B_W4 = (int)PackPreBwd::W4, B_B4 = BF3 ? (int)PackPreBwdL3::B4 : (int)PackPreBwd::B4;
   constexpr int B_B5 = BF3 ? (int)PackPreBwdL3::B5 : (int)PackPreBwd::B5;
   const int h = lane >> 5, j = lane & 31;
   {
@@ -220,10 +220,12 @@ __device__ __forceinline__ void pre_tile(const PreAllArgs& a, const float* lds, 
       const float nd2 = -d2;
       Frag H4;
       frag_bias(H4, lds_b + B_B4, h);
-      gemm_w64<96>(lds_b + B_W4, lane, H4, [&](int s) {
+      auto in4 = [&](int s) {
         const float v = FRAG_AT(S, s & 31);
         return s < 32 ? v : (s < 64 ? v * nd2 : v * d1);
-      });
+      };
+      if (BF3) gemm_w64_bf3<3>(lds_b + PackPreBwdL3::W43, lane, H4, in4);
+      else gemm_w64<96>(lds_b + B_W4, lane, H4, in4);
       frag_relu(H4);
       Frag Pb;                                   // bc2_1 and the first half of bc4 are one folded 64x64 map
       frag_bias(Pb, lds_b + B_B5, h);
@@ -234,40 +236,57 @@ __device__ __forceinline__ void pre_tile(const PreAllArgs& a, const float* lds, 
   }
 }
 
+#ifndef PRE_WAVES
+#define PRE_WAVES 16      // the weights (150 KB) allow one workgroup per CU: 16 waves of <= 128 registers fill it
+#endif
 template <bool BF3>
-__global__ __launch_bounds__(WG_MLP, 2) void k_pre(PreAllArgs a) {
+__global__ __launch_bounds__(PRE_WAVES * 64) void k_pre(PreAllArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* lds_b = lds + (BF3 ? (int)PackPreFwdL3::FLOATS : (int)PackPreFwd::FLOATS);
-  if (BF3) {
-    copy_to_lds(lds_b + PackPreBwdL3::W1, a.pack_b + PackPreBwd::W1, 512 + 64);                    // W1, B1
-    copy_to_lds(lds_b + PackPreBwdL3::B2, a.pack_b + PackPreBwd::B2, 64);
-    copy_to_lds(lds_b + PackPreBwdL3::B3, a.pack_b + PackPreBwd::B3, 64);
-    copy_to_lds(lds_b + PackPreBwdL3::W4, a.pack_b + PackPreBwd::W4, 12288 + 64);                  // W4, B4
-    copy_to_lds(lds_b + PackPreBwdL3::B5, a.pack_b + PackPreBwd::B5, 64);
-    copy_to_lds(lds_b + PackPreBwdL3::W23, a.pack_b + PackPreBwd::W23, 3 * 6144);                  // W23, W33, W53
-    copy_to_lds(lds + PackPreFwdL3::W1, a.pack_f + PackPreFwd::W1, 512 + 64);
-    copy_to_lds(lds + PackPreFwdL3::B2, a.pack_f + PackPreFwd::B2, 64);
-    stage_pack(lds + PackPreFwdL3::W23, a.pack_f + PackPreFwd::W23, 6144);
-  } else {
-    copy_to_lds(lds_b, a.pack_b, PackPreBwd::FLOATS);
-    stage_pack(lds, a.pack_f, PackPreFwd::FLOATS);
-  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   long nhalf = 0;
   for (int k = 0; k < a.L; ++k) nhalf += (long)((a.cnt[4 * k + 1] + 31) / 32);
-  const long ntiles = nhalf * (a.do_bwd ? 2 : 1);
-  for (long tile = (long)wave * gridDim.x + blockIdx.x; tile < ntiles; tile += (long)gridDim.x * WAVES_MLP) {
-    // which layer / direction (wave-uniform)
-    const bool bwd = a.do_bwd && tile < nhalf;
+  // tile t of one direction: which layer (wave-uniform)
+  auto run = [&](long t, bool bwd, const float* lf, const float* lb) {
     int k = 0, count = 0;
-    long t = (a.do_bwd && !bwd) ? tile - nhalf : tile;
     for (; k < a.L; ++k) {
       count = a.cnt[4 * k + 1];
       const long tk = (count + 31) / 32;
       if (t < tk) break;
       t -= tk;
     }
-    pre_tile<BF3>(a, lds, lds_b, k, bwd, a.list[k], count, t, lane);
+    pre_tile<BF3>(a, lf, lb, k, bwd, a.list[k], count, t, lane);
+  };
+  if (BF3) {
+    // forward image + everything of the backward image behind its head; forward tiles; then the head; backward tiles
+    copy_to_lds(lds + PackPreFwdL3::W1, a.pack_f + PackPreFwd::W1, 512 + 64);
+    copy_to_lds(lds + PackPreFwdL3::B2, a.pack_f + PackPreFwd::B2, 64);
+    copy_to_lds(lds + PackPreFwdL3::W23, a.pack_f + PackPreFwd::W23, 6144);
+    if (a.do_bwd) {
+      copy_to_lds(lds + PackPreBwdL3::B3, a.pack_b + PackPreBwd::B3, 64);
+      copy_to_lds(lds + PackPreBwdL3::B4, a.pack_b + PackPreBwd::B4, 64);
+      copy_to_lds(lds + PackPreBwdL3::B5, a.pack_b + PackPreBwd::B5, 64);
+      copy_to_lds(lds + PackPreBwdL3::W33, a.pack_b + PackPreBwd::W33, 6144);
+      copy_to_lds(lds + PackPreBwdL3::W43, a.pack_b + PackPreBwd::W43, 18432);
+      copy_to_lds(lds + PackPreBwdL3::W53, a.pack_b + PackPreBwd::W53, 6144);
+    }
+    __syncthreads();
+    for (long t = (long)wave * gridDim.x + blockIdx.x; t < nhalf; t += (long)gridDim.x * PRE_WAVES) run(t, false, lds, lds);
+    if (!a.do_bwd) return;
+    __syncthreads();
+    copy_to_lds(lds + PackPreBwdL3::W1, a.pack_b + PackPreBwd::W1, 512 + 64);                      // W1, B1
+    copy_to_lds(lds + PackPreBwdL3::B2, a.pack_b + PackPreBwd::B2, 64);
+    copy_to_lds(lds + PackPreBwdL3::W23, a.pack_b + PackPreBwd::W23, 6144);
+    __syncthreads();
+    for (long t = (long)wave * gridDim.x + blockIdx.x; t < nhalf; t += (long)gridDim.x * PRE_WAVES) run(t, true, lds, lds);
+    return;
+  }
+  float* lds_b = lds + (int)PackPreFwd::FLOATS;
+  copy_to_lds(lds_b, a.pack_b, PackPreBwd::FLOATS);
+  stage_pack(lds, a.pack_f, PackPreFwd::FLOATS);
+  const long ntiles = nhalf * (a.do_bwd ? 2 : 1);
+  for (long tile = (long)wave * gridDim.x + blockIdx.x; tile < ntiles; tile += (long)gridDim.x * PRE_WAVES) {
+    const bool bwd = a.do_bwd && tile < nhalf;
+    run((a.do_bwd && !bwd) ? tile - nhalf : tile, bwd, lds, lds_b);
   }
 }
 

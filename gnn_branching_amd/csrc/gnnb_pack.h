@@ -177,12 +177,17 @@ struct PackUpdL3 { enum { BA = 0, BCB = BA + 64, BCBROW = BCB + 64, VAW = BCBROW
 struct PackPreBwd {
   enum { W1 = 0, B1 = W1 + 512, W2 = B1 + 64, B2 = W2 + 4096, W3 = B2 + 64, B3 = W3 + 4096, W4 = B3 + 64,
          B4 = W4 + 12288, W5 = B4 + 64, B5 = W5 + 4096, FLOATS = B5 + 64,
-         W23 = FLOATS, W33 = W23 + 6144, W53 = W33 + 6144, FLOATS3 = W53 + 6144 };      // W2, W3, W5 as bf16 x 3 (W4, 192 wide, stays fp32)
+         W23 = FLOATS, W33 = W23 + 6144, W53 = W33 + 6144, W43 = W53 + 6144, FLOATS3 = W43 + 18432 };   // W2, W3, W5 and the 192-wide W4 as bf16 x 3
 };
-struct PackPreBwdL3 {      // LDS image, bf16 x 3 form
-  enum { W1 = 0, B1 = W1 + 512, B2 = B1 + 64, B3 = B2 + 64, W4 = B3 + 64, B4 = W4 + 12288, B5 = B4 + 64, W23 = B5 + 64, W33 = W23 + 6144,
-         W53 = W33 + 6144, FLOATS = W53 + 6144 };
+// LDS image, bf16 x 3 form.  Its first PackPreFwdL3::FLOATS floats (W1, B1, B2, W23) share their place with the forward image:
+// k_pre runs the forward tiles first, with everything behind HEAD already in place, then drops these four pieces in.
+// (W4 as fp32 MFMAs was 12.3 k of a backward tile's 17 k matrix-pipe cycles; as three bf16 x 3 blocks it is 4.6 k, and the
+// image no longer fits beside the forward one: 147 KB.)
+struct PackPreBwdL3 {
+  enum { W1 = 0, B1 = W1 + 512, B2 = B1 + 64, W23 = B2 + 64, HEAD = W23 + 6144, B3 = HEAD, B4 = B3 + 64, B5 = B4 + 64, W33 = B5 + 64,
+         W43 = W33 + 6144, W53 = W43 + 18432, FLOATS = W53 + 6144 };
 };
+static_assert((int)PackPreBwdL3::HEAD == (int)PackPreFwdL3::FLOATS, "k_pre: the forward image takes the head of the backward image");
 // k_pre_inp: Q = inp_b2[:, :64] inp_b_1(relu(inp_b([l0,u0]))) + inp_b2.bias   (:380-384)
 // folded: Q = (inp_b2[:, :64].inp_b_1.W) relu(inp_b([l0,u0])) + (inp_b2[:, :64].inp_b_1.b + inp_b2.b)
 struct PackPreInp { enum { W1 = 0, B1 = W1 + 128, W2 = B1 + 64, B2 = W2 + 4096, W23 = B2 + 64 /* W2 as bf16 x 3 */, FLOATS = W23 + 6144 }; };
@@ -320,6 +325,7 @@ inline void build_packs(const float* blob, Packs& pk) {
   pack_w64_bf3(&pk.pre_bwd[PackPreBwd::W33], W(L_BC1_2), 64, 0, 1);
   pack_vec64(&pk.pre_bwd[PackPreBwd::B3], Bv(L_BC1_2));
   pack_w64(&pk.pre_bwd[PackPreBwd::W4], W(L_BC2), 192, 0, 3);
+  pack_w64_bf3(&pk.pre_bwd[PackPreBwd::W43], W(L_BC2), 192, 0, 3);
   pack_vec64(&pk.pre_bwd[PackPreBwd::B4], Bv(L_BC2));
   {
     float bcb[64], b5[64];

@@ -278,8 +278,8 @@ def test_pre_bwd_chain(packs):
     f7 = rng.standard_normal((32, 7)); d1 = rng.uniform(0, 1, 32); d2 = rng.uniform(0, 1, 32)
     p = pk["pre_bwd"]
     W1, B1, W2, B2, W3, B3, W4, B4, W5, B5 = 0, 512, 576, 4672, 4736, 8832, 8896, 21184, 21248, 25344
-    W23, W33, W53 = 25408, 25408 + 6144, 25408 + 2 * 6144          # W2, W3, W5 in three bf16 pieces
-    assert p.size == 25408 + 3 * 6144
+    W23, W33, W53, W43 = 25408, 25408 + 6144, 25408 + 2 * 6144, 25408 + 3 * 6144      # W2, W3, W5 and the 192-wide W4 in three bf16 pieces
+    assert p.size == 25408 + 3 * 6144 + 18432
     f8 = np.concatenate([f7, np.zeros((32, 1))], 1)
     x = [f8[J, 2 * s + H] for s in range(4)]
     H1 = frag_bias(p[B1:B1 + 64]); gemm_small(p[W1:], 4, H1, x); H1 = np.maximum(H1, 0)
@@ -295,11 +295,11 @@ def test_pre_bwd_chain(packs):
     w4, b4 = np.asarray(sd[E + "bc4.weight"], np.float64), np.asarray(sd[E + "bc4.bias"], np.float64)
     bcb = b4 + w4[:, 64:] @ np.asarray(sd[E + "bc3_1.bias"], np.float64)      # folded bias (PackUpd)
     np.testing.assert_allclose(got, relax @ w4[:, :64].T + bcb, atol=1e-5)
-    # the same chain with its 64x64 blocks on the bf16 matrix rate (W4 stays fp32)
+    # the same chain on the bf16 matrix rate: the 64x64 blocks and the 192-wide W4 as three input fragments
     H2 = frag_bias(p[B2:B2 + 64]); gemm_w64_bf3(p[W23:], 1, H2, lambda s: H1[:, s]); H2 = np.maximum(H2, 0)
     S = frag_bias(p[B3:B3 + 64]); gemm_w64_bf3(p[W33:], 1, S, lambda s: H2[:, s])
     H4 = frag_bias(p[B4:B4 + 64])
-    gemm_w64(p[W4:], 96, H4, lambda s: S[:, s & 31] * (1.0 if s < 32 else (-d2[J] if s < 64 else d1[J])))
+    gemm_w64_bf3(p[W43:], 3, H4, lambda s: S[:, s & 31] * (1.0 if s < 32 else (-d2[J] if s < 64 else d1[J])))
     H4 = np.maximum(H4, 0)
     Pb = frag_bias(p[B5:B5 + 64]); gemm_w64_bf3(p[W53:], 1, Pb, lambda s: H4[:, s])
     np.testing.assert_allclose(rows_from_frag(Pb), relax @ w4[:, :64].T + bcb, atol=1e-5)
