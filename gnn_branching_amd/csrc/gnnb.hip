@@ -858,7 +858,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       a.livef[i] = ws + w.lf[k];
       a.G[i] = (long)B * h->N[k]; a.N[i] = h->N[k]; a.off[i] = roff[k];
       a.blk0[i] = blk;
-      blk += (int)((a.G[i] + CLS_THREADS - 1) / CLS_THREADS);
+      blk += (int)((a.G[i] + CLS_BLOCK - 1) / CLS_BLOCK);
     }
     a.blk0[L] = blk;
     lz.run(PC_CLASSIFY, [&] { hipLaunchKernelGGL(k_classify, dim3((unsigned)blk), dim3(CLS_THREADS), 0, st, a); });

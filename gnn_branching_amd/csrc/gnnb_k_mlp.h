@@ -73,58 +73,74 @@ struct ClassifyArgs {    // every ReLU layer of the network in one launch
 };
 
 #define CLS_THREADS 1024
+#ifndef CLS_NPT
+#define CLS_NPT 2             // nodes per thread: a block's load -> ballot -> atomic -> write chain is ~5 us of latency whatever its
+                              // size, and with one node per thread the 800 blocks of base B=256 ran as two rounds of it
+                              // (base / wide, us: 1 node 15.1 / 24.5, 2 nodes 11.3 / 17.5, 4: 11.8 / 19.6, 8: 17.5 / 18.5)
+#endif
+#define CLS_BLOCK (CLS_THREADS * CLS_NPT)
 // one global atomic per list and workgroup (a single counter word only sustains ~90 atomics/us)
 __global__ __launch_bounds__(CLS_THREADS) void k_classify(ClassifyArgs a) {
-  __shared__ int wcnt[3][CLS_THREADS / 64];
-  __shared__ int wbase[3][CLS_THREADS / 64];
+  __shared__ int wcnt[3][CLS_NPT][CLS_THREADS / 64];
+  __shared__ int wbase[3][CLS_NPT][CLS_THREADS / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int k = 0;
   while (k + 1 < a.L && (int)blockIdx.x >= a.blk0[k + 1]) ++k;
   const long G = a.G[k];
   const int N = a.N[k];
-  const long g = (long)(blockIdx.x - a.blk0[k]) * CLS_THREADS + threadIdx.x;
-  const bool valid = g < G;
-  const long gc = valid ? g : G - 1;
-  const Ratio r = compute_ratio(a.lb[k][gc], a.ub[k][gc]);
-  const long b = gc / N;
-  const long sidx = b * a.R + a.off[k] + (gc - b * N);
-  bool flag[3];
-  const bool live = valid && r.live != 0.0f;
-  flag[1] = valid && r.amb != 0.0f;                 // ambiguous (a subset of live)
-  flag[0] = live && !flag[1];                       // live with r0 == r1: the cheap update path
-  flag[2] = valid && a.mask[sidx] != 0.0f;
-  if (valid) {
-    a.scores[sidx] = -INFINITY;
-    a.livef[k][g] = live ? 1.0f : 0.0f;
-  }
-  unsigned long long bal[3];
+  const long g0 = (long)(blockIdx.x - a.blk0[k]) * CLS_BLOCK + threadIdx.x;
+  bool flag[CLS_NPT][3], live[CLS_NPT], valid[CLS_NPT];
+  unsigned long long bal[CLS_NPT][3];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    bal[c] = __ballot(flag[c]);
-    if (lane == 0) wcnt[c][wave] = __popcll(bal[c]);
+  for (int i = 0; i < CLS_NPT; ++i) {
+    const long g = g0 + (long)i * CLS_THREADS;
+    valid[i] = g < G;
+    const long gc = valid[i] ? g : G - 1;
+    const Ratio r = compute_ratio(a.lb[k][gc], a.ub[k][gc]);
+    const long b = gc / N;
+    const long sidx = b * a.R + a.off[k] + (gc - b * N);
+    live[i] = valid[i] && r.live != 0.0f;
+    flag[i][1] = valid[i] && r.amb != 0.0f;                 // ambiguous (a subset of live)
+    flag[i][0] = live[i] && !flag[i][1];                    // live with r0 == r1: the cheap update path
+    flag[i][2] = valid[i] && a.mask[sidx] != 0.0f;
+    if (valid[i]) {
+      a.scores[sidx] = -INFINITY;
+      a.livef[k][g] = live[i] ? 1.0f : 0.0f;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      bal[i][c] = __ballot(flag[i][c]);
+      if (lane == 0) wcnt[c][i][wave] = __popcll(bal[i][c]);
+    }
   }
   __syncthreads();
   if (threadIdx.x < 3) {
     const int c = threadIdx.x;
     int total = 0;
-    for (int w = 0; w < CLS_THREADS / 64; ++w) { wbase[c][w] = total; total += wcnt[c][w]; }
+    for (int i = 0; i < CLS_NPT; ++i)
+      for (int w = 0; w < CLS_THREADS / 64; ++w) { wbase[c][i][w] = total; total += wcnt[c][i][w]; }
     const int base = total ? atomicAdd(a.cnt + 4 * k + c, total) : 0;
-    for (int w = 0; w < CLS_THREADS / 64; ++w) wbase[c][w] += base;
+    for (int i = 0; i < CLS_NPT; ++i)
+      for (int w = 0; w < CLS_THREADS / 64; ++w) wbase[c][i][w] += base;
   }
   __syncthreads();
   int* lists[3] = {a.live[k], a.amb[k], a.score[k]};
-#pragma unroll
-  for (int c = 0; c < 3; ++c)
-    if (flag[c]) lists[c][wbase[c][wave] + __popcll(bal[c] & ((1ull << lane) - 1ull))] = (int)gc;
-  unsigned long long dead = a.zero[k] ? __ballot(valid && !live) : 0ull;
   float* mu = a.mu[k];
   float* mu2 = k == 0 ? a.mu2 : nullptr;
-  while (dead) {                       // the whole wave zeroes one dead row per iteration (coalesced 256 B)
-    const int l = __ffsll((long long)dead) - 1;
-    dead &= dead - 1;
-    const long row = g - lane + l;
-    mu[row * 64 + lane] = 0.0f;
-    if (mu2) mu2[row * 64 + lane] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < CLS_NPT; ++i) {
+    const long g = g0 + (long)i * CLS_THREADS;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      if (flag[i][c]) lists[c][wbase[c][i][wave] + __popcll(bal[i][c] & ((1ull << lane) - 1ull))] = (int)g;
+    unsigned long long dead = a.zero[k] ? __ballot(valid[i] && !live[i]) : 0ull;
+    while (dead) {                       // the whole wave zeroes one dead row per iteration (coalesced 256 B)
+      const int l = __ffsll((long long)dead) - 1;
+      dead &= dead - 1;
+      const long row = g - lane + l;
+      mu[row * 64 + lane] = 0.0f;
+      if (mu2) mu2[row * 64 + lane] = 0.0f;
+    }
   }
 }
 
