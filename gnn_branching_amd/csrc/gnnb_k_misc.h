@@ -297,7 +297,10 @@ struct GSArgs {
   int N, C, H, W, Co, Ho, Wo, kh, kw, stride, pad, normalise;
 };
 #define GS_WAVES 8
-#define GS_MAXSLOTS 104      // C_out x (k/s)^2 <= 96 window slots (the host's limit) + padding to a multiple of 8
+#ifndef GS_INFLIGHT
+#define GS_INFLIGHT 16       // row loads in flight per wave (base, us: 8 -> 29.5, 16 -> 26.5, 32 -> 32.6)
+#endif
+#define GS_MAXSLOTS 112      // C_out x (k/s)^2 <= 96 window slots (the host's limit) + padding to a multiple of GS_INFLIGHT
 __global__ __launch_bounds__(GS_WAVES * 64) void k_gather_scored(GSArgs a) {
   __shared__ int s_row[GS_WAVES][GS_MAXSLOTS];
   __shared__ float s_w[GS_WAVES][GS_MAXSLOTS];
@@ -334,22 +337,22 @@ __global__ __launch_bounds__(GS_WAVES * 64) void k_gather_scored(GSArgs a) {
       }
       nlive += __popcll(bal);
     }
-    // pad to a multiple of 8 with (row 0, weight 0): whole rounds of eight independent row loads, no remainder loop
-    const int npad = (nlive + 7) & ~7;
+    // pad to a multiple of GS_INFLIGHT with (row 0, weight 0): whole rounds of independent row loads, no remainder loop
+    const int npad = (nlive + GS_INFLIGHT - 1) / GS_INFLIGHT * GS_INFLIGHT;
     if (lane < npad - nlive) { s_row[wave][nlive + lane] = 0; s_w[wave][nlive + lane] = 0.0f; }
     __builtin_amdgcn_wave_barrier();
     const float* src = a.mu_src + (long)b * Ns * 64 + lane;
     float acc = 0.0f, ssum = 0.0f;
-    for (int q = 0; q < npad; q += 8) {
-      float v[8], wq[8];
+    for (int q = 0; q < npad; q += GS_INFLIGHT) {
+      float v[GS_INFLIGHT], wq[GS_INFLIGHT];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < GS_INFLIGHT; ++u) {
         wq[u] = s_w[wave][q + u];
         v[u] = q + u < nlive ? src[(long)s_row[wave][q + u] * 64] : 0.0f;     // (wave-uniform; a padding slot must not touch memory:
                                                                               //  row 0 may be a dead node's never-written row)
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < GS_INFLIGHT; ++u) {
         acc = fmaf(wq[u], v[u], acc);
         ssum += wq[u];
       }
