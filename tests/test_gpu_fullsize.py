@@ -86,3 +86,35 @@ def test_fused_halfpass_kernel_at_size(monkeypatch, net, B):
             out[fuse] = (res.scores.cpu(), res.decisions.cpu().tolist())
     assert torch.equal(out["0"][0], out["1"][0])
     assert out["0"][1] == out["1"][1]
+
+
+@pytest.mark.parametrize("net,B", [("cifar_base_kw", 256), ("cifar_wide_kw", 256), ("cifar_deep_kw", 128)])
+@pytest.mark.parametrize("weights", ["shipped", "random"])
+def test_top_kernel_at_size(monkeypatch, net, B, weights):
+    """k_top (the last Linear edge both ways on the bf16x3 matrix rate, live-row lists in LDS, both node updates and the property
+    node, one workgroup per sample) against GNNB_NO_TOP=1 (separate kernels, fp32 MFMA edges, every row) at the bench batch
+    sizes: two independent GPU implementations of the same sums must agree inside the parity bar on every score, and pick the
+    same branching decision wherever the best score is not a near-tie."""
+    from gnn_branching_amd import synth
+    from oracle.gnn_oracle import random_gnn_state
+    from tests.common import RANDOM_ATOL, shipped_state
+    state = shipped_state() if weights == "shipped" else random_gnn_state(20240917)
+    batch = synth.make_batch(net, B, seed=7)
+    out = {}
+    for no_top in ("1", "0"):
+        monkeypatch.setenv("GNNB_NO_TOP", no_top)
+        model = model_for(state)
+        with torch.no_grad():
+            res = model.forward_device(*batch.forward_args()).check()
+            out[no_top] = (res.scores.cpu(), res.decisions.cpu())
+    a, b = out["0"][0], out["1"][0]
+    assert torch.equal(torch.isinf(a), torch.isinf(b))
+    fin = torch.isfinite(a)
+    tol = SCORE_ATOL if weights == "shipped" else RANDOM_ATOL
+    err = (a[fin] - b[fin]).abs().max().item()
+    print(f"{net} B={B} {weights}: max|k_top - separate kernels| = {err:.3e} (bar {tol:.1e})")
+    assert err <= tol
+    differ = (out["0"][1] != out["1"][1]).any(dim=1)
+    for s in torch.nonzero(differ).flatten().tolist():        # a different argmax is only acceptable between scores closer than the bar
+        row_a, row_b = a[s], b[s]
+        assert abs(row_a[torch.isfinite(row_a)].max().item() - row_b[torch.isfinite(row_b)].max().item()) <= tol
