@@ -256,6 +256,7 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   HIPCHK(hipFuncSetAttribute((const void*)k_gather<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   if (const char* e = getenv("GNNB_NO_GATHER")) h->use_gather = !(e[0] == '1');
   if (const char* e = getenv("GNNB_NO_TOP")) h->use_top = !(e[0] == '1');
+  if (!h->bf3) h->use_top = false;      // k_top's edges and chains only exist on the bf16 x 3 rate: GNNB_BF3=0 (every block exact fp32) takes the separate kernels
 #ifdef GNNB_DEV
   if (const char* e = getenv("GNNB_NO_SCORED_GATHER")) h->scored_gather = !(e[0] == '1');
 #endif
