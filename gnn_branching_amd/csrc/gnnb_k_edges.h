@@ -305,8 +305,6 @@ __device__ __forceinline__ void dense_bwd_sample(const DenseLArgs& a, const floa
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nch = (klist ? (K_eff + 15) / 16 * 16 : a.Kpad) / 16;      // chunks of 8 k-steps
   const int M = rlist ? n_rows : a.M, MT = rlist ? (n_rows + 31) / 32 : a.MT;
-  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.At, 0, 0x7fffffff, 0x00020000);
-  const unsigned ldb = (unsigned)a.ldA * 4u;
   for (int mt = wave; mt < MT; mt += 8) {
     const int arow = rlist ? rlist[mt * 32 + j < M ? mt * 32 + j : 0] : mt * 32 + j;
     const float* At = a.At + arow;
