@@ -49,3 +49,24 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(d, f)).read()
                 assert "oracle" not in src.replace("no oracle", ""), os.path.join(d, f)
+
+
+def test_status_word_maps_to_the_reference_s_failure_modes():
+    """gnnb_forward's status word: bit 0 = a NaN embedding (the reference drops into pdb there, graph_conv.py:184-186, :339-341) ->
+    FloatingPointError; bit 1 = a wait inside the fused half-pass kernel hit its iteration cap -> RuntimeError (results invalid);
+    the words of several chunks are OR-ed; 0 raises nothing."""
+    import pytest
+    import torch
+    from gnn_branching_amd import engine
+    assert engine._or_reduce(torch.tensor([0, 0], dtype=torch.int32)) == 0
+    assert engine._or_reduce(torch.tensor([1, 2], dtype=torch.int32)) == 3
+    engine._raise_for_status(0)
+    with pytest.raises(FloatingPointError, match="nan"):
+        engine._raise_for_status(1)
+    with pytest.raises(RuntimeError, match="timed out"):
+        engine._raise_for_status(2)
+    with pytest.raises(RuntimeError):                 # a timed-out wait outranks the NaN check: its rows are garbage anyway
+        engine._raise_for_status(3)
+    res = engine.ForwardResult(None, None, torch.tensor([0, 1], dtype=torch.int32), None)
+    with pytest.raises(FloatingPointError):
+        res.check()
