@@ -91,6 +91,7 @@ class ScorerEngine:
         if not torch.cuda.is_available():
             raise RuntimeError("gnn_branching_amd needs an AMD GPU (MI355X / gfx950); there is no CPU path")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.T, self.p = T, p
         # state_dict None: a handle for the GNN-free entry points only (gnnb_babsr) -- all-zero GNN weights
         blob = state_blob(state_dict) if state_dict is not None else np.zeros(GNN_BLOB_FLOATS, dtype=np.float32)
@@ -105,6 +106,7 @@ class ScorerEngine:
         self.R = 0
         self._ws = {}
         self._prop_cache = {}
+        self._prop_host_cache = None
         # batch pipelining: a large batch is cut into `n_streams` contiguous chunks that run on separate HIP streams,
         # so the launch ramps and tails of one chunk's ~40 dependent kernels overlap the other chunk's work
         self.n_streams = int(os.environ.get("GNNB_STREAMS", "1"))   # measured on base B=256 (round 2): 1 stream 0.92 ms, 2 streams 0.97, 3 streams 1.10
@@ -288,6 +290,30 @@ class ScorerEngine:
             return t.numpy()
         return np.ascontiguousarray(t, dtype=np.float32)
 
+    class _HostBuf:
+        """address + element count of a float32 C-contiguous host buffer (a CPU tensor as it is, or a numpy copy of a python list /
+        array / tensor of another layout); holds the owner alive.  (A decision is ~0.3 ms of device work: numpy views and
+        ``.ctypes`` objects for two dozen small inputs were a tenth of that again.)"""
+        __slots__ = ("ptr", "size", "keep")
+
+        def __init__(self, t):
+            if torch.is_tensor(t) and t.dtype == torch.float32 and t.is_contiguous() and not t.requires_grad:
+                self.ptr, self.size, self.keep = t.data_ptr(), t.numel(), t
+            else:
+                a = ScorerEngine._host(t)
+                self.ptr, self.size, self.keep = a.ctypes.data, a.size, a
+
+    def _prop_host(self, props):
+        """(B, N_L) weights and (B,) biases of the property layers as numpy arrays, cached on the layer objects' identity + version"""
+        key = tuple((id(l), l.weight._version, l.bias._version) for l in props)
+        hit = self._prop_host_cache
+        if hit is not None and hit[0] == key:
+            return hit[1], hit[2]
+        pw = np.ascontiguousarray(np.stack([self._host(l.weight)[0] for l in props]))
+        pb = np.ascontiguousarray(np.array([float(l.bias.detach()[0]) for l in props], dtype=np.float32))
+        self._prop_host_cache = (key, pw, pb, list(props))
+        return pw, pb
+
     def forward_host(self, lower_bounds_all, upper_bounds_all, dual_vars, primals, primal_inputs, layers, masks, want_scores=False):
         """``forward`` for CPU inputs through ``gnnb_forward_host``: every input the kernels read is packed into ONE pinned
         transfer by the library, and decisions / status (/ scores) come back in one block -- no torch device tensors, no
@@ -298,38 +324,42 @@ class ScorerEngine:
         B = int(lower_bounds_all[0].shape[0])
         if len(layers["prop_layers"]) != B:
             raise ValueError(f"{len(layers['prop_layers'])} property layers for a batch of {B}")
-        lbs = [self._host(t) for t in lower_bounds_all]
-        ubs = [self._host(t) for t in upper_bounds_all]
-        duals = [self._host(t) for t in dual_vars]
-        prim = [self._host(t) for t in primals]
-        x_lp, mask = self._host(primal_inputs), self._host(masks)
+        HB = self._HostBuf
+        lbs = [HB(t) for t in lower_bounds_all]
+        ubs = [HB(t) for t in upper_bounds_all]
+        duals = [HB(t) for t in dual_vars]
+        prim = [HB(t) for t in primals]
+        x_lp, mask = HB(primal_inputs), HB(masks)
         ng = len(self.sizes)
         if len(lbs) != ng or len(ubs) != ng:
             raise ValueError(f"{len(lbs)} bound tensors, layer graph has {ng} layers")
         for k, (l, u) in enumerate(zip(lbs, ubs)):
             if l.size != B * self.sizes[k] or u.size != B * self.sizes[k]:
-                raise ValueError(f"bounds of graph layer {k}: {l.shape} does not hold {B}x{self.sizes[k]} values")
+                raise ValueError(f"bounds of graph layer {k}: {l.size} values, expected {B}x{self.sizes[k]}")
         for k, d in enumerate(duals):
             if d.size != B * self.sizes[k + 1] * 3:
-                raise ValueError(f"dual_vars[{k}] has {d.shape}, expected ({B * self.sizes[k + 1]}, 3)")
+                raise ValueError(f"dual_vars[{k}] has {d.size} values, expected ({B * self.sizes[k + 1]}, 3)")
         if mask.size != B * self.R:
-            raise ValueError(f"masks has {mask.shape}, expected ({B}, {self.R})")
+            raise ValueError(f"masks has {mask.size} values, expected ({B}, {self.R})")
         if x_lp.size != B * self.sizes[0]:
             raise ValueError("primal_inputs has the wrong size")
         self._check_primals(fixed, prim, B)
-        props = layers["prop_layers"]
-        pw = np.ascontiguousarray(np.stack([self._host(l.weight)[0] for l in props]))
-        pb = np.ascontiguousarray(np.array([float(l.bias.detach()[0]) for l in props], dtype=np.float32))
-        tabs = [(C.c_void_p * len(g))(*[a.ctypes.data for a in g]) for g in (lbs, ubs, duals, prim)]
-        batch = _lib.Batch(tabs[0], tabs[1], tabs[2], tabs[3], x_lp.ctypes.data, pw.ctypes.data, pb.ctypes.data, mask.ctypes.data,
+        pw, pb = self._prop_host(layers["prop_layers"])
+        tabs = [(C.c_void_p * len(g))(*[a.ptr for a in g]) for g in (lbs, ubs, duals, prim)]
+        batch = _lib.Batch(tabs[0], tabs[1], tabs[2], tabs[3], x_lp.ptr, pw.ctypes.data, pb.ctypes.data, mask.ptr,
                            len(lbs), len(duals), len(prim))
         dec = np.empty((B, 2), dtype=np.int32)
         status = np.zeros(1, dtype=np.int32)
         scores = np.empty((B, self.R), dtype=np.float32) if want_scores else None
-        with torch.cuda.device(self.device):
+        if torch.cuda.current_device() == self._dev_index:
             st = torch.cuda.current_stream().cuda_stream
             rc = self.lib.gnnb_forward_host(self.h, C.byref(batch), B, scores.ctypes.data if want_scores else None, dec.ctypes.data,
                                             status.ctypes.data, C.c_void_p(st))
+        else:
+            with torch.cuda.device(self.device):
+                st = torch.cuda.current_stream().cuda_stream
+                rc = self.lib.gnnb_forward_host(self.h, C.byref(batch), B, scores.ctypes.data if want_scores else None, dec.ctypes.data,
+                                                status.ctypes.data, C.c_void_p(st))
         _lib.check(rc, "gnnb_forward_host")
         _raise_for_status(int(status[0]))
         return dec, scores
@@ -419,7 +449,7 @@ class ScorerEngine:
 
     def _check_primals(self, fixed, prim, B):
         def count(t):
-            return t.numel() if torch.is_tensor(t) else t.size
+            return t.numel() if torch.is_tensor(t) else t.size      # (tensors, numpy arrays, _HostBuf)
         if len(prim) != len(fixed) + 1:
             raise ValueError(f"{len(prim)} primal tensors for {len(fixed) + 1} network layers")
         k = 0

@@ -14,4 +14,4 @@ for _ in range(50): g.decision(*args)
 pr = cProfile.Profile(); pr.enable()
 for _ in range(200): g.decision(*args)
 pr.disable()
-pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+pstats.Stats(pr).sort_stats("tottime").print_stats(int(os.environ.get("NROWS", "14")))
