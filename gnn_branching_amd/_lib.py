@@ -53,6 +53,7 @@ SYMBOLS = [
     ("gnnb_online_grad", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     ("gnnb_last_error", C.c_char_p, []),
     ("gnnb_abi_version", C.c_int, []),
+    ("gnnb_build_id", C.c_char_p, []),
     ("gnnb_describe", C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     ("gnnb_mu_location", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     ("gnnb_set_halfpass_limit", C.c_int, [C.c_void_p, C.c_int]),
@@ -63,12 +64,39 @@ SYMBOLS = [
 ]
 
 
+BUILD_ID_MARK = b"GNNB_BUILD_ID:"
+
+
+def source_hash():
+    """sha256 (first 32 hex digits) over the compiler flags and the text of every source the library is built from.  It is
+    compiled into the library (`gnnb_build_id()`), so a binary always says which sources it came from."""
+    import hashlib
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+    for name in SOURCES:
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read() + b"\0")
+    with open(os.path.join(CSRC, "..", "..", "include", "gnnb.h"), "rb") as f:
+        h.update(b"include/gnnb.h\0" + f.read())
+    return h.hexdigest()[:32]
+
+
+def library_build_id(path=None):
+    """The source hash a built library carries (read from the file, without loading it); None if it carries none."""
+    try:
+        with open(path or LIB_PATH, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return None
+    i = blob.find(BUILD_ID_MARK)
+    if i < 0:
+        return None
+    return blob[i + len(BUILD_ID_MARK):i + len(BUILD_ID_MARK) + 32].decode("ascii", "replace")
+
+
 def needs_build():
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in SOURCES) or \
-        os.path.getmtime(os.path.join(CSRC, "..", "..", "include", "gnnb.h")) > t
+    """The library is current iff it carries the hash of the sources in the tree -- not its mtime: `*.so` is git-ignored but
+    ships to the GPU box with the snapshot, and a stale binary whose timestamp happens to be newer must not be reused."""
+    return library_build_id() != source_hash()
 
 
 def build_library(force=False, verbose=False):
@@ -85,7 +113,7 @@ def build_library(force=False, verbose=False):
             if not force and not needs_build():
                 return LIB_PATH
             tmp = LIB_PATH + f".tmp{os.getpid()}"
-            cmd = ["hipcc"] + HIPCC_FLAGS + ["-o", tmp, os.path.join(CSRC, "gnnb.hip")]
+            cmd = ["hipcc"] + HIPCC_FLAGS + [f'-DGNNB_SRC_HASH="{source_hash()}"', "-o", tmp, os.path.join(CSRC, "gnnb.hip")]
             if verbose:
                 print(" ".join(cmd).replace(tmp, LIB_PATH), file=sys.stderr)
             r = subprocess.run(cmd, capture_output=True, text=True)
@@ -115,6 +143,12 @@ def load():
         # ROCm-capable device is detected").  Importing torch does not initialise the GPU.
         import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
+        if "GNNB_LIB" not in os.environ and os.path.exists(os.path.join(CSRC, "gnnb.hip")):
+            lib.gnnb_build_id.restype = C.c_char_p
+            have, want = lib.gnnb_build_id().decode("ascii", "replace"), source_hash()
+            if have != want:
+                raise RuntimeError(f"{LIB_PATH} was built from other sources (library {have}, tree {want}): run "
+                                   "`python -c 'import __graft_entry__ as g; g.build()'`")
         for name, res, args in SYMBOLS:
             fn = getattr(lib, name)
             fn.restype = res

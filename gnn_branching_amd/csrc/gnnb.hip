@@ -183,6 +183,13 @@ static int load_weights(gnnb_t* h, const float* w_blob, hipStream_t st) {
 }
 
 extern "C" int gnnb_abi_version(void) { return GNNB_ABI_VERSION; }
+#ifndef GNNB_SRC_HASH
+#define GNNB_SRC_HASH "unhashed-build------------------"
+#endif
+// the hash of the sources this binary was compiled from (gnn_branching_amd/_lib.py source_hash): the loader refuses a library
+// whose id differs from the tree's, the build skips one whose id matches (mtimes are not trusted: *.so ships outside git)
+static const char g_build_id[] = "GNNB_BUILD_ID:" GNNB_SRC_HASH;
+extern "C" const char* gnnb_build_id(void) { return g_build_id + 14; }
 extern "C" const char* gnnb_last_error(void) { return g_err.c_str(); }
 
 extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, int T, int p) {
@@ -1267,8 +1274,14 @@ extern "C" int gnnb_forward_host(gnnb_t* h, const gnnb_batch* in, int B, float* 
   if (i_prim[in->n_primal - 1] == (size_t)-1) i_prim[in->n_primal - 1] = add(in->primal[in->n_primal - 1], (size_t)B);
   const size_t i_x = add(in->x_lp, (size_t)B * h->N[0]), i_pw = add(in->prop_w, (size_t)B * h->N[L]), i_pb = add(in->prop_b, (size_t)B);
   const size_t i_mask = add(in->mask, (size_t)B * R);
-  for (const Slot& sl : slots)
+  for (const Slot& sl : slots) {
     if (!sl.src) return fail(GNNB_E_INVALID, "gnnb_forward_host: null input pointer");
+    // these are read by memcpy on the host: device memory here is a caller bug (e.g. data_ptr() of a `.cuda()` tensor), refused
+    // rather than dereferenced.  ~0.2 us per pointer: the runtime's allocation map, no driver call
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, sl.src) != hipSuccess) { (void)hipGetLastError(); continue; }      // plain host memory
+    if (at.type == hipMemoryTypeDevice) return fail(GNNB_E_INVALID, "gnnb_forward_host: an input pointer is device memory; this entry point takes host pointers (gnnb_forward takes device pointers)");
+  }
   // ---- buffers
   if (h->hs_floats < total) {
     if (h->hs_pinned) (void)hipHostFree(h->hs_pinned);

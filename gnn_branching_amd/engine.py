@@ -282,9 +282,12 @@ class ScorerEngine:
     # ---- the reference's own call pattern: host tensors, one or two subproblems ---------------------------------
     @staticmethod
     def _host(t):
-        """float32 C-contiguous numpy view / copy of a CPU tensor, python list or array."""
+        """float32 C-contiguous numpy view / copy of a tensor (of ANY device: the reference's driver hands over `.cuda()`
+        layers next to CPU bounds, relu_conv_gnnkwthreshold.py:111-117), python list or array -- always HOST memory."""
         if torch.is_tensor(t):
             t = t.detach()
+            if t.device.type != "cpu":
+                t = t.cpu()
             if t.dtype != torch.float32 or not t.is_contiguous():
                 t = t.to(torch.float32).contiguous()
             return t.numpy()
@@ -297,7 +300,10 @@ class ScorerEngine:
         __slots__ = ("ptr", "size", "keep")
 
         def __init__(self, t):
-            if torch.is_tensor(t) and t.dtype == torch.float32 and t.is_contiguous() and not t.requires_grad:
+            # data_ptr() is taken as a HOST address only of a tensor that lives on the host: a device tensor slipping through
+            # here would be a wild host read inside gnnb_forward_host, so it is copied back by _host instead
+            if torch.is_tensor(t) and t.device.type == "cpu" and t.dtype == torch.float32 and t.is_contiguous() \
+                    and not t.requires_grad:
                 self.ptr, self.size, self.keep = t.data_ptr(), t.numel(), t
             else:
                 a = ScorerEngine._host(t)
@@ -305,12 +311,15 @@ class ScorerEngine:
 
     def _prop_host(self, props):
         """(B, N_L) weights and (B,) biases of the property layers as numpy arrays, cached on the layer objects' identity + version"""
-        key = tuple((id(l), l.weight._version, l.bias._version) for l in props)
+        key = tuple((id(l), l.weight.data_ptr(), l.weight._version, l.bias._version) for l in props)
         hit = self._prop_host_cache
         if hit is not None and hit[0] == key:
             return hit[1], hit[2]
+        for l in props:
+            if l.weight.shape[0] != 1:
+                raise NotImplementedError("the property layer must be Linear(., 1)")   # graph_conv.py:80
         pw = np.ascontiguousarray(np.stack([self._host(l.weight)[0] for l in props]))
-        pb = np.ascontiguousarray(np.array([float(l.bias.detach()[0]) for l in props], dtype=np.float32))
+        pb = np.ascontiguousarray(np.array([self._host(l.bias)[0] for l in props], dtype=np.float32))
         self._prop_host_cache = (key, pw, pb, list(props))
         return pw, pb
 

@@ -52,7 +52,7 @@ class GraphChoice:
             if host:                                              # CPU tensors (the reference's pattern): one pinned transfer
                 d, sc = self._eng().forward_host(*args, want_scores=True)
                 dec = d[0].tolist()
-                ragged = [torch.from_numpy(sc[0][mask_1d[0].numpy() != 0])]
+                ragged = [torch.from_numpy(sc[0][mask_1d[0].cpu().numpy() != 0])]
             else:
                 res = self._eng().forward(*args).check()
                 dec = res.decisions[0].tolist()

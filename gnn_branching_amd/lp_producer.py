@@ -83,7 +83,8 @@ class Subproblem:
 class LayerGraphLP:
     """LP relaxation of ``layers`` (net.layers with the folded Linear(., 1) property layer last) over an input box."""
 
-    def __init__(self, layers, input_lb, input_ub, bounds="kw"):
+    def __init__(self, layers, input_lb, input_ub, bounds="kw", lp_method="highs-ipm"):
+        self.lp_method = lp_method
         if bounds not in ("kw", "interval"):
             raise ValueError(bounds)
         self.bound_mode = bounds
@@ -308,11 +309,25 @@ class LayerGraphLP:
                 r += 1
         c = np.zeros(nvar)
         c[-1] = 1.0
+        # variables whose box is narrower than 1e-6 without being fixed (pre-activations that do not depend on the input: their
+        # two bounds differ by float64 rounding) get 1e-7 of slack: HiGHS' clean-up simplex after the crossover otherwise reports
+        # a feasible cifar_deep_kw root as infeasible (259 such variables there, primal residual 2e-8 before the push phase)
+        width = up_v - lo_v
+        tiny = (width > 0) & (width < 1e-6)
+        lo_b, up_b = np.where(tiny, lo_v - 1e-7, lo_v), np.where(tiny, up_v + 1e-7, up_v)
         args = dict(A_ub=sp.vstack(ub_rows, format="csr") if ub_rows else None, b_ub=np.concatenate(ub_rhs) if ub_rhs else None,
-                    A_eq=sp.vstack(eq_rows, format="csr"), b_eq=np.concatenate(eq_rhs), bounds=np.stack([lo_v, up_v], 1), method="highs")
-        res = linprog(c, **args)
+                    A_eq=sp.vstack(eq_rows, format="csr"), b_eq=np.concatenate(eq_rhs), bounds=np.stack([lo_b, up_b], 1))
+        # interior point + crossover: on the CIFAR networks (10^4 variables, 3*10^5 non-zeros, almost every row an equality)
+        # HiGHS' dual simplex needs 1.8*10^5 degenerate pivots = 180 s per LP, its IPM 17 iterations = 0.5 s; the crossover
+        # ends in a basic solution, so the marginals are vertex duals like the simplex's (and Gurobi's)
+        res = linprog(c, method=self.lp_method, **args)
+        if res.status == 2 and self.lp_method != "highs":
+            # "infeasible" from the clean-up simplex can still be rounding: once more with 1e-6 of slack on every free box
+            free = width > 0
+            args["bounds"] = np.stack([np.where(free, lo_v - 1e-6, lo_v), np.where(free, up_v + 1e-6, up_v)], 1)
+            res = linprog(c, method=self.lp_method, **args)
         if res.status not in (0, 2):         # HiGHS' presolve sometimes ends without a model status on an infeasible child
-            res = linprog(c, options={"presolve": False}, **args)
+            res = linprog(c, method="highs", options={"presolve": False}, **args)
         if res.status == 2:
             return None                      # infeasible domain
         if res.status != 0:

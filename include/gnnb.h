@@ -136,6 +136,9 @@ int gnnb_online_grad(const gnnb_t* h, float* grad, size_t n_floats);
 
 const char* gnnb_last_error(void);
 int gnnb_abi_version(void);
+/* 32 hex digits: hash of the sources (and compiler flags) the library was built from; the Python loader compares it with the
+ * tree's and refuses a stale binary. */
+const char* gnnb_build_id(void);
 
 /* ---- inspection hooks used by the parity tests and bench.py (not needed by a caller) ---- */
 

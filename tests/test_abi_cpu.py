@@ -70,3 +70,22 @@ def test_status_word_maps_to_the_reference_s_failure_modes():
     res = engine.ForwardResult(None, None, torch.tensor([0, 1], dtype=torch.int32), None)
     with pytest.raises(FloatingPointError):
         res.check()
+
+
+def test_library_carries_the_hash_of_its_sources(lib, tmp_path, monkeypatch):
+    """`*.so` is git-ignored yet ships with the snapshot, so mtimes say nothing: the build id compiled into the library is the
+    hash of the sources it came from; `needs_build()` compares it with the tree's, and a binary with another id is stale."""
+    want = _lib.source_hash()
+    assert re.fullmatch(r"[0-9a-f]{32}", want)
+    assert lib.gnnb_build_id().decode() == want == _lib.library_build_id()
+    assert not _lib.needs_build()
+    # a binary from other sources (here: the same bytes with a patched id), however new its timestamp, is not current
+    blob = open(_lib.LIB_PATH, "rb").read()
+    i = blob.find(_lib.BUILD_ID_MARK) + len(_lib.BUILD_ID_MARK)
+    stale = tmp_path / "libgnnb.so"
+    stale.write_bytes(blob[:i] + b"0" * 32 + blob[i + 32:])
+    assert _lib.library_build_id(str(stale)) == "0" * 32
+    monkeypatch.setattr(_lib, "LIB_PATH", str(stale))
+    assert _lib.needs_build()
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "missing.so"))
+    assert _lib.needs_build()

@@ -51,3 +51,72 @@ def test_random_batches_masks_and_weights(net):
                         assert dec[b] == [-1, -1]
                 n += 1
     print(f"{net}: {n} cases, worst |score - oracle| shipped {worst['shipped']:.3e}, random {worst['random']:.3e}")
+
+
+def lp_like(batch, rng, dual_scale, decided_frac=0.25):
+    """Turn a synthetic batch into what a BaB run hands the scorer some levels down the tree (conv_kwinter_gen.py:529-554,
+    :558-795): constraint duals in Gurobi's signs (Pi of `v >= pre` >= 0, Pi of `v <= slope pre + bias` <= 0) on the undecided
+    nodes, of magnitude up to `dual_scale`, plus a sprinkle of either sign anywhere; a quarter of the ambiguous nodes DECIDED
+    by earlier splits -- blocked: upper bound clamped to exactly 0, passing: lower bound clamped to exactly 0
+    (update_the_model sets pre_ub / pre_lb of the split node to 0), their BaB mask 0 / 1, no longer scored."""
+    args = list(batch.forward_args())
+    B = batch.batch_size
+    lbs, ubs = [t.clone() for t in args[0]], [t.clone() for t in args[1]]
+    duals, masks = [], []
+    for k in range(1, len(lbs) - 1):
+        lb, ub = lbs[k].reshape(B, -1), ubs[k].reshape(B, -1)
+        n = lb.shape[1]
+        amb = (lb < 0) & (ub > 0)
+        pick = amb & torch.from_numpy(rng.uniform(size=(B, n)) < decided_frac)
+        block = pick & torch.from_numpy(rng.uniform(size=(B, n)) < 0.5)
+        ub[block] = 0.0
+        lb[pick & ~block] = 0.0
+        still = amb & ~pick
+        d = np.zeros((B * n, 3), dtype=np.float32)
+        a = still.reshape(-1).numpy()
+        d[a, 1] = (rng.uniform(0, dual_scale, a.sum()) * (rng.uniform(size=a.sum()) < 0.6)).astype(np.float32)
+        d[a, 2] = (-rng.uniform(0, dual_scale, a.sum()) * (rng.uniform(size=a.sum()) < 0.6)).astype(np.float32)
+        extra = rng.uniform(size=B * n) < 0.02
+        d[extra, 1:] += rng.uniform(-dual_scale, dual_scale, (int(extra.sum()), 2)).astype(np.float32)
+        duals.append(torch.from_numpy(d))
+        masks.append(still.float())
+    args[0], args[1], args[2], args[6] = lbs, ubs, duals, torch.cat(masks, 1)
+    return args
+
+
+@pytest.mark.parametrize("net", ["cifar_base_kw", "cifar_wide_kw", "cifar_deep_kw"])
+def test_lp_like_duals_and_decided_nodes(net):
+    """Signed / large duals and masks with decided nodes (bounds clamped to exactly 0 on either side): what the synthetic
+    generator never produces and a BaB run always does.  Shipped weights: 1e-4 absolute while the scores stay in the range the
+    budget was stated for, 2e-6 of the largest score beyond it (large duals scale the scores; the reference's own fp32-vs-fp64
+    noise is ~5e-7 of the score range)."""
+    from oracle import gnn_oracle
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    models = {}
+    for fam in ("shipped", "random"):
+        m = GraphNet(2, 64)
+        m.load_state_dict({k: torch.as_tensor(v) for k, v in state_of(fam).items()})
+        models[fam] = m
+    for dual_scale in (0.05, 1.0, 30.0):
+        for B, seed in ((2, 7), (9, 8)):
+            batch = synth.make_batch(net, B, seed=seed)
+            rng = np.random.RandomState(1000 + seed)
+            args = lp_like(batch, rng, dual_scale)
+            for fam, model in models.items():
+                with torch.no_grad():
+                    want = gnn_oracle.padded_scores(gnn_oracle.oracle_forward(state_of(fam), *args), args[6]).numpy()
+                    res = model.forward_device(*args).check()
+                got = res.scores.cpu().numpy()
+                fin = np.isfinite(want)
+                assert np.array_equal(np.isfinite(got), fin) and fin.any()
+                err = float(np.abs(got[fin] - want[fin]).max())
+                big = float(np.abs(want[fin]).max())
+                tol = max(score_tol(fam, want[fin]), 2e-6 * big)
+                print(f"{net} B={B} duals<= {dual_scale:g} {fam}: max|score - oracle| {err:.3e} (bar {tol:.1e}), scores in [{want[fin].min():.4g}, {want[fin].max():.4g}]")
+                assert err <= tol, (net, B, dual_scale, fam, err, tol)
+                sizes = [int(np.prod(t.shape[1:])) for t in args[0][1:-1]]
+                for b in range(B):
+                    m1 = torch.from_numpy(want[b][fin[b]])
+                    srt = np.sort(want[b][fin[b]])[::-1]
+                    if len(srt) > 1 and srt[0] - srt[1] > 1e-3:          # a clear winner: the decision must be the oracle's
+                        assert res.decisions[b].cpu().tolist() == gnn_oracle.decision_from_scores(m1, args[6][b], sizes)

@@ -157,3 +157,58 @@ def test_bench_launcher_never_runs_fewer_ranks_than_asked(tmp_path):
     env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()
+
+
+# ---- the branch selector on the gathered matrix (graph_score.py:41-47) ---------------------------------------
+def test_branch_selector_on_the_gathered_matrix_takes_the_first_maximum():
+    """`decisions_from_scores` is what every rank applies to the all-gathered (B, R) matrix.  It must give what the
+    reference's `torch.max(scores, 0)` + `trans_len` walk gives per subproblem (graph_score.py:41-47, restated in the oracle's
+    `decision_from_scores` on the ragged vector) -- on the reference's golden scores, and on rows with exact ties (FIRST maximal
+    index: the device's k_score keeps the lowest flat index among equal scores, and N ranks must agree with one)."""
+    from oracle import gnn_oracle
+    from tests.common import GOLDEN_CASES, load_golden, relu_sizes
+    for case in GOLDEN_CASES:
+        g, batch = load_golden(case)
+        sizes = relu_sizes(batch)
+        for fam in ("shipped", "random"):
+            padded = torch.from_numpy(g[f"{fam}_scores"])
+            assert parallel.decisions_from_scores(padded, sizes).tolist() == g[f"{fam}_decisions"].tolist()
+    sizes = [5, 4, 3]
+    ninf = float("-inf")
+    rows = torch.tensor([
+        [ninf, 2.0, 2.0, ninf, 1.0, 2.0, ninf, ninf, 0.0, 2.0, ninf, ninf],       # tie inside layer 0 and across layers -> [0, 1]
+        [ninf, ninf, ninf, ninf, ninf, -3.0, ninf, -3.0, ninf, ninf, -3.0, ninf],  # tie across layers 1 and 2 -> [1, 0]
+        [ninf] * 12,                                                               # nothing undecided -> [-1, -1]
+        [ninf] * 11 + [7.0],                                                       # the last node of the last layer -> [2, 2]
+        [0.5] * 12,                                                                # all equal -> the first node
+    ])
+    want = [[0, 1], [1, 0], [-1, -1], [2, 2], [0, 0]]
+    assert parallel.decisions_from_scores(rows, sizes).tolist() == want
+    for r, w in zip(rows, want):
+        mask = torch.isfinite(r).float()
+        if mask.sum() > 0:
+            assert gnn_oracle.decision_from_scores(r[mask != 0], mask, sizes) == w
+    # sharding the rows over ranks and concatenating (what the all-gather does) cannot change a row's decision
+    for world in (2, 3):
+        parts = [rows[slice(*parallel.shard_bounds(len(rows), world, r))] for r in range(world)]
+        assert parallel.decisions_from_scores(torch.cat(parts), sizes).tolist() == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("net,B", [("cifar_base_kw", 64), ("cifar_deep_kw", 24)])
+def test_device_decisions_equal_the_selector_on_the_scores(net, B):
+    """Per-rank device decisions (k_score's argmax) == `decisions_from_scores` on the same padded scores: whether the selector
+    reads the (B/G, 2) decisions or the gathered (B, R) matrix it branches on the same nodes."""
+    from gnn_branching_amd import synth
+    from tests.common import relu_sizes
+    from tests.test_gpu_parity import make_model
+    model = make_model("shipped")
+    batch = synth.make_batch(net, B, seed=5)
+    with torch.no_grad():
+        res = model.forward_device(*batch.forward_args()).check()
+    dec = parallel.decisions_from_scores(res.scores.cpu(), relu_sizes(batch))
+    assert dec.tolist() == res.decisions.cpu().tolist()
+    # duplicated subproblems produce bit-identical rows (batched == per-sample): the gathered matrix of a 2-rank split of
+    # [batch, batch] is the concatenation, and both halves decide alike
+    both = torch.cat([res.scores.cpu(), res.scores.cpu()])
+    assert parallel.decisions_from_scores(both, relu_sizes(batch)).tolist() == dec.tolist() * 2
