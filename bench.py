@@ -41,6 +41,11 @@ CONFIGS = {
 
 PEAK_HBM_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6.3 TB/s achievable)
 PEAK_F32_MFMA_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32, same guide
+PEAK_L2_GBS = 34500.0        # aggregate L2 -> L1 rate, same guide ("L2 (per XCD)": ~34.5 TB/s)
+N_SIMD, PEAK_CLOCK_HZ = 1024, 2.4e9      # 256 CUs x 4 SIMDs; the clock the matrix peaks are quoted at
+TCP_REQ_BYTES = 64           # one TCP -> TCC request (calibrated in profiles/: TCP_TCC_WRITE_REQ x 64 B == WRITE_SIZE on the row stores)
+HALF_PASS_KERNELS = ("k_gather", "k_gather_update", "k_gather_input_update", "k_conv_fwd", "k_convT_bwd", "k_dense_agg", "k_prop", "k_top",
+                     "k_node_update", "k_input_update")
 
 
 MFMA_FLOP = 2 * 32 * 32 * 2          # one v_mfma_f32_32x32x2_f32
@@ -148,6 +153,47 @@ def pmc_rows(pmc, cls):
     return [v for k, v in pmc.items() if same(k) and "hbm_bytes_per_launch" in v]
 
 
+def binding_bounds(kern, pmc, steps):
+    """Per half-pass kernel class: which resource bounds it, from the committed counter passes of this same command
+    (profiles/pmc_latest_*.json) and the live launch durations.  speed of light = max of
+      hbm   HBM bytes the counters saw per launch ((2 FETCH_SIZE + WRITE_SIZE) KB, gfx950 correction)      / 8 TB/s
+      mfma  matrix-pipe busy cycles per launch (SQ_VALU_MFMA_BUSY_CYCLES, summed over the SIMDs)            / (1024 SIMDs x 2.4 GHz)
+      l2    bytes the L1s requested from L2 per launch ((TCP_TCC_READ_REQ + TCP_TCC_WRITE_REQ) x 64 B)      / 34.5 TB/s
+    and `frac` = that time / the measured launch time: how close the kernel is to the bound that binds it."""
+    out = {}
+    if not pmc:
+        return None
+    for k in HALF_PASS_KERNELS:
+        if k not in kern:
+            continue
+        rows = pmc_rows(pmc, k)
+        n = sum(v.get("launches_sampled", 1) for v in rows)
+        if not n:
+            continue
+
+        def mean(field):
+            have = [v for v in rows if field in v]
+            m = sum(v.get("launches_sampled", 1) for v in have)
+            return sum(v[field] * v.get("launches_sampled", 1) for v in have) / m if m else None
+        hbm, busy = mean("hbm_bytes_per_launch"), mean("SQ_VALU_MFMA_BUSY_CYCLES_per_launch")
+        rd, wr = mean("TCP_TCC_READ_REQ_sum_per_launch"), mean("TCP_TCC_WRITE_REQ_sum_per_launch")
+        t_us = kern[k]["avg_us"]
+        terms = {"hbm": hbm / (PEAK_HBM_GBS * 1e9) * 1e6 if hbm is not None else None,
+                 "mfma": busy / N_SIMD / PEAK_CLOCK_HZ * 1e6 if busy is not None else None,
+                 "l2": (rd + (wr or 0.0)) * TCP_REQ_BYTES / (PEAK_L2_GBS * 1e9) * 1e6 if rd is not None else None}
+        known = {a: b for a, b in terms.items() if b is not None}
+        if not known:
+            continue
+        bound = max(known, key=known.get)
+        out[k] = {"avg_launch_us": t_us, "launches_per_step": kern[k]["launches"] // steps,
+                  "sol_us": {a: round(b, 2) for a, b in known.items()}, "binding": bound,
+                  "frac_of_binding_bound": round(known[bound] / t_us, 4) if t_us > 0 else None,
+                  "hbm_bytes_per_launch": round(hbm) if hbm is not None else None,
+                  "l1_fill_bytes_per_launch": round((rd + (wr or 0.0)) * TCP_REQ_BYTES) if rd is not None else None,
+                  "mfma_busy_share": round(known["mfma"] / t_us, 4) if "mfma" in known and t_us > 0 else None}
+    return out or None
+
+
 def message_passing_bytes(sizes, B, T):
     """4*p*(N_src + N_dst) bytes per half-pass update src->dst, summed over the
     live half-passes (the last round's input-layer update is dead)."""
@@ -227,6 +273,7 @@ def parse_args(argv=None):
     ap.add_argument("--net", default=None)
     ap.add_argument("--batch", type=int, default=None, help="subproblems per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact-fp32", action="store_true", help="skip the GNNB_BF3=0 comparison leg (exact_fp32_ms_per_step, bf3_max_abs_delta)")
     ap.add_argument("--cpu-budget", type=float, default=75.0, help="seconds of CPU work for the cpu_baseline leg")
     args = ap.parse_args(argv)
     cfg = CONFIGS[args.config if args.config is not None else 2]
@@ -401,8 +448,7 @@ def main():
                            "reference_equivalent_tflops": round(nu_tf, 2)}
         # message passing is fused into the update kernels (the aggregate never reaches HBM): its algorithmic bytes
         # 4*p*(N_src+N_dst) per half-pass over the time of every kernel that performs an update
-        mp_names = ("k_gather", "k_gather_update", "k_gather_input_update", "k_conv_fwd", "k_convT_bwd", "k_dense_agg", "k_prop", "k_top",
-                    "k_node_update", "k_input_update")
+        mp_names = HALF_PASS_KERNELS
         mp_ms = sum(prof[k][0] for k in mp_names if k in prof)
         mp_bytes = message_passing_bytes(sizes, B, T) * args.steps
         mp_gbs = mp_bytes / (mp_ms * 1e-3) / 1e9 if mp_ms > 0 else 0.0
@@ -428,6 +474,32 @@ def main():
                        "bytes_per_subproblem": message_passing_bytes(sizes, 1, T),
                        "note": "achieved = SURVEY 8(d) algorithmic bytes 4*p*(N_src + N_dst) per half-pass / time of all half-pass kernels; "
                                "frac_counter = HBM bytes the counters saw (dead rows are skipped, round 0 computes its source rows) / the same time"}
+        # ---- the same batch with every block on the exact-fp32 MFMA (GNNB_BF3=0 is read by gnnb_create: a second handle),
+        # outside the timed region of the headline: what the three-piece bf16 blocks buy, and how far their scores are from it
+        exact_ms = bf3_delta = None
+        if plan.get("bf3") and not args.no_exact_fp32:
+            os.environ["GNNB_BF3"] = "0"
+            try:
+                model32 = GraphNet(2, 64)
+                model32.load_state_dict(sd)
+                eng32 = model32.eval().engine()
+                for _ in range(5):
+                    r32 = eng32.forward(*d_args)
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                for _ in range(args.steps):
+                    r32 = eng32.forward(*d_args)
+                torch.cuda.synchronize()
+                exact_ms = 1e3 * (time.perf_counter() - t2) / args.steps
+                r32.check()
+                a32, a16 = r32.scores.cpu().numpy(), res.scores.cpu().numpy()
+                fin = np.isfinite(a32)
+                assert np.array_equal(fin, np.isfinite(a16))
+                bf3_delta = float(np.abs(a32[fin] - a16[fin]).max()) if fin.any() else 0.0
+                assert torch.equal(r32.decisions, res.decisions) or bf3_delta > 0
+                del eng32, model32
+            finally:
+                del os.environ["GNNB_BF3"]
         cpu = None
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(sd, args.net, args.cpu_budget)
@@ -439,13 +511,17 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (bf16x3-split 64x64 blocks)" if plan.get("bf3") else "f32", "data": "synthetic",
-            "config": {"workload": f"{args.net}, batch={B} synthetic subproblems per GPU, T=2, p=64, shipped cifar_trained_gnn weights",
+            "config": {"workload": f"{args.net}, {B} synthetic subproblems per rank x {world} rank(s) = {world * B}, T=2, p=64, shipped cifar_trained_gnn weights",
+                       "batch_per_rank": B, "ranks": world, "global_batch": world * B,
                        "subproblems_per_s": round(world * B * args.steps / elapsed, 1),
                        "ambiguous_per_subproblem": round(total_amb / (world * B), 1),
                        "parallelism": f"dp{world}" + (" + 1 all-gather(scores)/step" if world > 1 else "")},
             "roofline": roofline,
             "roofline_node_update": roofline_nu,
             "roofline_message_passing": roofline_mp,
+            "binding_bounds": binding_bounds(kern, pmc, args.steps),
+            "exact_fp32_ms_per_step": round(exact_ms, 4) if exact_ms is not None else None,
+            "bf3_max_abs_delta": bf3_delta,
             "cpu_baseline": cpu,
             "kernels": kern,
             "plan": plan["updates"],

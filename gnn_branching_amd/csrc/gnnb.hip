@@ -119,6 +119,7 @@ struct gnnb_handle {
   bool scored_gather = true;    // the restricted last step's aggregate one wave per scored node (k_gather_scored); GNNB_DEV: GNNB_NO_SCORED_GATHER=1
   bool use_top = true;          // fuse the top of the network (last Linear edge, last ReLU layer, property node) into k_top
   bool top_ok = false;          // ... which the bound network allows (set by gnnb_bind_network)
+  int top_split_max = 4;        // GNNB_TOP_SPLIT: 4 (default) = four workgroups per sample while B <= n_cu / 4; 2 = two while B <= n_cu / 2; 1 = never
   int per_sample_min_b = 0;     // GNNB_PER_SAMPLE_MIN_B: batches below it take the per-tile dense kernel + separate launches
                                 // instead of the one-workgroup-per-sample kernels (k_top, k_dense_*_lds), which need a batch
                                 // that fills the CUs (B=2: 0.40 vs 0.49 ms, B=64: 0.64 vs 0.66, B=128: 0.96 vs 0.88 ms; 96 is
@@ -273,7 +274,10 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   FUSEDQ_ATTR(16, 0, false); FUSEDQ_ATTR(16, 1, false); FUSEDQ_ATTR(16, 2, false); FUSEDQ_ATTR(32, 1, false); FUSEDQ_ATTR(32, 1, true);
 #undef FUSEDQ_ATTR
   if (const char* e = getenv("GNNB_PER_SAMPLE_MIN_B")) h->per_sample_min_b = atoi(e);
-  HIPCHK(hipFuncSetAttribute((const void*)k_top, hipFuncAttributeMaxDynamicSharedMemorySize, TOP_LDS_FLOATS * 4));
+  if (const char* e = getenv("GNNB_TOP_SPLIT")) h->top_split_max = atoi(e) >= 4 ? 4 : (atoi(e) >= 2 ? 2 : 1);
+  HIPCHK(hipFuncSetAttribute((const void*)k_top<4>, hipFuncAttributeMaxDynamicSharedMemorySize, TOP_LDS_FLOATS * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_top<2>, hipFuncAttributeMaxDynamicSharedMemorySize, TOP_LDS_FLOATS * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_top<1>, hipFuncAttributeMaxDynamicSharedMemorySize, TOP_LDS_FLOATS * 4));
   *out = h;
   return GNNB_OK;
 }
@@ -649,7 +653,9 @@ struct WsLayout {                // plain arrays: gnnb_forward computes it on it
   size_t sf[MAXL + 2], sb[MAXL + 2];   // k_livesum outputs: sf[k] (B, N_k) over edge k, sb[k] (B, N_k) over edge k+1 transposed
   size_t F1 = 0;                // rows of layer 1 after the producer-side map of the input update (PackPostInp)
   size_t cnt = 0, best = 0, nb = 0, Q = 0, total = 0;     // best: B 64-bit decision keys + the finished-workgroup counter of k_score
+  size_t topflag = 0, topx = 0;                           // k_top's workgroup split: arrival counters, (B, 8, 64) exchange buffer
 };
+#define TOP_SPLIT_MAXB 128      // k_top only splits a sample over workgroups while B x S workgroups fit the chip: B <= n_cu / 2
 static size_t align64(size_t nfloats) { return (nfloats + 63) & ~(size_t)63; }
 static WsLayout ws_layout(const gnnb_t* h, int B) {
   WsLayout w;
@@ -658,6 +664,8 @@ static WsLayout ws_layout(const gnnb_t* h, int B) {
   size_t off = 0;
   w.cnt = off; off += 64;                      // int counters: 4 per ReLU layer (live, amb, score, pad), zeroed every forward
   w.best = off; off += align64((size_t)2 * B + 2);
+  w.topflag = off; off += align64(TOP_SPLIT_MAXB);
+  w.topx = off; off += align64((size_t)std::min(B, TOP_SPLIT_MAXB) * 512);
   for (int k = 0; k <= K; ++k) { w.mu[k] = off; off += align64((size_t)B * h->N[k] * 64); }
   size_t maxn = 0;
   for (int k = 0; k < K; ++k) maxn = std::max(maxn, (size_t)h->N[k]);
@@ -812,7 +820,8 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
 
   unsigned long long* best = reinterpret_cast<unsigned long long*>(ws + w.best);
   int* done_ctr = reinterpret_cast<int*>(ws + w.best + 2 * (size_t)B);
-  hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, st, status, reinterpret_cast<int*>(ws + w.cnt), best, done_ctr, B);
+  hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, st, status, reinterpret_cast<int*>(ws + w.cnt), best, done_ctr, B,
+                     reinterpret_cast<int*>(ws + w.topflag), std::min(B, TOP_SPLIT_MAXB));
   int* cnt = reinterpret_cast<int*>(ws + w.cnt);
   auto ilist = [&](size_t off) { return reinterpret_cast<int*>(ws + off); };
   int roff[MAXL + 2] = {0};                 // offset of layer k inside the flat ReLU index
@@ -1164,6 +1173,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   };
 
   // the top of the network as one launch per round (k_top); with a half-pass limit (inspection) the separate kernels run
+  int top_launches = 0;
   auto top = [&]() {
     const Edge& e = h->edges[L];
     const DevEdge& de = h->dev[L];
@@ -1178,7 +1188,20 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     a.lbm = in->lb[L - 1]; a.ubm = in->ub[L - 1];
     a.prop_w = in->prop_w; a.prop_b = in->prop_b; a.lbK = in->lb[K]; a.ubK = in->ub[K]; a.z_out = in->primal[in->n_primal - 1];
     a.mu_prop = mu(K); a.mu = mu(L); a.status = status; a.N = h->N[L];
-    lz.run(PC_TOP, [&] { hipLaunchKernelGGL(k_top, dim3(B), dim3(512), TOP_LDS_FLOATS * 4, st, a); });
+    // A sample's top spread over S = 2 / 4 workgroups (by output tile of both Linear edges) while all B x S of them are resident
+    // at one per CU (they wait for each other); GNNB_TOP_SPLIT = 1 / 2 / 4 caps S.  The results do not depend on S.
+    // Measured (deep, B = 128, S = 2): the two hand-offs cost what the shorter edges save (50 us either way), so a sample is only
+    // split when all four quarters fit: B <= n_cu / 4 (base B = 1: 52 -> 38 us per launch).  GNNB_TOP_SPLIT = 2 forces halves.
+    int S = 1;
+    if (h->top_split_max >= 4 && (long)B * 4 <= h->n_cu) S = 4;
+    else if (h->top_split_max == 2 && (long)B * 2 <= h->n_cu && B <= TOP_SPLIT_MAXB) S = 2;
+    a.xbuf = ws + w.topx; a.xflag = reinterpret_cast<int*>(ws + w.topflag); a.xbase = top_launches * 2 * S;
+    ++top_launches;
+    lz.run(PC_TOP, [&] {
+      if (S == 4) hipLaunchKernelGGL(k_top<1>, dim3(B * 4), dim3(512), TOP_LDS_FLOATS * 4, st, a);
+      else if (S == 2) hipLaunchKernelGGL(k_top<2>, dim3(B * 2), dim3(512), TOP_LDS_FLOATS * 4, st, a);
+      else hipLaunchKernelGGL(k_top<4>, dim3(B), dim3(512), TOP_LDS_FLOATS * 4, st, a);
+    });
     proj[L] = L_BC4_1;
   };
 

@@ -415,9 +415,12 @@ typedef unsigned short top_idx_t;      // live-row lists of k_top: 16-bit (layer
 // klist (LDS, or null: all a.K rows): the K_eff live source rows, padded with a.Kpad (a zero row of At) up to K_eff + 1.
 // s_fin (LDS, 128 floats) != null: s_fin[m] = sum over the walked rows of W[m][k] (the bias sum of this edge); spart: 256 floats.
 // store(row, channel, value).  Requires 512 threads.
-template <class Store1>
+// TS (4 / 2 / 1): row tiles this workgroup computes, t0 .. t0 + TS - 1 (k_top_split: a sample's rows spread over 4 / TS workgroups by
+// OUTPUT tile, every sum in the order of the unsplit kernel -- the results do not depend on the split); the weight load narrows
+// with it (16 / 8 / 4 bytes per lane and list entry).
+template <int TS, class Store1>
 __device__ __forceinline__ void dense_fwd_sample_bf3(const DenseLArgs& a, int b, float* scratch, float* spart, Store1 store,
-                                                     const top_idx_t* klist, int K_eff, float* s_fin) {
+                                                     const top_idx_t* klist, int K_eff, float* s_fin, int t0 = 0) {
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int Kw = klist ? K_eff : a.K;
@@ -427,17 +430,19 @@ __device__ __forceinline__ void dense_fwd_sample_bf3(const DenseLArgs& a, int b,
   const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + (long)b * a.K * 64), 0, a.K * 256, 0x00020000);
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.At, 0, 0x7fffffff, 0x00020000);
   const unsigned ldb = (unsigned)a.ldA * 4u;
-  const unsigned acol = 4 * j < a.ldA ? 16u * (unsigned)j : 0u;       // (rows 4 j + t >= ldA do not exist: any finite weights will do)
-  f32x16 acc[4][2];
+  const unsigned acol = (4 * j < a.ldA ? 16u * (unsigned)j : 0u) + 4u * (unsigned)t0;       // (rows 4 j + t >= ldA do not exist: any finite weights will do)
+  f32x16 acc[TS][2];
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < TS; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[t][0][r] = 0.0f; acc[t][1][r] = 0.0f; }
-  float sacc[4] = {0.f, 0.f, 0.f, 0.f};
+  float sacc[TS];
+#pragma unroll
+  for (int t = 0; t < TS; ++t) sacc[t] = 0.0f;
   // One set of raw registers: they are free as soon as they are split, and the loads of the wave's next k-step go out right
   // there, under this step's MFMAs (8 accumulator tiles leave no room for a second buffer).
   float2 x[8];
-  f32x4 A[8];
+  float A[8][TS];
   auto rowof = [&](int s, int q) {
     const int i = s * 16 + 8 * h + q;
     const bool v = i < Kw;
@@ -453,8 +458,17 @@ __device__ __forceinline__ void dense_fwd_sample_bf3(const DenseLArgs& a, int b,
   auto issueA = [&](int s) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const auto v = __builtin_amdgcn_raw_buffer_load_b128(rA, rowof(s, q) * ldb + acol, 0, 0);
-      A[q] = f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+      const unsigned off = rowof(s, q) * ldb + acol;
+      if constexpr (TS == 4) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rA, off, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) A[q][t] = __uint_as_float(v[t]);
+      } else if constexpr (TS == 2) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b64(rA, off, 0, 0);
+        A[q][0] = __uint_as_float(v[0]); A[q][1] = __uint_as_float(v[1]);
+      } else {
+        A[q][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rA, off, 0, 0));
+      }
     }
   };
   auto splitA = [&](u32x4 (&wa)[3], int t) {
@@ -479,42 +493,57 @@ __device__ __forceinline__ void dense_fwd_sample_bf3(const DenseLArgs& a, int b,
     __builtin_amdgcn_sched_barrier(0);
     issueX(s + 8);                             // (past the end: padding entries -> zeros)
     __builtin_amdgcn_sched_barrier(0);
-    {
-      u32x4 wa[3];
-      splitA(wa, 0);
+    if constexpr (TS == 4) {
+      {
+        u32x4 wa[3];
+        splitA(wa, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0][0] = mfma6(wa, xb0, acc[0][0]);
+        acc[0][1] = mfma6(wa, xb1, acc[0][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        splitA(wa, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[1][0] = mfma6(wa, xb0, acc[1][0]);
+        acc[1][1] = mfma6(wa, xb1, acc[1][1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      {
+        u32x4 wa[3], wb[3];
+        splitA(wa, 2);
+        splitA(wb, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        issueA(s + 8);                           // all four tiles' weights are split: their registers take the next step's
+        __builtin_amdgcn_sched_barrier(0);
+        acc[2][0] = mfma6(wa, xb0, acc[2][0]);
+        acc[2][1] = mfma6(wa, xb1, acc[2][1]);
+        acc[3][0] = mfma6(wb, xb0, acc[3][0]);
+        acc[3][1] = mfma6(wb, xb1, acc[3][1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      u32x4 wa[TS][3];
+#pragma unroll
+      for (int t = 0; t < TS; ++t) splitA(wa[t], t);
       __builtin_amdgcn_sched_barrier(0);
-      acc[0][0] = mfma6(wa, xb0, acc[0][0]);
-      acc[0][1] = mfma6(wa, xb1, acc[0][1]);
+      issueA(s + 8);
       __builtin_amdgcn_sched_barrier(0);
-      splitA(wa, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      acc[1][0] = mfma6(wa, xb0, acc[1][0]);
-      acc[1][1] = mfma6(wa, xb1, acc[1][1]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    {
-      u32x4 wa[3], wb[3];
-      splitA(wa, 2);
-      splitA(wb, 3);
-      __builtin_amdgcn_sched_barrier(0);
-      issueA(s + 8);                           // all four tiles' weights are split: their registers take the next step's
-      __builtin_amdgcn_sched_barrier(0);
-      acc[2][0] = mfma6(wa, xb0, acc[2][0]);
-      acc[2][1] = mfma6(wa, xb1, acc[2][1]);
-      acc[3][0] = mfma6(wb, xb0, acc[3][0]);
-      acc[3][1] = mfma6(wb, xb1, acc[3][1]);
+#pragma unroll
+      for (int t = 0; t < TS; ++t) {
+        acc[t][0] = mfma6(wa[t], xb0, acc[t][0]);
+        acc[t][1] = mfma6(wa[t], xb1, acc[t][1]);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   }
   // ---- the 8 partial sums of every tile meet in LDS, two tiles per phase; every wave adds up a quarter of a tile in wave order
+  // (phase p: row tile t0 + p % TS ... the pair (row tile, channel tile 0 / 1): the same two tiles, the same order, for every TS)
   float (*sc)[2][16][64] = reinterpret_cast<float (*)[2][16][64]>(scratch);
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
+  for (int p = 0; p < TS; ++p) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int id = 2 * p + u;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sc[wave][u][r][lane] = acc[id & 3][id >> 2][r];
+      for (int r = 0; r < 16; ++r) sc[wave][u][r][lane] = acc[p][u][r];
     }
     if (s_fin) {
       const float sp = sacc[p] + __shfl_xor(sacc[p], 32);
@@ -522,7 +551,7 @@ __device__ __forceinline__ void dense_fwd_sample_bf3(const DenseLArgs& a, int b,
     }
     __syncthreads();
     {
-      const int u = wave & 1, rq = wave >> 1, id = 2 * p + u, t = id & 3, nt = id >> 2;
+      const int u = wave & 1, rq = wave >> 1, t = t0 + p, nt = u;
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         float tot = sc[0][u][4 * rq + rr][lane];
@@ -535,38 +564,56 @@ __device__ __forceinline__ void dense_fwd_sample_bf3(const DenseLArgs& a, int b,
         float tot = spart[j];
 #pragma unroll
         for (int w8 = 1; w8 < 8; ++w8) tot += spart[w8 * 32 + j];
-        s_fin[4 * j + p] = tot;
+        s_fin[4 * j + t] = tot;
       }
     }
     __syncthreads();
   }
 }
 
-// transposed edge (short K <= 128) of one sample: out[row][c] = sum_k W[k][row] C[k][c], the rows of C (layer L) in LDS (`Cr`,
-// fp32, rows >= K zero).  First the walked rows of C are split into three bf16 pieces and laid down as the B operands of
-// every k-step (`img`: 12288 floats; one ds_read_b128 per operand and lane afterwards); then 8 waves walk the row tiles, the
-// weights from L2 two k-steps ahead, split in registers.
-// rlist / n_rows (LDS): only these output rows (the live nodes of the layer below); klist / K_eff: only these source rows,
-// padded with a.Kpad (a zero row of At and of C) up to round_up(K_eff, 16) + 32 entries.  sout as in dense_bwd_sample.
-// (Measured against this: 64 consecutive rows per wave with 8-B weight loads for two row tiles at once, every row computed and
-// the live ones stored -- equal on cifar_base, 11 us slower on cifar_wide, whose 40 % dead rows it cannot skip.)
+// transposed edge (short K <= 128) of one sample: out[row][c] = sum_k W[row][k] C[k][c], the rows of C (layer L) in LDS (`Cr`,
+// fp32, rows >= K zero).  First the rows of C are split into three bf16 pieces and laid down as the B operands of every k-step
+// (`img`: 12288 floats; one ds_read_b128 per operand and lane afterwards); then the waves walk the row tiles.
+// rlist / n_rows (LDS): only these output rows (the live nodes of the layer below); null: every row.
+// The weights come k-contiguous out of the FORWARD edge's image Wk[row][k] (ldK floats per row): a lane's 8 k of a k-step are 32
+// contiguous bytes of its row, two 16-B loads.  Every k < a.Kpad is walked (the rows of dead layer-L nodes are zero in C);
+// livek[k] (LDS, 0 / 1) says which k count for the bias sums `sout` (see dense_bwd_sample; null: not wanted).
+// ALL k-steps of a row tile are requested at once and the NEXT tile's weights are requested before this tile's MFMAs start (two
+// register sets in ping-pong, out-of-range offsets instead of control flow around the loads): with the loads only three k-steps
+// ahead -- a k-step is 0.15 us of work, an L2 round trip under load ~1 us -- the edge spent 4 of its 5 us per tile waiting
+// (base B = 256: 19.7 -> see DESIGN 5.6).  part / nparts: this workgroup takes row tiles part, part + nparts, ... (k_top_split).
 template <class Store>
-// Wk != null (then klist must be null): the weights are read from the FORWARD edge's image Wk[row][k] (ldK floats per row) --
-// a lane's 8 k of a k-step are 32 contiguous bytes of its row, two 16-B loads instead of eight 4-B ones (this edge is bound by
-// load instructions, not bytes: without its loads it runs 10 / 39 us faster on base / wide).  Every k < a.Kpad is walked then
-// (the rows of dead layer-L nodes are zero in C), and livek[k] (LDS, 0 / 1) says which k count for sout.
 __device__ __forceinline__ void dense_bwd_sample_bf3(const DenseLArgs& a, const float* Cr, float* img, Store store, const top_idx_t* rlist,
-                                                     int n_rows, const int* klist, int K_eff, float* sout, const float* Wk = nullptr,
-                                                     int ldK = 0, const float* livek = nullptr) {
+                                                     int n_rows, float* sout, const float* Wk, int ldK, const float* livek,
+                                                     int part = 0, int nparts = 1) {
+  constexpr int NST = 8;                           // k-steps of 16: Kpad <= 128 (bind: kpad_bwd <= 128)
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nst = (klist ? (K_eff + 15) / 16 * 16 : a.Kpad) / 16;
+  const int nst = a.Kpad / 16;
+  const int M = rlist ? n_rows : a.M, MT = (M + 31) / 32;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)Wk, 0, 0x7fffffff, 0x00020000);
+  struct Raw { f32x4 v[NST][2]; };
+  // the weights of row tile mt (all k-steps); a tile past the end reads nothing (out-of-range offsets return zeros)
+  auto arow_of = [&](int mt) { return rlist ? (int)rlist[mt * 32 + j < M ? mt * 32 + j : 0] : mt * 32 + j; };
+  auto load_tile = [&](Raw& R, int mt) {
+    const bool in = mt < MT;
+    const unsigned acol = (unsigned)arow_of(in ? mt : 0) * (unsigned)ldK * 4u + 32u * (unsigned)h;
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      const unsigned off = (in && st < nst) ? acol + 64u * (unsigned)st : 0x80000000u;
+      const auto v0 = __builtin_amdgcn_raw_buffer_load_b128(rA, off, 0, 0), v1 = __builtin_amdgcn_raw_buffer_load_b128(rA, off, 16, 0);
+      R.v[st][0] = f32x4{__uint_as_float(v0[0]), __uint_as_float(v0[1]), __uint_as_float(v0[2]), __uint_as_float(v0[3])};
+      R.v[st][1] = f32x4{__uint_as_float(v1[0]), __uint_as_float(v1[1]), __uint_as_float(v1[2]), __uint_as_float(v1[3])};
+    }
+  };
+  const int first = part + nparts * wave, stride = nparts * 8;
+  Raw R0, R1;
+  load_tile(R0, first);                            // (in flight under the image build)
   unsigned* im = reinterpret_cast<unsigned*>(img);
   for (int e = threadIdx.x; e < nst * 256; e += 512) {
     const int q = e & 3, n = (e >> 2) & 31, kg = (e >> 7) & 1, st = e >> 8;
-    const int i0 = st * 16 + kg * 8 + 2 * q;
-    const int k0 = klist ? klist[i0] : i0, k1 = klist ? klist[i0 + 1] : i0 + 1;
-    const float2 v0 = *reinterpret_cast<const float2*>(Cr + k0 * 64 + 2 * n), v1 = *reinterpret_cast<const float2*>(Cr + k1 * 64 + 2 * n);
+    const int k0 = st * 16 + kg * 8 + 2 * q;
+    const float2 v0 = *reinterpret_cast<const float2*>(Cr + k0 * 64 + 2 * n), v1 = *reinterpret_cast<const float2*>(Cr + (k0 + 1) * 64 + 2 * n);
     const Split3 sx = split3(v0.x, v1.x), sy = split3(v0.y, v1.y);
     const unsigned u[2][3] = {{sx.u1, sx.u2, sx.u3}, {sy.u1, sy.u2, sy.u3}};
 #pragma unroll
@@ -576,77 +623,49 @@ __device__ __forceinline__ void dense_bwd_sample_bf3(const DenseLArgs& a, const 
   }
   __syncthreads();
   const u32x4* im4 = reinterpret_cast<const u32x4*>(img) + lane;
-  const int M = rlist ? n_rows : a.M, MT = rlist ? (n_rows + 31) / 32 : a.MT;
-  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)(Wk ? Wk : a.At), 0, 0x7fffffff, 0x00020000);
-  const unsigned ldb = (unsigned)a.ldA * 4u;
-  for (int mt = wave; mt < MT; mt += 8) {
-    const int arow = rlist ? (int)rlist[mt * 32 + j < M ? mt * 32 + j : 0] : mt * 32 + j;
-    const unsigned acol = Wk ? (unsigned)arow * (unsigned)ldK * 4u + 32u * (unsigned)h : 4u * (unsigned)arow;
+  auto compute = [&](const Raw& R, int mt) {
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
-    // Software pipeline: while the 12 MFMAs of k-step st run, the wave splits the weights of st + 1 (5 vector instructions fit
-    // under each MFMA's 32 cycles: MI355X_MICROARCH.md, vector-instruction issue cost) and the loads of st + 3 go out into
-    // the registers just split.
-    float A0[8], A1[8];
-    auto loadA = [&](float (&A)[8], int st) {
-      if (Wk) {
-        const unsigned off = st < nst ? acol + 64u * (unsigned)st : 0x80000000u;      // (past the end: out of range -> zeros)
-        const auto v0 = __builtin_amdgcn_raw_buffer_load_b128(rA, off, 0, 0), v1 = __builtin_amdgcn_raw_buffer_load_b128(rA, off, 16, 0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { A[q] = __uint_as_float(v0[q]); A[4 + q] = __uint_as_float(v1[q]); }
-        return;
-      }
-      const int sc = st < nst ? st : nst;          // (past the end: the padding entries / zero rows behind the walked ones)
-#pragma unroll
-      for (int q = 0; q < 8; ++q)
-        A[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rA, (unsigned)(klist ? klist[sc * 16 + 8 * h + q] : sc * 16 + 8 * h + q) * ldb + acol, 0, 0));
-    };
     float sacc = 0.0f;
-    auto split = [&](u32x4 (&w)[3], const float (&A)[8], int st) {         // st: the k-step these weights belong to
+    auto split = [&](u32x4 (&w)[3], int st) {          // the weights of k-step st -> three bf16 pieces (+ the bias sum)
       float lk[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) lk[q] = 1.0f;
       if (sout && livek) {
-        const f32x4* l4 = reinterpret_cast<const f32x4*>(livek + 16 * (st < nst ? st : nst - 1) + 8 * h);
+        const f32x4* l4 = reinterpret_cast<const f32x4*>(livek + 16 * st + 8 * h);
         const f32x4 u0 = l4[0], u1 = l4[1];
 #pragma unroll
         for (int q = 0; q < 4; ++q) { lk[q] = u0[q]; lk[4 + q] = u1[q]; }
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        split3_to(w, q, A[2 * q], A[2 * q + 1]);
-        if (sout) sacc += A[2 * q] * lk[2 * q] + A[2 * q + 1] * lk[2 * q + 1];
+        const float w0 = R.v[st][q >> 1][2 * (q & 1)], w1 = R.v[st][q >> 1][2 * (q & 1) + 1];
+        split3_to(w, q, w0, w1);
+        if (sout) sacc += w0 * lk[2 * q] + w1 * lk[2 * q + 1];
       }
     };
-    auto body = [&](const u32x4 (&cur)[3], int st, u32x4 (&nxt)[3], const float (&Araw)[8]) {
-      __builtin_amdgcn_sched_barrier(0);
-      const u32x4 xa[3] = {im4[((st * 2 + 0) * 3 + 0) * 64], im4[((st * 2 + 0) * 3 + 1) * 64], im4[((st * 2 + 0) * 3 + 2) * 64]};
-      const u32x4 xb[3] = {im4[((st * 2 + 1) * 3 + 0) * 64], im4[((st * 2 + 1) * 3 + 1) * 64], im4[((st * 2 + 1) * 3 + 2) * 64]};
-      split(nxt, Araw, st + 1);
-      acc0 = mfma6(cur, xa, acc0);
-      acc1 = mfma6(cur, xb, acc1);
-      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);       // the six operand reads first
+    u32x4 w[2][3];
+    split(w[0], 0);
 #pragma unroll
-      for (int i = 0; i < 12; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);     // five vector instructions under it
+    for (int st = 0; st < NST; ++st) {
+      if (st < nst) {                                  // (wave-uniform)
+        __builtin_amdgcn_sched_barrier(0);
+        const u32x4 xa[3] = {im4[((st * 2 + 0) * 3 + 0) * 64], im4[((st * 2 + 0) * 3 + 1) * 64], im4[((st * 2 + 0) * 3 + 2) * 64]};
+        const u32x4 xb[3] = {im4[((st * 2 + 1) * 3 + 0) * 64], im4[((st * 2 + 1) * 3 + 1) * 64], im4[((st * 2 + 1) * 3 + 2) * 64]};
+        if (st + 1 < NST) split(w[(st + 1) & 1], st + 1);      // next k-step's pieces under this step's MFMAs (5 vector instructions per MFMA)
+        acc0 = mfma6(w[st & 1], xa, acc0);
+        acc1 = mfma6(w[st & 1], xb, acc1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);       // the six operand reads first
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);     // five vector instructions under it
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    u32x4 wa[3], wb[3];
-    loadA(A0, 0);
-    loadA(A1, 1);
-    split(wa, A0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    loadA(A0, 2);
-    for (int st = 0; st < nst; st += 2) {
-      body(wa, st, wb, A1);
-      loadA(A1, st + 3);
-      if (st + 1 >= nst) break;
-      body(wb, st + 1, wa, A0);
-      loadA(A0, st + 4);
     }
+    const int arow = arow_of(mt);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -656,6 +675,17 @@ __device__ __forceinline__ void dense_bwd_sample_bf3(const DenseLArgs& a, const 
       sacc += __shfl_xor(sacc, 32);
       if (h == 0 && mt * 32 + j < M) sout[arow] = sacc;
     }
+  };
+  for (int mt = first; mt < MT; mt += 2 * stride) {
+    load_tile(R1, mt + stride);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(R0, mt);
+    __builtin_amdgcn_sched_barrier(0);
+    if (mt + stride >= MT) break;
+    load_tile(R0, mt + 2 * stride);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(R1, mt + stride);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -759,44 +789,64 @@ struct TopArgs {
   float* mu;                // (B, N, 64) rows of layer L (backward-produced)
   int* status;
   int N;
+  // k_top_split (S > 1 workgroups per sample): exchange buffer (B, 8, 64) for the property node's partial sums, one arrival
+  // counter per sample (zeroed by k_reset) and the count it stood at when this launch started (2 S per earlier launch)
+  float* xbuf; int* xflag; int xbase;
 };
 #define TOP_A_FLOATS (PackUpd::FLOATS > DENSE_FWD_LDS_FLOATS ? PackUpd::FLOATS : DENSE_FWD_LDS_FLOATS)
 #define TOP_FIXED_FLOATS (TOP_A_FLOATS + PackProp::FLOATS + DENSE_BWD_ROWS * 64 + 8 * 64 + 128 + 64 + 64)
 #define TOP_LDS_FLOATS 40960                   // all 160 KB: what the fixed regions leave holds the live-row lists
-#define TOP_K2_INTS (128 + 48)                  // live rows of layer L, padded for the chunks read ahead
+#define TOP_K2_INTS (128 + 48)                  // spare
 #define TOP_LIST_INTS (TOP_LDS_FLOATS - TOP_FIXED_FLOATS - TOP_K2_INTS)
 // the live-row list of layer L-1 (16-bit entries): behind the fixed regions when it fits (then the transposed edge walks only
 // live rows too), else in the region PackProp takes after F1, else the edge walks every row
 #define TOP_LIST_KEEP_OK(K) ((K) + 96 <= 2 * (int)TOP_LIST_INTS && (K) < 65535)
 #define TOP_LIST_OK(K) (TOP_LIST_KEEP_OK(K) || ((K) + 96 <= 2 * (int)PackProp::FLOATS && (K) < 65535))
+#define TOP_POLL_CAP (1 << 20)
 static_assert(TOP_A_FLOATS >= 16384 && TOP_A_FLOATS >= 12288, "k_top: F1's reduction scratch and B2's operand image live in region A");
 static_assert(TOP_A_FLOATS + PackProp::FLOATS >= PackUpdL3::FLOATS, "k_top: the bf16 x 3 node-update image spans regions A and Bp");
+static_assert(DENSE_BWD_ROWS >= 128 + 16, "k_top: rows 128.. of C are the property node's scratch");
 
-// needs 512 threads (threads beyond that idle) and TOP_LDS_FLOATS of LDS
-__device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float* lds) {
+// One sample's top of the network on workgroup `part` of S = 4 / TS (TS row tiles of the last ReLU layer per workgroup; S = 1: the
+// whole sample, no exchange).  Layer L's node n sits in row tile n % 4 (lane n / 4 of wave n % 4 in the update phases, rows
+// 4 i + t of F1's tile t), so a workgroup owns whole tiles through F1, F2, B1; what crosses workgroups goes through global memory
+// behind an agent-scope release / acquire on the sample's arrival counter (the XCDs' L2s are not coherent with each other):
+//   after F2: the 8 per-wave partial sums of the property node's aggregate (wave w sums rows w, w + 8, ...: all of one tile) --
+//             every workgroup then evaluates the property node itself, from the same 8 vectors in the same order;
+//   after B1: the rows of layer L (they go to a.mu anyway) -- every workgroup loads the rows it does not own and computes its
+//             share of B2's row tiles.
+// Every sum keeps the order of the unsplit kernel, so the results do not depend on S (tests: bit-identical for S = 1, 2, 4).
+// The S workgroups of a sample must be resident together: the host only splits when B x S workgroups fit the chip at one per CU,
+// and every wait has an iteration cap that raises status bit 1 instead of hanging.
+// needs 512 threads and TOP_LDS_FLOATS of LDS
+template <int TS>
+__device__ __forceinline__ void top_sample(const TopArgs& a, const int b, const int part, float* lds) {
+  constexpr int S = 4 / TS;
+  const int t0 = part * TS;
   float* A = lds;
   float* Bp = A + TOP_A_FLOATS;
   float* Cr = Bp + PackProp::FLOATS;
-  float* part = Cr + DENSE_BWD_ROWS * 64;     // [8][64]
-  float* xs = part + 8 * 64;                  // [128]
+  float* part_ = Cr + DENSE_BWD_ROWS * 64;    // [8][64]
+  float* xs = part_ + 8 * 64;                 // [128]
   float* outv = xs + 128;                     // [64]
   float* spart = outv + 64;                   // [8]
+  float* part2 = Cr + 128 * 64;               // [4][64] + [8][64]: the property node's partial sums (rows >= 128 of C are never read)
+  float* part3 = part2 + 4 * 64;
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int N = a.N;
   FT_DECL;
   for (int i = tid; i < DENSE_BWD_ROWS * 16; i += 512) reinterpret_cast<f32x4*>(Cr)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // live source rows of layer L-1 (the dead ones are all zero: ~45 % of the forward edge's k-steps), compacted in node order
-  // into the region PackProp takes afterwards
+  // live source rows of layer L-1 (the dead ones are all zero: ~45 % of the forward edge's k-steps), compacted in node order.
   // The list goes behind the fixed regions when it fits there (then the transposed edge B2 also uses it, to compute only the
   // live rows of layer L-1), else into the region PackProp takes after F1.
-  int* tail = reinterpret_cast<int*>(spart + 8) + TOP_K2_INTS;       // (TOP_K2_INTS: spare, once the list of layer L's live rows)
+  int* tail = reinterpret_cast<int*>(spart + 8) + TOP_K2_INTS;
   const bool keep = TOP_LIST_KEEP_OK(a.df.K);
   top_idx_t* klist = reinterpret_cast<top_idx_t*>(keep ? tail : reinterpret_cast<int*>(Bp));
   int K_eff = 0;
   const bool compact = TOP_LIST_OK(a.df.K);
   if (compact) {
-    int* wc = reinterpret_cast<int*>(part);              // per-wave counts
+    int* wc = reinterpret_cast<int*>(part_);             // per-wave counts
     const int K = a.df.K;
     for (int n0 = 0; n0 < K; n0 += 512) {
       const int n = n0 + tid;
@@ -820,25 +870,25 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
 #if defined(TOP_STOP) && TOP_STOP == 1     // dev, timing only (TOP_STOP = 1 / 2 / 3: leave before F1 / after F1 / before B2)
   if (a.N > 0) return;
 #endif
-  // ---- F1: rows of C <- W_L . mu_{L-1}
+  // ---- F1: this workgroup's rows of C <- W_L . mu_{L-1}
   const bool own_s = compact && !a.sf;                    // the bias sums of the forward edge come out of F1's own walk (-> xs)
 #if defined(TOP_ABL) && (TOP_ABL & 2)     // dev, timing only: no F1
   if (K_eff < 0)
 #endif
-  dense_fwd_sample_bf3(a.df, b, A, part, [&](int row, int ch, float v) { Cr[row * 64 + ch] = v; }, compact ? klist : nullptr, K_eff,
-                       own_s ? xs : nullptr);
+  dense_fwd_sample_bf3<TS>(a.df, b, A, part_, [&](int row, int ch, float v) { Cr[row * 64 + ch] = v; }, compact ? klist : nullptr, K_eff,
+                           own_s ? xs : nullptr, t0);
 #if defined(TOP_STOP) && TOP_STOP == 2
   if (a.N > 0) { if (Cr[tid] == 12345.0f) a.mu_prop[0] = 1.0f; return; }
 #endif
   FT_MARK(1);        // F1 dense forward edge
 
-  // per-lane node of the update phases (waves 0..3: one tile of 32 nodes each)
-  const int n = wave * 32 + j;
-  const bool upd_wave = wave * 32 < N;
-  const bool valid = n < N;
+  // per-lane node of the update phases: wave t < 4 = row tile t, lane j = node 4 j + t
+  const int n = 4 * j + wave;
+  const bool upd_wave = wave < 4 && wave >= t0 && wave < t0 + TS && wave < N;
+  const bool valid = upd_wave && n < N;
   const long g = (long)b * N + (valid ? n : 0);
   const float* pw = a.prop_w + (long)b * N;
-  const float s_own = (own_s && upd_wave) ? xs[wave * 32 + j] : 0.0f;      // (xs is rewritten in F3, behind a barrier)
+  const float s_own = (own_s && valid) ? xs[n] : 0.0f;      // (xs is rewritten in F3, behind a barrier)
   Ratio r{};
   if (upd_wave) r = compute_ratio(a.lb[g], a.ub[g]);
   auto load_row = [&](Frag& x_, int row) {       // fragment <- LDS row (row-major 64 floats)
@@ -862,7 +912,6 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
   };
   // general folded node chain on fragment X, the arithmetic of k_node_update / k_gather_update_q (bf16 x 3 blocks, LDS image
   // PackUpdL3 in W: Wa.[r0 x, r1 x] = WAS.(r0 x) + Wa[:, 64:].((r1 - r0) x)); `sx`: small k-step input of a deferred projection.
-  // (As fp32 MFMAs a chain of 4 tiles took 5 us of this one-CU kernel, twice per call.)
   auto chain = [&](const Frag& X, const float* Prow, bool deferred, float sx, Frag& H2) {
     Frag H;
     frag_load_rowptr(H2, Prow, h);             // P' row (global): requested before the first block, wanted after it
@@ -880,12 +929,64 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
     frag_scale(H2, r.live);
   };
   // the bf16 x 3 image of a node-update pack -> W, by threads t0 .. t0 + nthr - 1 (no barrier)
-  auto stage_l3 = [&](const float* pack, int t0, int nthr) {
-    copy_to_lds_part(A + PackUpdL3::BA, pack + PackUpd::BA, 64, tid - t0, nthr);
-    copy_to_lds_part(A + PackUpdL3::BCB, pack + PackUpd::BCB, 64 + 64 + 128, tid - t0, nthr);        // BCB, BCBROW, VAW
-    copy_to_lds_part(A + PackUpdL3::WAS3, pack + PackUpd::WAS3, 6144, tid - t0, nthr);
-    copy_to_lds_part(A + PackUpdL3::WCB3, pack + PackUpd::WCB3, 6144, tid - t0, nthr);
-    copy_to_lds_part(A + PackUpdL3::WA1S3, pack + PackUpd::WA1S3, 6144, tid - t0, nthr);
+  auto stage_l3 = [&](const float* pack, int th0, int nthr) {
+    copy_to_lds_part(A + PackUpdL3::BA, pack + PackUpd::BA, 64, tid - th0, nthr);
+    copy_to_lds_part(A + PackUpdL3::BCB, pack + PackUpd::BCB, 64 + 64 + 128, tid - th0, nthr);        // BCB, BCBROW, VAW
+    copy_to_lds_part(A + PackUpdL3::WAS3, pack + PackUpd::WAS3, 6144, tid - th0, nthr);
+    copy_to_lds_part(A + PackUpdL3::WCB3, pack + PackUpd::WCB3, 6144, tid - th0, nthr);
+    copy_to_lds_part(A + PackUpdL3::WA1S3, pack + PackUpd::WA1S3, 6144, tid - th0, nthr);
+  };
+  // Hand-off between the S workgroups of this sample WITHOUT cache maintenance (MI355X_MICROARCH.md "Valid forms", first row of
+  // its table): every handed-off byte is stored write-through (`sc1`: relaxed agent-scope atomic stores) and loaded `sc1`; every
+  // storing wave drains its stores (vmcnt(0)), the workgroup meets at a barrier, ONE lane adds to the sample's counter; the
+  // consumer's lane 0 polls the counter with `sc1` loads, the workgroup meets at a barrier, then everybody loads.  (With agent-scope
+  // release / acquire fences instead -- a write-back of the XCD's whole L2 per arrival -- each hand-off cost 40-50 us at B = 128.)
+  auto st_sc1 = [](float* p, float2 v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto ld_sc1 = [](const float* p) {
+    return __builtin_bit_cast(float2, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  };
+  auto arrive = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(a.xflag + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto await = [&](int target) -> bool {
+    int* okp = reinterpret_cast<int*>(spart + 8);      // (first of the TOP_K2_INTS spare words)
+    if (tid == 0) {
+      int ok = 0;
+      for (int it = 0; it < TOP_POLL_CAP; ++it) {
+        if (__hip_atomic_load(a.xflag + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (!ok) atomicOr(a.status, 2);
+      *okp = ok;
+    }
+    __syncthreads();
+    return *okp != 0;
+  };
+  // The backward pack's image (74 KB) is fetched into the REGISTERS of waves 4..7 while waves 0..3 run the forward chain (they
+  // would idle), and written to LDS behind the chain's barrier: the property node then has no staging beside it.
+  constexpr int PRE_N = PackUpdL3::FLOATS / 4 / 256 + 1;           // f32x4 per thread of waves 4..7 (18 of the blocks + 1 of the small vectors)
+  static_assert((PackUpdL3::FLOATS - PackUpdL3::WAS3) % (4 * 256) == 0 && (PackUpdL3::WAS3 / 4) <= 256, "k_top: backward image prefetch");
+  f32x4 pre[PRE_N];
+  auto prefetch_b = [&]() {                      // (waves 4..7)
+    const int t = tid - 256;
+    const f32x4* big = reinterpret_cast<const f32x4*>(a.pack_b + PackUpd::WAS3);
+#pragma unroll
+    for (int u = 0; u < PRE_N - 1; ++u) pre[u] = big[t + 256 * u];
+    // the small vectors: BA (16 f32x4) then BCB, BCBROW, VAW (64 f32x4)
+    const int sidx = t < 16 ? PackUpd::BA / 4 + t : PackUpd::BCB / 4 + (t < 80 ? t - 16 : 0);
+    pre[PRE_N - 1] = reinterpret_cast<const f32x4*>(a.pack_b)[sidx];
+  };
+  auto commit_b = [&]() {                        // (waves 4..7, behind the barrier that ends the forward chain)
+    const int t = tid - 256;
+    f32x4* big = reinterpret_cast<f32x4*>(A + PackUpdL3::WAS3);
+#pragma unroll
+    for (int u = 0; u < PRE_N - 1; ++u) big[t + 256 * u] = pre[u];
+    if (t < 16) reinterpret_cast<f32x4*>(A + PackUpdL3::BA)[t] = pre[PRE_N - 1];
+    else if (t < 80) reinterpret_cast<f32x4*>(A + PackUpdL3::BCB)[t - 16] = pre[PRE_N - 1];
   };
 
   // ---- F2: forward node update of layer L (rows stay in C)
@@ -895,6 +996,7 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
   if (a.N > 0) return;
 #endif
   FT_MARK(2);        // staging the forward pack
+  if (wave >= 4) prefetch_b();
   if (upd_wave) {
     Frag X, E;
     load_row(X, valid ? n : 0);
@@ -905,16 +1007,23 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
     }
   }
   __syncthreads();
+  if (wave >= 4) commit_b();                   // (nothing reads the image again before the barriers of F3)
 #if defined(TOP_STOP) && TOP_STOP == 6
   if (a.N > 0) return;
 #endif
   FT_MARK(3);        // F2 chain
 
-  // ---- F3: property node (k_prop) on the rows in C; meanwhile waves 1..7 stage the backward pack
+  // ---- F3: property node (k_prop).  Wave w sums W_prop[m] . row m over m = w, w + 8, ... (one row tile: w % 4), the 8 partial
+  // vectors are added in wave order; its three small layers are split over the waves by k (every weight row is requested at
+  // once: one L2 round trip per layer instead of a serial 196-step chain on one wave).
   {
-    float acc = 0.0f;
-    for (int m = wave; m < N; m += 8) acc = fmaf(pw[m], Cr[m * 64 + lane], acc);
-    part[wave * 64 + lane] = acc;
+    const bool mine = (wave & 3) >= t0 && (wave & 3) < t0 + TS;
+    if (mine) {
+      float acc = 0.0f;
+      for (int m = wave; m < N; m += 8) acc = fmaf(pw[m], Cr[m * 64 + lane], acc);
+      if (S == 1) part_[wave * 64 + lane] = acc;
+      else __hip_atomic_store(a.xbuf + ((long)b * 8 + wave) * 64 + lane, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     float sp = 0.0f;
     for (int m = tid; m < N; m += 512) {
       const long gm = (long)b * N + m;
@@ -924,37 +1033,53 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
     for (int o = 32; o > 0; o >>= 1) sp += __shfl_xor(sp, o);
     if (lane == 0) spart[wave] = sp;
   }
+  if (S > 1) {
+    arrive();
+    if (!await(a.xbase + S)) return;
+    part_[wave * 64 + lane] = __hip_atomic_load(a.xbuf + ((long)b * 8 + wave) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   __syncthreads();
-  if (wave == 0) {
+  const float* Pp = a.pack_p;                 // the property node's weights (PackProp, 51 KB) come straight from L2
+  float w3r[8];                                // this wave's 8 rows of the last layer, requested now
+#pragma unroll
+  for (int q = 0; q < 8; ++q) w3r[q] = Pp[PackProp::W3T + (8 * wave + q) * 64 + lane];
+  if (wave < 4) {
+    float w2r[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) w2r[q] = Pp[PackProp::W2T + (32 * wave + q) * 64 + lane];
     float nbv = 0.0f, spt = 0.0f;
 #pragma unroll
-    for (int w8 = 0; w8 < 8; ++w8) { nbv += part[w8 * 64 + lane]; spt += spart[w8]; }
-    // The property node's weights (PackProp, 51 KB) come straight from L2, 16 coalesced 256-B rows in flight: one wave reads
-    // them once, so staging them in LDS first bought nothing and its region now belongs to the node-update image W.
-    const float* Pp = a.pack_p;
+    for (int w8 = 0; w8 < 8; ++w8) { nbv += part_[w8 * 64 + lane]; spt += spart[w8]; }
     const float f[4] = {a.lbK[b], a.ubK[b], a.z_out[b], a.prop_b[b]};
     float h1 = Pp[PackProp::B1 + lane];
 #pragma unroll
     for (int k = 0; k < 4; ++k) h1 = fmaf(Pp[PackProp::W1T + k * 64 + lane], f[k], h1);
+    // element k of the hidden layer's input [relu(h1), nb] is held by lane k % 64: through LDS (every wave writes the same values)
     xs[lane] = relu_nan(h1);
     xs[64 + lane] = nbv;
     __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): this wave's LDS writes are visible to its own reads
-    float w3[64];                                     // the last layer's weights do not wait for the hidden layer
+    float h2 = wave == 0 ? fmaf(spt, Pp[PackProp::V2 + lane], Pp[PackProp::B2 + lane]) : 0.0f;
 #pragma unroll
-    for (int k = 0; k < 64; ++k) w3[k] = Pp[PackProp::W3T + k * 64 + lane];
-    float h2 = fmaf(spt, Pp[PackProp::V2 + lane], Pp[PackProp::B2 + lane]);
-#pragma unroll 32
-    for (int k = 0; k < 128; ++k) h2 = fmaf(Pp[PackProp::W2T + k * 64 + lane], xs[k], h2);
+    for (int q = 0; q < 32; ++q) h2 = fmaf(w2r[q], xs[32 * wave + q], h2);
+    part2[wave * 64 + lane] = h2;
+  }
+  __syncthreads();
+  {
+    const float h2 = ((part2[lane] + part2[64 + lane]) + part2[128 + lane]) + part2[192 + lane];
+    xs[lane] = relu_nan(h2);                           // (every wave writes the same values)
     __builtin_amdgcn_s_waitcnt(0xc07f);
-    xs[lane] = relu_nan(h2);
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    float o = Pp[PackProp::B3 + lane];
+    float o = wave == 0 ? Pp[PackProp::B3 + lane] : 0.0f;
 #pragma unroll
-    for (int k = 0; k < 64; ++k) o = fmaf(w3[k], xs[k], o);
-    a.mu_prop[(long)b * 64 + lane] = o;
+    for (int q = 0; q < 8; ++q) o = fmaf(w3r[q], xs[8 * wave + q], o);
+    part3[wave * 64 + lane] = o;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float o = part3[lane];
+#pragma unroll
+    for (int w8 = 1; w8 < 8; ++w8) o += part3[w8 * 64 + lane];
+    if (part == 0) a.mu_prop[(long)b * 64 + lane] = o;
     outv[lane] = o;
-  } else {
-    stage_l3(a.pack_b, 64, 448);
   }
   __syncthreads();
 #if defined(TOP_STOP) && TOP_STOP == 7
@@ -979,11 +1104,29 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
     if (valid) {
       if (frag_has_nan(E)) atomicOr(a.status, 1);
       store_row(E, Cr + n * 64);
-      store_row(E, a.mu + g * 64);
+      if (S == 1) store_row(E, a.mu + g * 64);
+      else {                                           // the other workgroups of the sample read these rows: write-through stores
+        float* base = a.mu + g * 64 + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          st_sc1(base + 8 * q, make_float2(FRAG_AT(E, 4 * q), FRAG_AT(E, 4 * q + 1)));
+          st_sc1(base + 8 * q + 2, make_float2(FRAG_AT(E, 4 * q + 2), FRAG_AT(E, 4 * q + 3)));
+        }
+      }
     }
-    if (h == 0) xs[n] = valid ? r.live : 0.0f;        // which rows of C count for B2's bias sums (xs: free since F3)
-  } else if (wave < 4 && h == 0) {
-    xs[n] = 0.0f;
+  }
+  // which rows of C count for B2's bias sums (xs: free since F3): the live nodes of layer L
+  if (tid < 128) {
+    const long gm = (long)b * N + (tid < N ? tid : 0);
+    xs[tid] = (tid < N && node_is_live(a.lb[gm], a.ub[gm])) ? 1.0f : 0.0f;
+  }
+  if (S > 1) {
+    arrive();                                          // this workgroup's rows of layer L are in a.mu
+    if (!await(a.xbase + 2 * S)) return;
+    for (int e = tid; e < N * 32; e += 512) {          // the rows the other workgroups own -> C (8 bytes per load)
+      const int t = (e >> 5) & 3;
+      if (t < t0 || t >= t0 + TS) reinterpret_cast<float2*>(Cr)[e] = ld_sc1(a.mu + (long)b * N * 64 + 2 * e);
+    }
   }
   __syncthreads();
 #if defined(TOP_STOP) && TOP_STOP == 8
@@ -1003,10 +1146,10 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
   auto put = [&](int row, int jj, float2 v) { *reinterpret_cast<float2*>(out + (long)row * 64 + 2 * jj) = v; };
 #endif
 #if defined(TOP_ABL) && (TOP_ABL & 1)     // dev, timing only: no B2
-  if (N < 0) dense_bwd_sample_bf3(a.db, Cr, A, put, nullptr, 0, nullptr, 0, nullptr);
+  if (N < 0) dense_bwd_sample_bf3(a.db, Cr, A, put, nullptr, 0, nullptr, a.df.At, a.df.ldA, nullptr);
 #else
-  if (keep) dense_bwd_sample_bf3(a.db, Cr, A, put, klist, K_eff, nullptr, 0, a.sb_out ? a.sb_out + (long)b * a.db.M : nullptr, a.df.At, a.df.ldA, xs);
-  else dense_bwd_sample_bf3(a.db, Cr, A, put, nullptr, 0, nullptr, 0, nullptr, a.df.At, a.df.ldA, xs);
+  if (keep) dense_bwd_sample_bf3(a.db, Cr, A, put, klist, K_eff, a.sb_out ? a.sb_out + (long)b * a.db.M : nullptr, a.df.At, a.df.ldA, xs, part, S);
+  else dense_bwd_sample_bf3(a.db, Cr, A, put, nullptr, 0, nullptr, a.df.At, a.df.ldA, xs, part, S);
 #endif
 #ifdef FUSED_TIMING
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1015,7 +1158,10 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, float*
 #endif
 }
 
+// TS = 4: one workgroup per sample; TS = 2 / 1: 2 / 4 workgroups per sample (grid = B x 4 / TS, the parts of a sample adjacent)
+template <int TS>
 __global__ __launch_bounds__(512, 1) void k_top(TopArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  top_sample(a, blockIdx.x, lds);
+  constexpr int S = 4 / TS;
+  top_sample<TS>(a, blockIdx.x / S, blockIdx.x % S, lds);
 }

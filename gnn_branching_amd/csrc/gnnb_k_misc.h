@@ -272,9 +272,11 @@ __global__ __launch_bounds__(256) void k_babsr(BabsrArgs a) {
 }
 
 // start of a forward: the status word, the list counters and the decision keys back to zero (one launch instead of memset nodes)
-__global__ __launch_bounds__(64) void k_reset(int32_t* status, int* cnt, unsigned long long* best, int* done, int B) {
+// topflag: the per-sample arrival counters of k_top's workgroup split (TOP_SPLIT_MAXB of them)
+__global__ __launch_bounds__(64) void k_reset(int32_t* status, int* cnt, unsigned long long* best, int* done, int B, int* topflag, int nflag) {
   cnt[threadIdx.x] = 0;
   for (int b = threadIdx.x; b < B; b += 64) best[b] = 0ull;        // per-sample best score key of k_score
+  for (int b = threadIdx.x; b < nflag; b += 64) topflag[b] = 0;
   if (threadIdx.x == 0) { *status = 0; *done = 0; }
 }
 

@@ -254,12 +254,24 @@ def test_separate_top_kernels_path_matches(monkeypatch, case):
     assert res.decisions.cpu().tolist() == g["random_decisions"].tolist()
 
 
-@pytest.mark.parametrize("case", ["cifar_base_kw_B3", "cifar_wide_kw_B2"])
+# What the three-piece bf16 blocks may differ from the exact-fp32 MFMA path by (absolute).  Two exact-fp32 evaluations of this
+# network that merely add in a different order -- the reference's aten kernels and GNNB_BF3=0 -- already differ by 2-3e-5 on the
+# shipped checkpoint (scores of magnitude 5..50; the reference's own fp32-vs-fp64 noise is 1-3e-5), so the bar
+# between the two paths is 3e-5 there (measured 1.9e-5 on base) and 1e-6 on the seeded random weight set (scores in [-1, 0.05]).
+# The sharper statement is against float64: the bf16x3 path may not be further from the fp64 truth than 1.25x the worse of the two
+# exact-fp32 evaluations (+ 2e-6).
+BF3_DELTA_ATOL = {"shipped": 3e-5, "random": 1e-6}
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
 @pytest.mark.parametrize("fam", ["shipped", "random"])
 def test_bf16x3_blocks_match_the_fp32_mfma(monkeypatch, case, fam):
-    """The 64x64 blocks of the node update and of the input update run on the bf16 matrix rate with three-piece operands
-    (default); GNNB_BF3=0 keeps every block on the exact-fp32 MFMA.  Both must sit inside the parity bar against the
-    reference, agree with each other to fp32 rounding, and take the same decisions."""
+    """The 64x64 blocks of the node update, of the input update and of k_top's edges run on the bf16 matrix rate with three-piece
+    operands (default); GNNB_BF3=0 keeps every block on the exact-fp32 MFMA.  Both must sit inside the parity bar against the
+    reference and take its decisions; their difference is printed and bounded (BF3_DELTA_ATOL); and against the float64
+    evaluation of the same network (the oracle in double precision) the bf16x3 path is an fp32-grade evaluation like the other
+    two: its error is bounded by theirs."""
+    from oracle import gnn_oracle
     g, batch = load_golden(case)
     want = g[f"{fam}_scores"]
     fin = np.isfinite(want)
@@ -272,8 +284,18 @@ def test_bf16x3_blocks_match_the_fp32_mfma(monkeypatch, case, fam):
         out[bf3] = res.scores.cpu().numpy()
         assert np.abs(out[bf3][fin] - want[fin]).max() <= score_tol(fam, want[fin])
         assert res.decisions.cpu().tolist() == g[f"{fam}_decisions"].tolist()
-    scale = np.abs(want[fin]).max()
-    assert np.abs(out["1"][fin] - out["0"][fin]).max() <= 2e-6 * max(scale, 1.0)
+    with torch.no_grad():
+        a64 = [[t.double() for t in grp] if isinstance(grp, (list, tuple)) else grp for grp in batch.forward_args()]
+        a64[4] = batch.primal_inputs.double()
+        layers64 = {k: [__import__("copy").deepcopy(l).double() for l in v] for k, v in batch.layers.items()}
+        a64[5] = layers64
+        truth = gnn_oracle.padded_scores(gnn_oracle.oracle_forward(state_of(fam), *a64, dtype=torch.float64), batch.masks).numpy()
+    delta = float(np.abs(out["1"][fin] - out["0"][fin]).max())
+    e_bf3, e_f32, e_ref = (float(np.abs(x[fin] - truth[fin]).max()) for x in (out["1"], out["0"], want))
+    print(f"{case} {fam}: max|bf16x3 - fp32 MFMA| = {delta:.3e} (bar {BF3_DELTA_ATOL[fam]:.0e}); against float64: bf16x3 {e_bf3:.3e}, "
+          f"fp32 MFMA {e_f32:.3e}, the reference's fp32 {e_ref:.3e}; max|score| {np.abs(want[fin]).max():.3g}")
+    assert delta <= BF3_DELTA_ATOL[fam]
+    assert e_bf3 <= 1.25 * max(e_f32, e_ref) + 2e-6
 
 
 @pytest.mark.parametrize("case", ["cifar_base_kw_B3", "cifar_wide_kw_B2", "cifar_deep_kw_B2"])
@@ -349,3 +371,44 @@ def test_two_stream_batch_pipelining_is_bit_identical():
         finally:
             eng.n_streams = 1
     assert torch.equal(one.scores, two.scores) and torch.equal(one.decisions, two.decisions)
+
+
+@pytest.mark.parametrize("net,B", [("cifar_base_kw", 1), ("cifar_base_kw", 3), ("cifar_deep_kw", 2), ("cifar_wide_kw", 2), ("cifar_base_kw", 40)])
+@pytest.mark.parametrize("fam", ["shipped", "random"])
+def test_top_workgroup_split_is_bit_identical(monkeypatch, net, B, fam):
+    """k_top spreads one sample over S = 2 / 4 workgroups (by output tile of its two Linear edges, partial sums and rows exchanged
+    through global memory) while B x S workgroups fit the chip; GNNB_TOP_SPLIT caps S.  Every sum keeps its order, so S = 1, 2, 4
+    must give IDENTICAL scores -- which is also what makes a large batch (S = 1) agree with its samples scored alone (S = 4)."""
+    from gnn_branching_amd import synth
+    from oracle import gnn_oracle
+    batch = synth.make_batch(net, B, seed=21 + B)
+    out = {}
+    for S in ("1", "2", "4"):
+        monkeypatch.setenv("GNNB_TOP_SPLIT", S)
+        model = make_model(fam)                      # a new engine: the knob is read by gnnb_create
+        with torch.no_grad():
+            res = model.forward_device(*batch.forward_args()).check()
+            eng = model.engine()
+            eng.workspace(B).view(torch.float32).fill_(float("nan"))          # exchange buffers and counters included
+            again = model.forward_device(*batch.forward_args()).check()
+        out[S] = res.scores.cpu().numpy()
+        assert np.array_equal(again.scores.cpu().numpy(), out[S], equal_nan=True)
+        plan = eng.describe()
+        assert any("k_top" in u["kernel"] for u in plan["updates"])
+    assert np.array_equal(out["1"], out["2"]) and np.array_equal(out["1"], out["4"])
+    with torch.no_grad():
+        want = gnn_oracle.padded_scores(gnn_oracle.oracle_forward(state_of(fam), *batch.forward_args()), batch.masks).numpy()
+    fin = np.isfinite(want)
+    assert np.abs(out["4"][fin] - want[fin]).max() <= score_tol(fam, want[fin])
+
+
+def test_large_batch_equals_its_samples_scored_alone():
+    """B = 160 runs k_top with one workgroup per sample, a single subproblem with four: same bits."""
+    from gnn_branching_amd import synth
+    model = make_model("shipped")
+    batch = synth.make_batch("cifar_base_kw", 160, seed=9)
+    with torch.no_grad():
+        full = model.forward_device(*batch.forward_args()).check().scores.cpu()
+        for b in (0, 77, 159):
+            one = model.forward_device(*batch.slice(b, b + 1).forward_args()).check().scores.cpu()
+            assert torch.equal(one[0], full[b])

@@ -31,7 +31,8 @@ for name in sorted(merged):
         e.update({"fetch_size_kb_per_launch": round(f, 1), "write_size_kb_per_launch": round(w, 1),
                   "hbm_bytes_per_launch": round((2 * f + w) * 1024), "launches_sampled": len(v['FETCH_SIZE'])})
     for c in ('SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_INSTS_MFMA', 'SQ_INSTS_VALU', 'SQ_WAVE_CYCLES', 'SQ_WAIT_INST_ANY', 'SQ_WAIT_ANY',
-              'GRBM_GUI_ACTIVE', 'TCC_HIT_sum', 'TCC_MISS_sum', 'SQ_LDS_BANK_CONFLICT'):
+              'GRBM_GUI_ACTIVE', 'TCC_HIT_sum', 'TCC_MISS_sum', 'SQ_LDS_BANK_CONFLICT', 'SQ_ACTIVE_INST_LDS', 'SQ_INSTS_LDS',
+              'TCP_TCC_READ_REQ_sum', 'TCP_TCC_WRITE_REQ_sum', 'TCP_TOTAL_CACHE_ACCESSES_sum', 'TCC_REQ_sum'):
         if c in v: out.setdefault(name, {})[c + "_per_launch"] = round(sum(v[c]) / len(v[c]), 1)
 if len(sys.argv) > 2:
     json.dump(out, open(sys.argv[2], 'w'), indent=1)
