@@ -43,7 +43,9 @@ PEAK_HBM_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH
 PEAK_F32_MFMA_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32, same guide
 PEAK_L2_GBS = 34500.0        # aggregate L2 -> L1 rate, same guide ("L2 (per XCD)": ~34.5 TB/s)
 N_SIMD, PEAK_CLOCK_HZ = 1024, 2.4e9      # 256 CUs x 4 SIMDs; the clock the matrix peaks are quoted at
-TCP_REQ_BYTES = 64           # one TCP -> TCC request (calibrated in profiles/: TCP_TCC_WRITE_REQ x 64 B == WRITE_SIZE on the row stores)
+# bytes per TCP -> TCC request, calibrated on this pool (profiles/r03a_base_pmc_summary.json): k_dense_fwd_lds reads 67 MB of rows + 134 MB of
+# weights = 201 MB in 1.64 M read requests -> 128 B (a cache line); k_dense_bwd_lds writes 67.1 MB in 1.05 M write requests -> 64 B
+TCP_READ_REQ_BYTES, TCP_WRITE_REQ_BYTES = 128, 64
 HALF_PASS_KERNELS = ("k_gather", "k_gather_update", "k_gather_input_update", "k_conv_fwd", "k_convT_bwd", "k_dense_agg", "k_prop", "k_top",
                      "k_node_update", "k_input_update")
 
@@ -158,7 +160,7 @@ def binding_bounds(kern, pmc, steps):
     (profiles/pmc_latest_*.json) and the live launch durations.  speed of light = max of
       hbm   HBM bytes the counters saw per launch ((2 FETCH_SIZE + WRITE_SIZE) KB, gfx950 correction)      / 8 TB/s
       mfma  matrix-pipe busy cycles per launch (SQ_VALU_MFMA_BUSY_CYCLES, summed over the SIMDs)            / (1024 SIMDs x 2.4 GHz)
-      l2    bytes the L1s requested from L2 per launch ((TCP_TCC_READ_REQ + TCP_TCC_WRITE_REQ) x 64 B)      / 34.5 TB/s
+      l2    bytes the L1s exchanged with L2 per launch (TCP_TCC_READ_REQ x 128 B + TCP_TCC_WRITE_REQ x 64 B)  / 34.5 TB/s
     and `frac` = that time / the measured launch time: how close the kernel is to the bound that binds it."""
     out = {}
     if not pmc:
@@ -180,7 +182,7 @@ def binding_bounds(kern, pmc, steps):
         t_us = kern[k]["avg_us"]
         terms = {"hbm": hbm / (PEAK_HBM_GBS * 1e9) * 1e6 if hbm is not None else None,
                  "mfma": busy / N_SIMD / PEAK_CLOCK_HZ * 1e6 if busy is not None else None,
-                 "l2": (rd + (wr or 0.0)) * TCP_REQ_BYTES / (PEAK_L2_GBS * 1e9) * 1e6 if rd is not None else None}
+                 "l2": (rd * TCP_READ_REQ_BYTES + (wr or 0.0) * TCP_WRITE_REQ_BYTES) / (PEAK_L2_GBS * 1e9) * 1e6 if rd is not None else None}
         known = {a: b for a, b in terms.items() if b is not None}
         if not known:
             continue
@@ -189,7 +191,7 @@ def binding_bounds(kern, pmc, steps):
                   "sol_us": {a: round(b, 2) for a, b in known.items()}, "binding": bound,
                   "frac_of_binding_bound": round(known[bound] / t_us, 4) if t_us > 0 else None,
                   "hbm_bytes_per_launch": round(hbm) if hbm is not None else None,
-                  "l1_fill_bytes_per_launch": round((rd + (wr or 0.0)) * TCP_REQ_BYTES) if rd is not None else None,
+                  "l1_fill_bytes_per_launch": round(rd * TCP_READ_REQ_BYTES + (wr or 0.0) * TCP_WRITE_REQ_BYTES) if rd is not None else None,
                   "mfma_busy_share": round(known["mfma"] / t_us, 4) if "mfma" in known and t_us > 0 else None}
     return out or None
 

@@ -20,7 +20,7 @@
 //
 // One translation unit: gnnb_dev.h (fragments, GEMM blocks, tile maps), gnnb_k_mlp.h (setup + node-MLP kernels),
 // gnnb_k_gather.h (conv-edge message passing + score head), gnnb_k_fusedq.h (gather + node update in one kernel), gnnb_k_edges.h (other edges, k_top), gnnb_k_misc.h (k_livesum,
-// k_babsr, k_reset), gnnb_train.h (online learning) are included below; this file holds the host side and the C-ABI.
+// k_babsr, k_gather_scored), gnnb_train.h (online learning) are included below; this file holds the host side and the C-ABI.
 //
 // gfx950 only.  No HIP call at load time.
 #include <hip/hip_runtime.h>
@@ -130,6 +130,14 @@ struct gnnb_handle {
   gnnb_train::Trainer* trainer = nullptr;     // online learning (gnnb_online_create)
   float* d_pack[N_PACKS] = {nullptr};
   float* d_zero = nullptr;      // 64 zero floats: where masked gather loads point
+  // List counters of a forward (64 ints) live HERE, not in the caller's workspace: a control block per workspace address (CTL_SLOTS
+  // of them, least recently used replaced), zero whenever no forward is running on it -- the last workgroup of k_score, the last
+  // kernel of a forward and the last reader of the counters, puts them back to zero.  So no launch has to zero them first
+  // (k_reset is gone), and what the caller's workspace holds between calls does not matter.
+  int* d_ctl = nullptr;
+  const void* ctl_ws[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  unsigned long ctl_age[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long ctl_clock = 0;
   // gnnb_forward_host: pinned staging of the host inputs, their device image, workspace and outputs (grown on demand)
   float* hs_pinned = nullptr; float* hs_dev = nullptr; size_t hs_floats = 0;
   void* hs_ws = nullptr; size_t hs_ws_bytes = 0;
@@ -211,6 +219,8 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   if (int rc = load_weights(h, w_blob, nullptr)) return rc;
   HIPCHK(hipMalloc((void**)&h->d_zero, 256 * sizeof(float)));
   HIPCHK(hipMemset(h->d_zero, 0, 256 * sizeof(float)));
+  HIPCHK(hipMalloc((void**)&h->d_ctl, 8 * 64 * sizeof(int)));
+  HIPCHK(hipMemset(h->d_ctl, 0, 8 * 64 * sizeof(int)));
   // > 64 KiB of dynamic LDS needs the attribute
   HIPCHK(hipFuncSetAttribute((const void*)k_pre<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackPreFwd::FLOATS + PackPreBwd::FLOATS) * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_pre<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PackPreBwdL3::FLOATS * 4));
@@ -331,6 +341,7 @@ extern "C" int gnnb_destroy(gnnb_t* h) {
   for (int i = 0; i < N_PACKS; ++i)
     if (h->d_pack[i]) (void)hipFree(h->d_pack[i]);
   if (h->d_zero) (void)hipFree(h->d_zero);
+  if (h->d_ctl) (void)hipFree(h->d_ctl);
   if (h->d_s1) (void)hipFree(h->d_s1);
   if (h->hs_pinned) (void)hipHostFree(h->hs_pinned);
   if (h->hs_out_pinned) (void)hipHostFree(h->hs_out_pinned);
@@ -662,7 +673,7 @@ static WsLayout ws_layout(const gnnb_t* h, int B) {
   for (int k = 0; k < MAXL + 2; ++k) w.mu[k] = w.Pf[k] = w.Pb[k] = w.live[k] = w.amb[k] = w.score[k] = w.lf[k] = w.sf[k] = w.sb[k] = 0;
   const int K = (int)h->N.size() - 1;
   size_t off = 0;
-  w.cnt = off; off += 64;                      // int counters: 4 per ReLU layer (live, amb, score, pad), zeroed every forward
+  w.cnt = off; off += 64;                      // (unused: the list counters live in the handle's control blocks)
   w.best = off; off += align64((size_t)2 * B + 2);
   w.topflag = off; off += align64(TOP_SPLIT_MAXB);
   w.topx = off; off += align64((size_t)std::min(B, TOP_SPLIT_MAXB) * 512);
@@ -820,9 +831,20 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
 
   unsigned long long* best = reinterpret_cast<unsigned long long*>(ws + w.best);
   int* done_ctr = reinterpret_cast<int*>(ws + w.best + 2 * (size_t)B);
-  hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, st, status, reinterpret_cast<int*>(ws + w.cnt), best, done_ctr, B,
-                     reinterpret_cast<int*>(ws + w.topflag), std::min(B, TOP_SPLIT_MAXB));
-  int* cnt = reinterpret_cast<int*>(ws + w.cnt);
+  // the counters' control block of this workspace (see gnnb_handle::d_ctl); a workspace seen for the first time (or after a failed
+  // call) gets a freshly zeroed one -- an async memset on the stream, the only time anything but kernels is enqueued
+  int slot = -1;
+  for (int i = 0; i < 8; ++i)
+    if (h->ctl_ws[i] == workspace) slot = i;
+  if (slot < 0) {
+    slot = 0;
+    for (int i = 1; i < 8; ++i)
+      if (h->ctl_age[i] < h->ctl_age[slot]) slot = i;
+    HIPCHK(hipMemsetAsync(h->d_ctl + 64 * slot, 0, 64 * sizeof(int), st));
+    h->ctl_ws[slot] = workspace;
+  }
+  h->ctl_age[slot] = ++h->ctl_clock;
+  int* cnt = h->d_ctl + 64 * slot;
   auto ilist = [&](size_t off) { return reinterpret_cast<int*>(ws + off); };
   int roff[MAXL + 2] = {0};                 // offset of layer k inside the flat ReLU index
   for (int k = 2; k <= L + 1; ++k) roff[k] = roff[k - 1] + h->N[k - 1];
@@ -866,6 +888,8 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   {
     ClassifyArgs a{};
     a.L = L; a.mask = in->mask; a.scores = scores; a.cnt = cnt + 4; a.R = h->R;
+    a.status = status; a.best = best; a.done = done_ctr; a.B = B;
+    a.topflag = reinterpret_cast<int*>(ws + w.topflag); a.nflag = std::min(B, TOP_SPLIT_MAXB);
     a.mu2 = debug_full ? ws + w.F1 : nullptr;      // inspection runs keep the plain rows in mu[1] and the mapped ones in F1
     int blk = 0;
     for (int k = 1; k <= L; ++k) {
@@ -1255,7 +1279,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   {
     ScoreArgs a{};
     a.best = best; a.done = done_ctr; a.dec = decisions; a.B = B; a.n_relu = L;
-    a.pack = h->d_pack[proj[1] == L_FC4_2 ? PK_SCORE_F : PK_SCORE_B]; a.scores = scores; a.L = L; a.R = h->R; a.cnt = cnt + 4;
+    a.pack = h->d_pack[proj[1] == L_FC4_2 ? PK_SCORE_F : PK_SCORE_B]; a.scores = scores; a.L = L; a.R = h->R; a.cnt = cnt + 4; a.cnt_all = cnt;
     long nt = 0;
     for (int k = 1; k <= L; ++k) {
       const int i = k - 1;
@@ -1267,6 +1291,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     lz.run(PC_SCORE, [&] { hipLaunchKernelGGL(k_score, dim3(mlp_grid(h, nt / 4)), dim3(WG_MLP), PackScore::FLOATS * 4, st, a); });
   }
   for (int k = 0; k < MAXL + 2; ++k) h->last_proj[k] = proj[k];      // inspection (gnnb_mu_projection); one handle per thread
+  if (lz.rc) h->ctl_ws[slot] = nullptr;          // a launch failed: the counters may be left non-zero, the block is re-zeroed on its next use
   return lz.rc;
 }
 

@@ -790,7 +790,7 @@ struct TopArgs {
   int* status;
   int N;
   // k_top_split (S > 1 workgroups per sample): exchange buffer (B, 8, 64) for the property node's partial sums, one arrival
-  // counter per sample (zeroed by k_reset) and the count it stood at when this launch started (2 S per earlier launch)
+  // counter per sample (zeroed by k_classify) and the count it stood at when this launch started (2 S per earlier launch)
   float* xbuf; int* xflag; int xbase;
 };
 #define TOP_A_FLOATS (PackUpd::FLOATS > DENSE_FWD_LDS_FLOATS ? PackUpd::FLOATS : DENSE_FWD_LDS_FLOATS)

@@ -938,10 +938,11 @@ struct ScoreArgs {        // every ReLU layer in one launch
   const float* mu[MAXL]; const int* list[MAXL];
   const float* lb[MAXL]; const float* ub[MAXL];
   const int* cnt;         // cnt[4k + 2] = number of scored nodes of layer k
+  int* cnt_all;           // the forward's whole counter block (64 ints): this is the last kernel that reads it and leaves it zero
   int N[MAXL], off[MAXL]; // nodes per sample in layer k, offset of layer k in the flat ReLU index
   // the decision (graph_score.py:41-47: first maximal score -> [layer, idx]) in the same launch: every tile folds its scores into
   // best[b] = max over (order-preserving score bits << 32 | ~flat index) -- ties go to the lower index -- and the workgroup that
-  // finishes last turns the B keys into decisions.  best / done are zeroed by k_reset.
+  // finishes last turns the B keys into decisions.  best / done are zeroed by k_classify.
   unsigned long long* best; int* done; int* dec; int B, n_relu; int cum[16];
 };
 
@@ -1031,6 +1032,7 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_score(ScoreArgs a) {
   __syncthreads();
   if (!last) return;
   __threadfence();
+  if (threadIdx.x < 64) a.cnt_all[threadIdx.x] = 0;      // every workgroup has read its counts: the block is zero again for the next forward
   for (int b = threadIdx.x; b < a.B; b += blockDim.x) {
     const unsigned long long key = __hip_atomic_load(a.best + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int lay = -1, idx = -1;

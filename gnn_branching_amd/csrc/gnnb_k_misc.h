@@ -1,5 +1,5 @@
 // gnnb_k_misc.h -- part of libgnnb.so, included by gnnb.hip (one translation unit; see its header comment).
-// k_livesum (bias sums of the deferred projections), k_babsr (BaBSR heuristic), k_reset (the decision itself: k_score).
+// k_livesum (bias sums of the deferred projections), k_babsr (BaBSR heuristic), k_gather_scored.
 #pragma once
 
 // ------------------------------------------------------------------------------------------
@@ -270,16 +270,6 @@ __global__ __launch_bounds__(256) void k_babsr(BabsrArgs a) {
     float* t = cur; cur = nxt; nxt = t;
   }
 }
-
-// start of a forward: the status word, the list counters and the decision keys back to zero (one launch instead of memset nodes)
-// topflag: the per-sample arrival counters of k_top's workgroup split (TOP_SPLIT_MAXB of them)
-__global__ __launch_bounds__(64) void k_reset(int32_t* status, int* cnt, unsigned long long* best, int* done, int B, int* topflag, int nflag) {
-  cnt[threadIdx.x] = 0;
-  for (int b = threadIdx.x; b < B; b += 64) best[b] = 0ull;        // per-sample best score key of k_score
-  for (int b = threadIdx.x; b < nflag; b += 64) topflag[b] = 0;
-  if (threadIdx.x == 0) { *status = 0; *done = 0; }
-}
-
 
 // ------------------------------------------------------------------------------------------
 // k_gather_scored: the restricted last step's transposed conv aggregate (graph_conv.py:299-318), list-driven.

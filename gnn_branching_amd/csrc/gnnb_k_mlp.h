@@ -68,8 +68,11 @@ struct ClassifyArgs {    // every ReLU layer of the network in one launch
   int N[MAXL], off[MAXL], blk0[MAXL + 1];   // first workgroup of each layer
   const float* mask;
   float* scores;                   // (B, R)
-  int* cnt;                        // 4 ints per layer: plain (live, not ambiguous), ambiguous, scored, 0
+  int* cnt;                        // 4 ints per layer: plain (live, not ambiguous), ambiguous, scored, 0 -- ZERO on entry (gnnb_handle::d_ctl)
   int R;
+  // the words a forward starts from zero and nothing touches before the kernels that use them: the status word, k_score's
+  // decision keys and its finished-workgroup counter, k_top's arrival counters (this is the first kernel of a forward)
+  int32_t* status; unsigned long long* best; int* done; int B; int* topflag; int nflag;
 };
 
 #define CLS_THREADS 1024
@@ -84,6 +87,12 @@ __global__ __launch_bounds__(CLS_THREADS) void k_classify(ClassifyArgs a) {
   __shared__ int wcnt[3][CLS_NPT][CLS_THREADS / 64];
   __shared__ int wbase[3][CLS_NPT][CLS_THREADS / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  {
+    const long gid = (long)blockIdx.x * CLS_THREADS + threadIdx.x, nthr = (long)gridDim.x * CLS_THREADS;
+    for (long i = gid; i < a.B; i += nthr) a.best[i] = 0ull;
+    for (long i = gid; i < a.nflag; i += nthr) a.topflag[i] = 0;
+    if (gid == 0) { *a.status = 0; *a.done = 0; }
+  }
   int k = 0;
   while (k + 1 < a.L && (int)blockIdx.x >= a.blk0[k + 1]) ++k;
   const long G = a.G[k];
