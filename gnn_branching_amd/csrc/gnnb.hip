@@ -119,6 +119,10 @@ struct gnnb_handle {
   bool scored_gather = true;    // the restricted last step's aggregate one wave per scored node (k_gather_scored); GNNB_DEV: GNNB_NO_SCORED_GATHER=1
   bool use_top = true;          // fuse the top of the network (last Linear edge, last ReLU layer, property node) into k_top
   bool top_ok = false;          // ... which the bound network allows (set by gnnb_bind_network)
+  int clspre_max_b = 1;         // GNNB_CLSPRE_MAX_B: batches up to it classify and run the hoisted feature chains in one launch (k_classify_pre);
+                                // measured (base, us): B = 1 27.5 vs 7.6 + 22.1, B = 2 34.0 vs 30.0, B = 8 42.5 vs 31.8 -- a block's share of
+                                // the ambiguous nodes is uneven, so beyond one subproblem the two kernels' even dealing wins
+  int tail_max_b = 8;           // GNNB_TAIL_MAX_B: batches up to it end in k_scored_tail (scored gather + restricted update + score head in one launch)
   int top_split_max = 4;        // GNNB_TOP_SPLIT: 4 (default) = four workgroups per sample while B <= n_cu / 4; 2 = two while B <= n_cu / 2; 1 = never
   int per_sample_min_b = 0;     // GNNB_PER_SAMPLE_MIN_B: batches below it take the per-tile dense kernel + separate launches
                                 // instead of the one-workgroup-per-sample kernels (k_top, k_dense_*_lds), which need a batch
@@ -284,7 +288,11 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   FUSEDQ_ATTR(16, 0, false); FUSEDQ_ATTR(16, 1, false); FUSEDQ_ATTR(16, 2, false); FUSEDQ_ATTR(32, 1, false); FUSEDQ_ATTR(32, 1, true);
 #undef FUSEDQ_ATTR
   if (const char* e = getenv("GNNB_PER_SAMPLE_MIN_B")) h->per_sample_min_b = atoi(e);
+  if (const char* e = getenv("GNNB_TAIL_MAX_B")) h->tail_max_b = atoi(e);
+  if (const char* e = getenv("GNNB_CLSPRE_MAX_B")) h->clspre_max_b = atoi(e);
   if (const char* e = getenv("GNNB_TOP_SPLIT")) h->top_split_max = atoi(e) >= 4 ? 4 : (atoi(e) >= 2 ? 2 : 1);
+  HIPCHK(hipFuncSetAttribute((const void*)k_classify_pre, hipFuncAttributeMaxDynamicSharedMemorySize, CLSPRE_LDS_BYTES));
+  HIPCHK(hipFuncSetAttribute((const void*)k_scored_tail, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS_FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_top<4>, hipFuncAttributeMaxDynamicSharedMemorySize, TOP_LDS_FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_top<2>, hipFuncAttributeMaxDynamicSharedMemorySize, TOP_LDS_FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_top<1>, hipFuncAttributeMaxDynamicSharedMemorySize, TOP_LDS_FLOATS * 4));
@@ -885,6 +893,20 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     return !(reads_live_rows_only(k + 1, false) && reads_live_rows_only(k, true));
   };
   // ---- once per forward: classification lists, input embedding, embedding-independent feature chains ----
+  PreAllArgs pre{};
+  {
+    pre.pack_f = h->d_pack[PK_PRE_FWD]; pre.pack_b = h->d_pack[PK_PRE_BWD];
+    pre.L = L; pre.do_bwd = limit >= 2 ? 1 : 0; pre.cnt = cnt + 4;
+    for (int k = 1; k <= L; ++k) {
+      const int i = k - 1, q = h->relu_q[k];
+      pre.lb[i] = in->lb[k]; pre.ub[i] = in->ub[k]; pre.dual[i] = in->dual[k - 1];
+      pre.z_pre[i] = in->primal[q - 1]; pre.z_post[i] = in->primal[q]; pre.bias[i] = h->dev[k].bias;
+      pre.Pf[i] = ws + w.Pf[k]; pre.Pb[i] = ws + w.Pb[k]; pre.list[i] = ilist(w.amb[k]);
+      pre.N[i] = h->N[k]; pre.hw[i] = h->hw[k];
+    }
+  }
+  // a single subproblem: k_classify and k_pre in one launch (k_classify_pre; GNNB_CLSPRE_MAX_B, default 1)
+  const bool cls_pre = h->bf3 && B <= h->clspre_max_b;
   {
     ClassifyArgs a{};
     a.L = L; a.mask = in->mask; a.scores = scores; a.cnt = cnt + 4; a.R = h->R;
@@ -902,7 +924,8 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       blk += (int)((a.G[i] + CLS_BLOCK - 1) / CLS_BLOCK);
     }
     a.blk0[L] = blk;
-    lz.run(PC_CLASSIFY, [&] { hipLaunchKernelGGL(k_classify, dim3((unsigned)blk), dim3(CLS_THREADS), 0, st, a); });
+    if (cls_pre) lz.run(PC_CLASSIFY, [&] { hipLaunchKernelGGL(k_classify_pre, dim3((unsigned)blk), dim3(CLS_THREADS), CLSPRE_LDS_BYTES, st, a, pre); });
+    else lz.run(PC_CLASSIFY, [&] { hipLaunchKernelGGL(k_classify, dim3((unsigned)blk), dim3(CLS_THREADS), 0, st, a); });
   }
 
   {   // bias-sum scalars of every edge and direction (the rows carry deferred projections)
@@ -959,19 +982,10 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     if (!embed_in_gather) lz.run(PC_EMBED, [&] { hipLaunchKernelGGL(k_embed, dim3((unsigned)grid), dim3(256), 0, st, a); });
     proj[0] = L_INP_F_1;
   }
-  {
-    PreAllArgs a{};
-    a.pack_f = h->d_pack[PK_PRE_FWD]; a.pack_b = h->d_pack[PK_PRE_BWD];
-    a.L = L; a.do_bwd = limit >= 2 ? 1 : 0; a.cnt = cnt + 4;
+  if (!cls_pre) {
     long nt = 0;                                      // upper bound: the kernel reads the real counts on the device
-    for (int k = 1; k <= L; ++k) {
-      const int i = k - 1, q = h->relu_q[k];
-      a.lb[i] = in->lb[k]; a.ub[i] = in->ub[k]; a.dual[i] = in->dual[k - 1];
-      a.z_pre[i] = in->primal[q - 1]; a.z_post[i] = in->primal[q]; a.bias[i] = h->dev[k].bias;
-      a.Pf[i] = ws + w.Pf[k]; a.Pb[i] = ws + w.Pb[k]; a.list[i] = ilist(w.amb[k]);
-      a.N[i] = h->N[k]; a.hw[i] = h->hw[k];
-      nt += (((long)B * h->N[k] + 31) / 32) * 2;
-    }
+    for (int k = 1; k <= L; ++k) nt += (((long)B * h->N[k] + 31) / 32) * 2;
+    const PreAllArgs& a = pre;
     const size_t lds = (h->bf3 ? (size_t)PackPreBwdL3::FLOATS : (size_t)PackPreFwd::FLOATS + PackPreBwd::FLOATS) * 4;
     lz.run(PC_PRE, [&] {
       if (h->bf3) hipLaunchKernelGGL(k_pre<true>, dim3(mlp_grid(h, nt / 8)), dim3(PRE_WAVES * 64), lds, st, a);
@@ -1229,6 +1243,24 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     proj[L] = L_BC4_1;
   };
 
+  // Small batches: the restricted last step (scored gather + node update of layer 1) and the score head are ONE launch,
+  // k_scored_tail (GNNB_TAIL_MAX_B, default 8: above it the three kernels' better balance wins)
+  bool tail_fused = false;
+  TailArgs tail{};
+  auto try_tail = [&](int k) -> bool {
+    const Edge& e = h->edges[k + 1];
+    if (!(B <= h->tail_max_b && h->bf3 && k == 1 && L >= 2 && h->restrict_last && !debug_full && e.kind == 0 && h->gb[k + 1].ok && h->scored_gather &&
+          (h->gather_sparse & 2) && e.c_out * ((e.kh + e.stride - 1) / e.stride) * ((e.kw + e.stride - 1) / e.stride) <= 96))
+      return false;
+    tail.g = GSArgs{ilist(w.score[k]), cnt + 4 * k + 2, mu(k + 1), h->dev[k + 1].w_bwd, in->lb[k + 1], in->ub[k + 1], nullptr, nullptr,
+                    h->N[k], e.c_in, e.h_in, e.w_in, e.c_out, e.h_out, e.w_out, e.kh, e.kw, e.stride, e.pad, 1};
+    tail.f = FArgs{};
+    tail.f.u = upd_args(k, false, true, false);
+    tail.f.sw_from_gather = 1;
+    tail_fused = true;
+    proj[k] = L_BC4_1;
+    return true;
+  };
   int done = 0;
   for (int t = 0; t < h->T && done < limit; ++t) {
     if (top_fused) {
@@ -1240,6 +1272,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       top();                                     // F1 .. B2: both half-passes of layer L, aggregate of layer L-1 in `nb`
       for (int k = L - 1; k >= 1; --k) {
         const bool scored = h->restrict_last && t == h->T - 1 && k == 1;
+        if (scored && k < L - 1 && try_tail(k)) continue;
         if (k < L - 1 && !scored && fused_halfpass(k, false, k == 1 && t < h->T - 1)) continue;
         if (k < L - 1) agg_bwd(k, 1, scored);
         node_update(k, false, scored, k == 1 && t < h->T - 1);
@@ -1288,6 +1321,11 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       nt += ((long)B * h->N[k] + 31) / 32;
       a.cum[k - 1] = roff[k] + h->N[k];
     }
+    if (tail_fused) {
+      tail.s = a;
+      int grid = (int)std::min<long>(h->n_cu, std::max<long>(1, ((long)B * h->N[1] + TAIL_TILE - 1) / TAIL_TILE));
+      lz.run(PC_SCORE, [&] { hipLaunchKernelGGL(k_scored_tail, dim3(grid), dim3(TAIL_WAVES * 64), TAIL_LDS_FLOATS * 4, st, tail); });
+    } else
     lz.run(PC_SCORE, [&] { hipLaunchKernelGGL(k_score, dim3(mlp_grid(h, nt / 4)), dim3(WG_MLP), PackScore::FLOATS * 4, st, a); });
   }
   for (int k = 0; k < MAXL + 2; ++k) h->last_proj[k] = proj[k];      // inspection (gnnb_mu_projection); one handle per thread

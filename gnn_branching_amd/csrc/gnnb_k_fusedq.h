@@ -23,7 +23,7 @@
 // one wave's operations in order, so the count lands after the rows).  Tile T's rows were reserved before tile T + QTILES's, and a
 // wave publishes its part of T before it waits for T + 1: no cycle.  Chain wave c takes tiles c, c + 4, ...; it leaves when all
 // gather waves are done and `reserve` says there is no tile T (a last, partly filled tile runs with its missing lanes masked).
-// Every poll loop has an iteration cap that raises status bit 2 and leaves: a protocol bug must never hang the GPU.
+// Every poll loop has an iteration cap that raises status bit 1 (value 2) and leaves: a protocol bug must never hang the GPU.
 // Ambiguous nodes ride in the same tiles: every node goes through H = WAS.(r0 x) + Wa[:, 64:].((r1 - r0) x) (PackUpdL3), the second
 // block -- exact zeros for r0 == r1 -- only runs when the tile holds such a node.  k_node_update does the same arithmetic per node, so
 // the fused and the two-kernel half-pass are bit-identical and which one runs is a pure scheduling decision.
@@ -53,8 +53,9 @@ static_assert(sizeof(QHdr) == QHDR_INTS * 4, "queue header");
 __device__ __forceinline__ int q_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // the folded node update (see node_update_loop) on ring slot `ring` (32 rows of QROW floats); `release` runs once the rows are in registers
+// keep != nullptr: the rows E are handed back in *keep (k_scored_tail feeds them to the score head) and not stored
 template <bool POST, class Release>
-__device__ __forceinline__ void q_chain(const FArgs& a, const float* lds, const float* ring, int nvalid, int lane, Release release) {
+__device__ __forceinline__ void q_chain(const FArgs& a, const float* lds, const float* ring, int nvalid, int lane, Release release, Frag* keep = nullptr) {
   const int h = lane >> 5, j = lane & 31;
   const bool valid = j < nvalid;
   const float* row = ring + j * QROW;
@@ -95,8 +96,9 @@ __device__ __forceinline__ void q_chain(const FArgs& a, const float* lds, const 
   frag_relu(H2);
   if (valid) {
     if (frag_has_nan(H2)) atomicOr(a.u.status, 1);
-    if (a.u.mu) frag_store_rows(H2, a.u.mu, gc, h);
+    if (a.u.mu && !keep) frag_store_rows(H2, a.u.mu, gc, h);
   }
+  if (keep) *keep = H2;
   if (POST) {
 #pragma unroll
     for (int R = 0; R < 32; ++R) FRAG_AT(H, R) = 0.0f;
@@ -268,3 +270,4 @@ __global__ __launch_bounds__((QG_WAVES + QC_WAVES) * 64, 4) void k_gather_update
   __builtin_amdgcn_s_waitcnt(0xc07f);
   if (lane == 0) __hip_atomic_fetch_add(&q->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+

@@ -949,80 +949,69 @@ struct ScoreArgs {        // every ReLU layer in one launch
 // score = fscore(relu(fnode(mu_g))) for the nodes g whose BaB mask is -1 (the rest stays -inf)    graph_conv.py:445-450
 // the rows hold E_g with mu_g = (Wp.E_g + bp).live: fnode is pre-multiplied by Wp, fnode.bp.live enters as a small k-step
 // one tile (32 scored nodes `list[32 t ..]` of layer k); lds: PackScore
-__device__ __forceinline__ void score_tile(const ScoreArgs& a, const float* lds, int k, const int* list, int count, long t, int lane) {
-  const int h = lane >> 5, j = lane & 31;
+// the score head on the rows X of a tile (lane (j, h): node gc of layer k, `live` its [r0 != 0]); writes the scores and folds them
+// into the per-sample keys
+__device__ __forceinline__ void score_rows(const ScoreArgs& a, const float* lds, int k, long gc, bool valid, float live, const Frag& X, int lane) {
+  const int h = lane >> 5;
   const float bs = lds[PackScore::BS];
+  const int N = a.N[k];
+  const long b = gc / N;
+  Frag H;
+  frag_bias(H, lds + PackScore::B1, h);
   {
-    const long idx = t * 32 + j;
-    const bool valid = idx < count;
-    const long gc = list[valid ? idx : 0];
-    const int N = a.N[k];
-    const long b = gc / N;
-    Frag X;
-    frag_load_rows(X, a.mu[k], gc, h);
-    Frag H;
-    frag_bias(H, lds + PackScore::B1, h);
-    {
-      const float live = node_is_live(a.lb[k][gc], a.ub[k][gc]) ? 1.0f : 0.0f;
-      const float x[1] = {h ? 0.0f : live};
-      gemm_small<1>(lds + PackScore::V1, lane, H, x);
-      if (live == 0.0f) {                      // a dead node marked undecided: its row is zero by definition (and need not be in memory)
+    const float x[1] = {h ? 0.0f : live};
+    gemm_small<1>(lds + PackScore::V1, lane, H, x);
+  }
+  gemm_w64<32>(lds + PackScore::W1, lane, H, [&](int s) { return FRAG_AT(X, s); });
+  frag_relu(H);
+  const f32x4* w4 = reinterpret_cast<const f32x4*>(lds + PackScore::WS + h * 32);
+  float part = 0.0f;
 #pragma unroll
-        for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = 0.0f;
-      }
+  for (int q = 0; q < 8; ++q) {
+    const f32x4 w = w4[q];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) part = fmaf(FRAG_AT(H, 4 * q + c), w[c], part);
+  }
+  part += __shfl_xor(part, 32);
+  const int flat = a.off[k] + (int)(gc - b * N);
+  if (valid && h == 0) a.scores[b * a.R + flat] = part + bs;
+  // fold into the per-sample best key: lanes of one sample are reduced in the wave first (a tile spans at most a few samples)
+  const unsigned u = __float_as_uint(part + bs);
+  const unsigned ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  unsigned long long key = (valid && h == 0) ? (((unsigned long long)ord << 32) | (0xffffffffu - (unsigned)flat)) : 0ull;
+  unsigned long long todo = __ballot(key != 0ull);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const long bl = __shfl((int)b, leader);                 // (B < 2^31)
+    const bool mine = key != 0ull && b == bl;
+    unsigned long long m = mine ? key : 0ull;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long other = ((unsigned long long)__shfl_xor((unsigned)(m >> 32), o) << 32) | (unsigned)__shfl_xor((unsigned)m, o);
+      m = other > m ? other : m;
     }
-    gemm_w64<32>(lds + PackScore::W1, lane, H, [&](int s) { return FRAG_AT(X, s); });
-    frag_relu(H);
-    const f32x4* w4 = reinterpret_cast<const f32x4*>(lds + PackScore::WS + h * 32);
-    float part = 0.0f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const f32x4 w = w4[q];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) part = fmaf(FRAG_AT(H, 4 * q + c), w[c], part);
-    }
-    part += __shfl_xor(part, 32);
-    const int flat = a.off[k] + (int)(gc - b * N);
-    if (valid && h == 0) a.scores[b * a.R + flat] = part + bs;
-    // fold into the per-sample best key: lanes of one sample are reduced in the wave first (a tile spans at most a few samples)
-    const unsigned u = __float_as_uint(part + bs);
-    const unsigned ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-    unsigned long long key = (valid && h == 0) ? (((unsigned long long)ord << 32) | (0xffffffffu - (unsigned)flat)) : 0ull;
-    unsigned long long todo = __ballot(key != 0ull);
-    while (todo) {
-      const int leader = __ffsll((long long)todo) - 1;
-      const long bl = __shfl((int)b, leader);                 // (B < 2^31)
-      const bool mine = key != 0ull && b == bl;
-      unsigned long long m = mine ? key : 0ull;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long other = ((unsigned long long)__shfl_xor((unsigned)(m >> 32), o) << 32) | (unsigned)__shfl_xor((unsigned)m, o);
-        m = other > m ? other : m;
-      }
-      if (lane == leader) atomicMax(a.best + bl, m);
-      todo &= ~__ballot(mine);
-    }
+    if (lane == leader) atomicMax(a.best + bl, m);
+    todo &= ~__ballot(mine);
   }
 }
 
-__global__ __launch_bounds__(WG_MLP, 2) void k_score(ScoreArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  stage_pack(lds, a.pack, PackScore::FLOATS);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  long ntiles = 0;
-  for (int k = 0; k < a.L; ++k) ntiles += (a.cnt[4 * k + 2] + 31) / 32;
-  for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < ntiles; tile += (long)gridDim.x * WAVES_MLP) {
-    int k = 0, count = 0;
-    long t = tile;
-    for (; k < a.L; ++k) {
-      count = a.cnt[4 * k + 2];
-      const long tk = (count + 31) / 32;
-      if (t < tk) break;
-      t -= tk;
-    }
-    score_tile(a, lds, k, a.list[k], count, t, lane);
+__device__ __forceinline__ void score_tile(const ScoreArgs& a, const float* lds, int k, const int* list, int count, long t, int lane) {
+  const int h = lane >> 5, j = lane & 31;
+  const long idx = t * 32 + j;
+  const bool valid = idx < count;
+  const long gc = list[valid ? idx : 0];
+  Frag X;
+  frag_load_rows(X, a.mu[k], gc, h);
+  const float live = node_is_live(a.lb[k][gc], a.ub[k][gc]) ? 1.0f : 0.0f;
+  if (live == 0.0f) {                      // a dead node marked undecided: its row is zero by definition (and need not be in memory)
+#pragma unroll
+    for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = 0.0f;
   }
-  // the workgroup that finishes last converts the keys
+  score_rows(a, lds, k, gc, valid, live, X, lane);
+}
+
+// the workgroup that finishes last converts the per-sample keys into decisions and leaves the forward's counters zero
+__device__ __forceinline__ void score_finish(const ScoreArgs& a) {
   __shared__ int last;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -1045,4 +1034,24 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_score(ScoreArgs a) {
     a.dec[b * 2] = lay;
     a.dec[b * 2 + 1] = idx;
   }
+}
+
+__global__ __launch_bounds__(WG_MLP, 2) void k_score(ScoreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_pack(lds, a.pack, PackScore::FLOATS);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long ntiles = 0;
+  for (int k = 0; k < a.L; ++k) ntiles += (a.cnt[4 * k + 2] + 31) / 32;
+  for (long tile = (long)blockIdx.x * WAVES_MLP + wave; tile < ntiles; tile += (long)gridDim.x * WAVES_MLP) {
+    int k = 0, count = 0;
+    long t = tile;
+    for (; k < a.L; ++k) {
+      count = a.cnt[4 * k + 2];
+      const long tk = (count + 31) / 32;
+      if (t < tk) break;
+      t -= tk;
+    }
+    score_tile(a, lds, k, a.list[k], count, t, lane);
+  }
+  score_finish(a);
 }

@@ -293,69 +293,164 @@ struct GSArgs {
 #define GS_INFLIGHT 16       // row loads in flight per wave (base, us: 8 -> 29.5, 16 -> 26.5, 32 -> 32.6)
 #endif
 #define GS_MAXSLOTS 112      // C_out x (k/s)^2 <= 96 window slots (the host's limit) + padding to a multiple of GS_INFLIGHT
+// the aggregate row of ONE scored node by one wave (lane = channel): acc = its channel of the (normalised) aggregate, ssum = the
+// bias sum; s_row / s_w: this wave's GS_MAXSLOTS-entry LDS lists.  Shared by k_gather_scored and k_scored_tail.
+__device__ __forceinline__ void gather_scored_node(const GSArgs& a, int gc, int lane, int* s_row, float* s_w, float& acc_out, float& ssum_out) {
+  const int Ns = a.Co * a.Ho * a.Wo;
+  // window slots (co, dy, dx): the taps ky = (y + pad) % s + s dy that can hit a source pixel at all (k/s per axis, not k)
+  const int ty_n = (a.kh + a.stride - 1) / a.stride, tx_n = (a.kw + a.stride - 1) / a.stride;
+  const int nslots = a.Co * ty_n * tx_n;
+  const int b = gc / a.N, n = gc - b * a.N;
+  const int ci = n / (a.H * a.W), y = (n / a.W) % a.H, x = n % a.W;
+  const float* slb = a.src_lb + (long)b * Ns;
+  const float* sub = a.src_ub + (long)b * Ns;
+  const int ky0 = (y + a.pad) % a.stride, kx0 = (x + a.pad) % a.stride;
+  int nlive = 0, freq = 0;
+  for (int s0 = 0; s0 < nslots; s0 += 64) {
+    const int sl = s0 + lane;
+    const int co = sl / (ty_n * tx_n), dy = (sl / tx_n) % ty_n, dx = sl % tx_n;
+    const int ky = ky0 + a.stride * dy, kx = kx0 + a.stride * dx;
+    const int ty = y + a.pad - ky, tx = x + a.pad - kx;              // multiples of the stride by construction
+    const int oy = ty / a.stride, ox = tx / a.stride;
+    const bool hit = sl < nslots && ky < a.kh && kx < a.kw && ty >= 0 && tx >= 0 && oy < a.Ho && ox < a.Wo;
+    const int row = hit ? (co * a.Ho + oy) * a.Wo + ox : 0;
+    if (s0 == 0) freq = __popcll(__ballot(hit && co == 0));           // taps that touch this pixel (the reference's `freq`)
+    const bool live = hit && node_is_live(slb[row], sub[row]);
+    const float wv = live ? a.w[((co * a.kh + ky) * a.kw + kx) * a.C + ci] : 0.0f;
+    const unsigned long long bal = __ballot(live);
+    if (live) {
+      const int p = nlive + __popcll(bal & ((1ull << lane) - 1ull));
+      s_row[p] = row;
+      s_w[p] = wv;
+    }
+    nlive += __popcll(bal);
+  }
+  // pad to a multiple of GS_INFLIGHT with (row 0, weight 0): whole rounds of independent row loads, no remainder loop
+  const int npad = (nlive + GS_INFLIGHT - 1) / GS_INFLIGHT * GS_INFLIGHT;
+  if (lane < npad - nlive) { s_row[nlive + lane] = 0; s_w[nlive + lane] = 0.0f; }
+  __builtin_amdgcn_wave_barrier();
+  const float* src = a.mu_src + (long)b * Ns * 64 + lane;
+  float acc = 0.0f, ssum = 0.0f;
+  for (int q = 0; q < npad; q += GS_INFLIGHT) {
+    float v[GS_INFLIGHT], wq[GS_INFLIGHT];
+#pragma unroll
+    for (int u = 0; u < GS_INFLIGHT; ++u) {
+      wq[u] = s_w[q + u];
+      v[u] = q + u < nlive ? src[(long)s_row[q + u] * 64] : 0.0f;     // (wave-uniform; a padding slot must not touch memory:
+                                                                      //  row 0 may be a dead node's never-written row)
+    }
+#pragma unroll
+    for (int u = 0; u < GS_INFLIGHT; ++u) {
+      acc = fmaf(wq[u], v[u], acc);
+      ssum += wq[u];
+    }
+  }
+  if (a.normalise) {
+    const float f = (float)(freq > 0 ? freq : 1);
+    acc = acc / f;
+    ssum = ssum / f;
+  }
+  acc_out = acc;
+  ssum_out = ssum;
+  __builtin_amdgcn_wave_barrier();
+}
+
 __global__ __launch_bounds__(GS_WAVES * 64) void k_gather_scored(GSArgs a) {
   __shared__ int s_row[GS_WAVES][GS_MAXSLOTS];
   __shared__ float s_w[GS_WAVES][GS_MAXSLOTS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int total = *a.cnt;
-  const int Ns = a.Co * a.Ho * a.Wo;
-  // window slots (co, dy, dx): the taps ky = (y + pad) % s + s dy that can hit a source pixel at all (k/s per axis, not k)
-  const int ty_n = (a.kh + a.stride - 1) / a.stride, tx_n = (a.kw + a.stride - 1) / a.stride;
-  const int nslots = a.Co * ty_n * tx_n;
   for (int idx = blockIdx.x * GS_WAVES + wave; idx < total; idx += gridDim.x * GS_WAVES) {
     const int gc = a.list[idx];
-    const int b = gc / a.N, n = gc - b * a.N;
-    const int ci = n / (a.H * a.W), y = (n / a.W) % a.H, x = n % a.W;
-    const float* slb = a.src_lb + (long)b * Ns;
-    const float* sub = a.src_ub + (long)b * Ns;
-    const int ky0 = (y + a.pad) % a.stride, kx0 = (x + a.pad) % a.stride;
-    int nlive = 0, freq = 0;
-    for (int s0 = 0; s0 < nslots; s0 += 64) {
-      const int sl = s0 + lane;
-      const int co = sl / (ty_n * tx_n), dy = (sl / tx_n) % ty_n, dx = sl % tx_n;
-      const int ky = ky0 + a.stride * dy, kx = kx0 + a.stride * dx;
-      const int ty = y + a.pad - ky, tx = x + a.pad - kx;              // multiples of the stride by construction
-      const int oy = ty / a.stride, ox = tx / a.stride;
-      const bool hit = sl < nslots && ky < a.kh && kx < a.kw && ty >= 0 && tx >= 0 && oy < a.Ho && ox < a.Wo;
-      const int row = hit ? (co * a.Ho + oy) * a.Wo + ox : 0;
-      if (s0 == 0) freq = __popcll(__ballot(hit && co == 0));           // taps that touch this pixel (the reference's `freq`)
-      const bool live = hit && node_is_live(slb[row], sub[row]);
-      const float wv = live ? a.w[((co * a.kh + ky) * a.kw + kx) * a.C + ci] : 0.0f;
-      const unsigned long long bal = __ballot(live);
-      if (live) {
-        const int p = nlive + __popcll(bal & ((1ull << lane) - 1ull));
-        s_row[wave][p] = row;
-        s_w[wave][p] = wv;
-      }
-      nlive += __popcll(bal);
-    }
-    // pad to a multiple of GS_INFLIGHT with (row 0, weight 0): whole rounds of independent row loads, no remainder loop
-    const int npad = (nlive + GS_INFLIGHT - 1) / GS_INFLIGHT * GS_INFLIGHT;
-    if (lane < npad - nlive) { s_row[wave][nlive + lane] = 0; s_w[wave][nlive + lane] = 0.0f; }
-    __builtin_amdgcn_wave_barrier();
-    const float* src = a.mu_src + (long)b * Ns * 64 + lane;
-    float acc = 0.0f, ssum = 0.0f;
-    for (int q = 0; q < npad; q += GS_INFLIGHT) {
-      float v[GS_INFLIGHT], wq[GS_INFLIGHT];
-#pragma unroll
-      for (int u = 0; u < GS_INFLIGHT; ++u) {
-        wq[u] = s_w[wave][q + u];
-        v[u] = q + u < nlive ? src[(long)s_row[wave][q + u] * 64] : 0.0f;     // (wave-uniform; a padding slot must not touch memory:
-                                                                              //  row 0 may be a dead node's never-written row)
-      }
-#pragma unroll
-      for (int u = 0; u < GS_INFLIGHT; ++u) {
-        acc = fmaf(wq[u], v[u], acc);
-        ssum += wq[u];
-      }
-    }
-    if (a.normalise) {
-      const float f = (float)(freq > 0 ? freq : 1);
-      acc = acc / f;
-      ssum = ssum / f;
-    }
+    float acc, ssum;
+    gather_scored_node(a, gc, lane, s_row[wave], s_w[wave], acc, ssum);
     a.nb[(long)gc * 64 + lane] = acc;
     if (lane == 0 && a.sout) a.sout[gc] = ssum;
-    __builtin_amdgcn_wave_barrier();
   }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// k_scored_tail: the end of a forward at SMALL batch sizes in one launch instead of three (k_gather_scored, the restricted
+// k_node_update, k_score): after the last backward sweep mu[1] is read by the score head only, at the scored nodes, so their
+// transposed aggregate (one wave per node, lane = channel: gather_scored_node, the code of k_gather_scored), the folded node
+// update (q_chain, the arithmetic of k_node_update) and the score head (score_rows) run back to back on a tile of 32 scored
+// nodes without the rows ever leaving the CU; the scored nodes of the other layers go through the score head as in k_score, and
+// the workgroup that finishes last turns the per-sample keys into decisions.  Same arithmetic per node as the three kernels:
+// bit-identical scores (tests).  At B <= 8 each of the three launches was its own ramp (weights staged, one tile's dependent
+// loads): 10 + 13 + 15 us at B = 1.
+// Per workgroup (16 waves): waves 1..15 gather the 32 nodes of a tile into an LDS row buffer (two buffers: the next tile is
+// gathered while wave 0 runs chain + score head of this one).
+// ------------------------------------------------------------------------------------------
+struct TailArgs { GSArgs g; FArgs f; ScoreArgs s; };
+#define TAIL_WAVES 16
+#define TAIL_TILE 16          // scored nodes of layer 1 per tile: half-filled MFMA tiles, but twice the workgroups gather in parallel and
+                              // a wave gathers one node, not two or three in a row (B = 1: 38 -> see DESIGN 5.3)
+#define TAIL_LDS_FLOATS (PackUpdL3::FLOATS + PackScore::FLOATS + 2 * TAIL_TILE * QROW + TAIL_WAVES * GS_MAXSLOTS * 2 + 16)
+
+__global__ __launch_bounds__(TAIL_WAVES * 64, 1) void k_scored_tail(TailArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* lds_sc = lds + PackUpdL3::FLOATS;
+  float* rows = lds_sc + PackScore::FLOATS;                       // [2][TAIL_TILE][QROW]
+  int* s_row = reinterpret_cast<int*>(rows + 2 * TAIL_TILE * QROW);      // [TAIL_WAVES][GS_MAXSLOTS]
+  float* s_w = reinterpret_cast<float*>(s_row + TAIL_WAVES * GS_MAXSLOTS);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  copy_to_lds(lds + PackUpdL3::BA, a.f.u.pack + PackUpd::BA, 64);
+  copy_to_lds(lds + PackUpdL3::BCB, a.f.u.pack + PackUpd::BCB, 64 + 64 + 128);
+  copy_to_lds(lds + PackUpdL3::WAS3, a.f.u.pack + PackUpd::WAS3, 3 * 6144);
+  copy_to_lds(lds_sc, a.s.pack, PackScore::FLOATS);
+  const int total = *a.g.cnt;                                      // scored nodes of layer 1
+  const int T1 = (total + TAIL_TILE - 1) / TAIL_TILE;
+  // ---- layer 1: gather -> chain -> score, tile by tile
+  int buf = 0;
+  for (int tile = blockIdx.x; tile < T1; tile += gridDim.x, buf ^= 1) {
+    float* rb = rows + buf * TAIL_TILE * QROW;
+    if (wave >= 1) {
+      for (int l = wave - 1; l < TAIL_TILE; l += TAIL_WAVES - 1) {
+        const int idx = tile * TAIL_TILE + l;
+        float* row = rb + l * QROW;
+        if (idx < total) {
+          const int gc = a.g.list[idx];
+          const float lb = a.f.u.lb[gc], ub = a.f.u.ub[gc];
+          const Ratio rt = compute_ratio(lb, ub);
+          float acc = 0.0f, ssum = 0.0f;
+          if (rt.live != 0.0f) gather_scored_node(a.g, gc, lane, s_row + wave * GS_MAXSLOTS, s_w + wave * GS_MAXSLOTS, acc, ssum);
+          row[lane] = acc;
+          if (lane == 0) *reinterpret_cast<f32x4*>(row + 64) = f32x4{__int_as_float(gc | (rt.amb != 0.0f ? (int)0x80000000 : 0)), rt.r0, rt.r1, ssum};
+        }
+      }
+    }
+    __syncthreads();                          // (first pass: also the weights; every pass: this tile's rows are in LDS, the previous tile's chain is done)
+    if (wave == 0) {
+      const int nvalid = total - tile * TAIL_TILE < TAIL_TILE ? total - tile * TAIL_TILE : TAIL_TILE;
+      Frag E;
+      q_chain<false>(a.f, lds, rb, nvalid, lane, [] {}, &E);
+      const int j = lane & 31;
+      const bool valid = j < nvalid;
+      const int gc = valid ? (__float_as_int(rb[j * QROW + 64]) & 0x7fffffff) : 0;
+      const float live = valid && node_is_live(a.f.u.lb[gc], a.f.u.ub[gc]) ? 1.0f : 0.0f;
+      if (live == 0.0f) {                     // a dead node marked undecided: its row is zero by definition
+#pragma unroll
+        for (int R = 0; R < 32; ++R) FRAG_AT(E, R) = 0.0f;
+      }
+      score_rows(a.s, lds_sc, 0, gc, valid, live, E, lane);
+    }
+  }
+  __syncthreads();
+  // ---- the scored nodes of the other layers: the score head on their rows in memory (k_score's tiles), dealt from the LAST
+  // workgroup backwards -- those have no layer-1 tile and start here at once
+  long ntiles = 0;
+  for (int k = 1; k < a.s.L; ++k) ntiles += (a.s.cnt[4 * k + 2] + 31) / 32;
+  for (long tile = (long)(gridDim.x - 1 - blockIdx.x) * TAIL_WAVES + wave; tile < ntiles; tile += (long)gridDim.x * TAIL_WAVES) {
+    int k = 1, count = 0;
+    long t = tile;
+    for (; k < a.s.L; ++k) {
+      count = a.s.cnt[4 * k + 2];
+      const long tk = (count + 31) / 32;
+      if (t < tk) break;
+      t -= tk;
+    }
+    score_tile(a.s, lds_sc, k, a.s.list[k], count, t, lane);
+  }
+  score_finish(a.s);
 }

@@ -83,9 +83,12 @@ struct ClassifyArgs {    // every ReLU layer of the network in one launch
 #endif
 #define CLS_BLOCK (CLS_THREADS * CLS_NPT)
 // one global atomic per list and workgroup (a single counter word only sustains ~90 atomics/us)
-__global__ __launch_bounds__(CLS_THREADS) void k_classify(ClassifyArgs a) {
+// amb_local != nullptr (k_classify_pre): the block's ambiguous nodes are also listed there (LDS), in block order; returns their
+// number and, in *layer, the block's layer.
+__device__ __forceinline__ int classify_block(const ClassifyArgs& a, int* amb_local, int* layer) {
   __shared__ int wcnt[3][CLS_NPT][CLS_THREADS / 64];
   __shared__ int wbase[3][CLS_NPT][CLS_THREADS / 64];
+  __shared__ int amb_total;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   {
     const long gid = (long)blockIdx.x * CLS_THREADS + threadIdx.x, nthr = (long)gridDim.x * CLS_THREADS;
@@ -129,6 +132,11 @@ __global__ __launch_bounds__(CLS_THREADS) void k_classify(ClassifyArgs a) {
     for (int i = 0; i < CLS_NPT; ++i)
       for (int w = 0; w < CLS_THREADS / 64; ++w) { wbase[c][i][w] = total; total += wcnt[c][i][w]; }
     const int base = total ? atomicAdd(a.cnt + 4 * k + c, total) : 0;
+    if (c == 1) amb_total = total;
+    if (amb_local && c == 1) {                             // block-local positions first, then the global ones
+      for (int i = 0; i < CLS_NPT; ++i)
+        for (int w = 0; w < CLS_THREADS / 64; ++w) wcnt[c][i][w] = wbase[c][i][w];
+    }
     for (int i = 0; i < CLS_NPT; ++i)
       for (int w = 0; w < CLS_THREADS / 64; ++w) wbase[c][i][w] += base;
   }
@@ -142,6 +150,7 @@ __global__ __launch_bounds__(CLS_THREADS) void k_classify(ClassifyArgs a) {
 #pragma unroll
     for (int c = 0; c < 3; ++c)
       if (flag[i][c]) lists[c][wbase[c][i][wave] + __popcll(bal[i][c] & ((1ull << lane) - 1ull))] = (int)g;
+    if (amb_local && flag[i][1]) amb_local[wcnt[1][i][wave] + __popcll(bal[i][1] & ((1ull << lane) - 1ull))] = (int)g;
     unsigned long long dead = a.zero[k] ? __ballot(valid[i] && !live[i]) : 0ull;
     while (dead) {                       // the whole wave zeroes one dead row per iteration (coalesced 256 B)
       const int l = __ffsll((long long)dead) - 1;
@@ -151,7 +160,11 @@ __global__ __launch_bounds__(CLS_THREADS) void k_classify(ClassifyArgs a) {
       if (mu2) mu2[row * 64 + lane] = 0.0f;
     }
   }
+  if (layer) *layer = k;
+  return amb_total;
 }
+
+__global__ __launch_bounds__(CLS_THREADS) void k_classify(ClassifyArgs a) { (void)classify_block(a, nullptr, nullptr); }
 
 struct PreArgs {
   const float* pack;
@@ -313,6 +326,45 @@ __global__ __launch_bounds__(PRE_WAVES * 64) void k_pre(PreAllArgs a) {
     const bool bwd = a.do_bwd && tile < nhalf;
     run((a.do_bwd && !bwd) ? tile - nhalf : tile, bwd, lds, lds_b);
   }
+}
+
+// k_classify_pre: small batches -- k_classify and k_pre in ONE launch.  A block classifies its nodes (classify_block, the code
+// of k_classify) and then runs the hoisted feature chains of ITS OWN ambiguous nodes (kept in an LDS list) with its 16 waves; P'
+// rows are addressed by node id, so who computes them does not matter.  One launch less for the BaB loop's own call (B = 1: 27.5 us
+// against 7.6 + 22.1); from B = 2 on k_pre's even tile dealing wins (a block's share of the ambiguous nodes varies: B = 8 42.5 us
+// against 31.8), so the host only uses it for a single subproblem (GNNB_CLSPRE_MAX_B).
+// Dynamic LDS: the bf16 x 3 image of the feature chains (PackPreBwdL3) + CLS_BLOCK ints.
+static_assert(CLS_THREADS == PRE_WAVES * 64, "k_classify_pre: one block = the 16 waves of k_pre");
+#define CLSPRE_LDS_BYTES ((size_t)(PackPreBwdL3::FLOATS + CLS_BLOCK) * 4)
+static_assert(CLSPRE_LDS_BYTES + 2048 <= 160 * 1024, "k_classify_pre: image + list + the classification's static LDS must fit one CU");
+__global__ __launch_bounds__(CLS_THREADS) void k_classify_pre(ClassifyArgs ca, PreAllArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int* amb_local = reinterpret_cast<int*>(lds + PackPreBwdL3::FLOATS);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the forward image and the tail of the backward image go out first: their loads fly under the classification
+  copy_to_lds(lds + PackPreFwdL3::W1, a.pack_f + PackPreFwd::W1, 512 + 64);
+  copy_to_lds(lds + PackPreFwdL3::B2, a.pack_f + PackPreFwd::B2, 64);
+  copy_to_lds(lds + PackPreFwdL3::W23, a.pack_f + PackPreFwd::W23, 6144);
+  if (a.do_bwd) {
+    copy_to_lds(lds + PackPreBwdL3::B3, a.pack_b + PackPreBwd::B3, 64);
+    copy_to_lds(lds + PackPreBwdL3::B4, a.pack_b + PackPreBwd::B4, 64);
+    copy_to_lds(lds + PackPreBwdL3::B5, a.pack_b + PackPreBwd::B5, 64);
+    copy_to_lds(lds + PackPreBwdL3::W33, a.pack_b + PackPreBwd::W33, 6144);
+    copy_to_lds(lds + PackPreBwdL3::W43, a.pack_b + PackPreBwd::W43, 18432);
+    copy_to_lds(lds + PackPreBwdL3::W53, a.pack_b + PackPreBwd::W53, 6144);
+  }
+  int k = 0;
+  const int count = classify_block(ca, amb_local, &k);
+  __syncthreads();                                   // the block's list and the images are in LDS
+  const long nt = (count + 31) / 32;
+  for (long t = wave; t < nt; t += PRE_WAVES) pre_tile<true>(a, lds, lds, k, false, amb_local, count, t, lane);
+  if (!a.do_bwd) return;
+  __syncthreads();
+  copy_to_lds(lds + PackPreBwdL3::W1, a.pack_b + PackPreBwd::W1, 512 + 64);                      // W1, B1
+  copy_to_lds(lds + PackPreBwdL3::B2, a.pack_b + PackPreBwd::B2, 64);
+  copy_to_lds(lds + PackPreBwdL3::W23, a.pack_b + PackPreBwd::W23, 6144);
+  __syncthreads();
+  for (long t = wave; t < nt; t += PRE_WAVES) pre_tile<true>(a, lds, lds, k, true, amb_local, count, t, lane);
 }
 
 // Q = inp_b2[:, :64] . inp_b_1(relu(inp_b([l0, u0]))) + inp_b2.bias       graph_conv.py:380-384

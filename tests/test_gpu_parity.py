@@ -412,3 +412,67 @@ def test_large_batch_equals_its_samples_scored_alone():
         for b in (0, 77, 159):
             one = model.forward_device(*batch.slice(b, b + 1).forward_args()).check().scores.cpu()
             assert torch.equal(one[0], full[b])
+
+
+@pytest.mark.parametrize("net,B", [("cifar_base_kw", 1), ("cifar_base_kw", 2), ("cifar_base_kw", 8), ("cifar_deep_kw", 1), ("cifar_deep_kw", 5)])
+@pytest.mark.parametrize("fam", ["shipped", "random"])
+def test_small_batch_tail_kernel_is_bit_identical(monkeypatch, net, B, fam):
+    """Batches up to 8 end in ONE launch, k_scored_tail (the restricted last step's scored gather + node update of layer 1 + the
+    score head + the decision), instead of three; GNNB_TAIL_MAX_B=0 keeps the three kernels.  Same arithmetic per node: identical
+    scores and decisions -- also with some dead nodes marked undecided and with a sample that has nothing to score."""
+    from gnn_branching_amd import synth
+    batch = synth.make_batch(net, B, seed=40 + B)
+    args = list(batch.forward_args())
+    rng = np.random.RandomState(B)
+    extra = torch.from_numpy((rng.uniform(size=tuple(batch.masks.shape)) < 0.02).astype(np.float32))
+    args[6] = torch.clamp(batch.masks + extra, max=1.0)                  # a few decided / dead nodes scored as well
+    if B > 1:
+        args[6][B - 1] = 0
+    out, dec, launches = {}, {}, {}
+    for knob in ("0", "8"):
+        monkeypatch.setenv("GNNB_TAIL_MAX_B", knob)
+        model = make_model(fam)
+        eng = model.engine()
+        with torch.no_grad():
+            model.forward_device(*args).check()
+            eng.workspace(B).view(torch.float32).fill_(float("nan"))
+            eng.profile_enable(True)
+            eng.profile_read(reset=True)
+            res = model.forward_device(*args).check()
+            prof = eng.profile_read(reset=True)
+            eng.profile_enable(False)
+        out[knob], dec[knob] = res.scores.cpu().numpy(), res.decisions.cpu().tolist()
+        launches[knob] = sum(v[1] for v in prof.values())
+    assert np.array_equal(out["0"], out["8"], equal_nan=True) and dec["0"] == dec["8"]
+    assert launches["8"] == launches["0"] - 2, launches
+    if B > 1:
+        assert dec["8"][B - 1] == [-1, -1]
+    print(f"{net} B={B} {fam}: {launches['8']} launches per forward (three-kernel tail: {launches['0']})")
+
+
+@pytest.mark.parametrize("net,B", [("cifar_base_kw", 1), ("cifar_base_kw", 8), ("cifar_deep_kw", 3), ("cifar_wide_kw", 2)])
+@pytest.mark.parametrize("fam", ["shipped", "random"])
+def test_small_batch_classify_pre_kernel_is_bit_identical(monkeypatch, net, B, fam):
+    """Batches up to 8 classify their nodes and run the hoisted feature chains in ONE launch (k_classify_pre: a block handles the
+    ambiguous nodes it found itself); GNNB_CLSPRE_MAX_B=0 keeps k_classify + k_pre.  P' rows are addressed by node id and every
+    node's chain is its own column of an MFMA tile, so the scores must be identical."""
+    from gnn_branching_amd import synth
+    batch = synth.make_batch(net, B, seed=60 + B)
+    out, launches = {}, {}
+    for knob in ("0", "8"):                          # (default: 1 -- only a single subproblem takes the merged kernel)
+        monkeypatch.setenv("GNNB_CLSPRE_MAX_B", knob)
+        model = make_model(fam)
+        eng = model.engine()
+        with torch.no_grad():
+            model.forward_device(*batch.forward_args()).check()
+            eng.workspace(B).view(torch.float32).fill_(float("nan"))
+            eng.profile_enable(True)
+            eng.profile_read(reset=True)
+            res = model.forward_device(*batch.forward_args()).check()
+            prof = eng.profile_read(reset=True)
+            eng.profile_enable(False)
+        out[knob] = (res.scores.cpu().numpy(), res.decisions.cpu().tolist())
+        launches[knob] = sum(v[1] for v in prof.values())
+    assert np.array_equal(out["0"][0], out["8"][0], equal_nan=True) and out["0"][1] == out["8"][1]
+    assert launches["8"] == launches["0"] - 1, launches
+    print(f"{net} B={B} {fam}: {launches['8']} launches per forward")
