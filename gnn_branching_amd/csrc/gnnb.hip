@@ -1481,8 +1481,8 @@ extern "C" int gnnb_online_create(gnnb_t* h, float lr, float weight_decay) {
     HIPCHK(hipMemset(*p, 0, n * sizeof(float)));
   }
   HIPCHK(hipMemcpy(t->d_w, h->blob.data(), n * sizeof(float), hipMemcpyHostToDevice));
-  HIPCHK(hipFuncSetAttribute((const void*)gnnb_train::k_tlin_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-  HIPCHK(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));      // weight-gradient kernels run beside the rest of the backward pass
+  HIPCHK(hipFuncSetAttribute((const void*)gnnb_train::k_tchain_fwd<TL_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)gnnb_train::k_tchain_fwd<TL_ROWS_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   return GNNB_OK;
 }
 
@@ -1513,6 +1513,7 @@ extern "C" int gnnb_online_step(gnnb_t* h, const gnnb_batch* in, int B, const in
   Trainer& t = *h->trainer;
   hipStream_t st = (hipStream_t)stream;
   t.st = st;
+  t.n_cu = h->n_cu;
   t.ev_next = 0;
   t.tape.clear();
   if (t.arena.reset(st)) return fail(GNNB_E_HIP, "gnnb_online_step: arena reset failed");
@@ -1605,61 +1606,62 @@ extern "C" int gnnb_online_step(gnnb_t* h, const gnnb_batch* in, int B, const in
   };
   auto S = [](const TT& x, const float* s = nullptr) { return Trainer::seg(x, s); };
   auto SF = [](const TT& x, const float* s = nullptr) { return Trainer::seg(x, s, true); };     // a segment addressed by node
+  auto P = [](const float* s = nullptr) { return Trainer::prev(s); };                            // the previous op of the chain
+  using Spec = Trainer::Spec;
 
   // ---- relaxation terms (graph_conv.py:153-161, :273-293): functions of the node features only, so the same in every round
   // -- computed once (the reference recomputes them per round; their gradient contributions from all rounds add up in
-  // relax.g before the chain is walked back once) and only for the ambiguous nodes (`* amb` zeroes every other row)
+  // relax.g before the chain is walked back once) and only for the ambiguous nodes (`* amb` zeroes every other row).
+  // Each MLP chain is one launch (Trainer::chain).
   std::vector<TT> relax_f(L + 1), relax_b(L + 1);
   for (int k = 1; k <= L; ++k) {
     const LC& c = lc[k];
     const long n = (long)B * h->N[k];
-    TT a = t.lin(L_FC1, {}, c.ff, n, true, nullptr, &c.ambl);
-    relax_f[k] = t.lin(L_FC1_1, {S(a)}, nullptr, n, false, c.amb, &c.ambl, true);      // :160-161
-    TT a1 = t.lin(L_BC1, {}, c.fb, n, true, nullptr, &c.ambl);
-    TT a2 = t.lin(L_BC1_1, {S(a1)}, nullptr, n, true, nullptr, &c.ambl);
-    TT sb = t.lin(L_BC1_2, {S(a2)}, nullptr, n, false, nullptr, &c.ambl);              // :285
-    TT b1 = t.lin(L_BC2, {S(sb), S(sb, c.nd2), S(sb, c.d1)}, nullptr, n, true, nullptr, &c.ambl);    // :287-291
-    relax_b[k] = t.lin(L_BC2_1, {S(b1)}, nullptr, n, false, c.amb, &c.ambl, true);     // :293
+    relax_f[k] = t.chain({Spec{L_FC1, {}, c.ff, true, nullptr, false},
+                          Spec{L_FC1_1, {P()}, nullptr, false, c.amb, true}}, n, &c.ambl)[1];                    // :160-161
+    relax_b[k] = t.chain({Spec{L_BC1, {}, c.fb, true, nullptr, false},
+                          Spec{L_BC1_1, {P()}, nullptr, true, nullptr, false},
+                          Spec{L_BC1_2, {P()}, nullptr, false, nullptr, false},                                   // :285
+                          Spec{L_BC2, {P(), P(c.nd2), P(c.d1)}, nullptr, true, nullptr, false},                   // :287-291
+                          Spec{L_BC2_1, {P()}, nullptr, false, c.amb, true}}, n, &c.ambl)[4];                     // :293
   }
 
   // ---- the forward of graph_conv.py:77-388, every Linear on the tape ----
   std::vector<TT> mu(K + 1);
   for (int r = 0; r < T; ++r) {
-    if (r == 0) {
-      TT a = t.lin(L_INP_F, {}, inp3, n0, true, nullptr);
-      mu[0] = t.lin(L_INP_F_1, {S(a)}, nullptr, n0, false, nullptr);                     // :94
-    }
+    if (r == 0)
+      mu[0] = t.chain({Spec{L_INP_F, {}, inp3, true, nullptr, false}, Spec{L_INP_F_1, {P()}, nullptr, false, nullptr, false}}, n0)[1];   // :94
     for (int k = 1; k <= L; ++k) {                                                       // :107-192
       const LC& c = lc[k];
       const long n = (long)B * h->N[k];
       TT nb = edge(k, 0, 0, mu[k - 1]);
       // the update chain over the live nodes only (`* live` zeroes the rows of the others, :178)
-      TT e1 = t.lin(L_FC3, {SF(nb, c.r0), SF(nb, c.r1)}, nullptr, n, true, nullptr, &c.livel);      // :169-170
-      TT e = t.lin(L_FC3_2, {S(e1)}, nullptr, n, false, nullptr, &c.livel);
-      TT d = t.lin(L_FC4, {SF(relax_f[k]), S(e)}, nullptr, n, true, nullptr, &c.livel);             // :176-177
-      mu[k] = t.lin(L_FC4_2, {S(d)}, nullptr, n, false, c.live, &c.livel, true);                     // :178
+      mu[k] = t.chain({Spec{L_FC3, {SF(nb, c.r0), SF(nb, c.r1)}, nullptr, true, nullptr, false},                  // :169-170
+                       Spec{L_FC3_2, {P()}, nullptr, false, nullptr, false},
+                       Spec{L_FC4, {SF(relax_f[k]), P()}, nullptr, true, nullptr, false},                         // :176-177
+                       Spec{L_FC4_2, {P()}, nullptr, false, c.live, true}}, n, &c.livel)[3];                      // :178
     }
     {                                                                                    // :194-210
       TT nb = prop_edge(0, mu[L]);
-      TT hh = t.lin(L_OUT1, {}, featp, B, true, nullptr);
-      TT o = t.lin(L_OUT2, {S(hh), S(nb)}, nullptr, B, true, nullptr);
-      mu[K] = t.lin(L_OUT3, {S(o)}, nullptr, B, false, nullptr);
+      mu[K] = t.chain({Spec{L_OUT1, {}, featp, true, nullptr, false},
+                       Spec{L_OUT2, {P(), S(nb)}, nullptr, true, nullptr, false},
+                       Spec{L_OUT3, {P()}, nullptr, false, nullptr, false}}, B)[2];
     }
     for (int k = L; k >= 1; --k) {                                                       // :222-350
       const LC& c = lc[k];
       const long n = (long)B * h->N[k];
       TT nb = k == L ? prop_edge(1, mu[K]) : edge(k + 1, 1, h->edges[k + 1].kind == 0 ? 1 : 0, mu[k + 1]);   // :299-326
-      TT e1 = t.lin(L_BC3, {SF(nb, c.r0), SF(nb, c.r1)}, nullptr, n, true, nullptr, &c.livel);      // :331-336
-      TT e = t.lin(L_BC3_1, {S(e1)}, nullptr, n, false, nullptr, &c.livel);
-      TT d = t.lin(L_BC4, {SF(relax_b[k]), S(e)}, nullptr, n, true, nullptr, &c.livel);             // :344-345
-      mu[k] = t.lin(L_BC4_1, {S(d)}, nullptr, n, false, c.live, &c.livel, true);                     // :347
+      mu[k] = t.chain({Spec{L_BC3, {SF(nb, c.r0), SF(nb, c.r1)}, nullptr, true, nullptr, false},                  // :331-336
+                       Spec{L_BC3_1, {P()}, nullptr, false, nullptr, false},
+                       Spec{L_BC4, {SF(relax_b[k]), P()}, nullptr, true, nullptr, false},                         // :344-345
+                       Spec{L_BC4_1, {P()}, nullptr, false, c.live, true}}, n, &c.livel)[3];                      // :347
     }
     if (r + 1 < T) {                                                                     // :360-385 (the last round's input rows feed nothing)
       TT nb = edge(1, 1, 0, mu[1]);
-      TT a = t.lin(L_INP_B, {}, inp2, n0, true, nullptr);
-      TT relax = t.lin(L_INP_B_1, {S(a)}, nullptr, n0, false, nullptr);
-      TT c2 = t.lin(L_INP_B2, {S(relax), S(nb)}, nullptr, n0, true, nullptr);
-      mu[0] = t.lin(L_INP_B2_2, {S(c2)}, nullptr, n0, false, nullptr);
+      mu[0] = t.chain({Spec{L_INP_B, {}, inp2, true, nullptr, false},
+                       Spec{L_INP_B_1, {P()}, nullptr, false, nullptr, false},
+                       Spec{L_INP_B2, {P(), S(nb)}, nullptr, true, nullptr, false},
+                       Spec{L_INP_B2_2, {P()}, nullptr, false, nullptr, false}}, n0)[3];
     }
   }
   // ---- scores (:442-450) and the loss ----
@@ -1681,9 +1683,10 @@ extern "C" int gnnb_online_step(gnnb_t* h, const gnnb_batch* in, int B, const in
   TLoss la{t.d_scores, t.d_ds, t.d_kw, t.d_imp, t.d_loss, R, t.d_sel};
   hipLaunchKernelGGL(k_tloss, dim3(B), dim3(256), 0, st, la);
   // ---- backward: the tape in reverse ----
+  t.wops.clear();
   for (auto it = t.tape.rbegin(); it != t.tape.rend(); ++it) (*it)();
   t.tape.clear();
-  if (t.join()) return fail(GNNB_E_HIP, "gnnb_online_step: joining the weight-gradient stream failed");
+  if (t.weight_grads()) return fail(GNNB_E_HIP, "gnnb_online_step: the weight-gradient launches failed");
   if (t.arena.err) return fail(GNNB_E_NOMEM, "gnnb_online_step: out of device memory");
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(GNNB_E_HIP, "gnnb_online_step: a launch failed: %s", hipGetErrorString(e));

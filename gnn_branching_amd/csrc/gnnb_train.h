@@ -10,7 +10,12 @@
 // folded weight packs are rebuilt from the new parameters after the step (gnnb_online_step ends with build_packs + upload).
 //
 // This is a latency path (the reference takes one subproblem per step; B > 1 sums the B losses), so the kernels are plain
-// VALU/LDS kernels, one launch per op, a few thousand rows each -- not the MFMA pipeline of gnnb_forward.
+// VALU/LDS kernels over a few thousand rows each -- not the MFMA pipeline of gnnb_forward.  Round 3: the Linears of one MLP
+// chain over the same rows (fc3 -> fc3_2 -> fc4 -> fc4_2, bc1 -> ... -> bc2_1, ...) are ONE launch forward (k_tchain_fwd: a row
+// tile goes through all of them, each output kept in memory for the backward pass and handed to the next layer through LDS) and
+// ONE launch backward (k_tchain_bwd_x); all weight gradients of a step are two launches at its end (k_tlin_bwd_w_all over every
+// (op, row chunk), k_tlin_reduce_all adding the partials in tape order).  Every sum keeps the order of the one-launch-per-op form,
+// so values and gradients are bit-identical to it.
 //
 // Included at the end of gnnb.hip (one translation unit: it uses the bound network of gnnb_handle).
 #pragma once
@@ -18,6 +23,7 @@
 
 namespace gnnb_train {
 using namespace gnnb;
+typedef float tf4 __attribute__((ext_vector_type(4)));
 
 // ---- device memory: a bump arena, zeroed at the start of every step (gradient buffers start at 0) ----
 struct Arena {
@@ -98,9 +104,13 @@ struct TLin {
   float* y; const float* gy; long n;      // n: rows (compact form: capacity of the list)
   const int* ridx; const int* n_dev; int out_full;
   float* part; int nchunks;
-  int jbase;      // k_tlin_bwd_x: first segment of this launch
+  int layer;      // index of this Linear in the checkpoint (k_tlin_reduce_all adds up the ops of one layer in tape order)
+  unsigned prev;  // bit j: segment j is the output tile of the PREVIOUS op of the chain (read from LDS, not from memory)
 };
-#define TL_ROWS 32
+#define TC_MAXOPS 5
+struct TChain { TLin op[TC_MAXOPS]; int nops; };
+#define TL_ROWS 32      // rows per block of a chain kernel when there are many (TL_ROWS_SMALL otherwise: more, lighter blocks)
+#define TL_ROWS_SMALL 8
 #define TL_CHUNK 64
 
 __device__ __forceinline__ TSeg tl_seg(const TLin& a, int j) { return j == 0 ? a.seg[0] : j == 1 ? a.seg[1] : a.seg[2]; }
@@ -117,50 +127,107 @@ __device__ __forceinline__ void tl_stage_rows(const TLin& a, long row0, long n, 
   }
 }
 
-__global__ __launch_bounds__(256) void k_tlin_fwd(TLin a) {
-  extern __shared__ float tl_lds[];
-  __shared__ int Rs[TL_ROWS];
-  const long n = tl_rows(a), row0 = (long)blockIdx.x * TL_ROWS;
+// A chain of Linears over one set of rows, forward: a tile of TL_ROWS rows goes through op 0 .. nops-1; every output is written
+// to memory (the backward pass needs it) and stays in LDS (`Ys`) for the segments of the next op that read it (TLin.prev).
+// Per op the arithmetic of the former one-launch-per-Linear kernel: acc = bias, then one fma per input feature in order.
+template <int R>
+__global__ __launch_bounds__(256) void k_tchain_fwd(TChain c) {
+  extern __shared__ __attribute__((aligned(16))) float tl_lds[];
+  __shared__ int Rs[R];
+  const long n = tl_rows(c.op[0]), row0 = (long)blockIdx.x * R;
   if (row0 >= n) return;
-  const int K = a.K, KP = a.K | 1, tid = threadIdx.x;
-  float* Ws = tl_lds;                    // [64][KP]: row-major like the checkpoint, odd row stride (lane c reads bank c + k)
-  float* Xs = tl_lds + 64 * KP;          // [TL_ROWS][K]
-  tl_stage_rows(a, row0, n, Rs, TL_ROWS);
-  for (int i = tid; i < 64 * K; i += 256) { const int c = i / K, k = i - c * K; Ws[c * KP + k] = a.W[i]; }
-  __syncthreads();
-  for (int i = tid; i < TL_ROWS * K; i += 256) {
-    const int r = i / K, k = i - r * K;
-    const int node = Rs[r];
-    float v = 0.0f;
-    if (node >= 0) {
-      if (a.nseg) {
-        const TSeg sg = tl_seg(a, k >> 6);
-        v = sg.x[(sg.full ? (long)node : row0 + r) * 64 + (k & 63)];
-        if (sg.s) v *= sg.s[node];
-      } else v = a.feat[(long)node * a.kf + k];
+  const int tid = threadIdx.x;
+  int Kmax = 0;
+  for (int i = 0; i < c.nops; ++i) Kmax = c.op[i].K > Kmax ? c.op[i].K : Kmax;
+  float* Ws = tl_lds;                         // [64][KP]: row-major like the checkpoint, odd row stride (lane c reads bank c + k)
+  float* Xs = Ws + 64 * (Kmax | 1);           // [R][K]
+  float* Ys = Xs + R * Kmax;            // [R][64]: the previous op's output tile
+  tl_stage_rows(c.op[0], row0, n, Rs, R);
+  for (int i = 0; i < c.nops; ++i) {
+    const TLin& a = c.op[i];
+    const int K = a.K, KP = a.K | 1;
+    __syncthreads();                          // Rs is there (i = 0); the previous op is done with Ws / Xs and its Ys is complete
+    // Staging with every load of a thread in flight at once (a plain copy loop keeps one load in flight per thread: 16-32
+    // dependent L2 round trips per op were most of the former kernels' ~10 us)
+    if ((K & 63) == 0) {                      // weights of a 64 / 128 / 192-wide layer: 16-B loads, 4 KB per wave instruction
+      const tf4* W4 = reinterpret_cast<const tf4*>(a.W);
+      const int n4 = 16 * K, k4n = K >> 2;    // tf4 per matrix, per row
+      tf4 v[12];                            // (n4 <= 3072 = 12 x 256)
+#pragma unroll
+      for (int u = 0; u < 12; ++u) { const int q = tid + 256 * u; if (q < n4) v[u] = W4[q]; }
+#pragma unroll
+      for (int u = 0; u < 12; ++u) {
+        const int q = tid + 256 * u;
+        if (q < n4) {
+          const int cc = q / k4n, k = (q - cc * k4n) * 4;
+          float* d = Ws + cc * KP + k;
+          d[0] = v[u][0]; d[1] = v[u][1]; d[2] = v[u][2]; d[3] = v[u][3];
+        }
+      }
+    } else {
+      for (int q = tid; q < 64 * K; q += 256) { const int cc = q / K, k = q - cc * K; Ws[cc * KP + k] = a.W[q]; }      // (K <= 7)
     }
-    Xs[i] = v;
-  }
-  __syncthreads();
-  const int c = tid & 63, rq = tid >> 6;
-  float acc[8];
-  const float bias = a.b[c];
+    if (a.nseg) {                             // 64-wide row segments: one 16-B load per (row, segment, 4 features)
+      const int items = R * a.nseg * 16;                  // <= 1536 = 6 x 256
+      tf4 v[6];
+      float sc[6];
 #pragma unroll
-  for (int r = 0; r < 8; ++r) acc[r] = bias;
-  const float* xr = Xs + rq * 8 * K;
-  const float* wr = Ws + c * KP;
-  for (int k = 0; k < K; ++k) {
-    const float w = wr[k];
+      for (int u = 0; u < 6; ++u) {
+        const int q = tid + 256 * u;
+        v[u] = tf4{0.f, 0.f, 0.f, 0.f};
+        sc[u] = 1.0f;
+        if (q < items) {
+          const int f4 = q & 15, j = (q >> 4) % a.nseg, r = q / (16 * a.nseg);
+          const int node = Rs[r];
+          if (node >= 0) {
+            const TSeg sg = tl_seg(a, j);
+            if ((a.prev >> j) & 1u) v[u] = *reinterpret_cast<const tf4*>(Ys + r * 64 + 4 * f4);
+            else v[u] = *reinterpret_cast<const tf4*>(sg.x + (sg.full ? (long)node : row0 + r) * 64 + 4 * f4);
+            if (sg.s) sc[u] = sg.s[node];
+          }
+        }
+      }
 #pragma unroll
-    for (int r = 0; r < 8; ++r) acc[r] = fmaf(xr[r * K + k], w, acc[r]);
-  }
+      for (int u = 0; u < 6; ++u) {
+        const int q = tid + 256 * u;
+        if (q < items) {
+          const int f4 = q & 15, j = (q >> 4) % a.nseg, r = q / (16 * a.nseg);
+          float* d = Xs + r * K + 64 * j + 4 * f4;
+          // (x * s: the product the one-load-per-element form made, 0 for a row past the end)
+          d[0] = v[u][0] * sc[u]; d[1] = v[u][1] * sc[u]; d[2] = v[u][2] * sc[u]; d[3] = v[u][3] * sc[u];
+        }
+      }
+    } else {
+      for (int q = tid; q < R * K; q += 256) {
+        const int r = q / K, k = q - r * K;
+        const int node = Rs[r];
+        Xs[q] = node >= 0 ? a.feat[(long)node * a.kf + k] : 0.0f;
+      }
+    }
+    __syncthreads();
+    const int cc = tid & 63, rq = tid >> 6;
+    float acc[R / 4];
+    const float bias = a.b[cc];
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const int node = Rs[rq * 8 + r];
-    if (node < 0) continue;
-    float v = a.relu ? fmaxf(acc[r], 0.0f) : acc[r];
-    if (a.omask) v *= a.omask[node];
-    a.y[(a.out_full ? (long)node : row0 + rq * 8 + r) * 64 + c] = v;
+    for (int r = 0; r < R / 4; ++r) acc[r] = bias;
+    const float* xr = Xs + rq * (R / 4) * K;
+    const float* wr = Ws + cc * KP;
+    for (int k = 0; k < K; ++k) {
+      const float w = wr[k];
+#pragma unroll
+      for (int r = 0; r < R / 4; ++r) acc[r] = fmaf(xr[r * K + k], w, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < R / 4; ++r) {
+      const int node = Rs[rq * (R / 4) + r];
+      float v = 0.0f;
+      if (node >= 0) {
+        v = a.relu ? fmaxf(acc[r], 0.0f) : acc[r];
+        if (a.omask) v *= a.omask[node];
+        a.y[(a.out_full ? (long)node : row0 + rq * (R / 4) + r) * 64 + cc] = v;
+      }
+      Ys[(rq * (R / 4) + r) * 64 + cc] = v;
+    }
   }
 }
 
@@ -172,51 +239,128 @@ __device__ __forceinline__ float tl_dym(const TLin& a, long orow, int node, int 
   return d;
 }
 
-// gx_seg += s_seg * (dym . W[:, seg]);  blockIdx.y = segment
-__global__ __launch_bounds__(256) void k_tlin_bwd_x(TLin a) {
-  __shared__ float Ws[64 * 64];          // [c][k]
-  __shared__ float Ds[TL_ROWS * 64];     // [r][c]
-  __shared__ int Rs[TL_ROWS];
-  const long n = tl_rows(a), row0 = (long)blockIdx.x * TL_ROWS;
+// The same chain backwards (input gradients): op nops-1 .. 0 on one row tile.  gx_seg += s_seg * (dym . W[:, seg]), the segments
+// of an op in order (the order of the former one-launch-per-segment form).  The gradient of a segment that is the previous op's
+// output -- whose total is that op's gy -- is added to what memory already holds for it (contributions of consumers outside the
+// chain, which ran earlier on the tape), written back, and handed to the next iteration through LDS (`Gs`).
+template <int R>
+__global__ __launch_bounds__(256) void k_tchain_bwd_x(TChain c) {
+  __shared__ __attribute__((aligned(16))) float Ws[64 * 64];          // [c][k]
+  __shared__ __attribute__((aligned(16))) float Ds[R * 64];     // [r][c]
+  __shared__ __attribute__((aligned(16))) float Gs[R * 64];     // [r][k]: gy of the op about to be walked, when it was produced by the op above it
+  __shared__ int Rs[R];
+  const long n = tl_rows(c.op[0]), row0 = (long)blockIdx.x * R;
   if (row0 >= n) return;
-  const int j = blockIdx.y + a.jbase, tid = threadIdx.x;
-  const TSeg sg = tl_seg(a, j);
-  if (!sg.gx) return;
-  tl_stage_rows(a, row0, n, Rs, TL_ROWS);
-  for (int i = tid; i < 4096; i += 256) Ws[i] = a.W[(i >> 6) * a.K + 64 * j + (i & 63)];
-  __syncthreads();
-  for (int i = tid; i < TL_ROWS * 64; i += 256) {
-    const int r = i >> 6, node = Rs[r];
-    Ds[i] = node >= 0 ? tl_dym(a, a.out_full ? (long)node : row0 + r, node, i & 63) : 0.0f;
-  }
-  __syncthreads();
-  const int k = tid & 63, rq = tid >> 6;
-  float acc[8];
+  const int tid = threadIdx.x;
+  tl_stage_rows(c.op[0], row0, n, Rs, R);
+  bool carried = false;
+  for (int i = c.nops - 1; i >= 0; --i) {
+    const TLin& a = c.op[i];
+    bool any = false;
+    for (int j = 0; j < a.nseg; ++j) any = any || tl_seg(a, j).gx != nullptr;
+    if (!any) { carried = false; continue; }
+    __syncthreads();                          // Rs (first pass); Gs of the iteration before is complete; Ds free
+    {                                         // dym of the tile: 2 x 16-B items per thread, their loads issued together
+      tf4 gv[2], yv[2];
+      float om[2];
 #pragma unroll
-  for (int r = 0; r < 8; ++r) acc[r] = 0.0f;
-  for (int c = 0; c < 64; ++c) {
-    const float w = Ws[c * 64 + k];
+      for (int u = 0; u < 2; ++u) {
+        const int q = tid + 256 * u, r = q >> 4, f4 = q & 15;
+        const int node = q < R * 16 ? Rs[r] : -1;
+        gv[u] = tf4{0.f, 0.f, 0.f, 0.f}; yv[u] = tf4{1.f, 1.f, 1.f, 1.f}; om[u] = 1.0f;
+        if (node >= 0) {
+          const long orow = a.out_full ? (long)node : row0 + r;
+          gv[u] = carried ? *reinterpret_cast<const tf4*>(Gs + r * 64 + 4 * f4) : *reinterpret_cast<const tf4*>(a.gy + orow * 64 + 4 * f4);
+          if (a.relu) yv[u] = *reinterpret_cast<const tf4*>(a.y + orow * 64 + 4 * f4);
+          if (a.omask) om[u] = a.omask[node];
+        }
+      }
 #pragma unroll
-    for (int r = 0; r < 8; ++r) acc[r] = fmaf(Ds[(rq * 8 + r) * 64 + c], w, acc[r]);
-  }
+      for (int u = 0; u < 2; ++u) {
+        const int q = tid + 256 * u, r = q >> 4, f4 = q & 15;
+        if (q >= R * 16) continue;
+        float* d = Ds + r * 64 + 4 * f4;
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const int node = Rs[rq * 8 + r];
-    if (node < 0) continue;
-    const float s = sg.s ? sg.s[node] : 1.0f;
-    sg.gx[(sg.full ? (long)node : row0 + rq * 8 + r) * 64 + k] += s * acc[r];
+        for (int e = 0; e < 4; ++e) {
+          float dv = gv[u][e];
+          if (a.relu && !(yv[u][e] > 0.0f)) dv = 0.0f;
+          if (a.omask) dv *= om[u];
+          d[e] = dv;
+        }
+      }
+    }
+    const int k = tid & 63, rq = tid >> 6;
+    float g[R / 4];
+    bool have_prev = false;
+    long paddr[R / 4];
+    float* pgx = nullptr;
+    for (int j = 0; j < a.nseg; ++j) {
+      const TSeg sg = tl_seg(a, j);
+      if (!sg.gx) continue;
+      const bool pv = ((a.prev >> j) & 1u) != 0;
+      __syncthreads();                        // Ds is complete (first segment); the segment before is done with Ws
+      {                                       // W[:, 64 j .. 64 j + 63] -> Ws: four 16-B loads per thread in flight
+        tf4 wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int q = tid + 256 * u; wv[u] = *reinterpret_cast<const tf4*>(a.W + (q >> 4) * a.K + 64 * j + 4 * (q & 15)); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int q = tid + 256 * u; *reinterpret_cast<tf4*>(Ws + (q >> 4) * 64 + 4 * (q & 15)) = wv[u]; }
+      }
+      __syncthreads();
+      float acc[R / 4];
+#pragma unroll
+      for (int r = 0; r < R / 4; ++r) acc[r] = 0.0f;
+      for (int cc = 0; cc < 64; ++cc) {
+        const float w = Ws[cc * 64 + k];
+#pragma unroll
+        for (int r = 0; r < R / 4; ++r) acc[r] = fmaf(Ds[(rq * (R / 4) + r) * 64 + cc], w, acc[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < R / 4; ++r) {
+        const int node = Rs[rq * (R / 4) + r];
+        if (node < 0) continue;
+        const float sc = sg.s ? sg.s[node] : 1.0f;
+        const long addr = (sg.full ? (long)node : row0 + rq * (R / 4) + r) * 64 + k;
+        if (pv) {
+          if (!have_prev) { g[r] = sg.gx[addr]; paddr[r] = addr; }
+          g[r] += sc * acc[r];
+        } else sg.gx[addr] += sc * acc[r];
+      }
+      if (pv) { have_prev = true; pgx = sg.gx; }
+    }
+    if (have_prev) {
+      __syncthreads();                        // everybody has read Gs (through Ds) before it is rewritten
+#pragma unroll
+      for (int r = 0; r < R / 4; ++r) {
+        const int node = Rs[rq * (R / 4) + r];
+        if (node >= 0) pgx[paddr[r]] = g[r];
+        Gs[(rq * (R / 4) + r) * 64 + k] = node >= 0 ? g[r] : 0.0f;
+      }
+    }
+    carried = have_prev;
   }
 }
 
-// partial weight gradients of one chunk of rows: part[chunk][c][col] = sum_r dym[r][c] * (s x)[r][col], col K = bias
-// blockIdx.y = segment (or 0 for a feature block)
-__global__ __launch_bounds__(256) void k_tlin_bwd_w(TLin a) {
+// Weight gradients of EVERY op of a step in one launch: block -> (op, chunk of TL_CHUNK rows), blockIdx.y = segment (or 0 for a
+// feature block).  part[chunk][c][col] = sum_r dym[r][c] * (s x)[r][col], col K = bias.  Runs after the whole backward walk, when
+// every gy is final; x, y, gy of all ops are still in the arena.  first[o] = first block of op o, first[nops] = the grid size.
+__global__ __launch_bounds__(256) void k_tlin_bwd_w_all(const TLin* ops, const int* first, int nops) {
   __shared__ __attribute__((aligned(16))) float Ds[TL_CHUNK * 64];
   __shared__ __attribute__((aligned(16))) float Xs[TL_CHUNK * 64];
   __shared__ int Rs[TL_CHUNK];
-  const long n = tl_rows(a), row0 = (long)blockIdx.x * TL_CHUNK;
-  if (row0 >= n) return;
-  const int j = blockIdx.y, tid = threadIdx.x;
+  __shared__ int s_op;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    int o = 0;
+    while (o + 1 < nops && first[o + 1] <= (int)blockIdx.x) ++o;
+    s_op = o;
+  }
+  __syncthreads();
+  const TLin a = ops[s_op];
+  const int chunk = (int)blockIdx.x - first[s_op];
+  const long n = tl_rows(a), row0 = (long)chunk * TL_CHUNK;
+  const int j = blockIdx.y;
+  if (row0 >= n || j >= (a.nseg ? a.nseg : 1)) return;
   const int KW = a.nseg ? 64 : a.kf;
   const TSeg sg = tl_seg(a, j);
   tl_stage_rows(a, row0, n, Rs, TL_CHUNK);
@@ -236,7 +380,7 @@ __global__ __launch_bounds__(256) void k_tlin_bwd_w(TLin a) {
     Xs[i] = v;
   }
   __syncthreads();
-  float* part = a.part + (long)blockIdx.x * 64 * (a.K + 1);
+  float* part = a.part + (long)chunk * 64 * (a.K + 1);
   if (a.nseg) {                    // 64 x 64 outputs: a 4 x 4 block per thread, two b128 LDS reads per row
     const int c0 = (tid >> 4) * 4, k0 = (tid & 15) * 4;
     float acc[4][4];
@@ -259,27 +403,32 @@ __global__ __launch_bounds__(256) void k_tlin_bwd_w(TLin a) {
       for (int q = 0; q < 4; ++q) part[(c0 + i) * (a.K + 1) + 64 * j + k0 + q] = acc[i][q];
   } else
   for (int o = tid; o < 64 * KW; o += 256) {
-    const int c = o / KW, k = o - c * KW;
-    float s = 0.0f;
-    for (int r = 0; r < TL_CHUNK; ++r) s = fmaf(Ds[r * 64 + c], Xs[r * KW + k], s);
-    part[c * (a.K + 1) + 64 * j + k] = s;
+    const int cq = o / KW, k = o - cq * KW;
+    float sm = 0.0f;
+    for (int r = 0; r < TL_CHUNK; ++r) sm = fmaf(Ds[r * 64 + cq], Xs[r * KW + k], sm);
+    part[cq * (a.K + 1) + 64 * j + k] = sm;
   }
   if (j == 0 && tid < 64) {
-    float s = 0.0f;
-    for (int r = 0; r < TL_CHUNK; ++r) s += Ds[r * 64 + tid];
-    part[tid * (a.K + 1) + a.K] = s;
+    float sm = 0.0f;
+    for (int r = 0; r < TL_CHUNK; ++r) sm += Ds[r * 64 + tid];
+    part[tid * (a.K + 1) + a.K] = sm;
   }
 }
-// gW / gb += the chunk partials, in chunk order (deterministic)
-__global__ void k_tlin_reduce(TLin a) {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= 64 * (a.K + 1)) return;
-  const int nch = (int)((tl_rows(a) + TL_CHUNK - 1) / TL_CHUNK);
-  float s = 0.0f;
-  for (int ch = 0; ch < nch; ++ch) s += a.part[(long)ch * 64 * (a.K + 1) + o];
-  const int c = o / (a.K + 1), col = o - c * (a.K + 1);
-  if (col < a.K) a.gW[c * a.K + col] += s;
-  else a.gb[c] += s;
+// gW / gb += the chunk partials of every op of a layer: the ops in tape order, the chunks of an op in chunk order (deterministic,
+// and the order of the former one-reduction-per-op form).  blockIdx.y = Linear of the checkpoint.
+__global__ void k_tlin_reduce_all(const TLin* ops, int nops) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x, layer = blockIdx.y;
+  for (int q = 0; q < nops; ++q) {
+    if (ops[q].layer != layer) continue;
+    const TLin a = ops[q];
+    if (o >= 64 * (a.K + 1)) return;
+    const int nch = (int)((tl_rows(a) + TL_CHUNK - 1) / TL_CHUNK);
+    float sm = 0.0f;
+    for (int ch = 0; ch < nch; ++ch) sm += a.part[(long)ch * 64 * (a.K + 1) + o];
+    const int cq = o / (a.K + 1), col = o - cq * (a.K + 1);
+    if (col < a.K) a.gW[cq * a.K + col] += sm;
+    else a.gb[cq] += sm;
+  }
 }
 
 // ordered list of the rows with a non-zero flag, and their number: one workgroup
@@ -490,6 +639,7 @@ struct Trainer {
   std::vector<float*> edge_w;            // torch-layout weights of the bound network's edges, device
   std::vector<std::function<void()>> tape;
   hipStream_t st = nullptr;
+  int n_cu = 256;
   // weight-gradient kernels never feed the rest of the backward pass: they run on a side stream, ordered behind the point of
   // the main stream where their gy is final (same order among themselves as on one stream, so the sums stay reproducible)
   hipStream_t side = nullptr;
@@ -525,42 +675,85 @@ struct Trainer {
   // a node list: idx (cap) ordered node ids, *cnt their number
   struct List { const int* idx = nullptr; const int* cnt = nullptr; long cap = 0; };
 
-  // y = omask * act(W x + b); records the adjoint.  list: compact form over that node list (rows of `y` = list entries,
-  // or nodes when out_full); n: rows of the plain form / nodes of the layer.
-  TT lin(int layer, std::vector<TSeg> segs, const float* feat, long n, bool relu, const float* omask, const List* list = nullptr,
-         bool out_full = false) {
-    TT y = rows(list && !out_full ? list->cap : n);
-    TLin a{};
-    a.W = d_w + weight_offset(layer); a.b = d_w + bias_offset(layer);
-    a.gW = d_g + weight_offset(layer); a.gb = d_g + bias_offset(layer);
-    a.K = kLin[layer].in; a.nseg = (int)segs.size(); a.kf = feat ? a.K : 0;
-    for (int j = 0; j < a.nseg; ++j) a.seg[j] = segs[j];
-    a.feat = feat; a.omask = omask; a.relu = relu ? 1 : 0; a.y = y.v; a.gy = y.g;
-    a.n = list ? list->cap : n;
-    if (list) { a.ridx = list->idx; a.n_dev = list->cnt; a.out_full = out_full ? 1 : 0; }
-    const unsigned nblk = (unsigned)((a.n + TL_ROWS - 1) / TL_ROWS);
-    const size_t lds = ((size_t)(a.K | 1) * 64 + (size_t)TL_ROWS * a.K) * 4;
-    hipLaunchKernelGGL(k_tlin_fwd, dim3(nblk), dim3(256), lds, st, a);
-    tape.push_back([this, a, nblk]() mutable {
+  // One Linear of a chain: y = omask * act(W [segments] + b).  A segment with x == nullptr is the previous op's output.
+  struct Spec { int layer; std::vector<TSeg> segs; const float* feat; bool relu; const float* omask; bool out_full; };
+  std::vector<TLin> wops;                // every op of the step, in tape (backward) order: the weight-gradient launches walk it
+
+  // A chain of Linears over the same rows (all of them the plain form over n rows, or the compact form over `list`): one launch
+  // forward, one backward.  Returns the outputs of the ops.  list: compact form (rows of an output = list entries, or nodes when
+  // its op is out_full); n: rows of the plain form / nodes of the layer.
+  std::vector<TT> chain(const std::vector<Spec>& specs, long n, const List* list = nullptr) {
+    std::vector<TT> out;
+    TChain c{};
+    c.nops = (int)specs.size();
+    int Kmax = 0;
+    for (int i = 0; i < c.nops; ++i) {
+      const Spec& sp = specs[i];
+      TT y = rows(list && !sp.out_full ? list->cap : n);
+      TLin& a = c.op[i];
+      a.layer = sp.layer;
+      a.W = d_w + weight_offset(sp.layer); a.b = d_w + bias_offset(sp.layer);
+      a.gW = d_g + weight_offset(sp.layer); a.gb = d_g + bias_offset(sp.layer);
+      a.K = kLin[sp.layer].in; a.nseg = (int)sp.segs.size(); a.kf = sp.feat ? a.K : 0;
+      for (int j = 0; j < a.nseg; ++j) {
+        a.seg[j] = sp.segs[j];
+        if (!sp.segs[j].x) {                       // the previous op's output tile
+          a.prev |= 1u << j;
+          a.seg[j].x = out[i - 1].v; a.seg[j].gx = out[i - 1].g; a.seg[j].full = specs[i - 1].out_full ? 1 : 0;
+        }
+      }
+      a.feat = sp.feat; a.omask = sp.omask; a.relu = sp.relu ? 1 : 0; a.y = y.v; a.gy = y.g;
+      a.n = list ? list->cap : n;
+      if (list) { a.ridx = list->idx; a.n_dev = list->cnt; a.out_full = sp.out_full ? 1 : 0; }
       a.nchunks = (int)((a.n + TL_CHUNK - 1) / TL_CHUNK);
       a.part = arena.alloc((size_t)a.nchunks * 64 * (a.K + 1));
-      if (!a.part) return;
-      hipStream_t ws = fork();
-      hipLaunchKernelGGL(k_tlin_bwd_w, dim3((unsigned)a.nchunks, a.nseg ? a.nseg : 1), dim3(256), 0, ws, a);
-      hipLaunchKernelGGL(k_tlin_reduce, dim3((64 * (a.K + 1) + 255) / 256), dim3(256), 0, ws, a);
-      bool any = false, alias = false;
-      for (int j = 0; j < a.nseg; ++j) {
-        any = any || a.seg[j].gx;
-        for (int i = 0; i < j; ++i) alias = alias || (a.seg[j].gx && a.seg[j].gx == a.seg[i].gx);
+      Kmax = a.K > Kmax ? a.K : Kmax;
+      out.push_back(y);
+    }
+    // few rows (the latency case: one subproblem has ~1000 live nodes per layer): 8-row tiles -- four times the blocks, each a
+    // quarter of the inner loop, the weights staged per block either way; many rows: 32-row tiles amortise the staging
+    const long nrows = list ? list->cap : n;
+    const bool small = nrows <= (long)TL_ROWS * 4 * n_cu;
+    const int R = small ? TL_ROWS_SMALL : TL_ROWS;
+    const unsigned nblk = (unsigned)((nrows + R - 1) / R);
+    const size_t lds = ((size_t)(Kmax | 1) * 64 + (size_t)R * Kmax + (size_t)R * 64) * 4;
+    if (small) hipLaunchKernelGGL(k_tchain_fwd<TL_ROWS_SMALL>, dim3(nblk), dim3(256), lds, st, c);
+    else hipLaunchKernelGGL(k_tchain_fwd<TL_ROWS>, dim3(nblk), dim3(256), lds, st, c);
+    tape.push_back([this, c, nblk, small]() {
+      bool any = false;
+      for (int i = 0; i < c.nops; ++i)
+        for (int j = 0; j < c.op[i].nseg; ++j) any = any || c.op[i].seg[j].gx;
+      if (any) {
+        if (small) hipLaunchKernelGGL(k_tchain_bwd_x<TL_ROWS_SMALL>, dim3(nblk), dim3(256), 0, st, c);
+        else hipLaunchKernelGGL(k_tchain_bwd_x<TL_ROWS>, dim3(nblk), dim3(256), 0, st, c);
       }
-      if (!any) return;
-      if (!alias) hipLaunchKernelGGL(k_tlin_bwd_x, dim3(nblk, a.nseg), dim3(256), 0, st, a);
-      else                                 // segments of the same tensor (r0 nb | r1 nb) add into the same rows: one after the other
-        for (int j = 0; j < a.nseg; ++j) { a.jbase = j; hipLaunchKernelGGL(k_tlin_bwd_x, dim3(nblk, 1), dim3(256), 0, st, a); }
+      for (int i = c.nops - 1; i >= 0; --i) wops.push_back(c.op[i]);
     });
-    return y;
+    return out;
+  }
+  TT lin(int layer, std::vector<TSeg> segs, const float* feat, long n, bool relu, const float* omask, const List* list = nullptr,
+         bool out_full = false) {
+    return chain({Spec{layer, std::move(segs), feat, relu, omask, out_full}}, n, list)[0];
+  }
+  // the weight gradients of every recorded op: two launches behind the backward walk
+  std::vector<int> h_first;
+  int weight_grads() {
+    const int nops = (int)wops.size();
+    if (!nops) return 0;
+    h_first.assign(nops + 1, 0);
+    for (int o = 0; o < nops; ++o) h_first[o + 1] = h_first[o] + wops[o].nchunks;
+    const size_t op_floats = (sizeof(TLin) * nops + 3) / 4, first_floats = nops + 1;
+    TLin* d_ops = reinterpret_cast<TLin*>(arena.alloc(op_floats));
+    int* d_first = reinterpret_cast<int*>(arena.alloc(first_floats));
+    if (!d_ops || !d_first) return 1;
+    if (hipMemcpyAsync(d_ops, wops.data(), sizeof(TLin) * nops, hipMemcpyHostToDevice, st) != hipSuccess) return 1;
+    if (hipMemcpyAsync(d_first, h_first.data(), sizeof(int) * (nops + 1), hipMemcpyHostToDevice, st) != hipSuccess) return 1;
+    hipLaunchKernelGGL(k_tlin_bwd_w_all, dim3((unsigned)h_first[nops], 3), dim3(256), 0, st, d_ops, d_first, nops);
+    hipLaunchKernelGGL(k_tlin_reduce_all, dim3((64 * 193 + 255) / 256, (unsigned)L_COUNT), dim3(256), 0, st, d_ops, nops);
+    return 0;
   }
   static TSeg seg(const TT& t, const float* s = nullptr, bool full = false) { return TSeg{t.v, s, t.g, full ? 1 : 0}; }
+  static TSeg prev(const float* s = nullptr) { return TSeg{nullptr, s, nullptr, 0}; }      // the previous op's output (chain)
 };
 
 }  // namespace gnnb_train
