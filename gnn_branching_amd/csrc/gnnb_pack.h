@@ -209,18 +209,31 @@ struct PackScore { enum { W1 = 0, B1 = W1 + 4096, WS = B1 + 64, BS = WS + 64, V1
 // V2 = out2[:, 64:].fc4_2.b multiplies sum_n W_prop[n] live_n
 struct PackProp { enum { W1T = 0, B1 = W1T + 4 * 64, W2T = B1 + 64, B2 = W2T + 128 * 64, W3T = B2 + 64, B3 = W3T + 64 * 64, V2 = B3 + 64, FLOATS = V2 + 64 }; };
 
-// C (64 x 64) = A (64 x 64, row stride lda, columns [acol0, acol0+64)) . B (64 x 64 row-major), accumulated in double
-inline void matmul64(float* C, const float* A, int lda, int acol0, const float* B) {
-  for (int i = 0; i < 64; ++i) {          // k outer, j inner: the same sums in the same order, but contiguous and vectorisable
-    double acc[64];                       // (this runs after every online-learning step, gnnb_online_step)
+// The folds run on the host after every online-learning step (gnnb_online_step -> load_weights): their double-precision inner
+// loops are compiled for AVX-512 / AVX2 as well and picked at load time (function multiversioning; host pass only -- the device
+// pass of hipcc sees plain functions).  Same sums in the same order whichever clone runs.
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+#define GNNB_HOST_SIMD __attribute__((target_clones("avx512f", "avx2", "default")))
+#else
+#define GNNB_HOST_SIMD
+#endif
+// Cd (64 x 64, double) = A (64 x 64, row stride lda, columns [acol0, acol0+64)) . B (64 x 64 row-major)
+GNNB_HOST_SIMD inline void matmul64d(double* Cd, const float* A, int lda, int acol0, const float* B) {
+  for (int i = 0; i < 64; ++i) {          // k outer, j inner: contiguous and vectorisable
+    double* acc = Cd + (size_t)i * 64;
     for (int j = 0; j < 64; ++j) acc[j] = 0.0;
     for (int k = 0; k < 64; ++k) {
       const double a = (double)A[(size_t)i * lda + acol0 + k];
       const float* Bk = B + (size_t)k * 64;
       for (int j = 0; j < 64; ++j) acc[j] += a * (double)Bk[j];
     }
-    for (int j = 0; j < 64; ++j) C[(size_t)i * 64 + j] = (float)acc[j];
   }
+}
+// C (64 x 64) = the same product rounded to float once
+inline void matmul64(float* C, const float* A, int lda, int acol0, const float* B) {
+  double t[64 * 64];
+  matmul64d(t, A, lda, acol0, B);
+  for (int q = 0; q < 64 * 64; ++q) C[q] = (float)t[q];
 }
 // y (64) = A[:, acol0:acol0+64] . x (64) + y0 (64)
 inline void matvec64(float* y, const float* A, int lda, int acol0, const float* x, const float* y0) {
@@ -260,8 +273,10 @@ inline void build_packs(const float* blob, Packs& pk) {
     float bcb[64];
     std::memcpy(wa.data(), W(a), sizeof(float) * 64 * 128);
     if (proj >= 0) {
-      std::vector<double> t(64 * 128);
+      std::vector<double> t0(64 * 64), t1(64 * 64);          // Wa[:, :64].Wp and Wa[:, 64:].Wp in double
       float vaw[128];
+      matmul64d(t0.data(), W(a), 128, 0, W(proj));
+      matmul64d(t1.data(), W(a), 128, 64, W(proj));
       for (int i = 0; i < 64; ++i) {
         double s0 = 0.0, s1 = 0.0;
         for (int k = 0; k < 64; ++k) {
@@ -269,18 +284,12 @@ inline void build_packs(const float* blob, Packs& pk) {
           s1 += (double)W(a)[i * 128 + 64 + k] * (double)Bv(proj)[k];
         }
         vaw[2 * i] = (float)s0; vaw[2 * i + 1] = (float)s1;
-        for (int half = 0; half < 2; ++half) {
-          double* acc = &t[i * 128 + 64 * half];
-          for (int j = 0; j < 64; ++j) acc[j] = 0.0;
-          for (int k = 0; k < 64; ++k) {
-            const double wa_ik = (double)W(a)[i * 128 + 64 * half + k];
-            const float* Pk = W(proj) + k * 64;
-            for (int j = 0; j < 64; ++j) acc[j] += wa_ik * (double)Pk[j];
-          }
+        for (int j = 0; j < 64; ++j) {
+          was[i * 64 + j] = (float)(t0[i * 64 + j] + t1[i * 64 + j]);
+          wa[i * 128 + j] = (float)t0[i * 64 + j];
+          wa[i * 128 + 64 + j] = (float)t1[i * 64 + j];
         }
-        for (int j = 0; j < 64; ++j) was[i * 64 + j] = (float)(t[i * 128 + j] + t[i * 128 + 64 + j]);
       }
-      for (size_t q = 0; q < t.size(); ++q) wa[q] = (float)t[q];
       pack_wsmall(&v[PackUpd::VAW], vaw, 2, 1);
     } else {
       for (int i = 0; i < 64; ++i)

@@ -471,53 +471,87 @@ struct TConv {
   int norm;   // tap-count division (:306-312): dir 1: of the result; dir 0 (its adjoint): of the source rows
   int acc;    // dst += instead of dst =
 };
-// one wave per destination node, lane = embedding channel
+// one wave per destination node, lane = embedding channel.  The node's valid taps are listed first (lane-parallel, kept in the
+// order of the plain loops: ky, kx, channel), then walked in batches of TCONV_BATCH independent row loads -- the sums and their
+// order are those of the plain loops (which kept one dependent load in flight per tap: 23 us per launch).
+#define TCONV_MAXTAPS 512
+#define TCONV_BATCH 16
 __global__ __launch_bounds__(256) void k_tconv(TConv a) {
-  const int lane = threadIdx.x & 63;
-  const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  float acc = 0.0f;
-  long out;
+  __shared__ int s_row[4][TCONV_MAXTAPS];
+  __shared__ float s_w[4][TCONV_MAXTAPS];
+  __shared__ float s_f[4][TCONV_MAXTAPS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long wv = (long)blockIdx.x * 4 + wave;
+  const long ndst = a.dir == 0 ? (long)a.B * a.C_out * a.H_out * a.W_out : (long)a.B * a.C_in * a.H_in * a.W_in;
+  if (wv >= ndst) return;
+  const int C = a.dir == 0 ? a.C_in : a.C_out;          // channels of the source side
+  const int ntaps = a.kh * a.kw * C;
+  int nl = 0;
+  long sbase;                                            // first source row of this sample
+  float post = 1.0f;
   if (a.dir == 0) {
-    if (wv >= (long)a.B * a.C_out * a.H_out * a.W_out) return;
     const int ox = (int)(wv % a.W_out), oy = (int)((wv / a.W_out) % a.H_out);
     const int co = (int)((wv / ((long)a.W_out * a.H_out)) % a.C_out), b = (int)(wv / ((long)a.W_out * a.H_out * a.C_out));
-    for (int ky = 0; ky < a.kh; ++ky) {
-      const int iy = oy * a.stride - a.pad + ky;
-      if ((unsigned)iy >= (unsigned)a.H_in) continue;
-      for (int kx = 0; kx < a.kw; ++kx) {
-        const int ix = ox * a.stride - a.pad + kx;
-        if ((unsigned)ix >= (unsigned)a.W_in) continue;
-        const float f = a.norm ? (float)(t_taps(iy, a.H_out, a.kh, a.stride, a.pad) * t_taps(ix, a.W_out, a.kw, a.stride, a.pad)) : 1.0f;
-        for (int ci = 0; ci < a.C_in; ++ci) {
-          float v = a.src[((((long)b * a.C_in + ci) * a.H_in + iy) * a.W_in + ix) * 64 + lane];
-          if (a.norm) v = v / f;
-          acc = fmaf(a.w[(((long)co * a.C_in + ci) * a.kh + ky) * a.kw + kx], v, acc);
-        }
+    sbase = (long)b * a.C_in * a.H_in * a.W_in;
+    for (int t0 = 0; t0 < ntaps; t0 += 64) {
+      const int t = t0 + lane;
+      const int ci = t % C, kx = (t / C) % a.kw, ky = t / (C * a.kw);
+      const int iy = oy * a.stride - a.pad + ky, ix = ox * a.stride - a.pad + kx;
+      const bool ok = t < ntaps && (unsigned)iy < (unsigned)a.H_in && (unsigned)ix < (unsigned)a.W_in;
+      const unsigned long long bal = __ballot(ok);
+      if (ok) {
+        const int p = nl + __popcll(bal & ((1ull << lane) - 1ull));
+        s_row[wave][p] = (ci * a.H_in + iy) * a.W_in + ix;
+        s_w[wave][p] = a.w[(((long)co * a.C_in + ci) * a.kh + ky) * a.kw + kx];
+        s_f[wave][p] = a.norm ? (float)(t_taps(iy, a.H_out, a.kh, a.stride, a.pad) * t_taps(ix, a.W_out, a.kw, a.stride, a.pad)) : 1.0f;
       }
+      nl += __popcll(bal);
     }
-    out = wv;
   } else {
-    if (wv >= (long)a.B * a.C_in * a.H_in * a.W_in) return;
     const int x = (int)(wv % a.W_in), y = (int)((wv / a.W_in) % a.H_in);
     const int ci = (int)((wv / ((long)a.W_in * a.H_in)) % a.C_in), b = (int)(wv / ((long)a.W_in * a.H_in * a.C_in));
-    for (int ky = 0; ky < a.kh; ++ky) {
-      const int ty = y + a.pad - ky;
-      if (ty < 0 || ty % a.stride != 0 || ty / a.stride >= a.H_out) continue;
-      const int oy = ty / a.stride;
-      for (int kx = 0; kx < a.kw; ++kx) {
-        const int tx = x + a.pad - kx;
-        if (tx < 0 || tx % a.stride != 0 || tx / a.stride >= a.W_out) continue;
-        const int ox = tx / a.stride;
-        for (int co = 0; co < a.C_out; ++co)
-          acc = fmaf(a.w[(((long)co * a.C_in + ci) * a.kh + ky) * a.kw + kx],
-                     a.src[((((long)b * a.C_out + co) * a.H_out + oy) * a.W_out + ox) * 64 + lane], acc);
+    sbase = (long)b * a.C_out * a.H_out * a.W_out;
+    for (int t0 = 0; t0 < ntaps; t0 += 64) {
+      const int t = t0 + lane;
+      const int co = t % C, kx = (t / C) % a.kw, ky = t / (C * a.kw);
+      const int ty = y + a.pad - ky, tx = x + a.pad - kx;
+      const bool ok = t < ntaps && ty >= 0 && ty % a.stride == 0 && ty / a.stride < a.H_out && tx >= 0 && tx % a.stride == 0 && tx / a.stride < a.W_out;
+      const unsigned long long bal = __ballot(ok);
+      if (ok) {
+        const int p = nl + __popcll(bal & ((1ull << lane) - 1ull));
+        s_row[wave][p] = (co * a.H_out + ty / a.stride) * a.W_out + tx / a.stride;
+        s_w[wave][p] = a.w[(((long)co * a.C_in + ci) * a.kh + ky) * a.kw + kx];
+        s_f[wave][p] = 1.0f;
+      }
+      nl += __popcll(bal);
+    }
+    if (a.norm) post = (float)(t_taps(y, a.H_out, a.kh, a.stride, a.pad) * t_taps(x, a.W_out, a.kw, a.stride, a.pad));
+  }
+  __builtin_amdgcn_wave_barrier();
+  const float* src = a.src + sbase * 64 + lane;
+  const bool nrm0 = a.dir == 0 && a.norm;
+  float acc = 0.0f;
+  for (int q = 0; q < nl; q += TCONV_BATCH) {
+    float v[TCONV_BATCH], w[TCONV_BATCH], f[TCONV_BATCH];
+#pragma unroll
+    for (int u = 0; u < TCONV_BATCH; ++u) {
+      const bool in = q + u < nl;                        // (wave-uniform)
+      w[u] = in ? s_w[wave][q + u] : 0.0f;
+      f[u] = in ? s_f[wave][q + u] : 1.0f;
+      v[u] = in ? src[(long)s_row[wave][q + u] * 64] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < TCONV_BATCH; ++u) {
+      if (q + u < nl) {
+        float vv = v[u];
+        if (nrm0) vv = vv / f[u];
+        acc = fmaf(w[u], vv, acc);
       }
     }
-    if (a.norm) acc = acc / (float)(t_taps(y, a.H_out, a.kh, a.stride, a.pad) * t_taps(x, a.W_out, a.kw, a.stride, a.pad));
-    out = wv;
   }
-  if (a.acc) a.dst[out * 64 + lane] += acc;
-  else a.dst[out * 64 + lane] = acc;
+  if (a.dir == 1 && a.norm) acc = acc / post;
+  if (a.acc) a.dst[wv * 64 + lane] += acc;
+  else a.dst[wv * 64 + lane] = acc;
 }
 
 struct TDense {
@@ -527,9 +561,12 @@ struct TDense {
   int dir;    // 0: dst (B, n_out, 64) = A src (B, n_in, 64);  1: dst (B, n_in, 64) = A^T src (B, n_out, 64)
   int acc;
 };
-// one workgroup per destination row: its 4 waves take every 4th source row, partial sums added in wave order
-__global__ __launch_bounds__(256) void k_tdense(TDense a) {
-  __shared__ float red[4][64];
+// one workgroup of TD_WAVES waves per destination row: wave w takes the source rows w, w + TD_WAVES, ... (16 independent loads at a
+// time, their fmas in row order), the partial sums are added in wave order.  (4 waves walked the 1024 source rows of the Linear
+// edge in 16 dependent batches: 20 us per launch.)
+#define TD_WAVES 16
+__global__ __launch_bounds__(TD_WAVES * 64) void k_tdense(TDense a) {
+  __shared__ float red[TD_WAVES][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long wv = blockIdx.x;
   const int nd = a.dir == 0 ? a.n_out : a.n_in, ns = a.dir == 0 ? a.n_in : a.n_out;
@@ -537,12 +574,25 @@ __global__ __launch_bounds__(256) void k_tdense(TDense a) {
   const float* A = a.A + (long)b * a.a_bstride;
   const float* src = a.src + (long)b * ns * 64 + lane;
   float acc = 0.0f;
-  if (a.dir == 0) for (int k = wave; k < ns; k += 4) acc = fmaf(A[(long)i * a.n_in + k], src[(long)k * 64], acc);
-  else for (int k = wave; k < ns; k += 4) acc = fmaf(A[(long)k * a.n_in + i], src[(long)k * 64], acc);
+  for (int k0 = wave; k0 < ns; k0 += 16 * TD_WAVES) {
+    float w[16], v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int k = k0 + TD_WAVES * u;
+      const bool in = k < ns;                            // (wave-uniform)
+      w[u] = in ? (a.dir == 0 ? A[(long)i * a.n_in + k] : A[(long)k * a.n_in + i]) : 0.0f;
+      v[u] = in ? src[(long)k * 64] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (k0 + TD_WAVES * u < ns) acc = fmaf(w[u], v[u], acc);
+  }
   red[wave][lane] = acc;
   __syncthreads();
   if (wave) return;
-  acc = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  acc = red[0][lane];
+#pragma unroll
+  for (int w = 1; w < TD_WAVES; ++w) acc += red[w][lane];
   if (a.acc) a.dst[wv * 64 + lane] += acc;
   else a.dst[wv * 64 + lane] = acc;
 }
