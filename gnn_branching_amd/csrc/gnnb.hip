@@ -1495,6 +1495,7 @@ extern "C" int gnnb_online_create(gnnb_t* h, float lr, float weight_decay) {
   HIPCHK(hipMemcpy(t->d_w, h->blob.data(), n * sizeof(float), hipMemcpyHostToDevice));
   HIPCHK(hipFuncSetAttribute((const void*)gnnb_train::k_tchain_fwd<TL_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)gnnb_train::k_tchain_fwd<TL_ROWS_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)gnnb_train::k_tchain_fwd<TL_ROWS_TINY>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   return GNNB_OK;
 }
 

@@ -111,6 +111,7 @@ struct TLin {
 struct TChain { TLin op[TC_MAXOPS]; int nops; };
 #define TL_ROWS 32      // rows per block of a chain kernel when there are many (TL_ROWS_SMALL otherwise: more, lighter blocks)
 #define TL_ROWS_SMALL 8
+#define TL_ROWS_TINY 4
 #define TL_CHUNK 64
 
 __device__ __forceinline__ TSeg tl_seg(const TLin& a, int j) { return j == 0 ? a.seg[0] : j == 1 ? a.seg[1] : a.seg[2]; }
@@ -760,21 +761,23 @@ struct Trainer {
       Kmax = a.K > Kmax ? a.K : Kmax;
       out.push_back(y);
     }
-    // few rows (the latency case: one subproblem has ~1000 live nodes per layer): 8-row tiles -- four times the blocks, each a
-    // quarter of the inner loop, the weights staged per block either way; many rows: 32-row tiles amortise the staging
+    // few rows (the latency case: one subproblem has ~1000 live nodes per layer): 4-row tiles -- eight times the blocks, each an
+    // eighth of the inner loop, the weights staged per block either way (base B = 1, ms per step: 32-row tiles 3.31, 16: 2.64, 8:
+    // 2.56, 4: 2.21); a few thousand rows: 8-row tiles; many rows: 32-row tiles amortise the staging
     const long nrows = list ? list->cap : n;
-    const bool small = nrows <= (long)TL_ROWS * 4 * n_cu;
-    const int R = small ? TL_ROWS_SMALL : TL_ROWS;
+    const int R = nrows <= 16L * n_cu ? TL_ROWS_TINY : (nrows <= 128L * n_cu ? TL_ROWS_SMALL : TL_ROWS);
     const unsigned nblk = (unsigned)((nrows + R - 1) / R);
     const size_t lds = ((size_t)(Kmax | 1) * 64 + (size_t)R * Kmax + (size_t)R * 64) * 4;
-    if (small) hipLaunchKernelGGL(k_tchain_fwd<TL_ROWS_SMALL>, dim3(nblk), dim3(256), lds, st, c);
+    if (R == TL_ROWS_TINY) hipLaunchKernelGGL(k_tchain_fwd<TL_ROWS_TINY>, dim3(nblk), dim3(256), lds, st, c);
+    else if (R == TL_ROWS_SMALL) hipLaunchKernelGGL(k_tchain_fwd<TL_ROWS_SMALL>, dim3(nblk), dim3(256), lds, st, c);
     else hipLaunchKernelGGL(k_tchain_fwd<TL_ROWS>, dim3(nblk), dim3(256), lds, st, c);
-    tape.push_back([this, c, nblk, small]() {
+    tape.push_back([this, c, nblk, R]() {
       bool any = false;
       for (int i = 0; i < c.nops; ++i)
         for (int j = 0; j < c.op[i].nseg; ++j) any = any || c.op[i].seg[j].gx;
       if (any) {
-        if (small) hipLaunchKernelGGL(k_tchain_bwd_x<TL_ROWS_SMALL>, dim3(nblk), dim3(256), 0, st, c);
+        if (R == TL_ROWS_TINY) hipLaunchKernelGGL(k_tchain_bwd_x<TL_ROWS_TINY>, dim3(nblk), dim3(256), 0, st, c);
+        else if (R == TL_ROWS_SMALL) hipLaunchKernelGGL(k_tchain_bwd_x<TL_ROWS_SMALL>, dim3(nblk), dim3(256), 0, st, c);
         else hipLaunchKernelGGL(k_tchain_bwd_x<TL_ROWS>, dim3(nblk), dim3(256), 0, st, c);
       }
       for (int i = c.nops - 1; i >= 0; --i) wops.push_back(c.op[i]);
