@@ -321,8 +321,6 @@ static void free_trainer(gnnb_t* h) {
   for (float* p : t->edge_w)
     if (p) (void)hipFree(p);
   t->arena.release();
-  for (hipEvent_t e : t->events) (void)hipEventDestroy(e);
-  if (t->side) (void)hipStreamDestroy(t->side);
   delete t;
   h->trainer = nullptr;
 }
@@ -1527,7 +1525,6 @@ extern "C" int gnnb_online_step(gnnb_t* h, const gnnb_batch* in, int B, const in
   hipStream_t st = (hipStream_t)stream;
   t.st = st;
   t.n_cu = h->n_cu;
-  t.ev_next = 0;
   t.tape.clear();
   if (t.arena.reset(st)) return fail(GNNB_E_HIP, "gnnb_online_step: arena reset failed");
   if (t.edge_w.empty()) {                                  // torch-layout copies of the verified network's weights

@@ -691,32 +691,6 @@ struct Trainer {
   std::vector<std::function<void()>> tape;
   hipStream_t st = nullptr;
   int n_cu = 256;
-  // weight-gradient kernels never feed the rest of the backward pass: they run on a side stream, ordered behind the point of
-  // the main stream where their gy is final (same order among themselves as on one stream, so the sums stay reproducible)
-  hipStream_t side = nullptr;
-  std::vector<hipEvent_t> events;
-  size_t ev_next = 0;
-  hipStream_t fork() {
-    if (!side) return st;
-    if (ev_next == events.size()) {
-      hipEvent_t e;
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return st;
-      events.push_back(e);
-    }
-    hipEvent_t e = events[ev_next++];
-    if (hipEventRecord(e, st) != hipSuccess || hipStreamWaitEvent(side, e, 0) != hipSuccess) return st;
-    return side;
-  }
-  int join() {                     // the main stream continues behind everything on the side stream
-    if (!side) return 0;
-    if (ev_next == events.size()) {
-      hipEvent_t e;
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return 1;
-      events.push_back(e);
-    }
-    hipEvent_t e = events[ev_next++];
-    return hipEventRecord(e, side) != hipSuccess || hipStreamWaitEvent(st, e, 0) != hipSuccess;
-  }
   float *d_scores = nullptr, *d_ds = nullptr, *d_loss = nullptr, *d_imp = nullptr; int *d_kw = nullptr, *d_sel = nullptr;
   int cap_B = 0;
   std::vector<float> h_loss;
