@@ -53,7 +53,7 @@ static_assert(sizeof(QHdr) == QHDR_INTS * 4, "queue header");
 __device__ __forceinline__ int q_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // the folded node update (see node_update_loop) on ring slot `ring` (32 rows of QROW floats); `release` runs once the rows are in registers
-// keep != nullptr: the rows E are handed back in *keep (k_scored_tail feeds them to the score head) and not stored
+// keep != nullptr: the rows E are also handed back in *keep (k_scored_tail feeds them to the score head without reading them back)
 template <bool POST, class Release>
 __device__ __forceinline__ void q_chain(const FArgs& a, const float* lds, const float* ring, int nvalid, int lane, Release release, Frag* keep = nullptr) {
   const int h = lane >> 5, j = lane & 31;
@@ -96,7 +96,7 @@ __device__ __forceinline__ void q_chain(const FArgs& a, const float* lds, const 
   frag_relu(H2);
   if (valid) {
     if (frag_has_nan(H2)) atomicOr(a.u.status, 1);
-    if (a.u.mu && !keep) frag_store_rows(H2, a.u.mu, gc, h);
+    if (a.u.mu) frag_store_rows(H2, a.u.mu, gc, h);
   }
   if (keep) *keep = H2;
   if (POST) {

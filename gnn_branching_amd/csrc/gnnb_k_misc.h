@@ -374,8 +374,8 @@ __global__ __launch_bounds__(GS_WAVES * 64) void k_gather_scored(GSArgs a) {
 // k_scored_tail: the end of a forward at SMALL batch sizes in one launch instead of three (k_gather_scored, the restricted
 // k_node_update, k_score): after the last backward sweep mu[1] is read by the score head only, at the scored nodes, so their
 // transposed aggregate (one wave per node, lane = channel: gather_scored_node, the code of k_gather_scored), the folded node
-// update (q_chain, the arithmetic of k_node_update) and the score head (score_rows) run back to back on a tile of 32 scored
-// nodes without the rows ever leaving the CU; the scored nodes of the other layers go through the score head as in k_score, and
+// update (q_chain, the arithmetic of k_node_update) and the score head (score_rows) run back to back on a tile of 16 scored
+// nodes (the rows are still written to mu[1], as the three kernels did: inspection reads them, the score head does not); the scored nodes of the other layers go through the score head as in k_score, and
 // the workgroup that finishes last turns the per-sample keys into decisions.  Same arithmetic per node as the three kernels:
 // bit-identical scores (tests).  At B <= 8 each of the three launches was its own ramp (weights staged, one tile's dependent
 // loads): 10 + 13 + 15 us at B = 1.
