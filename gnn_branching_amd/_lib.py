@@ -14,7 +14,7 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.environ.get("GNNB_LIB", os.path.join(CSRC, "libgnnb.so"))     # GNNB_LIB: dev override (ablation builds)
 SOURCES = ["gnnb.hip", "gnnb_dev.h", "gnnb_k_mlp.h", "gnnb_k_gather.h", "gnnb_k_fusedq.h", "gnnb_k_edges.h", "gnnb_k_misc.h", "gnnb_pack.h", "gnnb_train.h"]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread"]
 
 GNNB_CONV, GNNB_LINEAR, GNNB_RELU, GNNB_FLATTEN = 0, 1, 2, 3
 

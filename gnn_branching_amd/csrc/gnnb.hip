@@ -32,6 +32,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <chrono>
 
 #include "../../include/gnnb.h"
 #include "gnnb_pack.h"
@@ -179,8 +180,11 @@ static int upload(float** d, const float* h, size_t n) {
 
 // (re)build the operand packs of the scorer from a parameter blob and put them on the device
 static int load_weights(gnnb_t* h, const float* w_blob, hipStream_t st) {
+  static const bool timing = std::getenv("GNNB_PACK_TIMING") != nullptr;       // dev aid: where the time of this call goes, to stderr
+  const auto t_start = std::chrono::steady_clock::now();
   h->blob.assign(w_blob, w_blob + blob_floats());
   build_packs(h->blob.data(), h->packs);
+  const auto t_built = std::chrono::steady_clock::now();
   const std::vector<float>* pv[N_PACKS] = {&h->packs.embed, &h->packs.pre_fwd, &h->packs.pre_bwd, &h->packs.pre_inp, &h->packs.prop,
                                            &h->packs.upd_fwd_e, &h->packs.upd_fwd_i, &h->packs.upd_fwd_f, &h->packs.upd_bwd,
                                            &h->packs.upd_bwd_b, &h->packs.upd_inp, &h->packs.post_inp, &h->packs.score_b,
@@ -195,14 +199,25 @@ static int load_weights(gnnb_t* h, const float* w_blob, hipStream_t st) {
     HIPCHK(hipHostMalloc((void**)&h->pack_stage, total * sizeof(float), hipHostMallocDefault));
     h->pack_stage_floats = total;
   }
+  if (!h->d_pack[0]) {                    // one device block, pack i at the offset it has in the staging buffer: one copy per call
+    float* base = nullptr;
+    HIPCHK(hipMalloc((void**)&base, total * sizeof(float)));
+    size_t o = 0;
+    for (int i = 0; i < N_PACKS; ++i) { h->d_pack[i] = base + o; o += (pv[i]->size() + 63) & ~(size_t)63; }
+  }
   size_t off = 0;
   for (int i = 0; i < N_PACKS; ++i) {
-    if (!h->d_pack[i]) HIPCHK(hipMalloc((void**)&h->d_pack[i], pv[i]->size() * sizeof(float)));
     std::memcpy(h->pack_stage + off, pv[i]->data(), pv[i]->size() * sizeof(float));
-    HIPCHK(hipMemcpyAsync(h->d_pack[i], h->pack_stage + off, pv[i]->size() * sizeof(float), hipMemcpyHostToDevice, st));
     off += (pv[i]->size() + 63) & ~(size_t)63;
   }
+  HIPCHK(hipMemcpyAsync(h->d_pack[0], h->pack_stage, total * sizeof(float), hipMemcpyHostToDevice, st));
+  const auto t_issued = std::chrono::steady_clock::now();
   HIPCHK(hipStreamSynchronize(st));       // the staging buffer is reused by the next call
+  if (timing) {
+    const auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    fprintf(stderr, "load_weights: build %.0f us, stage+issue %.0f us (%zu KiB), wait %.0f us\n", us(t_start, t_built), us(t_built, t_issued),
+            total * sizeof(float) / 1024, us(t_issued, std::chrono::steady_clock::now()));
+  }
   return 0;
 }
 
@@ -321,6 +336,7 @@ static void free_trainer(gnnb_t* h) {
   for (float* p : t->edge_w)
     if (p) (void)hipFree(p);
   t->arena.release();
+  if (t->desc) (void)hipHostFree(t->desc);
   delete t;
   h->trainer = nullptr;
 }
@@ -355,8 +371,7 @@ static void free_network(gnnb_t* h) {
 extern "C" int gnnb_destroy(gnnb_t* h) {
   if (!h) return GNNB_OK;
   free_network(h);
-  for (int i = 0; i < N_PACKS; ++i)
-    if (h->d_pack[i]) (void)hipFree(h->d_pack[i]);
+  if (h->d_pack[0]) (void)hipFree(h->d_pack[0]);      // one block (load_weights)
   if (h->d_zero) (void)hipFree(h->d_zero);
   if (h->d_ctl) (void)hipFree(h->d_ctl);
   if (h->pack_stage) (void)hipHostFree(h->pack_stage);
@@ -1491,6 +1506,10 @@ extern "C" int gnnb_online_create(gnnb_t* h, float lr, float weight_decay) {
     HIPCHK(hipMemset(*p, 0, n * sizeof(float)));
   }
   HIPCHK(hipMemcpy(t->d_w, h->blob.data(), n * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(hipHostMalloc((void**)&t->desc, sizeof(gnnb_train::TChain) * gnnb_train::Trainer::kDescCap, hipHostMallocDefault));
+  HIPCHK(hipFuncSetAttribute((const void*)gnnb_train::k_tchain_fwd_multi<TL_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)gnnb_train::k_tchain_fwd_multi<TL_ROWS_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)gnnb_train::k_tchain_fwd_multi<TL_ROWS_TINY>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)gnnb_train::k_tchain_fwd<TL_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)gnnb_train::k_tchain_fwd<TL_ROWS_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)gnnb_train::k_tchain_fwd<TL_ROWS_TINY>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
@@ -1526,6 +1545,7 @@ extern "C" int gnnb_online_step(gnnb_t* h, const gnnb_batch* in, int B, const in
   t.st = st;
   t.n_cu = h->n_cu;
   t.tape.clear();
+  t.ndesc = 0;
   if (t.arena.reset(st)) return fail(GNNB_E_HIP, "gnnb_online_step: arena reset failed");
   if (t.edge_w.empty()) {                                  // torch-layout copies of the verified network's weights
     t.edge_w.assign(h->edges.size(), nullptr);
@@ -1552,37 +1572,48 @@ extern "C" int gnnb_online_step(gnnb_t* h, const gnnb_batch* in, int B, const in
   // ---- per-node constants ----
   struct LC { float *r0, *r1, *amb, *live, *nd2, *d1, *ff, *fb; Trainer::List ambl, livel; };
   std::vector<LC> lc(L + 1);
-  for (int k = 1; k <= L; ++k) {
-    const long n = (long)B * h->N[k];
-    LC& c = lc[k];
-    for (float** p : {&c.r0, &c.r1, &c.amb, &c.live, &c.nd2, &c.d1}) *p = t.arena.alloc(n);
-    c.ff = t.arena.alloc(7 * n);
-    c.fb = t.arena.alloc(7 * n);
-    if (t.arena.err) return fail(GNNB_E_NOMEM, "gnnb_online_step: out of device memory");
-    const int q = h->relu_q[k];
-    TPrepArgs a{in->lb[k], in->ub[k], in->dual[k - 1], in->primal[q - 1], in->primal[q], h->dev[k].bias, h->N[k], h->hw[k], n,
-                c.r0, c.r1, c.amb, c.live, c.nd2, c.d1, c.ff, c.fb};
-    hipLaunchKernelGGL(k_tprep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
-    // node lists: the relaxation chains run over the ambiguous nodes, the update chains over the live ones
-    int* buf = reinterpret_cast<int*>(t.arena.alloc(2 * n + 2));
-    if (!buf) return fail(GNNB_E_NOMEM, "gnnb_online_step: out of device memory");
-    c.ambl = Trainer::List{buf, buf + 2 * n, n};
-    c.livel = Trainer::List{buf + n, buf + 2 * n + 1, n};
-    hipLaunchKernelGGL(k_tcompact, dim3(1), dim3(256), 0, st, TCompact{c.amb, buf, buf + 2 * n, n});
-    hipLaunchKernelGGL(k_tcompact, dim3(1), dim3(256), 0, st, TCompact{c.live, buf + n, buf + 2 * n + 1, n});
+  if (L > T_MAXL) return fail(GNNB_E_INVALID, "gnnb_online_step: more than %d ReLU layers", T_MAXL);
+  {
+    TPrepMulti pm{};
+    TCompactMulti cm{};
+    long nmax = 0;
+    for (int k = 1; k <= L; ++k) {
+      const long n = (long)B * h->N[k];
+      nmax = n > nmax ? n : nmax;
+      LC& c = lc[k];
+      for (float** p : {&c.r0, &c.r1, &c.amb, &c.live, &c.nd2, &c.d1}) *p = t.arena.alloc(n);
+      c.ff = t.arena.alloc(7 * n);
+      c.fb = t.arena.alloc(7 * n);
+      // node lists: the relaxation chains run over the ambiguous nodes, the update chains over the live ones
+      int* buf = reinterpret_cast<int*>(t.arena.alloc(2 * n + 2));
+      if (t.arena.err || !buf) return fail(GNNB_E_NOMEM, "gnnb_online_step: out of device memory");
+      const int q = h->relu_q[k];
+      pm.a[k - 1] = TPrepArgs{in->lb[k], in->ub[k], in->dual[k - 1], in->primal[q - 1], in->primal[q], h->dev[k].bias, h->N[k], h->hw[k], n,
+                              c.r0, c.r1, c.amb, c.live, c.nd2, c.d1, c.ff, c.fb};
+      c.ambl = Trainer::List{buf, buf + 2 * n, n};
+      c.livel = Trainer::List{buf + n, buf + 2 * n + 1, n};
+      cm.a[2 * (k - 1)] = TCompact{c.amb, buf, buf + 2 * n, n};
+      cm.a[2 * (k - 1) + 1] = TCompact{c.live, buf + n, buf + 2 * n + 1, n};
+    }
+    hipLaunchKernelGGL(k_tprep, dim3((unsigned)((nmax + 255) / 256), (unsigned)L), dim3(256), 0, st, pm);      // every layer, one launch
+    hipLaunchKernelGGL(k_tcompact, dim3((unsigned)(2 * L)), dim3(256), 0, st, cm);                              // every list, one launch
   }
-  auto cols = [&](std::initializer_list<const float*> cs, long n) {
-    TColsArgs a{};
-    int w = 0;
-    for (const float* c : cs) a.c[w++] = c;
-    a.w = w; a.n = n; a.dst = t.arena.alloc((size_t)n * w);
-    hipLaunchKernelGGL(k_tcols, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
-    return (const float*)a.dst;
-  };
   const long n0 = (long)B * h->N[0];
-  const float* inp3 = cols({in->lb[0], in->x_lp, in->ub[0]}, n0);                       // graph_conv.py:90-93
-  const float* inp2 = cols({in->lb[0], in->ub[0]}, n0);                                 // :380-381
-  const float* featp = cols({in->lb[K], in->ub[K], in->primal[in->n_primal - 1], in->prop_b}, B);     // :202-205
+  const float *inp3, *inp2, *featp;
+  {
+    TColsMulti m{};
+    auto job = [&](int j, std::initializer_list<const float*> cs, long n) {
+      TColsArgs& a = m.a[j];
+      int w = 0;
+      for (const float* c : cs) a.c[w++] = c;
+      a.w = w; a.n = n; a.dst = t.arena.alloc((size_t)n * w);
+      return (const float*)a.dst;
+    };
+    inp3 = job(0, {in->lb[0], in->x_lp, in->ub[0]}, n0);                                                    // graph_conv.py:90-93
+    inp2 = job(1, {in->lb[0], in->ub[0]}, n0);                                                              // :380-381
+    featp = job(2, {in->lb[K], in->ub[K], in->primal[in->n_primal - 1], in->prop_b}, B);                   // :202-205
+    hipLaunchKernelGGL(k_tcols, dim3((unsigned)(((n0 > B ? n0 : B) + 255) / 256), 3), dim3(256), 0, st, m);
+  }
 
   auto edge = [&](int k, int dir, int norm, const TT& src) {       // nb = A_k src (dir 0) or A_k^T src (dir 1, / tap count if norm)
     const Edge& e = h->edges[k];
@@ -1624,16 +1655,22 @@ extern "C" int gnnb_online_step(gnnb_t* h, const gnnb_batch* in, int B, const in
   // relax.g before the chain is walked back once) and only for the ambiguous nodes (`* amb` zeroes every other row).
   // Each MLP chain is one launch (Trainer::chain).
   std::vector<TT> relax_f(L + 1), relax_b(L + 1);
-  for (int k = 1; k <= L; ++k) {
-    const LC& c = lc[k];
-    const long n = (long)B * h->N[k];
-    relax_f[k] = t.chain({Spec{L_FC1, {}, c.ff, true, nullptr, false},
-                          Spec{L_FC1_1, {P()}, nullptr, false, c.amb, true}}, n, &c.ambl)[1];                    // :160-161
-    relax_b[k] = t.chain({Spec{L_BC1, {}, c.fb, true, nullptr, false},
-                          Spec{L_BC1_1, {P()}, nullptr, true, nullptr, false},
-                          Spec{L_BC1_2, {P()}, nullptr, false, nullptr, false},                                   // :285
-                          Spec{L_BC2, {P(), P(c.nd2), P(c.d1)}, nullptr, true, nullptr, false},                   // :287-291
-                          Spec{L_BC2_1, {P()}, nullptr, false, c.amb, true}}, n, &c.ambl)[4];                     // :293
+  {
+    std::vector<Trainer::Job> jf, jb;
+    for (int k = 1; k <= L; ++k) {
+      const LC& c = lc[k];
+      const long n = (long)B * h->N[k];
+      jf.push_back({{Spec{L_FC1, {}, c.ff, true, nullptr, false},
+                     Spec{L_FC1_1, {P()}, nullptr, false, c.amb, true}}, n, &c.ambl});                            // :160-161
+      jb.push_back({{Spec{L_BC1, {}, c.fb, true, nullptr, false},
+                     Spec{L_BC1_1, {P()}, nullptr, true, nullptr, false},
+                     Spec{L_BC1_2, {P()}, nullptr, false, nullptr, false},                                        // :285
+                     Spec{L_BC2, {P(), P(c.nd2), P(c.d1)}, nullptr, true, nullptr, false},                        // :287-291
+                     Spec{L_BC2_1, {P()}, nullptr, false, c.amb, true}}, n, &c.ambl});                            // :293
+    }
+    auto of = t.chain_multi(jf);         // every layer's chain in one launch
+    auto ob = t.chain_multi(jb);
+    for (int k = 1; k <= L; ++k) { relax_f[k] = of[k - 1][1]; relax_b[k] = ob[k - 1][4]; }
   }
 
   // ---- the forward of graph_conv.py:77-388, every Linear on the tape ----
@@ -1675,18 +1712,26 @@ extern "C" int gnnb_online_step(gnnb_t* h, const gnnb_batch* in, int B, const in
     }
   }
   // ---- scores (:442-450) and the loss ----
-  int off = 0;
-  for (int k = 1; k <= L; ++k) {
-    const long n = (long)B * h->N[k];
-    TT hk = t.lin(L_FNODE, {S(mu[k])}, nullptr, n, true, nullptr);
-    TScore a{hk.v, hk.g, t.d_w + weight_offset(L_FSCORE), t.d_w + bias_offset(L_FSCORE), in->mask, t.d_scores, t.d_ds, h->N[k], R, off, n,
-             t.d_g + weight_offset(L_FSCORE), t.d_g + bias_offset(L_FSCORE), t.d_sel, B};
-    hipLaunchKernelGGL(k_tscore_fwd, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, a);
-    t.tape.push_back([a, n, st]() {
-      hipLaunchKernelGGL(k_tscore_bwd, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, a);
-      hipLaunchKernelGGL(k_tscore_bwd_w, dim3(1), dim3(64), 0, st, a);
+  {
+    std::vector<Trainer::Job> jn;
+    for (int k = 1; k <= L; ++k) jn.push_back({{Spec{L_FNODE, {S(mu[k])}, nullptr, true, nullptr, false}}, (long)B * h->N[k], nullptr});
+    auto hk = t.chain_multi(jn);
+    TScoreMulti sm{};
+    int off = 0;
+    long nmax = 0;
+    for (int k = 1; k <= L; ++k) {
+      const long n = (long)B * h->N[k];
+      nmax = n > nmax ? n : nmax;
+      sm.a[k - 1] = TScore{hk[k - 1][0].v, hk[k - 1][0].g, t.d_w + weight_offset(L_FSCORE), t.d_w + bias_offset(L_FSCORE), in->mask, t.d_scores,
+                           t.d_ds, h->N[k], R, off, n, t.d_g + weight_offset(L_FSCORE), t.d_g + bias_offset(L_FSCORE), t.d_sel, B};
+      off += h->N[k];
+    }
+    const dim3 grid((unsigned)((nmax + 3) / 4), (unsigned)L);
+    hipLaunchKernelGGL(k_tscore_fwd, grid, dim3(256), 0, st, sm);
+    t.tape.push_back([sm, grid, L, st]() {
+      hipLaunchKernelGGL(k_tscore_bwd, grid, dim3(256), 0, st, sm);
+      hipLaunchKernelGGL(k_tscore_bwd_w, dim3(1), dim3(64), 0, st, sm, L);
     });
-    off += h->N[k];
   }
   if (t.arena.err) return fail(GNNB_E_NOMEM, "gnnb_online_step: out of device memory");
   if (scores_padded) HIPCHK(hipMemcpyAsync(scores_padded, t.d_scores, (size_t)B * R * 4, hipMemcpyDeviceToDevice, st));

@@ -19,8 +19,11 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <thread>
+#include <system_error>
 
 namespace gnnb {
 
@@ -88,20 +91,51 @@ inline float bf16_f32(unsigned short b) {
   return f;
 }
 inline size_t w64_bf3_floats(int nfrag) { return (size_t)6144 * nfrag; }
+// three bf16 pieces of 512 weights: o[p * 512 + i] = piece p of w[i] (bf16_rne's rounding, branch-free so that it vectorises)
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+__attribute__((target_clones("avx512f", "avx2", "default")))
+#endif
+inline void bf3_split_512(unsigned short* o, const float* w) {
+  for (int i = 0; i < 512; ++i) {
+    float x = w[i];
+    for (int p = 0; p < 3; ++p) {
+      unsigned u;
+      std::memcpy(&u, &x, 4);
+      const unsigned special = (u >> 16) | ((u & 0xffffu) ? 0x40u : 0u);                 // inf / nan
+      const unsigned rounded = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+      const unsigned b = ((u & 0x7f800000u) == 0x7f800000u) ? special : rounded;
+      o[p * 512 + i] = (unsigned short)b;
+      const unsigned back = b << 16;
+      float bf;
+      std::memcpy(&bf, &back, 4);
+      x -= bf;
+    }
+  }
+}
 inline void pack_w64_bf3(float* dst, const float* W, int ldw, int col0, int nfrag) {
-  unsigned short* d = reinterpret_cast<unsigned short*>(dst);
-  for (int f = 0; f < nfrag; ++f)
+  // entry e = ((ks * 2 + ot) * 64 + lane) * 8 + j of a fragment reads W[row[e]][col0 + 64 f + col[e]]; its pieces go to
+  // ((f*4 + ks)*2 + ot)*3*512 + p*512 + lane*8 + j: 512 consecutive entries share (ks, ot), so a block of 512 is gathered through
+  // the table and split in one vectorised pass (this runs 25 fragment-times after every online-learning step: 22 -> 6 us each)
+  struct Tab { unsigned char row[4096], col[4096]; };
+  static const Tab tab = [] {
+    Tab t;
     for (int ks = 0; ks < 4; ++ks)
       for (int ot = 0; ot < 2; ++ot)
         for (int lane = 0; lane < 64; ++lane)
           for (int j = 0; j < 8; ++j) {
-            float w = W[(size_t)(32 * ot + (lane & 31)) * ldw + col0 + 64 * f + frag_feature(8 * ks + j, lane >> 5)];
-            for (int p = 0; p < 3; ++p) {
-              const unsigned short b = bf16_rne(w);
-              d[((((size_t)(f * 4 + ks) * 2 + ot) * 3 + p) * 64 + lane) * 8 + j] = b;
-              w -= bf16_f32(b);
-            }
+            const int e = ((ks * 2 + ot) * 64 + lane) * 8 + j;
+            t.row[e] = (unsigned char)(32 * ot + (lane & 31));
+            t.col[e] = (unsigned char)frag_feature(8 * ks + j, lane >> 5);
           }
+    return t;
+  }();
+  unsigned short* d = reinterpret_cast<unsigned short*>(dst);
+  float tmp[512];
+  for (int f = 0; f < nfrag; ++f)
+    for (int c = 0; c < 8; ++c) {
+      for (int i = 0; i < 512; ++i) tmp[i] = W[(size_t)tab.row[c * 512 + i] * ldw + col0 + 64 * f + tab.col[c * 512 + i]];
+      bf3_split_512(d + (size_t)f * 12288 + (size_t)c * 1536, tmp);
+    }
 }
 
 // First layers on scalar node features (K = 2,3,4,7): natural order, k-step s holds input feature
@@ -219,14 +253,22 @@ struct PackProp { enum { W1T = 0, B1 = W1T + 4 * 64, W2T = B1 + 64, B2 = W2T + 1
 #endif
 // Cd (64 x 64, double) = A (64 x 64, row stride lda, columns [acol0, acol0+64)) . B (64 x 64 row-major)
 GNNB_HOST_SIMD inline void matmul64d(double* Cd, const float* A, int lda, int acol0, const float* B) {
-  for (int i = 0; i < 64; ++i) {          // k outer, j inner: contiguous and vectorisable
-    double* acc = Cd + (size_t)i * 64;
-    for (int j = 0; j < 64; ++j) acc[j] = 0.0;
+  alignas(64) double Bd[64 * 64];          // B widened once (the conversions, not the fmas, bounded the plain loop)
+  for (int q = 0; q < 64 * 64; ++q) Bd[q] = (double)B[q];
+  for (int i = 0; i < 64; i += 2) {        // two rows share every load of B; per row: k ascending, one fma per term
+    alignas(64) double acc0[64], acc1[64];
+    for (int j = 0; j < 64; ++j) { acc0[j] = 0.0; acc1[j] = 0.0; }
+    const float* A0 = A + (size_t)i * lda + acol0;
+    const float* A1 = A0 + lda;
     for (int k = 0; k < 64; ++k) {
-      const double a = (double)A[(size_t)i * lda + acol0 + k];
-      const float* Bk = B + (size_t)k * 64;
-      for (int j = 0; j < 64; ++j) acc[j] += a * (double)Bk[j];
+      const double a0 = (double)A0[k], a1 = (double)A1[k];
+      const double* Bk = Bd + (size_t)k * 64;
+      for (int j = 0; j < 64; ++j) {
+        acc0[j] += a0 * Bk[j];
+        acc1[j] += a1 * Bk[j];
+      }
     }
+    for (int j = 0; j < 64; ++j) { Cd[(size_t)i * 64 + j] = acc0[j]; Cd[(size_t)(i + 1) * 64 + j] = acc1[j]; }
   }
 }
 // C (64 x 64) = the same product rounded to float once
@@ -251,6 +293,10 @@ struct Packs {
   std::vector<float> upd_bwd, upd_bwd_b;                // backward: none (top layer: aggregate from the property node) / bc4_1
   std::vector<float> upd_inp, post_inp;                 // input layer: bias small k-step; the producer-side map (PackPostInp)
   std::vector<float> score_b, score_f;                  // score head on rows with bc4_1 / fc4_2 deferred
+  // work space of build_packs, one per update pack (they may be built side by side), kept across calls: allocating and
+  // releasing these 190 KB per pack on every rebuild cost more in page faults than the arithmetic
+  struct Scratch { std::vector<float> was, wcb, wa; std::vector<double> t0, t1; };
+  Scratch scratch[5];
 };
 
 inline void build_packs(const float* blob, Packs& pk) {
@@ -266,22 +312,38 @@ inline void build_packs(const float* blob, Packs& pk) {
 
   // folded bias of the update chain: bcb = b_c + W_c[:, 64:].b_b  (also added to the P' the feature chains cache)
   auto bcb_of = [&](int b, int c, float* out) { matvec64(out, W(c), 128, 64, Bv(b), Bv(c)); };
+  // Wcb = W_c[:, 64:].W_b and bcb are the same for every update pack of a direction: folded once each, before the packs
+  struct CbFold { int b, c; std::vector<float> w; float bias[64]; };
+  CbFold cb_fold[2] = {{L_FC3_2, L_FC4, std::vector<float>(64 * 64), {}}, {L_BC3_1, L_BC4, std::vector<float>(64 * 64), {}}};
+  for (CbFold& f : cb_fold) {
+    matmul64(f.w.data(), W(f.c), 128, 64, W(f.b));
+    bcb_of(f.b, f.c, f.bias);
+  }
+  auto fold_cb = [&](int b, int c, float* wcb, float* bcb) {
+    const CbFold& f = cb_fold[(b == cb_fold[0].b && c == cb_fold[0].c) ? 0 : 1];
+    std::memcpy(wcb, f.w.data(), sizeof(float) * 64 * 64);
+    std::memcpy(bcb, f.bias, sizeof(float) * 64);
+  };
   // proj >= 0: the aggregate this update reads is built from rows whose projection Linear `proj` is deferred
-  auto upd = [&](std::vector<float>& v, int a, int b, int c, int d, int proj = -1) {
+  auto upd = [&](std::vector<float>& v, Packs::Scratch& sc, int a, int b, int c, int d, int proj = -1) {
     v.assign(PackUpd::FLOATS_ALL, 0.f);
-    std::vector<float> was(64 * 64), wcb(64 * 64), wa(64 * 128);
+    std::vector<float>&was = sc.was, &wcb = sc.wcb, &wa = sc.wa;
+    was.resize(64 * 64); wcb.resize(64 * 64); wa.resize(64 * 128);
     float bcb[64];
     std::memcpy(wa.data(), W(a), sizeof(float) * 64 * 128);
     if (proj >= 0) {
-      std::vector<double> t0(64 * 64), t1(64 * 64);          // Wa[:, :64].Wp and Wa[:, 64:].Wp in double
+      std::vector<double>&t0 = sc.t0, &t1 = sc.t1;           // Wa[:, :64].Wp and Wa[:, 64:].Wp in double
+      t0.resize(64 * 64); t1.resize(64 * 64);
       float vaw[128];
       matmul64d(t0.data(), W(a), 128, 0, W(proj));
       matmul64d(t1.data(), W(a), 128, 64, W(proj));
+      const float* Wa = W(a);                 // (weight_offset walks the layer table: not inside the loops)
+      const float* bp = Bv(proj);
       for (int i = 0; i < 64; ++i) {
         double s0 = 0.0, s1 = 0.0;
         for (int k = 0; k < 64; ++k) {
-          s0 += (double)W(a)[i * 128 + k] * (double)Bv(proj)[k];
-          s1 += (double)W(a)[i * 128 + 64 + k] * (double)Bv(proj)[k];
+          s0 += (double)Wa[i * 128 + k] * (double)bp[k];
+          s1 += (double)Wa[i * 128 + 64 + k] * (double)bp[k];
         }
         vaw[2 * i] = (float)s0; vaw[2 * i + 1] = (float)s1;
         for (int j = 0; j < 64; ++j) {
@@ -292,11 +354,11 @@ inline void build_packs(const float* blob, Packs& pk) {
       }
       pack_wsmall(&v[PackUpd::VAW], vaw, 2, 1);
     } else {
+      const float* Wa = W(a);
       for (int i = 0; i < 64; ++i)
-        for (int k = 0; k < 64; ++k) was[i * 64 + k] = (float)((double)W(a)[i * 128 + k] + (double)W(a)[i * 128 + 64 + k]);
+        for (int k = 0; k < 64; ++k) was[i * 64 + k] = (float)((double)Wa[i * 128 + k] + (double)Wa[i * 128 + 64 + k]);
     }
-    matmul64(wcb.data(), W(c), 128, 64, W(b));
-    bcb_of(b, c, bcb);
+    fold_cb(b, c, wcb.data(), bcb);
     pack_w64(&v[PackUpd::WA], wa.data(), 128, 0, 2);
     pack_w64(&v[PackUpd::WAS], was.data(), 64, 0, 1);
     pack_vec64(&v[PackUpd::BA], Bv(a));
@@ -308,11 +370,33 @@ inline void build_packs(const float* blob, Packs& pk) {
     (void)d;   // the last layer is folded into the consumers of the rows
     std::memcpy(&v[PackUpd::BCBROW], bcb, 64 * sizeof(float));
   };
-  upd(pk.upd_fwd_e, L_FC3, L_FC3_2, L_FC4, L_FC4_2, L_INP_F_1);      // layer 1, round 0: mu0 comes from the embedding
-  upd(pk.upd_fwd_i, L_FC3, L_FC3_2, L_FC4, L_FC4_2, L_INP_B2_2);     // layer 1, later rounds: from the input-layer update
-  upd(pk.upd_fwd_f, L_FC3, L_FC3_2, L_FC4, L_FC4_2, L_FC4_2);        // layers >= 2: from the forward update below
-  upd(pk.upd_bwd, L_BC3, L_BC3_1, L_BC4, L_BC4_1);                   // top layer: final aggregate from the property node
-  upd(pk.upd_bwd_b, L_BC3, L_BC3_1, L_BC4, L_BC4_1, L_BC4_1);        // below: from the backward update above
+  // The four update packs with a folded projection are two thirds of this function's work and independent of each other and of
+  // the rest: two helper threads take two each while this one builds everything else (the rebuild tails every online-learning
+  // step).  Without threads (creation refused) the same calls run here.
+  auto upd_e_i = [&]() {
+    upd(pk.upd_fwd_e, pk.scratch[0], L_FC3, L_FC3_2, L_FC4, L_FC4_2, L_INP_F_1);      // layer 1, round 0: mu0 comes from the embedding
+    upd(pk.upd_fwd_i, pk.scratch[1], L_FC3, L_FC3_2, L_FC4, L_FC4_2, L_INP_B2_2);     // layer 1, later rounds: from the input-layer update
+  };
+  auto upd_f_b = [&]() {
+    upd(pk.upd_fwd_f, pk.scratch[2], L_FC3, L_FC3_2, L_FC4, L_FC4_2, L_FC4_2);        // layers >= 2: from the forward update below
+    upd(pk.upd_bwd_b, pk.scratch[3], L_BC3, L_BC3_1, L_BC4, L_BC4_1, L_BC4_1);        // below: from the backward update above
+  };
+  std::thread helper[2];
+  bool threaded[2] = {false, false};
+#ifndef GNNB_PACK_NO_THREADS
+  static const bool use_threads = [] { const char* e = std::getenv("GNNB_PACK_THREADS"); return !e || std::atoi(e) != 0; }();
+  if (use_threads) {
+    try { helper[0] = std::thread(upd_e_i); threaded[0] = true; } catch (const std::system_error&) {}
+    try { helper[1] = std::thread(upd_f_b); threaded[1] = true; } catch (const std::system_error&) {}
+  }
+#endif
+  struct Join {
+    std::thread* t; bool* on;
+    ~Join() { for (int i = 0; i < 2; ++i) if (on[i]) t[i].join(); }
+  } join{helper, threaded};
+  if (!threaded[0]) upd_e_i();
+  if (!threaded[1]) upd_f_b();
+  upd(pk.upd_bwd, pk.scratch[4], L_BC3, L_BC3_1, L_BC4, L_BC4_1);                   // top layer: final aggregate from the property node
   {   // the feature chains cache P' = W4[:, :64].relax + bcb, relax = fc1_1(.) folded in
     float bcb[64], b2[64];
     std::vector<float> w2(64 * 64);

@@ -60,7 +60,10 @@ struct TPrepArgs {
   int N, hw; long n;
   float *r0, *r1, *amb, *live, *nd2, *d1, *featf, *featb;   // (n) each, features (n, 7)
 };
-__global__ void k_tprep(TPrepArgs a) {
+#define T_MAXL 8        // ReLU layers the merged per-layer launches of a step carry (gnnb_online_step rejects deeper networks)
+struct TPrepMulti { TPrepArgs a[T_MAXL]; };          // every ReLU layer in one launch: blockIdx.y = layer
+__global__ void k_tprep(TPrepMulti m) {
+  const TPrepArgs& a = m.a[blockIdx.y];
   const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= a.n) return;
   const float lb = a.lb[g], ub = a.ub[g];
@@ -81,7 +84,9 @@ __global__ void k_tprep(TPrepArgs a) {
 
 // columns interleaved into (n, w) feature rows: dst[g][j] = col_j[g]
 struct TColsArgs { const float* c[4]; int w; long n; float* dst; };
-__global__ void k_tcols(TColsArgs a) {
+struct TColsMulti { TColsArgs a[4]; };               // blockIdx.y = job
+__global__ void k_tcols(TColsMulti m) {
+  const TColsArgs& a = m.a[blockIdx.y];
   const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= a.n) return;
   for (int j = 0; j < a.w; ++j) a.dst[g * a.w + j] = (j == 0 ? a.c[0] : j == 1 ? a.c[1] : j == 2 ? a.c[2] : a.c[3])[g];
@@ -132,8 +137,7 @@ __device__ __forceinline__ void tl_stage_rows(const TLin& a, long row0, long n, 
 // to memory (the backward pass needs it) and stays in LDS (`Ys`) for the segments of the next op that read it (TLin.prev).
 // Per op the arithmetic of the former one-launch-per-Linear kernel: acc = bias, then one fma per input feature in order.
 template <int R>
-__global__ __launch_bounds__(256) void k_tchain_fwd(TChain c) {
-  extern __shared__ __attribute__((aligned(16))) float tl_lds[];
+__device__ __forceinline__ void tchain_fwd_body(const TChain& c, float* tl_lds) {
   __shared__ int Rs[R];
   const long n = tl_rows(c.op[0]), row0 = (long)blockIdx.x * R;
   if (row0 >= n) return;
@@ -245,7 +249,19 @@ __device__ __forceinline__ float tl_dym(const TLin& a, long orow, int node, int 
 // output -- whose total is that op's gy -- is added to what memory already holds for it (contributions of consumers outside the
 // chain, which ran earlier on the tape), written back, and handed to the next iteration through LDS (`Gs`).
 template <int R>
-__global__ __launch_bounds__(256) void k_tchain_bwd_x(TChain c) {
+__global__ __launch_bounds__(256) void k_tchain_fwd(TChain c) {
+  extern __shared__ __attribute__((aligned(16))) float tl_lds[];
+  tchain_fwd_body<R>(c, tl_lds);
+}
+// several independent chains (the same chain of different layers) in one launch: blockIdx.y = chain, descriptors in memory
+template <int R>
+__global__ __launch_bounds__(256) void k_tchain_fwd_multi(const TChain* cs) {
+  extern __shared__ __attribute__((aligned(16))) float tl_lds[];
+  tchain_fwd_body<R>(cs[blockIdx.y], tl_lds);
+}
+
+template <int R>
+__device__ __forceinline__ void tchain_bwd_x_body(const TChain& c) {
   __shared__ __attribute__((aligned(16))) float Ws[64 * 64];          // [c][k]
   __shared__ __attribute__((aligned(16))) float Ds[R * 64];     // [r][c]
   __shared__ __attribute__((aligned(16))) float Gs[R * 64];     // [r][k]: gy of the op about to be walked, when it was produced by the op above it
@@ -342,6 +358,11 @@ __global__ __launch_bounds__(256) void k_tchain_bwd_x(TChain c) {
   }
 }
 
+template <int R>
+__global__ __launch_bounds__(256) void k_tchain_bwd_x(TChain c) { tchain_bwd_x_body<R>(c); }
+template <int R>
+__global__ __launch_bounds__(256) void k_tchain_bwd_x_multi(const TChain* cs) { tchain_bwd_x_body<R>(cs[blockIdx.y]); }
+
 // Weight gradients of EVERY op of a step in one launch: block -> (op, chunk of TL_CHUNK rows), blockIdx.y = segment (or 0 for a
 // feature block).  part[chunk][c][col] = sum_r dym[r][c] * (s x)[r][col], col K = bias.  Runs after the whole backward walk, when
 // every gy is final; x, y, gy of all ops are still in the arena.  first[o] = first block of op o, first[nops] = the grid size.
@@ -434,7 +455,9 @@ __global__ void k_tlin_reduce_all(const TLin* ops, int nops) {
 
 // ordered list of the rows with a non-zero flag, and their number: one workgroup
 struct TCompact { const float* flag; int* idx; int* cnt; long n; };
-__global__ __launch_bounds__(256) void k_tcompact(TCompact a) {
+struct TCompactMulti { TCompact a[2 * T_MAXL]; };      // one workgroup per list: blockIdx.x = list
+__global__ __launch_bounds__(256) void k_tcompact(TCompactMulti m) {
+  const TCompact& a = m.a[blockIdx.x];
   __shared__ int wsum[4];
   __shared__ int base;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -608,7 +631,9 @@ struct TScore {
   float* gw; float* gb;
   const int* sel; int B;           // (B, 2): the two nodes of every sample the loss reads (argmax, KW), flat ReLU indices
 };
-__global__ __launch_bounds__(256) void k_tscore_fwd(TScore a) {
+struct TScoreMulti { TScore a[T_MAXL]; };              // blockIdx.y = ReLU layer
+__global__ __launch_bounds__(256) void k_tscore_fwd(TScoreMulti m) {
+  const TScore& a = m.a[blockIdx.y];
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.n) return;
@@ -617,7 +642,8 @@ __global__ __launch_bounds__(256) void k_tscore_fwd(TScore a) {
   const long f = (row / a.N) * a.R + a.off + row % a.N;
   if (lane == 0) a.scores[f] = a.mask[f] != 0.0f ? v + a.b[0] : -INFINITY;
 }
-__global__ __launch_bounds__(256) void k_tscore_bwd(TScore a) {        // gh = ds w^T  (ds is zero except at <= 2 nodes per sample)
+__global__ __launch_bounds__(256) void k_tscore_bwd(TScoreMulti m) {        // gh = ds w^T  (ds is zero except at <= 2 nodes per sample)
+  const TScore& a = m.a[blockIdx.y];
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.n) return;
@@ -626,19 +652,23 @@ __global__ __launch_bounds__(256) void k_tscore_bwd(TScore a) {        // gh = d
 }
 // d loss / d fscore: ds is +1 at the argmax and -1 at the KW node of every sample and zero elsewhere -- one wave walks those
 // 2 B nodes in order (deterministic) and takes the ones that belong to this layer
-__global__ __launch_bounds__(64) void k_tscore_bwd_w(TScore a) {
+// (all layers in one launch: the layers' contributions are added in the order of the former one-launch-per-layer form, last layer first)
+__global__ __launch_bounds__(64) void k_tscore_bwd_w(TScoreMulti m, int nlayers) {
   const int lane = threadIdx.x;
-  float gw = 0.0f, gb = 0.0f;
-  for (int b = 0; b < a.B; ++b)
-    for (int q = 0; q < 2; ++q) {
-      const int f = a.sel[2 * b + q] - a.off;
-      if (f < 0 || f >= a.N) continue;
-      const float d = q == 0 ? 1.0f : -1.0f;
-      gw = fmaf(d, a.h[((long)b * a.N + f) * 64 + lane], gw);
-      gb += d;
-    }
-  a.gw[lane] += gw;
-  if (lane == 0) a.gb[0] += gb;
+  for (int l = nlayers - 1; l >= 0; --l) {
+    const TScore& a = m.a[l];
+    float gw = 0.0f, gb = 0.0f;
+    for (int b = 0; b < a.B; ++b)
+      for (int q = 0; q < 2; ++q) {
+        const int f = a.sel[2 * b + q] - a.off;
+        if (f < 0 || f >= a.N) continue;
+        const float d = q == 0 ? 1.0f : -1.0f;
+        gw = fmaf(d, a.h[((long)b * a.N + f) * 64 + lane], gw);
+        gb += d;
+      }
+    a.gw[lane] += gw;
+    if (lane == 0) a.gb[0] += gb;
+  }
 }
 
 // loss_b = max_j s_b[j] - s_b[kw_b] + improvement_b (graph_score_online.py:73); ds = d loss / d scores
@@ -757,6 +787,74 @@ struct Trainer {
       for (int i = c.nops - 1; i >= 0; --i) wops.push_back(c.op[i]);
     });
     return out;
+  }
+  // Several independent chains (the same chain of different ReLU layers) as ONE launch forward and one backward: blockIdx.y =
+  // chain, the descriptors uploaded once and read from memory by both launches.  Returns the outputs per chain.
+  struct Job { std::vector<Spec> specs; long n; const List* list; };
+  TChain* desc = nullptr;                // pinned, device-visible descriptor slots of the step in flight (every step ends in a sync)
+  int ndesc = 0;
+  static constexpr int kDescCap = 8 * T_MAXL;
+  std::vector<std::vector<TT>> chain_multi(const std::vector<Job>& jobs) {
+    std::vector<std::vector<TT>> outs;
+    const int nj = (int)jobs.size();
+    if (!desc || ndesc + nj > kDescCap) { arena.err = true; return std::vector<std::vector<TT>>(nj, std::vector<TT>(TC_MAXOPS)); }
+    const int base = ndesc;
+    long maxrows = 0;
+    int Kmax = 0;
+    for (const Job& jb : jobs) {
+      std::vector<TT> out;
+      TChain c{};
+      c.nops = (int)jb.specs.size();
+      for (int i = 0; i < c.nops; ++i) {
+        const Spec& sp = jb.specs[i];
+        TT y = rows(jb.list && !sp.out_full ? jb.list->cap : jb.n);
+        TLin& a = c.op[i];
+        a.layer = sp.layer;
+        a.W = d_w + weight_offset(sp.layer); a.b = d_w + bias_offset(sp.layer);
+        a.gW = d_g + weight_offset(sp.layer); a.gb = d_g + bias_offset(sp.layer);
+        a.K = kLin[sp.layer].in; a.nseg = (int)sp.segs.size(); a.kf = sp.feat ? a.K : 0;
+        for (int j = 0; j < a.nseg; ++j) {
+          a.seg[j] = sp.segs[j];
+          if (!sp.segs[j].x) {
+            a.prev |= 1u << j;
+            a.seg[j].x = out[i - 1].v; a.seg[j].gx = out[i - 1].g; a.seg[j].full = jb.specs[i - 1].out_full ? 1 : 0;
+          }
+        }
+        a.feat = sp.feat; a.omask = sp.omask; a.relu = sp.relu ? 1 : 0; a.y = y.v; a.gy = y.g;
+        a.n = jb.list ? jb.list->cap : jb.n;
+        if (jb.list) { a.ridx = jb.list->idx; a.n_dev = jb.list->cnt; a.out_full = sp.out_full ? 1 : 0; }
+        a.nchunks = (int)((a.n + TL_CHUNK - 1) / TL_CHUNK);
+        a.part = arena.alloc((size_t)a.nchunks * 64 * (a.K + 1));
+        Kmax = a.K > Kmax ? a.K : Kmax;
+        out.push_back(y);
+      }
+      const long nrows = jb.list ? jb.list->cap : jb.n;
+      maxrows = nrows > maxrows ? nrows : maxrows;
+      desc[ndesc++] = c;
+      outs.push_back(out);
+    }
+    const TChain* d_cs = desc + base;
+    const int R = maxrows <= 16L * n_cu ? TL_ROWS_TINY : (maxrows <= 128L * n_cu ? TL_ROWS_SMALL : TL_ROWS);
+    const dim3 grid((unsigned)((maxrows + R - 1) / R), (unsigned)nj);
+    const size_t lds = ((size_t)(Kmax | 1) * 64 + (size_t)R * Kmax + (size_t)R * 64) * 4;
+    if (R == TL_ROWS_TINY) hipLaunchKernelGGL(k_tchain_fwd_multi<TL_ROWS_TINY>, grid, dim3(256), lds, st, d_cs);
+    else if (R == TL_ROWS_SMALL) hipLaunchKernelGGL(k_tchain_fwd_multi<TL_ROWS_SMALL>, grid, dim3(256), lds, st, d_cs);
+    else hipLaunchKernelGGL(k_tchain_fwd_multi<TL_ROWS>, grid, dim3(256), lds, st, d_cs);
+    std::vector<TChain> cs(desc + base, desc + ndesc);
+    tape.push_back([this, cs, d_cs, grid, R]() {
+      bool any = false;
+      for (const TChain& c : cs)
+        for (int i = 0; i < c.nops; ++i)
+          for (int j = 0; j < c.op[i].nseg; ++j) any = any || c.op[i].seg[j].gx;
+      if (any) {
+        if (R == TL_ROWS_TINY) hipLaunchKernelGGL(k_tchain_bwd_x_multi<TL_ROWS_TINY>, grid, dim3(256), 0, st, d_cs);
+        else if (R == TL_ROWS_SMALL) hipLaunchKernelGGL(k_tchain_bwd_x_multi<TL_ROWS_SMALL>, grid, dim3(256), 0, st, d_cs);
+        else hipLaunchKernelGGL(k_tchain_bwd_x_multi<TL_ROWS>, grid, dim3(256), 0, st, d_cs);
+      }
+      for (int q = (int)cs.size() - 1; q >= 0; --q)
+        for (int i = cs[q].nops - 1; i >= 0; --i) wops.push_back(cs[q].op[i]);
+    });
+    return outs;
   }
   TT lin(int layer, std::vector<TSeg> segs, const float* feat, long n, bool relu, const float* omask, const List* list = nullptr,
          bool out_full = false) {
