@@ -118,14 +118,14 @@ def plan_flops(plan, B, stats, restrict_last=True):
             # a tile that holds an ambiguous node 3; fp32 MFMA only (GNNB_BF3=0): 130 / 194 fp32 MFMAs
             live, amb = stats[k]["live"], stats[k]["amb"]
             post = u["update"] == "bwd" and k == 1 and t < T - 1 and upd in ("k_node_update", "k_gather_update")
-            if upd == "k_top":                   # one workgroup per sample: every node of the layer through the general fp32 chain
+            if upd == "k_top" and k == len(plan["sizes"]) - 2:      # layer L: one workgroup per sample, every node of the layer through the general chain
                 add(issued, upd, MFMA_FLOP * B * tiles(u["nodes"]) * 194)
             elif not bf3:
                 gen = tiles(n_upd) if restricted else tiles(amb)
                 add(issued, upd, MFMA_FLOP * ((0 if restricted else tiles(live - amb)) * 130 + gen * 194 + (tiles(live) * 64 if post else 0)))
             elif restricted:
                 add(issued, upd, MFMA_FLOP * tiles(n_upd) * (2 + 3 * W64))
-            elif fused:                          # ambiguous nodes ride in the same tiles: share of 32-node tiles that hold at least one
+            elif fused or upd == "k_top":        # (k_top: layer L-1's update on its transposed edge's live-row tiles) ambiguous nodes ride in the same tiles: share of 32-node tiles that hold at least one
                 p_amb = 1.0 - (1.0 - amb / max(live, 1)) ** 32
                 add(issued, upd, MFMA_FLOP * tiles(live) * (2 + (2 + p_amb) * W64 + (W64 if post else 0)))
             else:

@@ -124,6 +124,7 @@ struct gnnb_handle {
                                 // measured (base, us): B = 1 27.5 vs 7.6 + 22.1, B = 2 34.0 vs 30.0, B = 8 42.5 vs 31.8 -- a block's share of
                                 // the ambiguous nodes is uneven, so beyond one subproblem the two kernels' even dealing wins
   int tail_max_b = 8;           // GNNB_TAIL_MAX_B: batches up to it end in k_scored_tail (scored gather + restricted update + score head in one launch)
+  bool top_fuse_upd = true;     // GNNB_TOP_FUSE_UPD=0: the backward node update of layer L-1 as its own launch behind k_top (it runs inside k_top otherwise)
   int top_split_max = 4;        // GNNB_TOP_SPLIT: 4 (default) = four workgroups per sample while B <= n_cu / 4; 2 = two while B <= n_cu / 2; 1 = never
   int per_sample_min_b = 0;     // GNNB_PER_SAMPLE_MIN_B: batches below it take the per-tile dense kernel + separate launches
                                 // instead of the one-workgroup-per-sample kernels (k_top, k_dense_*_lds), which need a batch
@@ -316,6 +317,7 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   if (const char* e = getenv("GNNB_PER_SAMPLE_MIN_B")) h->per_sample_min_b = atoi(e);
   if (const char* e = getenv("GNNB_TAIL_MAX_B")) h->tail_max_b = atoi(e);
   if (const char* e = getenv("GNNB_CLSPRE_MAX_B")) h->clspre_max_b = atoi(e);
+  if (const char* e = getenv("GNNB_TOP_FUSE_UPD")) h->top_fuse_upd = !(e[0] == '0');
   if (const char* e = getenv("GNNB_TOP_SPLIT")) h->top_split_max = atoi(e) >= 4 ? 4 : (atoi(e) >= 2 ? 2 : 1);
   HIPCHK(hipFuncSetAttribute((const void*)k_classify_pre, hipFuncAttributeMaxDynamicSharedMemorySize, CLSPRE_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void*)k_scored_tail, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS_FLOATS * 4));
@@ -679,7 +681,8 @@ extern "C" int gnnb_describe(const gnnb_t* h, char* buf, size_t cap) {
   for (int k = L; k >= 1; --k) {
     o += ", ";
     if (k == L) item("bwd", k, nullptr, top ? "k_top+k_top" : "k_prop+k_node_update", 1);
-    else if (top && k == L - 1) item("bwd", k, nullptr, "k_top+k_node_update", h->N[k + 1]);
+    else if (top && k == L - 1)      // (the update of layer L-1 rides k_top's transposed edge when its live-row list is kept: gnnb_forward `top_upd`)
+      item("bwd", k, nullptr, h->top_fuse_upd && L >= 3 && TOP_LIST_KEEP_OK(h->edges[L].n_in) ? "k_top+k_top" : "k_top+k_node_update", h->N[k + 1]);
     else item("bwd", k, &h->gb[k + 1], h->edges[k + 1].kind == 0 ? "k_convT_bwd+k_node_update" : "k_dense_agg+k_node_update", h->N[k + 1]);
   }
   o += ", ";
@@ -912,6 +915,10 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   const int topK = L >= 1 && h->edges[L].kind == 1 ? h->edges[L].n_in : 0;
   const bool top_s_fwd = top_fused && h->s_in_gather && TOP_LIST_OK(topK);
   const bool top_s_bwd = top_fused && h->s_in_gather && TOP_LIST_KEEP_OK(topK) && limit >= 2;
+  // k_top also runs the backward node update of layer L-1 on its transposed edge's row tiles (the aggregate never reaches memory):
+  // needs the kept live-row list (B2 then walks live rows only) and a layer L-1 that is not layer 1 (whose update has the
+  // restricted / input-mapping forms)
+  const bool top_upd = top_fused && h->top_fuse_upd && L >= 3 && TOP_LIST_KEEP_OK(topK);
   auto zero_dead_rows = [&](int k) {
     if (debug_full || h->zero_dead) return true;
     if (k == L) return !top_fused;                                // k_top writes every row of layer L itself
@@ -1259,6 +1266,8 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     if (h->top_split_max >= 4 && (long)B * 4 <= h->n_cu) S = 4;
     else if (h->top_split_max == 2 && (long)B * 2 <= h->n_cu && B <= TOP_SPLIT_MAXB) S = 2;
     a.xbuf = ws + w.topx; a.xflag = reinterpret_cast<int*>(ws + w.topflag); a.xbase = top_launches * 2 * S;
+    a.fuse_um = top_upd ? 1 : 0;
+    if (top_upd) a.um = upd_args(L - 1, false, false, false);
     ++top_launches;
     lz.run(PC_TOP, [&] {
       if (S == 4) hipLaunchKernelGGL(k_top<1>, dim3(B * 4), dim3(512), TOP_LDS_FLOATS * 4, st, a);
@@ -1296,6 +1305,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       }
       top();                                     // F1 .. B2: both half-passes of layer L, aggregate of layer L-1 in `nb`
       for (int k = L - 1; k >= 1; --k) {
+        if (k == L - 1 && top_upd) { proj[k] = L_BC4_1; continue; }      // done inside k_top
         const bool scored = h->restrict_last && t == h->T - 1 && k == 1;
         if (scored && k < L - 1 && try_tail(k)) continue;
         if (k < L - 1 && !scored && fused_halfpass(k, false, k == 1 && t < h->T - 1)) continue;

@@ -403,6 +403,18 @@ __device__ __forceinline__ f32x16 mfma6(const u32x4 (&w)[3], const u32x4 (&x)[3]
   acc = mfma_bf16(w1, x2, acc);
   return mfma_bf16(w1, x1, acc);
 }
+// the same six products in the same order with the operand roles exchanged: acc = (x pieces as rows) . (w pieces as columns), i.e. the
+// TRANSPOSE of mfma6's tile, sum for sum (dense_bwd_sample_bf3<FUSE>: the tile then is a node-update fragment)
+__device__ __forceinline__ f32x16 mfma6t(const u32x4 (&w)[3], const u32x4 (&x)[3], f32x16 acc) {
+  const bf16x8 w1 = __builtin_bit_cast(bf16x8, w[0]), w2 = __builtin_bit_cast(bf16x8, w[1]), w3 = __builtin_bit_cast(bf16x8, w[2]);
+  const bf16x8 x1 = __builtin_bit_cast(bf16x8, x[0]), x2 = __builtin_bit_cast(bf16x8, x[1]), x3 = __builtin_bit_cast(bf16x8, x[2]);
+  acc = mfma_bf16(x1, w3, acc);
+  acc = mfma_bf16(x2, w2, acc);
+  acc = mfma_bf16(x3, w1, acc);
+  acc = mfma_bf16(x1, w2, acc);
+  acc = mfma_bf16(x2, w1, acc);
+  return mfma_bf16(x1, w1, acc);
+}
 typedef unsigned short top_idx_t;      // live-row lists of k_top: 16-bit (layers up to 65535 nodes), so that they fit beside the weights
 
 // forward edge (long K) of sample b: out[m][c] = sum_k W[m][k] X[k][c], m < 128 (a.ldA <= 128 columns of At), c < 64.
@@ -582,10 +594,17 @@ __device__ __forceinline__ void dense_fwd_sample_bf3(const DenseLArgs& a, int b,
 // register sets in ping-pong, out-of-range offsets instead of control flow around the loads): with the loads only three k-steps
 // ahead -- a k-step is 0.15 us of work, an L2 round trip under load ~1 us -- the edge spent 4 of its 5 us per tile waiting
 // (base B = 256: 19.7 -> see DESIGN 5.6).  part / nparts: this workgroup takes row tiles part, part + nparts, ... (k_top_split).
-template <class Store>
+// FUSE (k_top with the node update of layer L-1 inside): a row tile is computed TRANSPOSED (operand roles exchanged, channel tile nt =
+// channels 32 nt .. 32 nt + 31) so that its accumulators ARE the node-update fragment of its 32 nodes (lane (j, h): node j, register
+// 4 q + c = channel 8 q + 4 h + c) -- every sum has the terms and the order of the plain form, so the aggregate is bit-identical to
+// the rows the plain form stores.  node(arow, in_range) is called when a tile starts (it requests what the node's chain needs from
+// memory), epi(arow, in_range, X, s, what node() returned) when its MFMAs are done; mid() runs once behind the barrier that ends the
+// image build (Cr is dead from there on).  `store` is unused.
+struct NoHook { __device__ void operator()() const {} };
+template <bool FUSE = false, class Store, class Mid = NoHook, class Node = NoHook, class Epi = NoHook>
 __device__ __forceinline__ void dense_bwd_sample_bf3(const DenseLArgs& a, const float* Cr, float* img, Store store, const top_idx_t* rlist,
                                                      int n_rows, float* sout, const float* Wk, int ldK, const float* livek,
-                                                     int part = 0, int nparts = 1) {
+                                                     int part = 0, int nparts = 1, Mid mid = Mid(), Node node = Node(), Epi epi = Epi()) {
   constexpr int NST = 8;                           // k-steps of 16: Kpad <= 128 (bind: kpad_bwd <= 128)
   const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -613,7 +632,14 @@ __device__ __forceinline__ void dense_bwd_sample_bf3(const DenseLArgs& a, const 
   for (int e = threadIdx.x; e < nst * 256; e += 512) {
     const int q = e & 3, n = (e >> 2) & 31, kg = (e >> 7) & 1, st = e >> 8;
     const int k0 = st * 16 + kg * 8 + 2 * q;
-    const float2 v0 = *reinterpret_cast<const float2*>(Cr + k0 * 64 + 2 * n), v1 = *reinterpret_cast<const float2*>(Cr + (k0 + 1) * 64 + 2 * n);
+    float2 v0, v1;                                   // .x / .y: channel tile 0 / 1 of column n (plain: channels 2 n, 2 n + 1; FUSE: n, 32 + n)
+    if (FUSE) {
+      v0 = make_float2(Cr[k0 * 64 + n], Cr[k0 * 64 + 32 + n]);
+      v1 = make_float2(Cr[(k0 + 1) * 64 + n], Cr[(k0 + 1) * 64 + 32 + n]);
+    } else {
+      v0 = *reinterpret_cast<const float2*>(Cr + k0 * 64 + 2 * n);
+      v1 = *reinterpret_cast<const float2*>(Cr + (k0 + 1) * 64 + 2 * n);
+    }
     const Split3 sx = split3(v0.x, v1.x), sy = split3(v0.y, v1.y);
     const unsigned u[2][3] = {{sx.u1, sx.u2, sx.u3}, {sy.u1, sy.u2, sy.u3}};
 #pragma unroll
@@ -622,8 +648,12 @@ __device__ __forceinline__ void dense_bwd_sample_bf3(const DenseLArgs& a, const 
       for (int p = 0; p < 3; ++p) im[((((st * 2 + nt) * 3 + p) * 64) + kg * 32 + n) * 4 + q] = u[nt][p];
   }
   __syncthreads();
+  if constexpr (FUSE) mid();
   const u32x4* im4 = reinterpret_cast<const u32x4*>(img) + lane;
   auto compute = [&](const Raw& R, int mt) {
+    [[maybe_unused]] const int arow_t = arow_of(mt);
+    [[maybe_unused]] const bool in_t = mt * 32 + j < M;
+    [[maybe_unused]] auto nd = [&]() { if constexpr (FUSE) return node(arow_t, in_t); else return 0; }();
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
@@ -654,8 +684,13 @@ __device__ __forceinline__ void dense_bwd_sample_bf3(const DenseLArgs& a, const 
         const u32x4 xa[3] = {im4[((st * 2 + 0) * 3 + 0) * 64], im4[((st * 2 + 0) * 3 + 1) * 64], im4[((st * 2 + 0) * 3 + 2) * 64]};
         const u32x4 xb[3] = {im4[((st * 2 + 1) * 3 + 0) * 64], im4[((st * 2 + 1) * 3 + 1) * 64], im4[((st * 2 + 1) * 3 + 2) * 64]};
         if (st + 1 < NST) split(w[(st + 1) & 1], st + 1);      // next k-step's pieces under this step's MFMAs (5 vector instructions per MFMA)
-        acc0 = mfma6(w[st & 1], xa, acc0);
-        acc1 = mfma6(w[st & 1], xb, acc1);
+        if (FUSE) {
+          acc0 = mfma6t(w[st & 1], xa, acc0);
+          acc1 = mfma6t(w[st & 1], xb, acc1);
+        } else {
+          acc0 = mfma6(w[st & 1], xa, acc0);
+          acc1 = mfma6(w[st & 1], xb, acc1);
+        }
         __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);       // the six operand reads first
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
@@ -666,14 +701,21 @@ __device__ __forceinline__ void dense_bwd_sample_bf3(const DenseLArgs& a, const 
       }
     }
     const int arow = arow_of(mt);
+    if constexpr (!FUSE) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (row < M) store(rlist ? (int)rlist[row] : row, j, make_float2(acc0[r], acc1[r]));
+      for (int r = 0; r < 16; ++r) {
+        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < M) store(rlist ? (int)rlist[row] : row, j, make_float2(acc0[r], acc1[r]));
+      }
     }
     if (sout) {
       sacc += __shfl_xor(sacc, 32);
       if (h == 0 && mt * 32 + j < M) sout[arow] = sacc;
+    }
+    if constexpr (FUSE) {
+      Frag X;
+      X.t[0] = acc0; X.t[1] = acc1;
+      epi(arow, in_t, X, sacc, nd);
     }
   };
   for (int mt = first; mt < MT; mt += 2 * stride) {
@@ -792,6 +834,9 @@ struct TopArgs {
   // k_top_split (S > 1 workgroups per sample): exchange buffer (B, 8, 64) for the property node's partial sums, one arrival
   // counter per sample (zeroed by k_classify) and the count it stood at when this launch started (2 S per earlier launch)
   float* xbuf; int* xflag; int xbase;
+  // fuse_um != 0: the backward node update of layer L-1 runs on B2's row tiles in here (its aggregate never reaches memory, the
+  // k_node_update launch behind k_top is gone); um = that update's arguments (list / nb fields unused)
+  UpdArgs um; int fuse_um;
 };
 #define TOP_A_FLOATS (PackUpd::FLOATS > DENSE_FWD_LDS_FLOATS ? PackUpd::FLOATS : DENSE_FWD_LDS_FLOATS)
 #define TOP_FIXED_FLOATS (TOP_A_FLOATS + PackProp::FLOATS + DENSE_BWD_ROWS * 64 + 8 * 64 + 128 + 64 + 64)
@@ -806,6 +851,10 @@ struct TopArgs {
 static_assert(TOP_A_FLOATS >= 16384 && TOP_A_FLOATS >= 12288, "k_top: F1's reduction scratch and B2's operand image live in region A");
 static_assert(TOP_A_FLOATS + PackProp::FLOATS >= PackUpdL3::FLOATS, "k_top: the bf16 x 3 node-update image spans regions A and Bp");
 static_assert(DENSE_BWD_ROWS >= 128 + 16, "k_top: rows 128.. of C are the property node's scratch");
+// fuse_um: B2's operand image takes the first TOP_IMG_FLOATS of region A; the node-update image of layer L-1 goes behind it, over
+// the rest of A, region Bp and the first rows of C (dead once the operand image is built); the live-row list must be the kept one
+#define TOP_IMG_FLOATS 12288
+static_assert(TOP_IMG_FLOATS + PackUpdL3::FLOATS <= TOP_A_FLOATS + PackProp::FLOATS + DENSE_BWD_ROWS * 64, "k_top: the L-1 update image fits behind B2's operand image");
 
 // One sample's top of the network on workgroup `part` of S = 4 / TS (TS row tiles of the last ReLU layer per workgroup; S = 1: the
 // whole sample, no exchange).  Layer L's node n sits in row tile n % 4 (lane n / 4 of wave n % 4 in the update phases, rows
@@ -1148,7 +1197,43 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, const 
 #if defined(TOP_ABL) && (TOP_ABL & 1)     // dev, timing only: no B2
   if (N < 0) dense_bwd_sample_bf3(a.db, Cr, A, put, nullptr, 0, nullptr, a.df.At, a.df.ldA, nullptr);
 #else
-  if (keep) dense_bwd_sample_bf3(a.db, Cr, A, put, klist, K_eff, a.sb_out ? a.sb_out + (long)b * a.db.M : nullptr, a.df.At, a.df.ldA, xs, part, S);
+  if (a.fuse_um && keep) {
+    // the image of layer L-1's update: requested now (registers), written behind the operand image's barrier (mid)
+    float* W2 = A + TOP_IMG_FLOATS;
+    constexpr int N4 = PackUpdL3::FLOATS / 4;                       // 16 f32x4 BA | 64 BCB, BCBROW, VAW | 3 x 1536 blocks
+    constexpr int PER = (N4 + 511) / 512;
+    f32x4 st2[PER];
+    const f32x4* p4 = reinterpret_cast<const f32x4*>(a.um.pack);
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int i = tid + 512 * u;                                  // index into the LDS image
+      int src = PackUpd::WAS3 / 4 + (i - PackUpdL3::WAS3 / 4);      // the three blocks are contiguous in both
+      if (i < 16) src = PackUpd::BA / 4 + i;
+      else if (i < PackUpdL3::WAS3 / 4) src = PackUpd::BCB / 4 + (i - 16);
+      st2[u] = p4[i < N4 ? src : 0];
+    }
+    const long mbase = (long)b * a.db.M;
+    struct NodeIn { float lb, ub, s; };
+    dense_bwd_sample_bf3<true>(
+        a.db, Cr, A, put, klist, K_eff, a.sb_out ? a.sb_out + mbase : nullptr, a.df.At, a.df.ldA, xs, part, S,
+        [&]() {
+#pragma unroll
+          for (int u = 0; u < PER; ++u) {
+            const int i = tid + 512 * u;
+            if (i < N4) reinterpret_cast<f32x4*>(W2)[i] = st2[u];
+          }
+          __syncthreads();
+        },
+        [&](int arow, bool in) {
+          const long gm = mbase + (in ? arow : 0);
+          return NodeIn{a.lbm[gm], a.ubm[gm], a.sb_out ? 0.0f : a.um.sarr[gm]};
+        },
+        [&](int arow, bool in, const Frag& X, float ssum, const NodeIn& nd) {
+          const Ratio rt = compute_ratio(nd.lb, nd.ub);
+          upd_chain_frag<false>(a.um, W2, X, in ? (int)(mbase + arow) : 0, in ? rt.r0 : 0.0f, in ? rt.r1 : 0.0f, in && rt.amb != 0.0f,
+                                in ? (a.sb_out ? ssum : nd.s) : 0.0f, in, lane);
+        });
+  } else if (keep) dense_bwd_sample_bf3(a.db, Cr, A, put, klist, K_eff, a.sb_out ? a.sb_out + (long)b * a.db.M : nullptr, a.df.At, a.df.ldA, xs, part, S);
   else dense_bwd_sample_bf3(a.db, Cr, A, put, nullptr, 0, nullptr, a.df.At, a.df.ldA, xs, part, S);
 #endif
 #ifdef FUSED_TIMING

@@ -52,8 +52,49 @@ static_assert(sizeof(QHdr) == QHDR_INTS * 4, "queue header");
 // (acquire / release at workgroup scope: LDS needs no cache maintenance, this only keeps compiler and wait counters honest)
 __device__ __forceinline__ int q_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-// the folded node update (see node_update_loop) on ring slot `ring` (32 rows of QROW floats); `release` runs once the rows are in registers
+// The folded node update (see node_update_loop) of one tile whose aggregate rows are in registers: X = fragment (lane (j, h):
+// node j, register 4 q + c = feature 8 q + 4 h + c), gc = node id, (r0, r1, amb) its ratios, sw its bias-sum scalar, valid = the lane
+// holds a node.  `lds`: the PackUpdL3 image.  Callers: k_gather_update_q / k_scored_tail (rows out of the LDS ring) and k_top (rows
+// out of the transposed Linear edge's accumulators) -- the same arithmetic per node as k_node_update, whatever tile a node rides in.
 // keep != nullptr: the rows E are also handed back in *keep (k_scored_tail feeds them to the score head without reading them back)
+template <bool POST>
+__device__ __forceinline__ void upd_chain_frag(const UpdArgs& u, const float* lds, const Frag& X, int gc, float r0, float r1, bool amb, float sw,
+                                               bool valid, int lane, Frag* keep = nullptr) {
+  const int h = lane >> 5;
+  Frag H, H2;
+  frag_bias(H, lds + PackUpdL3::BA, h);
+  {
+    const float x[1] = {(h ? r1 : r0) * sw};            // + s.(r0 Wa0.bp + r1 Wa1.bp): the bias of the source rows' deferred projection
+    gemm_small<1>(lds + PackUpdL3::VAW, lane, H, x);
+  }
+  gemm_w64_bf3<1>(lds + PackUpdL3::WAS3, lane, H, [&](int s) { return FRAG_AT(X, s) * r0; });
+#ifdef Q_ABL_NOAMB      // dev, timing only (wrong results): what the chain would cost if no tile held an ambiguous node
+  if (false) {
+#else
+  if (__any(amb)) {
+#endif
+    const float dr = r1 - r0;
+    gemm_w64_bf3<1>(lds + PackUpdL3::WA1S3, lane, H, [&](int s) { return FRAG_AT(X, s) * dr; });
+  }
+  // P' of an ambiguous node: its cached row (k_pre); of every other node: the bias row
+  frag_load_rowptr(H2, amb ? u.P + (long)gc * 64 : u.pack + PackUpd::BCBROW, h);
+  frag_relu(H);
+  gemm_w64_bf3<1>(lds + PackUpdL3::WCB3, lane, H2, [&](int s) { return FRAG_AT(H, s); });
+  frag_relu(H2);
+  if (valid) {
+    if (frag_has_nan(H2)) atomicOr(u.status, 1);
+    if (u.mu) frag_store_rows(H2, u.mu, gc, h);
+  }
+  if (keep) *keep = H2;
+  if (POST) {
+#pragma unroll
+    for (int R = 0; R < 32; ++R) FRAG_AT(H, R) = 0.0f;
+    gemm_w64_bf3<1>(lds + PackUpdL3::FLOATS, lane, H, [&](int s) { return FRAG_AT(H2, s); });
+    if (valid) frag_store_rows(H, u.post, gc, h);
+  }
+}
+
+// the same on ring slot `ring` (32 rows of QROW floats); `release` runs once the rows are in registers
 template <bool POST, class Release>
 __device__ __forceinline__ void q_chain(const FArgs& a, const float* lds, const float* ring, int nvalid, int lane, Release release, Frag* keep = nullptr) {
   const int h = lane >> 5, j = lane & 31;
@@ -74,37 +115,7 @@ __device__ __forceinline__ void q_chain(const FArgs& a, const float* lds, const 
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the rows and scalars are in registers
   release();
-  Frag H, H2;
-  frag_bias(H, lds + PackUpdL3::BA, h);
-  {
-    const float x[1] = {(h ? r1 : r0) * sw};            // + s.(r0 Wa0.bp + r1 Wa1.bp): the bias of the source rows' deferred projection
-    gemm_small<1>(lds + PackUpdL3::VAW, lane, H, x);
-  }
-  gemm_w64_bf3<1>(lds + PackUpdL3::WAS3, lane, H, [&](int s) { return FRAG_AT(X, s) * r0; });
-#ifdef Q_ABL_NOAMB      // dev, timing only (wrong results): what the chain would cost if no tile held an ambiguous node
-  if (false) {
-#else
-  if (__any(amb)) {
-#endif
-    const float dr = r1 - r0;
-    gemm_w64_bf3<1>(lds + PackUpdL3::WA1S3, lane, H, [&](int s) { return FRAG_AT(X, s) * dr; });
-  }
-  // P' of an ambiguous node: its cached row (k_pre); of every other node: the bias row
-  frag_load_rowptr(H2, amb ? a.u.P + (long)gc * 64 : a.u.pack + PackUpd::BCBROW, h);
-  frag_relu(H);
-  gemm_w64_bf3<1>(lds + PackUpdL3::WCB3, lane, H2, [&](int s) { return FRAG_AT(H, s); });
-  frag_relu(H2);
-  if (valid) {
-    if (frag_has_nan(H2)) atomicOr(a.u.status, 1);
-    if (a.u.mu) frag_store_rows(H2, a.u.mu, gc, h);
-  }
-  if (keep) *keep = H2;
-  if (POST) {
-#pragma unroll
-    for (int R = 0; R < 32; ++R) FRAG_AT(H, R) = 0.0f;
-    gemm_w64_bf3<1>(lds + PackUpdL3::FLOATS, lane, H, [&](int s) { return FRAG_AT(H2, s); });
-    if (valid) frag_store_rows(H, a.u.post, gc, h);
-  }
+  upd_chain_frag<POST>(a.u, lds, X, gc, r0, r1, amb, sw, valid, lane, keep);
 }
 
 // LANES: dst nodes per gather tile (16: forward edges, 32: transposed edges).  SRC: 0 dense source rows, 1 sparse walk (the source

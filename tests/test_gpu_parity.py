@@ -402,6 +402,34 @@ def test_top_workgroup_split_is_bit_identical(monkeypatch, net, B, fam):
     assert np.abs(out["4"][fin] - want[fin]).max() <= score_tol(fam, want[fin])
 
 
+@pytest.mark.parametrize("net,B", [("cifar_base_kw", 1), ("cifar_base_kw", 5), ("cifar_wide_kw", 3), ("cifar_deep_kw", 2), ("cifar_base_kw", 70)])
+@pytest.mark.parametrize("fam", ["shipped", "random"])
+def test_top_kernel_with_the_update_below_inside_is_bit_identical(monkeypatch, net, B, fam):
+    """k_top runs the backward node update of layer L-1 on its transposed edge's row tiles (computed transposed, so that a tile's
+    accumulators are the update's input fragment): the aggregate rows never reach memory and the k_node_update launch behind k_top
+    is gone.  GNNB_TOP_FUSE_UPD=0 keeps the launch.  Every sum keeps its terms and order: identical scores, decisions and rows of
+    layer L-1, for one workgroup per sample (B = 70) and for four (small B)."""
+    from gnn_branching_amd import synth
+    batch = synth.make_batch(net, B, seed=31 + B)
+    out = {}
+    for knob in ("0", "1"):
+        monkeypatch.setenv("GNNB_TOP_FUSE_UPD", knob)
+        model = make_model(fam)
+        with torch.no_grad():
+            eng = model.engine()
+            res = model.forward_device(*batch.forward_args()).check()
+            eng.workspace(B).view(torch.float32).fill_(float("nan"))
+            again = model.forward_device(*batch.forward_args()).check()
+        out[knob] = (res.scores.cpu().numpy(), res.decisions.cpu().numpy())
+        assert np.array_equal(again.scores.cpu().numpy(), out[knob][0], equal_nan=True)
+        launches = [u["kernel"] for u in eng.describe()["updates"]]
+        assert any("k_top" in k for k in launches)
+        n_upd = sum("k_node_update" in k for k in launches)
+        out[knob + "n"] = n_upd
+    assert out["1n"] < out["0n"], (out["0n"], out["1n"])          # the launches really went away
+    assert np.array_equal(out["0"][0], out["1"][0], equal_nan=True) and np.array_equal(out["0"][1], out["1"][1])
+
+
 def test_large_batch_equals_its_samples_scored_alone():
     """B = 160 runs k_top with one workgroup per sample, a single subproblem with four: same bits."""
     from gnn_branching_amd import synth

@@ -11,8 +11,8 @@ def build(name, src):
     open(f'/tmp/gnnb_{name}.hip', 'w').write(src)
     subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-o', f'/root/repo/tools/ablate/{name}.so', f'/tmp/gnnb_{name}.hip'])
 
-CH_OLD = "  release();\n  Frag H, H2;\n  frag_bias(H, lds + PackUpdL3::BA, h);"
-CH_NEW = "  release();\n  if (nvalid >= 0 && !keep) return;\n  Frag H, H2;\n  frag_bias(H, lds + PackUpdL3::BA, h);"
+CH_OLD = "  release();\n  upd_chain_frag<POST>(a.u, lds, X, gc, r0, r1, amb, sw, valid, lane, keep);"
+CH_NEW = "  release();\n  if (nvalid >= 0 && !keep) return;\n  upd_chain_frag<POST>(a.u, lds, X, gc, r0, r1, amb, sw, valid, lane, keep);"
 assert base.count(CH_OLD) == 1
 build('nochain', base.replace(CH_OLD, CH_NEW))
 
