@@ -125,7 +125,7 @@ struct gnnb_handle {
                                 // the ambiguous nodes is uneven, so beyond one subproblem the two kernels' even dealing wins
   int tail_max_b = 8;           // GNNB_TAIL_MAX_B: batches up to it end in k_scored_tail (scored gather + restricted update + score head in one launch)
   bool top_fuse_upd = true;     // GNNB_TOP_FUSE_UPD=0: the backward node update of layer L-1 as its own launch behind k_top (it runs inside k_top otherwise)
-  int top_split_max = 4;        // GNNB_TOP_SPLIT: 4 (default) = four workgroups per sample while B <= n_cu / 4; 2 = two while B <= n_cu / 2; 1 = never
+  int top_split_max = 4;        // GNNB_TOP_SPLIT: 4 (default) = four workgroups per sample while B <= n_cu / 4, two while B <= n_cu / 2; 2 = two at most; 1 = never
   int per_sample_min_b = 0;     // GNNB_PER_SAMPLE_MIN_B: batches below it take the per-tile dense kernel + separate launches
                                 // instead of the one-workgroup-per-sample kernels (k_top, k_dense_*_lds), which need a batch
                                 // that fills the CUs (B=2: 0.40 vs 0.49 ms, B=64: 0.64 vs 0.66, B=128: 0.96 vs 0.88 ms; 96 is
@@ -1260,11 +1260,12 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     a.mu_prop = mu(K); a.mu = mu(L); a.status = status; a.N = h->N[L];
     // A sample's top spread over S = 2 / 4 workgroups (by output tile of both Linear edges) while all B x S of them are resident
     // at one per CU (they wait for each other); GNNB_TOP_SPLIT = 1 / 2 / 4 caps S.  The results do not depend on S.
-    // Measured (deep, B = 128, S = 2): the two hand-offs cost what the shorter edges save (50 us either way), so a sample is only
-    // split when all four quarters fit: B <= n_cu / 4 (base B = 1: 52 -> 38 us per launch).  GNNB_TOP_SPLIT = 2 forces halves.
+    // S = 4 while B <= n_cu / 4 (base B = 1: 52 -> 38 us per launch), S = 2 while B <= n_cu / 2.  (Before k_top also ran the update of
+    // layer L-1, S = 2 was a draw -- the two hand-offs cost what the shorter edges saved; with the update's tiles split over both
+    // workgroups too it wins: deep B = 128 67 -> 59 us, wide B = 128 99 -> 79 us per launch.)
     int S = 1;
     if (h->top_split_max >= 4 && (long)B * 4 <= h->n_cu) S = 4;
-    else if (h->top_split_max == 2 && (long)B * 2 <= h->n_cu && B <= TOP_SPLIT_MAXB) S = 2;
+    else if (h->top_split_max >= 2 && (long)B * 2 <= h->n_cu && B <= TOP_SPLIT_MAXB) S = 2;
     a.xbuf = ws + w.topx; a.xflag = reinterpret_cast<int*>(ws + w.topflag); a.xbase = top_launches * 2 * S;
     a.fuse_um = top_upd ? 1 : 0;
     if (top_upd) a.um = upd_args(L - 1, false, false, false);
