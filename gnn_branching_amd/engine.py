@@ -7,6 +7,8 @@ memory here (``data_ptr()``); all arithmetic of the hot path runs in libgnnb.so.
 import ctypes as C
 import os
 
+from array import array as _array
+
 import numpy as np
 import torch
 from torch import nn
@@ -291,6 +293,13 @@ class ScorerEngine:
             if t.dtype != torch.float32 or not t.is_contiguous():
                 t = t.to(torch.float32).contiguous()
             return t.numpy()
+        if type(t) is list and t and type(t[0]) is float:
+            # the LP primals arrive as flat python lists of floats (graph_score.py:30): array('f') walks them in C, a third faster
+            # than numpy's generic sequence path (same round-to-nearest double -> float conversion)
+            try:
+                return np.frombuffer(_array("f", t), dtype=np.float32)
+            except TypeError:
+                pass
         return np.ascontiguousarray(t, dtype=np.float32)
 
     class _HostBuf:
