@@ -22,3 +22,9 @@ for name, args in (("pageable", host), ("pinned", pinned)):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 10
     print(f"{name}: {1e3 * dt:.3f} ms per call incl. H2D of {nbytes / 1e6:.1f} MB -> {n_amb / dt / 1e6:.1f} M scores/s")
+# the C-ABI host entry point (gnnb_forward_host: ONE pinned staging transfer each way, synchronous)
+for _ in range(3): eng.forward_host(*host)
+t0 = time.perf_counter()
+for _ in range(10): eng.forward_host(*host)
+dt = (time.perf_counter() - t0) / 10
+print(f"gnnb_forward_host: {1e3 * dt:.3f} ms per call incl. staging + H2D of {nbytes / 1e6:.1f} MB and decisions back -> {n_amb / dt / 1e6:.1f} M scores/s")
