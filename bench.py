@@ -276,6 +276,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=None, help="subproblems per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-fp32", action="store_true", help="skip the GNNB_BF3=0 comparison leg (exact_fp32_ms_per_step, bf3_max_abs_delta)")
+    ap.add_argument("--no-aggregate-only", action="store_true", help="skip the GNNB_FUSE=0 leg (roofline_aggregate_only: the stand-alone edge-aggregation kernel)")
     ap.add_argument("--cpu-budget", type=float, default=75.0, help="seconds of CPU work for the cpu_baseline leg")
     args = ap.parse_args(argv)
     cfg = CONFIGS[args.config if args.config is not None else 2]
@@ -502,6 +503,45 @@ def main():
                 del eng32, model32
             finally:
                 del os.environ["GNNB_BF3"]
+        # ---- the edge aggregation ALONE ("standalone message-passing (aggregate-only) kernel for the HBM-roofline
+        # measurement, plus the fused production variant"): the same batch through a second handle with GNNB_FUSE=0, where every conv
+        # half-pass is k_gather (aggregate rows -> HBM) + k_node_update; identical scores.  Outside the timed region of the headline.
+        agg_only = None
+        if not args.no_aggregate_only:
+            os.environ["GNNB_FUSE"] = "0"
+            try:
+                modelA = GraphNet(2, 64)
+                modelA.load_state_dict(sd)
+                engA = modelA.eval().engine()
+                for _ in range(5):
+                    rA = engA.forward(*d_args)
+                torch.cuda.synchronize()
+                engA.profile_enable(True)
+                for _ in range(args.steps):
+                    rA = engA.forward(*d_args)
+                torch.cuda.synchronize()
+                profA = engA.profile_read(reset=True)
+                engA.profile_enable(False)
+                rA.check()
+                assert torch.equal(rA.scores, res.scores), "the two-kernel half-passes must give the fused ones' scores bit for bit"
+                planA = engA.describe()
+                _, _, aggA = plan_flops(planA, B, stats)
+                msA, nA = profA.get("k_gather", (0.0, 0))
+                if nA:
+                    # SURVEY 8(d)'s count for the half-passes this class serves: every source row read once, every destination row written once
+                    strict = sum(planA["T"] * 4.0 * 64 * B * (u["n_src"] + u["nodes"]) for u in planA["updates"]
+                                 if u["update"] != "input" and u["kernel"].split("+")[0] == "k_gather")
+                    sA = msA * 1e-3 / args.steps
+                    agg_only = {"kernel": "k_gather (edge aggregate alone, GNNB_FUSE=0: rows to HBM, node update in its own launch)", "bound": "hbm",
+                                "avg_launch_us": round(1e3 * msA / nA, 2), "launches_per_step": int(nA // args.steps),
+                                "achieved": round(aggA.get("k_gather", 0.0) / sA / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                "frac": round(aggA.get("k_gather", 0.0) / sA / 1e9 / PEAK_HBM_GBS, 4),
+                                "achieved_survey_bytes": round(strict / sA / 1e9, 1), "frac_survey_bytes": round(strict / sA / 1e9 / PEAK_HBM_GBS, 4),
+                                "note": "achieved = rows actually needed (live source rows read once + updated rows written once) / time; "
+                                        "achieved_survey_bytes = SURVEY 8(d)'s 4*p*(N_src + N_dst) per half-pass (dead rows counted) / the same time"}
+                del engA, modelA
+            finally:
+                del os.environ["GNNB_FUSE"]
         cpu = None
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(sd, args.net, args.cpu_budget)
@@ -521,6 +561,7 @@ def main():
             "roofline": roofline,
             "roofline_node_update": roofline_nu,
             "roofline_message_passing": roofline_mp,
+            "roofline_aggregate_only": agg_only,
             "binding_bounds": binding_bounds(kern, pmc, args.steps),
             "exact_fp32_ms_per_step": round(exact_ms, 4) if exact_ms is not None else None,
             "bf3_max_abs_delta": bf3_delta,

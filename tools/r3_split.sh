@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-run() { timeout -k 10 200 python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-exact-fp32 $@ 2>/dev/null | python3 -c "
+run() { timeout -k 10 200 python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-exact-fp32 --no-aggregate-only $@ 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); k=d['kernels']
 print('  ', d['ms_per_step'], {n: v['avg_us'] for n, v in k.items() if n in ('k_top','k_node_update')})"; }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # dev helper (GPU box): the update of layer L-1 inside k_top (default) against its own launch (GNNB_TOP_FUSE_UPD=0), same box
 R=$GRAFT_REPO_ROOT; cd $R
-run() { timeout -k 10 200 python3 bench.py --steps ${STEPS:-30} --warmup 5 --no-cpu-baseline --no-exact-fp32 $@ 2>/dev/null | python3 -c "
+run() { timeout -k 10 200 python3 bench.py --steps ${STEPS:-30} --warmup 5 --no-cpu-baseline --no-exact-fp32 --no-aggregate-only $@ 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); k=d['kernels']
 print('  ', d['ms_per_step'], {n: v['avg_us'] for n, v in k.items() if n in ('k_top','k_node_update')})"; }
