@@ -11,7 +11,7 @@ from tests.common import shipped_state
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 # (round 3: the small batches cover k_top's four-workgroup hand-offs, k_scored_tail and k_classify_pre)
 for net, B in (("cifar_base_kw", 256), ("cifar_wide_kw", 256), ("cifar_deep_kw", 128), ("cifar_base_kw", 7), ("cifar_deep_kw", 1),
-               ("cifar_base_kw", 1), ("cifar_base_kw", 2), ("cifar_wide_kw", 3), ("cifar_base_kw", 33), ("cifar_deep_kw", 64)):
+               ("cifar_base_kw", 1), ("cifar_base_kw", 2), ("cifar_wide_kw", 3), ("cifar_base_kw", 33), ("cifar_deep_kw", 64), ("cifar_base_kw", 100), ("cifar_wide_kw", 128)):
     m = GraphNet(2, 64)
     m.load_state_dict({k: torch.as_tensor(v) for k, v in shipped_state().items()})
     batch = synth.make_batch(net, B, seed=11)
