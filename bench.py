@@ -69,7 +69,7 @@ def node_stats(batch):
     return out
 
 
-def plan_flops(plan, B, stats, restrict_last=True):
+def plan_flops(plan, B, stats, restrict_last=True, per_launch=None):
     """Per kernel class, for ONE forward of batch B: algorithmic flops (MACs the algorithm needs for the nodes that
     are updated, sparse edge sums 2*nnz*p) and issued matrix-pipe work in fp32-MFMA equivalents x 4096 flop (one
     v_mfma_f32_32x32x2_f32 = 64 pipe cycles = 1; one v_mfma_f32_32x32x16_bf16 of the three-piece blocks = 32 cycles = 0.5;
@@ -114,6 +114,11 @@ def plan_flops(plan, B, stats, restrict_last=True):
             # (round 0 with the embedding fused into the first gather reads three scalars per source node, not a 256-B row)
             src_row_bytes = 12.0 if (plan.get("embed_fused") and u["update"] == "fwd" and k == 1 and t == 0) else 4.0 * 64
             add(agg_bytes, agg, src_row_bytes * B * u["n_src"] + 4.0 * 64 * n_upd)
+            if per_launch is not None:       # (bench.py's aggregate-only leg prices single launches: half-pass, its aggregation kernel class, its bytes)
+                per_launch.append({"t": t, "update": u["update"], "layer": k, "agg": agg, "restricted": bool(restricted),
+                                   "embed_in_gather": src_row_bytes == 12.0,
+                                   "bytes": src_row_bytes * B * u["n_src"] + 4.0 * 64 * n_upd,
+                                   "survey_bytes": 4.0 * 64 * B * (u["n_src"] + u["nodes"])})
             # folded chains, last layer deferred.  bf16x3 (default): a tile of nodes with r0 == r1 runs 2 blocks of 48 bf16 MFMAs (+2 small),
             # a tile that holds an ambiguous node 3; fp32 MFMA only (GNNB_BF3=0): 130 / 194 fp32 MFMAs
             live, amb = stats[k]["live"], stats[k]["amb"]
@@ -525,7 +530,23 @@ def main():
                 rA.check()
                 assert torch.equal(rA.scores, res.scores), "the two-kernel half-passes must give the fused ones' scores bit for bit"
                 planA = engA.describe()
-                _, _, aggA = plan_flops(planA, B, stats)
+                launchesA = []
+                _, _, aggA = plan_flops(planA, B, stats, per_launch=launchesA)
+                # the stand-alone aggregates of one forward in launch order (forward sweep up, backward sweep down, per round), and the
+                # duration of each from the per-launch trace (averaged over the steps by position)
+                launchesA = sorted((x for x in launchesA if x["agg"] == "k_gather"),
+                                   key=lambda x: (x["t"], 0 if x["update"] == "fwd" else 1, x["layer"] if x["update"] == "fwd" else -x["layer"]))
+                traceA = [ms for name, ms in engA.profile_trace(65536) if name == "k_gather"]
+                per = []
+                if launchesA and len(traceA) == len(launchesA) * args.steps:
+                    for i, x in enumerate(launchesA):
+                        us = 1e3 * sum(traceA[i::len(launchesA)]) / args.steps
+                        what = ("round-0 embedding computed in the gather" if x["embed_in_gather"] else
+                                "restricted last step (scored nodes only)" if x["restricted"] else
+                                "dense source (input layer)" if (x["update"] == "fwd" and x["layer"] == 1) else "live rows of a ReLU layer")
+                        per.append({"half_pass": f"{x['update']} layer {x['layer']} round {x['t']}", "source": what, "avg_us": round(us, 2),
+                                    "achieved": round(x["bytes"] / us / 1e3, 1), "frac": round(x["bytes"] / us / 1e3 / PEAK_HBM_GBS, 4),
+                                    "frac_survey_bytes": round(x["survey_bytes"] / us / 1e3 / PEAK_HBM_GBS, 4)})
                 msA, nA = profA.get("k_gather", (0.0, 0))
                 if nA:
                     # SURVEY 8(d)'s count for the half-passes this class serves: every source row read once, every destination row written once
@@ -537,8 +558,11 @@ def main():
                                 "achieved": round(aggA.get("k_gather", 0.0) / sA / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                 "frac": round(aggA.get("k_gather", 0.0) / sA / 1e9 / PEAK_HBM_GBS, 4),
                                 "achieved_survey_bytes": round(strict / sA / 1e9, 1), "frac_survey_bytes": round(strict / sA / 1e9 / PEAK_HBM_GBS, 4),
-                                "note": "achieved = rows actually needed (live source rows read once + updated rows written once) / time; "
-                                        "achieved_survey_bytes = SURVEY 8(d)'s 4*p*(N_src + N_dst) per half-pass (dead rows counted) / the same time"}
+                                "per_launch": per, "best_launch_frac": max((x["frac"] for x in per), default=None),
+                                "note": "achieved = the `roofline` object's byte count (every source row read once + every UPDATED destination row written once; "
+                                        "round 0's first aggregate reads three scalars per source node) / time; achieved_survey_bytes = SURVEY 8(d)'s "
+                                        "4*p*(N_src + N_dst) per half-pass (rows of dead destination nodes counted too) / the same time; per_launch: the "
+                                        "class's launches of one forward in launch order, each priced the same two ways"}
                 del engA, modelA
             finally:
                 del os.environ["GNNB_FUSE"]

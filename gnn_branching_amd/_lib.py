@@ -61,6 +61,7 @@ SYMBOLS = [
     ("gnnb_profile_classes", C.c_int, []),
     ("gnnb_profile_class_name", C.c_char_p, [C.c_int]),
     ("gnnb_profile_read", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int, C.c_int]),
+    ("gnnb_profile_trace", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int]),
 ]
 
 

@@ -166,6 +166,8 @@ struct gnnb_handle {
   bool prof = false;
   struct Ev { int cls; hipEvent_t a, b; };
   std::vector<Ev> pending;
+  struct Tr { int cls; float ms; };
+  std::vector<Tr> trace;          // per-launch record of what gnnb_profile_read resolved (gnnb_profile_trace)
   std::vector<hipEvent_t> pool;
   double prof_ms[PC_COUNT] = {0};
   int64_t prof_n[PC_COUNT] = {0};
@@ -779,6 +781,7 @@ extern "C" int gnnb_profile_read(gnnb_t* h, double* total_ms, int64_t* launches,
       HIPCHK(hipEventElapsedTime(&ms, ev.a, ev.b));
       h->prof_ms[ev.cls] += ms;
       h->prof_n[ev.cls] += 1;
+      if (h->trace.size() < 65536) h->trace.push_back({ev.cls, ms});
       h->pool.push_back(ev.a);
       h->pool.push_back(ev.b);
     }
@@ -791,6 +794,18 @@ extern "C" int gnnb_profile_read(gnnb_t* h, double* total_ms, int64_t* launches,
   if (reset)
     for (int i = 0; i < PC_COUNT; ++i) { h->prof_ms[i] = 0; h->prof_n[i] = 0; }
   return GNNB_OK;
+}
+// The launches gnnb_profile_read has resolved since the last call of this function, in launch order: class and duration of each
+// (bench.py prices single launches of a class with it).  Returns their number (at most cap are copied); the list is cleared.
+extern "C" int gnnb_profile_trace(gnnb_t* h, int* cls, double* ms, int cap) {
+  if (!h) { fail(GNNB_E_INVALID, "null handle"); return -1; }
+  const int n = (int)h->trace.size();
+  for (int i = 0; i < n && i < cap; ++i) {
+    if (cls) cls[i] = h->trace[i].cls;
+    if (ms) ms[i] = h->trace[i].ms;
+  }
+  h->trace.clear();
+  return n;
 }
 
 struct Launcher {

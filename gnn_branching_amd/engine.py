@@ -534,6 +534,14 @@ class ScorerEngine:
     def profile_enable(self, on):
         _lib.check(self.lib.gnnb_profile_enable(self.h, int(on)), "gnnb_profile_enable")
 
+    def profile_trace(self, cap=4096):
+        """[(kernel class name, ms)] of the launches ``profile_read`` has resolved since the last call, in launch order."""
+        cls, ms = (C.c_int * cap)(), (C.c_double * cap)()
+        n = self.lib.gnnb_profile_trace(self.h, cls, ms, cap)
+        if n < 0:
+            raise RuntimeError("gnnb_profile_trace failed")
+        return [(self.lib.gnnb_profile_class_name(cls[i]).decode(), ms[i]) for i in range(min(n, cap))]
+
     def profile_read(self, reset=True):
         n = self.lib.gnnb_profile_classes()
         ms, cnt = (C.c_double * n)(), (C.c_int64 * n)()

@@ -165,6 +165,9 @@ int gnnb_profile_enable(gnnb_t* h, int on);
 int gnnb_profile_classes(void);                          /* number of classes */
 const char* gnnb_profile_class_name(int cls);            /* kernel (class) name */
 int gnnb_profile_read(gnnb_t* h, double* total_ms, int64_t* launches, int n, int reset);
+/* The launches resolved by gnnb_profile_read since the previous call of this function, in launch order: class index and duration
+ * (ms) of each.  Returns their number (>= 0; at most cap entries are written), or -1 for a null handle; clears the list. */
+int gnnb_profile_trace(gnnb_t* h, int* cls, double* ms, int cap);
 
 #ifdef __cplusplus
 }

@@ -504,3 +504,30 @@ def test_small_batch_classify_pre_kernel_is_bit_identical(monkeypatch, net, B, f
     assert np.array_equal(out["0"][0], out["8"][0], equal_nan=True) and out["0"][1] == out["8"][1]
     assert launches["8"] == launches["0"] - 1, launches
     print(f"{net} B={B} {fam}: {launches['8']} launches per forward")
+
+
+@pytest.mark.gpu
+def test_profile_trace_lists_the_launches_of_a_forward_in_order():
+    """gnnb_profile_trace: class and duration of every launch gnnb_profile_read resolved, in launch order (bench.py prices single launches
+    of the stand-alone aggregation class with it).  One forward of the default path: 13 launches at B = 40, 10 for a single subproblem,
+    the classification first and the score head last, the per-class sums equal to what profile_read returned."""
+    from gnn_branching_amd import synth
+    model = make_model("shipped")
+    eng = model.engine()
+    for B, want in ((40, 13), (1, 10)):
+        batch = synth.make_batch("cifar_base_kw", B, seed=5)
+        with torch.no_grad():
+            model.forward_device(*batch.forward_args()).check()
+            eng.profile_enable(True)
+            eng.profile_read(reset=True)
+            eng.profile_trace()
+            model.forward_device(*batch.forward_args()).check()
+            prof = eng.profile_read(reset=True)
+            trace = eng.profile_trace()
+            eng.profile_enable(False)
+        assert len(trace) == want == sum(v[1] for v in prof.values()), (B, [t[0] for t in trace])
+        assert trace[0][0] in ("k_classify", "k_pre") and all(ms > 0 for _, ms in trace)
+        for name, (ms, n) in prof.items():
+            mine = [m for c, m in trace if c == name]
+            assert len(mine) == n and abs(sum(mine) - ms) <= 1e-3 * max(ms, 1e-3)
+        assert eng.profile_trace() == []                      # read once
