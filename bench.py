@@ -514,6 +514,7 @@ def main():
         agg_only = None
         if not args.no_aggregate_only:
             os.environ["GNNB_FUSE"] = "0"
+            os.environ["GNNB_NO_EMBED_FUSE"] = "1"      # round 0's source rows come from k_embed, not out of the first gather: every launch of the class is a pure aggregate
             try:
                 modelA = GraphNet(2, 64)
                 modelA.load_state_dict(sd)
@@ -528,7 +529,10 @@ def main():
                 profA = engA.profile_read(reset=True)
                 engA.profile_enable(False)
                 rA.check()
-                assert torch.equal(rA.scores, res.scores), "the two-kernel half-passes must give the fused ones' scores bit for bit"
+                finA = torch.isfinite(res.scores)
+                assert torch.equal(finA, torch.isfinite(rA.scores)) and torch.equal(rA.decisions, res.decisions)
+                agg_delta = float((rA.scores[finA] - res.scores[finA]).abs().max()) if finA.any() else 0.0
+                assert agg_delta <= 2e-5, agg_delta      # (identical bits but for round 0's embedding, which k_embed computes on the vector ALU)
                 planA = engA.describe()
                 launchesA = []
                 _, _, aggA = plan_flops(planA, B, stats, per_launch=launchesA)
@@ -553,7 +557,8 @@ def main():
                     strict = sum(planA["T"] * 4.0 * 64 * B * (u["n_src"] + u["nodes"]) for u in planA["updates"]
                                  if u["update"] != "input" and u["kernel"].split("+")[0] == "k_gather")
                     sA = msA * 1e-3 / args.steps
-                    agg_only = {"kernel": "k_gather (edge aggregate alone, GNNB_FUSE=0: rows to HBM, node update in its own launch)", "bound": "hbm",
+                    agg_only = {"kernel": "k_gather (edge aggregate alone: GNNB_FUSE=0 GNNB_NO_EMBED_FUSE=1 -- rows to HBM, node update and input embedding in their own launches)",
+                                "bound": "hbm", "max_abs_score_delta_vs_default_path": agg_delta,
                                 "avg_launch_us": round(1e3 * msA / nA, 2), "launches_per_step": int(nA // args.steps),
                                 "achieved": round(aggA.get("k_gather", 0.0) / sA / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                 "frac": round(aggA.get("k_gather", 0.0) / sA / 1e9 / PEAK_HBM_GBS, 4),
@@ -565,7 +570,7 @@ def main():
                                         "class's launches of one forward in launch order, each priced the same two ways"}
                 del engA, modelA
             finally:
-                del os.environ["GNNB_FUSE"]
+                del os.environ["GNNB_FUSE"], os.environ["GNNB_NO_EMBED_FUSE"]
         cpu = None
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(sd, args.net, args.cpu_budget)

@@ -225,6 +225,26 @@ def test_fused_halfpass_kernel_matches(monkeypatch, case, fam):
     assert np.array_equal(out["0"], out["1"])
 
 
+@pytest.mark.parametrize("case", ["cifar_base_kw_B3", "cifar_deep_kw_B2"])
+@pytest.mark.parametrize("fuse", ["0", "1"])
+def test_round0_rows_from_the_embedding_kernel_match(monkeypatch, case, fuse):
+    """GNNB_NO_EMBED_FUSE=1: round 0's input-layer rows are written by k_embed and read back by the first aggregate, instead of being
+    computed inside it -- the form bench.py's aggregate-only leg runs (with GNNB_FUSE=0) so that every launch of the stand-alone
+    aggregation class is a pure aggregate.  Same scores within the parity bar, the reference's decisions."""
+    monkeypatch.setenv("GNNB_NO_EMBED_FUSE", "1")
+    monkeypatch.setenv("GNNB_FUSE", fuse)
+    g, batch = load_golden(case)
+    for fam in FAMILIES:
+        model = make_model(fam)
+        with torch.no_grad():
+            res = model.forward_device(*batch.forward_args()).check()
+        want = g[f"{fam}_scores"]
+        fin = np.isfinite(want)
+        assert np.abs(res.scores.cpu().numpy()[fin] - want[fin]).max() <= score_tol(fam, want[fin])
+        assert res.decisions.cpu().tolist() == g[f"{fam}_decisions"].tolist()
+        assert model.engine().describe()["embed_fused"] == 0
+
+
 def test_per_tile_dense_kernel_path_matches(monkeypatch):
     """GNNB_NO_DENSE_LDS=1 selects the per-tile dense edge kernels (the fallback for Linear layers whose source does
     not fit the LDS-staged kernels): same scores."""
