@@ -243,6 +243,13 @@ class StepLoop:
             self.pending = None
 
 
+def _status_word(res):
+    v = 0
+    for x in res.status.cpu().tolist():
+        v |= int(x)
+    return v
+
+
 def free_port():
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
@@ -266,6 +273,7 @@ def spawn_ranks(n, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    env["BENCH_SELF_LAUNCHED"] = "1"
     return subprocess.call(launch_command(n, argv, free_port()), env=env)
 
 
@@ -283,6 +291,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-exact-fp32", action="store_true", help="skip the GNNB_BF3=0 comparison leg (exact_fp32_ms_per_step, bf3_max_abs_delta)")
     ap.add_argument("--no-aggregate-only", action="store_true", help="skip the GNNB_FUSE=0 leg (roofline_aggregate_only: the stand-alone edge-aggregation kernel)")
     ap.add_argument("--cpu-budget", type=float, default=75.0, help="seconds of CPU work for the cpu_baseline leg")
+    ap.add_argument("--dist", action="store_true",
+                    help="run through torch.distributed even with --gpus 1: the process starts its rank(s) with torch.distributed.run exactly as "
+                         "--gpus N > 1 does, so init_process_group('nccl'), the score all-gather and StepLoop's overlap execute at world size 1")
     args = ap.parse_args(argv)
     cfg = CONFIGS[args.config if args.config is not None else 2]
     if args.net is None:
@@ -298,7 +309,7 @@ def main():
     args = parse_args()
     in_torchrun = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if not in_torchrun:
-        if args.gpus > 1:
+        if args.gpus > 1 or args.dist:
             sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
         rank, local_rank, world = 0, 0, 1
     else:
@@ -389,6 +400,21 @@ def main():
     else:
         total_amb = float(n_amb)
     res.check()
+    dist_record = None
+    if use_dist:
+        # the collective path against the plain one: the rows this rank received for its own shard in the LAST all-gather (launched while the
+        # next forward was being enqueued) must be the bits a forward with no collective in flight produces, and no kernel may have raised a
+        # status bit (k_top's split workgroups wait for each other while RCCL's kernel holds CUs)
+        plain = eng.forward(*d_args)
+        torch.cuda.synchronize()
+        plain.check()
+        got = loop.last_gathered[rank * B:(rank + 1) * B]
+        same = bool(torch.equal(got, plain.scores))
+        assert same, "all-gathered scores differ from the non-distributed forward"
+        assert loop.gathers_completed >= args.steps, (loop.gathers_completed, args.steps)
+        dist_record = {"backend": dist.get_backend(), "world_size": world, "gathers_completed": loop.gathers_completed,
+                       "gathered_rows": int(loop.last_gathered.shape[0]), "gathered_equals_plain_forward_bitwise": same,
+                       "status_word": int(_status_word(plain)), "self_launched": bool(os.environ.get("BENCH_SELF_LAUNCHED"))}
 
     # ---- per-kernel durations with HIP events on the launch stream (same K steps, instrumented) ----
     eng.profile_enable(True)
@@ -483,94 +509,27 @@ def main():
                        "note": "achieved = SURVEY 8(d) algorithmic bytes 4*p*(N_src + N_dst) per half-pass / time of all half-pass kernels; "
                                "frac_counter = HBM bytes the counters saw (dead rows are skipped, round 0 computes its source rows) / the same time"}
         # ---- the same batch with every block on the exact-fp32 MFMA (GNNB_BF3=0 is read by gnnb_create: a second handle),
-        # outside the timed region of the headline: what the three-piece bf16 blocks buy, and how far their scores are from it
+        # outside the timed region of the headline: what the three-piece bf16 blocks buy, and how far their scores are from it.
+        # A side leg never takes the headline down with it: a failure is recorded in the JSON (`side_leg_errors`).
+        side_errors = {}
         exact_ms = bf3_delta = None
         if plan.get("bf3") and not args.no_exact_fp32:
-            os.environ["GNNB_BF3"] = "0"
             try:
-                model32 = GraphNet(2, 64)
-                model32.load_state_dict(sd)
-                eng32 = model32.eval().engine()
-                for _ in range(5):
-                    r32 = eng32.forward(*d_args)
-                torch.cuda.synchronize()
-                t2 = time.perf_counter()
-                for _ in range(args.steps):
-                    r32 = eng32.forward(*d_args)
-                torch.cuda.synchronize()
-                exact_ms = 1e3 * (time.perf_counter() - t2) / args.steps
-                r32.check()
-                a32, a16 = r32.scores.cpu().numpy(), res.scores.cpu().numpy()
-                fin = np.isfinite(a32)
-                assert np.array_equal(fin, np.isfinite(a16))
-                bf3_delta = float(np.abs(a32[fin] - a16[fin]).max()) if fin.any() else 0.0
-                assert torch.equal(r32.decisions, res.decisions) or bf3_delta > 0
-                del eng32, model32
-            finally:
-                del os.environ["GNNB_BF3"]
+                with _env(GNNB_BF3="0"):
+                    exact_ms, bf3_delta = exact_fp32_leg(sd, d_args, res, args.steps)
+            except Exception as e:      # noqa: BLE001
+                side_errors["exact_fp32"] = f"{type(e).__name__}: {e}"
         # ---- the edge aggregation ALONE ("standalone message-passing (aggregate-only) kernel for the HBM-roofline
         # measurement, plus the fused production variant"): the same batch through a second handle with GNNB_FUSE=0, where every conv
         # half-pass is k_gather (aggregate rows -> HBM) + k_node_update; identical scores.  Outside the timed region of the headline.
         agg_only = None
         if not args.no_aggregate_only:
-            os.environ["GNNB_FUSE"] = "0"
-            os.environ["GNNB_NO_EMBED_FUSE"] = "1"      # round 0's source rows come from k_embed, not out of the first gather: every launch of the class is a pure aggregate
             try:
-                modelA = GraphNet(2, 64)
-                modelA.load_state_dict(sd)
-                engA = modelA.eval().engine()
-                for _ in range(5):
-                    rA = engA.forward(*d_args)
-                torch.cuda.synchronize()
-                engA.profile_enable(True)
-                for _ in range(args.steps):
-                    rA = engA.forward(*d_args)
-                torch.cuda.synchronize()
-                profA = engA.profile_read(reset=True)
-                engA.profile_enable(False)
-                rA.check()
-                finA = torch.isfinite(res.scores)
-                assert torch.equal(finA, torch.isfinite(rA.scores)) and torch.equal(rA.decisions, res.decisions)
-                agg_delta = float((rA.scores[finA] - res.scores[finA]).abs().max()) if finA.any() else 0.0
-                assert agg_delta <= 2e-5, agg_delta      # (identical bits but for round 0's embedding, which k_embed computes on the vector ALU)
-                planA = engA.describe()
-                launchesA = []
-                _, _, aggA = plan_flops(planA, B, stats, per_launch=launchesA)
-                # the stand-alone aggregates of one forward in launch order (forward sweep up, backward sweep down, per round), and the
-                # duration of each from the per-launch trace (averaged over the steps by position)
-                launchesA = sorted((x for x in launchesA if x["agg"] == "k_gather"),
-                                   key=lambda x: (x["t"], 0 if x["update"] == "fwd" else 1, x["layer"] if x["update"] == "fwd" else -x["layer"]))
-                traceA = [ms for name, ms in engA.profile_trace(65536) if name == "k_gather"]
-                per = []
-                if launchesA and len(traceA) == len(launchesA) * args.steps:
-                    for i, x in enumerate(launchesA):
-                        us = 1e3 * sum(traceA[i::len(launchesA)]) / args.steps
-                        what = ("round-0 embedding computed in the gather" if x["embed_in_gather"] else
-                                "restricted last step (scored nodes only)" if x["restricted"] else
-                                "dense source (input layer)" if (x["update"] == "fwd" and x["layer"] == 1) else "live rows of a ReLU layer")
-                        per.append({"half_pass": f"{x['update']} layer {x['layer']} round {x['t']}", "source": what, "avg_us": round(us, 2),
-                                    "achieved": round(x["bytes"] / us / 1e3, 1), "frac": round(x["bytes"] / us / 1e3 / PEAK_HBM_GBS, 4),
-                                    "frac_survey_bytes": round(x["survey_bytes"] / us / 1e3 / PEAK_HBM_GBS, 4)})
-                msA, nA = profA.get("k_gather", (0.0, 0))
-                if nA:
-                    # SURVEY 8(d)'s count for the half-passes this class serves: every source row read once, every destination row written once
-                    strict = sum(planA["T"] * 4.0 * 64 * B * (u["n_src"] + u["nodes"]) for u in planA["updates"]
-                                 if u["update"] != "input" and u["kernel"].split("+")[0] == "k_gather")
-                    sA = msA * 1e-3 / args.steps
-                    agg_only = {"kernel": "k_gather (edge aggregate alone: GNNB_FUSE=0 GNNB_NO_EMBED_FUSE=1 -- rows to HBM, node update and input embedding in their own launches)",
-                                "bound": "hbm", "max_abs_score_delta_vs_default_path": agg_delta,
-                                "avg_launch_us": round(1e3 * msA / nA, 2), "launches_per_step": int(nA // args.steps),
-                                "achieved": round(aggA.get("k_gather", 0.0) / sA / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                "frac": round(aggA.get("k_gather", 0.0) / sA / 1e9 / PEAK_HBM_GBS, 4),
-                                "achieved_survey_bytes": round(strict / sA / 1e9, 1), "frac_survey_bytes": round(strict / sA / 1e9 / PEAK_HBM_GBS, 4),
-                                "per_launch": per, "best_launch_frac": max((x["frac"] for x in per), default=None),
-                                "note": "achieved = the `roofline` object's byte count (every source row read once + every UPDATED destination row written once; "
-                                        "round 0's first aggregate reads three scalars per source node) / time; achieved_survey_bytes = SURVEY 8(d)'s "
-                                        "4*p*(N_src + N_dst) per half-pass (rows of dead destination nodes counted too) / the same time; per_launch: the "
-                                        "class's launches of one forward in launch order, each priced the same two ways"}
-                del engA, modelA
-            finally:
-                del os.environ["GNNB_FUSE"], os.environ["GNNB_NO_EMBED_FUSE"]
+                with _env(GNNB_FUSE="0", GNNB_NO_EMBED_FUSE="1"):
+                    agg_only = aggregate_only_leg(sd, d_args, res, args, batch, stats, B)
+            except Exception as e:      # noqa: BLE001
+                side_errors["aggregate_only"] = f"{type(e).__name__}: {e}"
+                agg_only = {"error": side_errors["aggregate_only"]}
         cpu = None
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(sd, args.net, args.cpu_budget)
@@ -599,11 +558,163 @@ def main():
             "plan": plan["updates"],
             "node_classes": {str(k): v for k, v in stats.items()},
             "instrumented_ms_per_step": round(1e3 * instrumented / args.steps, 4),
+            "dist": dist_record,
+            "side_leg_errors": side_errors or None,
         }
         print(json.dumps(out))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+class _env:
+    """Set environment variables for the duration of a side leg and put back what was there (a value the user exported survives)."""
+
+    def __init__(self, **kv):
+        self.kv, self.old = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = os.environ.get(k)
+            os.environ[k] = v
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        return False
+
+
+def exact_fp32_leg(sd, d_args, res, steps):
+    from gnn_branching_amd.graphnet.graph_conv import GraphNet
+    model32 = GraphNet(2, 64)
+    model32.load_state_dict(sd)
+    eng32 = model32.eval().engine()
+    for _ in range(5):
+        r32 = eng32.forward(*d_args)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for _ in range(steps):
+        r32 = eng32.forward(*d_args)
+    torch.cuda.synchronize()
+    exact_ms = 1e3 * (time.perf_counter() - t2) / steps
+    r32.check()
+    a32, a16 = r32.scores.cpu().numpy(), res.scores.cpu().numpy()
+    fin = np.isfinite(a32)
+    if not np.array_equal(fin, np.isfinite(a16)):
+        raise RuntimeError("exact-fp32 leg: different set of scored nodes")
+    return exact_ms, (float(np.abs(a32[fin] - a16[fin]).max()) if fin.any() else 0.0)
+
+
+def restricted_source_rows(batch, k):
+    """Rows the restricted last step's aggregate of ReLU layer k has to read: the LIVE nodes of layer k + 1 that lie in the
+    transposed-conv window of at least one scored node of layer k (graph_conv.py:299-318 evaluated where the score head looks)."""
+    import torch.nn.functional as F
+    affine = [l for l in batch.layers["fixed_layers"] if isinstance(l, (torch.nn.Conv2d, torch.nn.Linear))]
+    conv = affine[k]                               # edge k + 1: layer k -> layer k + 1
+    if not isinstance(conv, torch.nn.Conv2d):
+        return None
+    shape = batch.lower_bounds_all[k].shape        # (B, C, H, W)
+    off = sum(int(np.prod(t.shape[1:])) for t in batch.lower_bounds_all[1:k])
+    n = int(np.prod(shape[1:]))
+    scored = batch.masks[:, off:off + n].reshape(shape).amax(1, keepdim=True).float()
+    kh, kw = conv.kernel_size
+    need = F.conv2d(scored, torch.ones(1, 1, kh, kw), stride=conv.stride, padding=conv.padding) > 0
+    live = batch.upper_bounds_all[k + 1] > 0
+    return int((live & need).sum())
+
+
+def aggregate_only_leg(sd, d_args, res, args, batch, stats, B):
+    """roofline_aggregate_only: the stand-alone edge-aggregation launches of one forward, priced three ways each --
+      frac_rows_moved    256 B x (LIVE source rows the launch has to read + destination rows it writes) / time / 8 TB/s
+      frac_survey_bytes  SURVEY 8(d)'s 4 p (N_src + N_dst) (dead rows counted too)                      / time / 8 TB/s
+      frac_counter       HBM bytes the counters saw for that kernel template ((2 FETCH + WRITE) KB)     / time / 8 TB/s  (committed
+                         PMC passes of this leg: profiles/pmc_latest_<net>_B<B>_aggonly.json; null without them)."""
+    from gnn_branching_amd.graphnet.graph_conv import GraphNet
+    modelA = GraphNet(2, 64)
+    modelA.load_state_dict(sd)
+    engA = modelA.eval().engine()
+    for _ in range(5):
+        rA = engA.forward(*d_args)
+    torch.cuda.synchronize()
+    engA.profile_enable(True)
+    engA.profile_read(reset=True)
+    engA.profile_trace(65536)
+    for _ in range(args.steps):
+        rA = engA.forward(*d_args)
+    torch.cuda.synchronize()
+    profA = engA.profile_read(reset=True)
+    traceA = [ms for name, ms in engA.profile_trace(65536) if name == "k_gather"]
+    engA.profile_enable(False)
+    rA.check()
+    finA = torch.isfinite(res.scores)
+    same_set = bool(torch.equal(finA, torch.isfinite(rA.scores)))
+    agg_delta = float((rA.scores[finA] - res.scores[finA]).abs().max()) if (same_set and finA.any()) else None
+    same_dec = bool(torch.equal(rA.decisions, res.decisions))
+    planA = engA.describe()
+    launchesA = []
+    plan_flops(planA, B, stats, per_launch=launchesA)
+    by_key = {(u["update"], u["layer"]): u for u in planA["updates"]}
+    # the stand-alone aggregates of one forward in launch order (forward sweep up, backward sweep down, per round)
+    launchesA = sorted((x for x in launchesA if x["agg"] == "k_gather"),
+                       key=lambda x: (x["t"], 0 if x["update"] == "fwd" else 1, x["layer"] if x["update"] == "fwd" else -x["layer"]))
+    pmcA = None
+    pmc_path = os.path.join(ROOT, "profiles", f"pmc_latest_{args.net}_B{B}_aggonly.json")
+    if os.path.exists(pmc_path):
+        pmcA = json.load(open(pmc_path)).get("_templates")
+    per, tot_moved, tot_counter, counter_ok = [], 0.0, 0.0, pmcA is not None
+    if launchesA and len(traceA) == len(launchesA) * args.steps:
+        for i, x in enumerate(launchesA):
+            us = 1e3 * sum(traceA[i::len(launchesA)]) / args.steps
+            u = by_key[(x["update"], x["layer"])]
+            src = x["layer"] - 1 if x["update"] == "fwd" else x["layer"] + 1
+            n_upd = stats[x["layer"]]["scored"] if x["restricted"] else stats[x["layer"]]["live"]
+            if src == 0:
+                src_rows, what = B * u["n_src"], "dense source (input layer: every row live)"
+            elif x["restricted"]:
+                r = restricted_source_rows(batch, x["layer"])
+                src_rows = r if r is not None else stats[src]["live"]
+                what = "restricted last step (scored nodes only; live rows inside their windows)"
+            else:
+                src_rows, what = stats[src]["live"], "live rows of a ReLU layer (sparse walk)"
+            moved = 256.0 * (src_rows + n_upd)
+            lanes = u.get("tile_nodes", 32)
+            tmpl = ("k_gather16" if lanes == 16 else "k_gather") + ("<false, false>" if src == 0 else "<false, true>")
+            counter = None
+            if pmcA is not None:
+                row = (pmcA.get("k_gather_scored") if x["restricted"] and "k_gather_scored" in pmcA else None) or pmcA.get(tmpl)
+                counter = row.get("hbm_bytes_per_launch") if row else None
+                if row and x["restricted"] and "k_gather_scored" in pmcA:
+                    tmpl = "k_gather_scored"
+            counter_ok = counter_ok and counter is not None
+            tot_moved += moved
+            tot_counter += counter or 0.0
+            per.append({"half_pass": f"{x['update']} layer {x['layer']} round {x['t']}", "kernel": tmpl, "source": what, "avg_us": round(us, 2),
+                        "source_rows_read": int(src_rows), "rows_written": int(n_upd),
+                        "frac_rows_moved": round(moved / us / 1e3 / PEAK_HBM_GBS, 4),
+                        "frac_survey_bytes": round(x["survey_bytes"] / us / 1e3 / PEAK_HBM_GBS, 4),
+                        "frac_counter": round(counter / us / 1e3 / PEAK_HBM_GBS, 4) if counter else None,
+                        "counter_over_rows_moved": round(counter / moved, 3) if counter else None})
+    msA, nA = profA.get("k_gather", (0.0, 0))
+    if not nA:
+        return {"error": "no k_gather launch in the GNNB_FUSE=0 run"}
+    strict = sum(planA["T"] * 4.0 * 64 * B * (u["n_src"] + u["nodes"]) for u in planA["updates"]
+                 if u["update"] != "input" and u["kernel"].split("+")[0] == "k_gather")
+    sA = msA * 1e-3 / args.steps
+    return {"kernel": "k_gather (edge aggregate alone: GNNB_FUSE=0 GNNB_NO_EMBED_FUSE=1 -- rows to HBM, node update and input embedding in their own launches)",
+            "bound": "hbm", "same_scored_set_as_default_path": same_set, "same_decisions_as_default_path": same_dec,
+            "max_abs_score_delta_vs_default_path": agg_delta,
+            "avg_launch_us": round(1e3 * msA / nA, 2), "launches_per_step": int(nA // args.steps), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac_rows_moved": round(tot_moved / sA / 1e9 / PEAK_HBM_GBS, 4) if per else None,
+            "frac_survey_bytes": round(strict / sA / 1e9 / PEAK_HBM_GBS, 4),
+            "frac_counter": round(tot_counter / sA / 1e9 / PEAK_HBM_GBS, 4) if (per and counter_ok) else None,
+            "achieved_rows_moved": round(tot_moved / sA / 1e9, 1) if per else None, "achieved_survey_bytes": round(strict / sA / 1e9, 1),
+            "per_launch": per, "best_launch_frac_rows_moved": max((x["frac_rows_moved"] for x in per), default=None),
+            "note": "frac_rows_moved: 256 B x (live source rows the launch must read + rows it writes) / time; frac_survey_bytes: SURVEY 8(d)'s "
+                    "4 p (N_src + N_dst) per half-pass (dead rows counted too) / the same time; frac_counter: HBM bytes of the committed PMC passes of "
+                    "this leg ((2 FETCH_SIZE + WRITE_SIZE) KB per launch of the kernel template) / the same time"}
 
 
 def cpu_model_name():

@@ -145,6 +145,9 @@ def load():
         import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         if "GNNB_LIB" not in os.environ and os.path.exists(os.path.join(CSRC, "gnnb.hip")):
+            if not hasattr(lib, "gnnb_build_id"):      # a library from before the source hash was compiled in
+                raise RuntimeError(f"{LIB_PATH} carries no build id (built from older sources): run "
+                                   "`python -c 'import __graft_entry__ as g; g.build()'`")
             lib.gnnb_build_id.restype = C.c_char_p
             have, want = lib.gnnb_build_id().decode("ascii", "replace"), source_hash()
             if have != want:

@@ -1277,7 +1277,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     // layer L-1, S = 2 was a draw -- the two hand-offs cost what the shorter edges saved; with the update's tiles split over both
     // workgroups too it wins: deep B = 128 67 -> 59 us, wide B = 128 99 -> 79 us per launch.)
     int S = 1;
-    if (h->top_split_max >= 4 && (long)B * 4 <= h->n_cu) S = 4;
+    if (h->top_split_max >= 4 && (long)B * 4 <= h->n_cu && B <= TOP_SPLIT_MAXB) S = 4;      // (topflag / xbuf are sized for TOP_SPLIT_MAXB samples)
     else if (h->top_split_max >= 2 && (long)B * 2 <= h->n_cu && B <= TOP_SPLIT_MAXB) S = 2;
     a.xbuf = ws + w.topx; a.xflag = reinterpret_cast<int*>(ws + w.topflag); a.xbase = top_launches * 2 * S;
     a.fuse_um = top_upd ? 1 : 0;

@@ -858,15 +858,21 @@ static_assert(TOP_IMG_FLOATS + PackUpdL3::FLOATS <= TOP_A_FLOATS + PackProp::FLO
 
 // One sample's top of the network on workgroup `part` of S = 4 / TS (TS row tiles of the last ReLU layer per workgroup; S = 1: the
 // whole sample, no exchange).  Layer L's node n sits in row tile n % 4 (lane n / 4 of wave n % 4 in the update phases, rows
-// 4 i + t of F1's tile t), so a workgroup owns whole tiles through F1, F2, B1; what crosses workgroups goes through global memory
-// behind an agent-scope release / acquire on the sample's arrival counter (the XCDs' L2s are not coherent with each other):
+// 4 i + t of F1's tile t), so a workgroup owns whole tiles through F1, F2, B1; what crosses workgroups goes through global memory.
+// Ordering contract of a hand-off (no fences: the XCDs' L2s are not coherent with each other and a fence per arrival cost 40-50 us at
+// B = 128): EVERY store of the handed-off bytes is a write-through `sc1` store, every storing wave drains them (`s_waitcnt vmcnt(0)`)
+// before the workgroup barrier behind which ONE lane adds to the sample's arrival counter (agent-scope atomic); the consumer polls that
+// counter with `sc1` loads, joins a workgroup barrier, and EVERY load of the handed-off bytes is an `sc1` load to registers
+// (MI355X_MICROARCH.md, "Valid forms": the `sc1` row of the hand-off table).  tests/test_gpu_parity.py::test_top_workgroup_split_is_bit_identical
+// runs S = 1 / 2 / 4 on a NaN-poisoned exchange buffer and is the guard of this contract.  What crosses:
 //   after F2: the 8 per-wave partial sums of the property node's aggregate (wave w sums rows w, w + 8, ...: all of one tile) --
 //             every workgroup then evaluates the property node itself, from the same 8 vectors in the same order;
 //   after B1: the rows of layer L (they go to a.mu anyway) -- every workgroup loads the rows it does not own and computes its
 //             share of B2's row tiles.
 // Every sum keeps the order of the unsplit kernel, so the results do not depend on S (tests: bit-identical for S = 1, 2, 4).
 // The S workgroups of a sample must be resident together: the host only splits when B x S workgroups fit the chip at one per CU,
-// and every wait has an iteration cap that raises status bit 1 instead of hanging.
+// and every wait has an iteration cap that raises status bit 1 instead of hanging.  A caller that shares the GPU with long kernels of
+// other streams or processes (so that the partner workgroups may be dispatched late) should set GNNB_TOP_SPLIT=1.
 // needs 512 threads and TOP_LDS_FLOATS of LDS
 template <int TS>
 __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, const int part, float* lds) {

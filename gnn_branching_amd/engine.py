@@ -58,9 +58,12 @@ def _or_reduce(status):
 
 def _raise_for_status(st):
     """status word of gnnb_forward: bit 0 = an embedding was NaN (the reference enters pdb there, graph_conv.py:184-186, :339-341);
-    bit 1 = a wait inside k_gather_update_q ran into its iteration cap (a protocol bug or a wedged GPU: results are invalid)."""
+    bit 1 = a wait inside a kernel (k_gather_update_q's LDS ring, or k_top's workgroup split waiting for its partner workgroups)
+    ran into its iteration cap: a protocol bug, a wedged GPU, or -- for k_top -- partner workgroups kept off the chip by other work
+    (GNNB_TOP_SPLIT=1 turns the split off); results are invalid."""
     if st & 2:
-        msg = "k_gather_update_q: internal wait timed out (status bit 1); results are invalid"
+        msg = ("a wait inside a kernel (k_gather_update_q ring or k_top workgroup split) hit its iteration cap (status bit 1); "
+               "results are invalid; GNNB_TOP_SPLIT=1 disables the k_top split")
         print(f"[gnn_branching_amd] {msg}", flush=True)
         raise RuntimeError(msg)
     if st & 1:

@@ -87,8 +87,9 @@ size_t gnnb_workspace_bytes(const gnnb_t* h, int B);
  * flat ReLU order, -inf elsewhere (the reference returns the ragged list of graph_conv.py:470).
  * decisions: device (B, 2) int32 [dec_lay, dec_idx], first maximal score; [-1,-1] if a sample
  * has no ambiguous ReLU.  status: device int32[1], bit 0 set if an embedding was NaN (the reference
- * enters pdb, graph_conv.py:184-186, :339-341), bit 1 if a wait inside a kernel hit its iteration cap (never in a correct run;
- * the results are then invalid).  stream: hipStream_t (NULL = default). */
+ * enters pdb, graph_conv.py:184-186, :339-341), bit 1 if a wait inside a kernel (k_gather_update_q's LDS ring; k_top's workgroup
+ * split waiting for its partner workgroups -- GNNB_TOP_SPLIT=1 turns that split off) hit its iteration cap (never in a correct run on a
+ * GPU the caller does not share with long-running kernels; the results are then invalid).  stream: hipStream_t (NULL = default). */
 int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* scores_padded, int32_t* decisions,
                  int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
 

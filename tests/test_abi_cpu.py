@@ -53,7 +53,7 @@ def test_product_does_not_import_the_oracle():
 
 def test_status_word_maps_to_the_reference_s_failure_modes():
     """gnnb_forward's status word: bit 0 = a NaN embedding (the reference drops into pdb there, graph_conv.py:184-186, :339-341) ->
-    FloatingPointError; bit 1 = a wait inside the fused half-pass kernel hit its iteration cap -> RuntimeError (results invalid);
+    FloatingPointError; bit 1 = a wait inside a kernel (the fused half-pass ring, k_top's workgroup split) hit its iteration cap -> RuntimeError (results invalid);
     the words of several chunks are OR-ed; 0 raises nothing."""
     import pytest
     import torch
@@ -63,7 +63,7 @@ def test_status_word_maps_to_the_reference_s_failure_modes():
     engine._raise_for_status(0)
     with pytest.raises(FloatingPointError, match="nan"):
         engine._raise_for_status(1)
-    with pytest.raises(RuntimeError, match="timed out"):
+    with pytest.raises(RuntimeError, match="iteration cap"):
         engine._raise_for_status(2)
     with pytest.raises(RuntimeError):                 # a timed-out wait outranks the NaN check: its rows are garbage anyway
         engine._raise_for_status(3)

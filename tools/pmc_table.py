@@ -34,6 +34,22 @@ for name in sorted(merged):
               'GRBM_GUI_ACTIVE', 'TCC_HIT_sum', 'TCC_MISS_sum', 'SQ_LDS_BANK_CONFLICT', 'SQ_ACTIVE_INST_LDS', 'SQ_INSTS_LDS',
               'TCP_TCC_READ_REQ_sum', 'TCP_TCC_WRITE_REQ_sum', 'TCP_TOTAL_CACHE_ACCESSES_sum', 'TCC_REQ_sum'):
         if c in v: out.setdefault(name, {})[c + "_per_launch"] = round(sum(v[c]) / len(v[c]), 1)
+# the same per kernel TEMPLATE (bench.py's aggregate-only leg prices single launches: k_gather16<false, true> etc.)
+tmpl = {}
+for k in sorted(vals):
+    name = k.replace('void ', '')
+    if not name.startswith('k_'): continue
+    v = vals[k]
+    e = {}
+    if 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
+        f = sum(v['FETCH_SIZE']) / len(v['FETCH_SIZE']); w = sum(v['WRITE_SIZE']) / len(v['WRITE_SIZE'])
+        e.update({"fetch_size_kb_per_launch": round(f, 1), "write_size_kb_per_launch": round(w, 1),
+                  "hbm_bytes_per_launch": round((2 * f + w) * 1024), "launches_sampled": len(v['FETCH_SIZE'])})
+    for c in ('TCC_HIT_sum', 'TCC_MISS_sum', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_INSTS_VALU', 'SQ_INSTS_MFMA', 'SQ_WAIT_INST_ANY', 'SQ_WAVE_CYCLES',
+              'TCP_TCC_READ_REQ_sum', 'TCP_TCC_WRITE_REQ_sum', 'SQ_LDS_BANK_CONFLICT', 'SQ_VALU_MFMA_COEXEC_CYCLES'):
+        if c in v: e[c + "_per_launch"] = round(sum(v[c]) / len(v[c]), 1)
+    if e: tmpl[name] = e
+out["_templates"] = tmpl
 if len(sys.argv) > 2:
     json.dump(out, open(sys.argv[2], 'w'), indent=1)
     print('wrote', sys.argv[2])
