@@ -123,7 +123,7 @@ struct gnnb_handle {
   int clspre_max_b = 1;         // GNNB_CLSPRE_MAX_B: batches up to it classify and run the hoisted feature chains in one launch (k_classify_pre);
                                 // measured (base, us): B = 1 27.5 vs 7.6 + 22.1, B = 2 34.0 vs 30.0, B = 8 42.5 vs 31.8 -- a block's share of
                                 // the ambiguous nodes is uneven, so beyond one subproblem the two kernels' even dealing wins
-  int tail_max_b = 8;           // GNNB_TAIL_MAX_B: batches up to it end in k_scored_tail (scored gather + restricted update + score head in one launch)
+  int tail_max_b = 1 << 30;     // GNNB_TAIL_MAX_B: batches up to it end in k_scored_tail (scored gather + restricted update + score head in one launch); 0: three kernels
   bool top_fuse_upd = true;     // GNNB_TOP_FUSE_UPD=0: the backward node update of layer L-1 as its own launch behind k_top (it runs inside k_top otherwise)
   int top_split_max = 4;        // GNNB_TOP_SPLIT: 4 (default) = four workgroups per sample while B <= n_cu / 4, two while B <= n_cu / 2; 2 = two at most; 1 = never
   int per_sample_min_b = 0;     // GNNB_PER_SAMPLE_MIN_B: batches below it take the per-tile dense kernel + separate launches
@@ -293,15 +293,15 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
 #endif
   HIPCHK(hipFuncSetAttribute((const void*)k_gather16<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   if (const char* e = getenv("GNNB_NO_EMBED_FUSE")) h->embed_fuse = !(e[0] == '1');      // (bench.py's aggregate-only leg: round 0's rows from k_embed)
-  HIPCHK(hipFuncSetAttribute((const void*)k_livesum, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_livesum, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));      // (the kernel also has a few static words)
 #ifdef GNNB_DEV
   if (const char* e = getenv("GNNB_NO_RESTRICT")) h->restrict_last = !(e[0] == '1');
 #endif
   if (const char* e = getenv("GNNB_NO_DENSE_LDS")) h->dense_lds = !(e[0] == '1');
-  HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));      // (the kernel also has a few static words)
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));      // (the kernel also has a few static words)
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));      // (the kernel also has a few static words)
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));      // (the kernel also has a few static words)
   HIPCHK(hipFuncSetAttribute((const void*)k_gather<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   if (const char* e = getenv("GNNB_NO_GATHER")) h->use_gather = !(e[0] == '1');
   if (const char* e = getenv("GNNB_NO_TOP")) h->use_top = !(e[0] == '1');
@@ -320,7 +320,7 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   if (const char* e = getenv("GNNB_TOP_FUSE_UPD")) h->top_fuse_upd = !(e[0] == '0');
   if (const char* e = getenv("GNNB_TOP_SPLIT")) h->top_split_max = atoi(e) >= 4 ? 4 : (atoi(e) >= 2 ? 2 : 1);
   HIPCHK(hipFuncSetAttribute((const void*)k_classify_pre, hipFuncAttributeMaxDynamicSharedMemorySize, CLSPRE_LDS_BYTES));
-  HIPCHK(hipFuncSetAttribute((const void*)k_scored_tail, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS_FLOATS * 4));
+  HIPCHK(hipFuncSetAttribute((const void*)k_scored_tail, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));      // (the kernel also has a few static words)
   HIPCHK(hipFuncSetAttribute((const void*)k_top<4>, hipFuncAttributeMaxDynamicSharedMemorySize, TOP_LDS_FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_top<2>, hipFuncAttributeMaxDynamicSharedMemorySize, TOP_LDS_FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_top<1>, hipFuncAttributeMaxDynamicSharedMemorySize, TOP_LDS_FLOATS * 4));
@@ -1105,10 +1105,11 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     // the input layer (k = 0) aggregates the rows of layer 1 that already went through its 64x64 map (PackPostInp)
     const float* srcb = k == 0 ? rows1_for_input : mu(k + 1);
     if (k >= 1 && scored && h->gb[k + 1].ok && h->scored_gather && (h->gather_sparse & 2) &&
-        e.c_out * ((e.kh + e.stride - 1) / e.stride) * ((e.kw + e.stride - 1) / e.stride) <= 96) {
-      // the restricted last step: one wave per scored node instead of every tile that holds one (k_gather_scored).  Only for
-      // windows up to 96 source nodes: a scored node re-reads its whole window, a tile shares it among 32 nodes (base, 64 slots:
-      // 31 vs 38 us; deep 18 vs 38; wide, 128 slots: 116 vs 99 -> stays on the tile gather)
+        e.c_out * ((e.kh + e.stride - 1) / e.stride) * ((e.kw + e.stride - 1) / e.stride) <= GS_SLOT_LIMIT) {
+      // the restricted last step as three kernels (GNNB_TAIL_MAX_B=0; the default is k_scored_tail): one wave per scored node instead of
+      // every tile that holds one (k_gather_scored).  Windows up to GS_SLOT_LIMIT source nodes (base, 64 slots: 31 vs 38 us for the tile
+      // gather; deep 18 vs 38; wide, 128 slots: 116 vs 99 -- kept on the list-driven form all the same, so that this path and
+      // k_scored_tail evaluate a scored node's aggregate with the same arithmetic)
       GSArgs a{ilist(w.score[k]), cnt + 4 * k + 2, mu(k + 1), h->dev[k + 1].w_bwd, in->lb[k + 1], in->ub[k + 1], nb, h->s_in_gather ? ws + w.sb[k] : nullptr,
                h->N[k], e.c_in, e.h_in, e.w_in, e.c_out, e.h_out, e.w_out, e.kh, e.kw, e.stride, e.pad, normalise};
       lz.run(PC_GATHER, [&] { hipLaunchKernelGGL(k_gather_scored, dim3((unsigned)h->n_cu * 4), dim3(GS_WAVES * 64), 0, st, a); });
@@ -1291,14 +1292,15 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     proj[L] = L_BC4_1;
   };
 
-  // Small batches: the restricted last step (scored gather + node update of layer 1) and the score head are ONE launch,
-  // k_scored_tail (GNNB_TAIL_MAX_B, default 8: above it the three kernels' better balance wins)
+  // The restricted last step (scored gather + node update of layer 1) and the score head are ONE launch, k_scored_tail
+  // (GNNB_TAIL_MAX_B=0: the three kernels k_gather_scored, k_node_update, k_score)
   bool tail_fused = false;
   TailArgs tail{};
   auto try_tail = [&](int k) -> bool {
     const Edge& e = h->edges[k + 1];
     if (!(B <= h->tail_max_b && h->bf3 && k == 1 && L >= 2 && h->restrict_last && !debug_full && e.kind == 0 && h->gb[k + 1].ok && h->scored_gather &&
-          (h->gather_sparse & 2) && e.c_out * ((e.kh + e.stride - 1) / e.stride) * ((e.kw + e.stride - 1) / e.stride) <= 96))
+          (h->gather_sparse & 2) && e.c_out * ((e.kh + e.stride - 1) / e.stride) * ((e.kw + e.stride - 1) / e.stride) <= GS_SLOT_LIMIT &&
+          h->N[k + 1] < 65536))
       return false;
     tail.g = GSArgs{ilist(w.score[k]), cnt + 4 * k + 2, mu(k + 1), h->dev[k + 1].w_bwd, in->lb[k + 1], in->ub[k + 1], nullptr, nullptr,
                     h->N[k], e.c_in, e.h_in, e.w_in, e.c_out, e.h_out, e.w_out, e.kh, e.kw, e.stride, e.pad, 1};
@@ -1372,8 +1374,10 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     }
     if (tail_fused) {
       tail.s = a;
-      int grid = (int)std::min<long>(h->n_cu, std::max<long>(1, ((long)B * h->N[1] + TAIL_TILE - 1) / TAIL_TILE));
-      lz.run(PC_SCORE, [&] { hipLaunchKernelGGL(k_scored_tail, dim3(grid), dim3(TAIL_WAVES * 64), TAIL_LDS_FLOATS * 4, st, tail); });
+      int grid = (int)std::min<long>(h->n_cu, std::max<long>(1, ((long)B * h->N[1] + 15) / 16));
+      const int nslots = tail.g.Co * ((tail.g.kh + tail.g.stride - 1) / tail.g.stride) * ((tail.g.kw + tail.g.stride - 1) / tail.g.stride);
+      tail.sp = tail_slots_pad(nslots);
+      lz.run(PC_SCORE, [&] { hipLaunchKernelGGL(k_scored_tail, dim3(grid), dim3(TAIL_WAVES * 64), tail_lds_bytes(nslots), st, tail); });
     } else
     lz.run(PC_SCORE, [&] { hipLaunchKernelGGL(k_score, dim3(mlp_grid(h, nt / 4)), dim3(WG_MLP), PackScore::FLOATS * 4, st, a); });
   }

@@ -64,21 +64,69 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{a, b}, bf16x2v)); }
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 
-template <int NFRAG, class GetB>
+// three-piece split of the 8 B-operand values of k-step fk (registers 8 fk .. 8 fk + 7 of the input fragment)
+template <class GetB>
+__device__ __forceinline__ void split_bf3(GetB& getB, int fk, u32x4& p1, u32x4& p2, u32x4& p3) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float a = getB(8 * fk + 2 * q), b = getB(8 * fk + 2 * q + 1);
+    const unsigned u1 = pk_bf16(a, b);
+    const float ra = a - __uint_as_float(u1 << 16), rb = b - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned u2 = pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(u2 << 16), sb = rb - __uint_as_float(u2 & 0xffff0000u);
+    p1[q] = u1; p2[q] = u2; p3[q] = pk_bf16(sa, sb);
+  }
+}
+
+// GEMM_BF3_PIPE (default 1): software-pipelined form -- the split of k-step s + 1 (~56 vector instructions) is issued BETWEEN the 12
+// MFMAs of k-step s (sched_group_barrier: one MFMA, then up to five vector instructions, twelve times), so a wave keeps the matrix
+// pipe fed while it splits (an MFMA holds the vector issue for 8 of its 32 cycles: five 4-cycle instructions fit each gap).  The
+// sequential form (0) split a k-step, then issued its 12 MFMAs back to back: ~240 + 384 cycles per k-step with the matrix pipe idle
+// during every split unless another wave of the SIMD filled it.  Same operations on the same values in the same order per
+// accumulator: results are bit-identical.
+#ifndef GEMM_BF3_PIPE
+#define GEMM_BF3_PIPE 1
+#endif
+template <int NFRAG, bool PIPE = (GEMM_BF3_PIPE != 0), class GetB>
 __device__ __forceinline__ void gemm_w64_bf3(const float* wl, int lane, Frag& acc, GetB getB) {
   const u32x4* w = reinterpret_cast<const u32x4*>(wl) + lane;
+  if constexpr (PIPE) {
+  u32x4 p1, p2, p3;
+  split_bf3(getB, 0, p1, p2, p3);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int fk = 0; fk < 4 * NFRAG; ++fk) {
+    const bf16x8 x1 = __builtin_bit_cast(bf16x8, p1), x2 = __builtin_bit_cast(bf16x8, p2), x3 = __builtin_bit_cast(bf16x8, p3);
+    const bf16x8 w1a = __builtin_bit_cast(bf16x8, w[((fk * 2 + 0) * 3 + 0) * 64]), w1b = __builtin_bit_cast(bf16x8, w[((fk * 2 + 1) * 3 + 0) * 64]);
+    const bf16x8 w2a = __builtin_bit_cast(bf16x8, w[((fk * 2 + 0) * 3 + 1) * 64]), w2b = __builtin_bit_cast(bf16x8, w[((fk * 2 + 1) * 3 + 1) * 64]);
+    const bf16x8 w3a = __builtin_bit_cast(bf16x8, w[((fk * 2 + 0) * 3 + 2) * 64]), w3b = __builtin_bit_cast(bf16x8, w[((fk * 2 + 1) * 3 + 2) * 64]);
+    acc.t[0] = mfma_bf16(w3a, x1, acc.t[0]);
+    acc.t[1] = mfma_bf16(w3b, x1, acc.t[1]);
+    acc.t[0] = mfma_bf16(w2a, x2, acc.t[0]);
+    acc.t[1] = mfma_bf16(w2b, x2, acc.t[1]);
+    acc.t[0] = mfma_bf16(w1a, x3, acc.t[0]);
+    acc.t[1] = mfma_bf16(w1b, x3, acc.t[1]);
+    acc.t[0] = mfma_bf16(w2a, x1, acc.t[0]);
+    acc.t[1] = mfma_bf16(w2b, x1, acc.t[1]);
+    acc.t[0] = mfma_bf16(w1a, x2, acc.t[0]);
+    acc.t[1] = mfma_bf16(w1b, x2, acc.t[1]);
+    acc.t[0] = mfma_bf16(w1a, x1, acc.t[0]);
+    acc.t[1] = mfma_bf16(w1b, x1, acc.t[1]);
+    if (fk + 1 < 4 * NFRAG) split_bf3(getB, fk + 1, p1, p2, p3);
+    // the 6 weight reads first (their MFMAs wait on them), then MFMA / vector interleaved
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  } else {
 #pragma unroll
   for (int fk = 0; fk < 4 * NFRAG; ++fk) {         // fragment fk / 4, k-step fk % 4: registers 8 (fk % 4) .. + 7
     u32x4 p1, p2, p3;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float a = getB(8 * fk + 2 * q), b = getB(8 * fk + 2 * q + 1);
-      const unsigned u1 = pk_bf16(a, b);
-      const float ra = a - __uint_as_float(u1 << 16), rb = b - __uint_as_float(u1 & 0xffff0000u);
-      const unsigned u2 = pk_bf16(ra, rb);
-      const float sa = ra - __uint_as_float(u2 << 16), sb = rb - __uint_as_float(u2 & 0xffff0000u);
-      p1[q] = u1; p2[q] = u2; p3[q] = pk_bf16(sa, sb);
-    }
+    split_bf3(getB, fk, p1, p2, p3);
     const bf16x8 x1 = __builtin_bit_cast(bf16x8, p1), x2 = __builtin_bit_cast(bf16x8, p2), x3 = __builtin_bit_cast(bf16x8, p3);
     // the two output tiles' product chains alternate: an MFMA's accumulator was written two instructions earlier, not one
     // (back to back, each of the six waits out its predecessor's result latency); each accumulator still sees its six
@@ -99,6 +147,7 @@ __device__ __forceinline__ void gemm_w64_bf3(const float* wl, int lane, Frag& ac
     acc.t[0] = mfma_bf16(w1a, x1, acc.t[0]);
     acc.t[1] = mfma_bf16(w1b, x1, acc.t[1]);
     __builtin_amdgcn_sched_barrier(0);      // one k-step's pieces and weight fragments at a time (else hipcc hoists them all and spills)
+  }
   }
 }
 

@@ -57,7 +57,7 @@ __device__ __forceinline__ int q_ld(const int* p) { return __hip_atomic_load(p, 
 // holds a node.  `lds`: the PackUpdL3 image.  Callers: k_gather_update_q / k_scored_tail (rows out of the LDS ring) and k_top (rows
 // out of the transposed Linear edge's accumulators) -- the same arithmetic per node as k_node_update, whatever tile a node rides in.
 // keep != nullptr: the rows E are also handed back in *keep (k_scored_tail feeds them to the score head without reading them back)
-template <bool POST>
+template <bool POST, bool PIPE = (GEMM_BF3_PIPE != 0)>
 __device__ __forceinline__ void upd_chain_frag(const UpdArgs& u, const float* lds, const Frag& X, int gc, float r0, float r1, bool amb, float sw,
                                                bool valid, int lane, Frag* keep = nullptr) {
   const int h = lane >> 5;
@@ -67,19 +67,19 @@ __device__ __forceinline__ void upd_chain_frag(const UpdArgs& u, const float* ld
     const float x[1] = {(h ? r1 : r0) * sw};            // + s.(r0 Wa0.bp + r1 Wa1.bp): the bias of the source rows' deferred projection
     gemm_small<1>(lds + PackUpdL3::VAW, lane, H, x);
   }
-  gemm_w64_bf3<1>(lds + PackUpdL3::WAS3, lane, H, [&](int s) { return FRAG_AT(X, s) * r0; });
+  gemm_w64_bf3<1, PIPE>(lds + PackUpdL3::WAS3, lane, H, [&](int s) { return FRAG_AT(X, s) * r0; });
 #ifdef Q_ABL_NOAMB      // dev, timing only (wrong results): what the chain would cost if no tile held an ambiguous node
   if (false) {
 #else
   if (__any(amb)) {
 #endif
     const float dr = r1 - r0;
-    gemm_w64_bf3<1>(lds + PackUpdL3::WA1S3, lane, H, [&](int s) { return FRAG_AT(X, s) * dr; });
+    gemm_w64_bf3<1, PIPE>(lds + PackUpdL3::WA1S3, lane, H, [&](int s) { return FRAG_AT(X, s) * dr; });
   }
   // P' of an ambiguous node: its cached row (k_pre); of every other node: the bias row
   frag_load_rowptr(H2, amb ? u.P + (long)gc * 64 : u.pack + PackUpd::BCBROW, h);
   frag_relu(H);
-  gemm_w64_bf3<1>(lds + PackUpdL3::WCB3, lane, H2, [&](int s) { return FRAG_AT(H, s); });
+  gemm_w64_bf3<1, PIPE>(lds + PackUpdL3::WCB3, lane, H2, [&](int s) { return FRAG_AT(H, s); });
   frag_relu(H2);
   if (valid) {
     if (frag_has_nan(H2)) atomicOr(u.status, 1);
@@ -89,13 +89,13 @@ __device__ __forceinline__ void upd_chain_frag(const UpdArgs& u, const float* ld
   if (POST) {
 #pragma unroll
     for (int R = 0; R < 32; ++R) FRAG_AT(H, R) = 0.0f;
-    gemm_w64_bf3<1>(lds + PackUpdL3::FLOATS, lane, H, [&](int s) { return FRAG_AT(H2, s); });
+    gemm_w64_bf3<1, PIPE>(lds + PackUpdL3::FLOATS, lane, H, [&](int s) { return FRAG_AT(H2, s); });
     if (valid) frag_store_rows(H, u.post, gc, h);
   }
 }
 
 // the same on ring slot `ring` (32 rows of QROW floats); `release` runs once the rows are in registers
-template <bool POST, class Release>
+template <bool POST, bool PIPE = (GEMM_BF3_PIPE != 0), class Release>
 __device__ __forceinline__ void q_chain(const FArgs& a, const float* lds, const float* ring, int nvalid, int lane, Release release, Frag* keep = nullptr) {
   const int h = lane >> 5, j = lane & 31;
   const bool valid = j < nvalid;
@@ -115,7 +115,7 @@ __device__ __forceinline__ void q_chain(const FArgs& a, const float* lds, const 
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the rows and scalars are in registers
   release();
-  upd_chain_frag<POST>(a.u, lds, X, gc, r0, r1, amb, sw, valid, lane, keep);
+  upd_chain_frag<POST, PIPE>(a.u, lds, X, gc, r0, r1, amb, sw, valid, lane, keep);
 }
 
 // LANES: dst nodes per gather tile (16: forward edges, 32: transposed edges).  SRC: 0 dense source rows, 1 sparse walk (the source

@@ -757,15 +757,20 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_gather(GArgs a) {
   const int lane = threadIdx.x & 63, j = lane & 31, wave = threadIdx.x >> 6;
   uint2* tab = reinterpret_cast<uint2*>(gl.kvo + ((gather_slots(a.g.K2, 32) + 1) & ~1)) + wave * (2 * a.g.K2 + 32);      // SPARSE
   const EmbedLane el = embed_lane<EMBED>(a, j);
-  long t0, t1;
-  tile_range(a.ntiles, WAVES_MLP, t0, t1);
-  long tile = t0 + wave;
-  if (tile >= t1) return;
-  // tile, sample and t are wave-uniform by construction; make them provably so (scalar registers, scalar base address)
-  int sample = __builtin_amdgcn_readfirstlane((int)(tile / a.tm.TPS));
-  int t = __builtin_amdgcn_readfirstlane((int)(tile - (long)sample * a.tm.TPS));
-  for (; tile < t1; tile += WAVES_MLP, t += WAVES_MLP) {
-    while (t >= a.tm.TPS) { t -= a.tm.TPS; ++sample; }
+  // rounds of 8 tiles dealt round-robin over the workgroups in the XCD-grouped order (see k_gather16): the 64 workgroups of an XCD
+  // work on neighbouring rounds, i.e. on a handful of samples whose source rows stay in that L2.  With one contiguous chunk per
+  // workgroup (round 3) an XCD had 32 samples open at once and the counters saw every source row of the transposed layer-1
+  // aggregate fetched twice (profiles/r04a_base_aggonly_pmc_summary.json: 150 MB for 110 MB of rows moved)
+  int wg = blockIdx.x;
+  const int nwg = gridDim.x;
+  if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
+  const long nrounds = (a.ntiles + WAVES_MLP - 1) / WAVES_MLP;
+  for (long r = wg; r < nrounds; r += nwg) {
+    const long tile = r * WAVES_MLP + wave;
+    if (tile >= a.ntiles) break;
+    // tile, sample and t are wave-uniform by construction; make them provably so (scalar registers, scalar base address)
+    const int sample = __builtin_amdgcn_readfirstlane((int)(tile / a.tm.TPS));
+    const int t = __builtin_amdgcn_readfirstlane((int)(tile - (long)sample * a.tm.TPS));
     const TileCtx tc = block_decode(a.tm, gl.tt, sample, t, j);
     gather_process_tile<EMBED, SPARSE>(a, tc, sample, gl.cm, gl.ko, gl.kvo, tab, el, lane);
   }
@@ -918,15 +923,17 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_gather_input_update(GIArgs a) {
   stage_pack(lds, a.pack, PackUpdInp::FLOATS);
   const int lane = threadIdx.x & 63, j = lane & 31, wave = threadIdx.x >> 6;
   uint2* tab = reinterpret_cast<uint2*>(gl.kvo + ((gather_slots(a.g.K2, 32) + 1) & ~1)) + wave * (2 * a.g.K2 + 32);      // SPARSE
-  long t0, t1;
-  tile_range(a.ntiles, WAVES_MLP, t0, t1);
-  long tile = t0 + wave;
-  if (tile >= t1) return;
-  // tile, sample and t are wave-uniform by construction; make them provably so (scalar registers, scalar base address)
-  int sample = __builtin_amdgcn_readfirstlane((int)(tile / a.tm.TPS));
-  int t = __builtin_amdgcn_readfirstlane((int)(tile - (long)sample * a.tm.TPS));
-  for (; tile < t1; tile += WAVES_MLP, t += WAVES_MLP) {
-    while (t >= a.tm.TPS) { t -= a.tm.TPS; ++sample; }
+  // rounds of 8 tiles round-robin over the workgroups, XCD-grouped (see k_gather / k_gather16): an XCD keeps a handful of samples
+  // open instead of 32 (contiguous chunks: the counters saw the rows of layer 1 fetched 2.2 times, profiles/r04a_base_aggonly_*)
+  int wg = blockIdx.x;
+  const int nwg = gridDim.x;
+  if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
+  const long nrounds = (a.ntiles + WAVES_MLP - 1) / WAVES_MLP;
+  for (long r = wg; r < nrounds; r += nwg) {
+    const long tile = r * WAVES_MLP + wave;
+    if (tile >= a.ntiles) break;
+    const int sample = __builtin_amdgcn_readfirstlane((int)(tile / a.tm.TPS));
+    const int t = __builtin_amdgcn_readfirstlane((int)(tile - (long)sample * a.tm.TPS));
     const TileCtx tc = block_decode(a.tm, gl.tt, sample, t, j);
     input_update_tile<SPARSE, BF3>(a, tc, sample, lds, lds_pre, gl, tab, lane);
   }

@@ -292,7 +292,8 @@ struct GSArgs {
 #ifndef GS_INFLIGHT
 #define GS_INFLIGHT 16       // row loads in flight per wave (base, us: 8 -> 29.5, 16 -> 26.5, 32 -> 32.6)
 #endif
-#define GS_MAXSLOTS 112      // C_out x (k/s)^2 <= 96 window slots (the host's limit) + padding to a multiple of GS_INFLIGHT
+#define GS_SLOT_LIMIT 128    // C_out x (k/s)^2 window slots at most (the host's limit: cifar_wide_kw's second conv has 32 x 2 x 2)
+#define GS_MAXSLOTS (GS_SLOT_LIMIT + 16)      // + padding to a multiple of GS_INFLIGHT
 // the aggregate row of ONE scored node by one wave (lane = channel): acc = its channel of the (normalised) aggregate, ssum = the
 // bias sum; s_row / s_w: this wave's GS_MAXSLOTS-entry LDS lists.  Shared by k_gather_scored and k_scored_tail.
 __device__ __forceinline__ void gather_scored_node(const GSArgs& a, int gc, int lane, int* s_row, float* s_w, float& acc_out, float& ssum_out) {
@@ -315,8 +316,9 @@ __device__ __forceinline__ void gather_scored_node(const GSArgs& a, int gc, int 
     const bool hit = sl < nslots && ky < a.kh && kx < a.kw && ty >= 0 && tx >= 0 && oy < a.Ho && ox < a.Wo;
     const int row = hit ? (co * a.Ho + oy) * a.Wo + ox : 0;
     if (s0 == 0) freq = __popcll(__ballot(hit && co == 0));           // taps that touch this pixel (the reference's `freq`)
+    // (the tap weight is requested together with the bounds, not behind the liveness test: one memory round trip instead of two)
+    const float wv = hit ? a.w[((co * a.kh + ky) * a.kw + kx) * a.C + ci] : 0.0f;
     const bool live = hit && node_is_live(slb[row], sub[row]);
-    const float wv = live ? a.w[((co * a.kh + ky) * a.kw + kx) * a.C + ci] : 0.0f;
     const unsigned long long bal = __ballot(live);
     if (live) {
       const int p = nlive + __popcll(bal & ((1ull << lane) - 1ull));
@@ -360,7 +362,16 @@ __global__ __launch_bounds__(GS_WAVES * 64) void k_gather_scored(GSArgs a) {
   __shared__ float s_w[GS_WAVES][GS_MAXSLOTS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int total = *a.cnt;
-  for (int idx = blockIdx.x * GS_WAVES + wave; idx < total; idx += gridDim.x * GS_WAVES) {
+  // The list holds a sample's scored nodes next to each other (k_classify: one block per 2048 nodes), and neighbouring scored nodes
+  // share window rows.  Each workgroup takes ONE contiguous segment of the list, and the segments of the workgroups of one XCD
+  // (blockIdx % 8) are neighbours: a sample's rows are then fetched into ONE L2 and re-read there.  (Round 3 dealt list entries
+  // round-robin over the workgroups, i.e. one sample over all eight XCDs: 131 MB fetched for ~42 MB of distinct rows, L2 hit rate 26 %.)
+  int wg = blockIdx.x;
+  const int nwg = gridDim.x;
+  if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
+  const int seg = (total + nwg - 1) / nwg;
+  const int i0 = wg * seg, i1 = i0 + seg < total ? i0 + seg : total;
+  for (int idx = i0 + wave; idx < i1; idx += GS_WAVES) {
     const int gc = a.list[idx];
     float acc, ssum;
     gather_scored_node(a, gc, lane, s_row[wave], s_w[wave], acc, ssum);
@@ -371,77 +382,282 @@ __global__ __launch_bounds__(GS_WAVES * 64) void k_gather_scored(GSArgs a) {
 
 
 // ------------------------------------------------------------------------------------------
-// k_scored_tail: the end of a forward at SMALL batch sizes in one launch instead of three (k_gather_scored, the restricted
-// k_node_update, k_score): after the last backward sweep mu[1] is read by the score head only, at the scored nodes, so their
-// transposed aggregate (one wave per node, lane = channel: gather_scored_node, the code of k_gather_scored), the folded node
-// update (q_chain, the arithmetic of k_node_update) and the score head (score_rows) run back to back on a tile of 16 scored
-// nodes (the rows are still written to mu[1], as the three kernels did: inspection reads them, the score head does not); the scored nodes of the other layers go through the score head as in k_score, and
-// the workgroup that finishes last turns the per-sample keys into decisions.  Same arithmetic per node as the three kernels:
-// bit-identical scores (tests).  At B <= 8 each of the three launches was its own ramp (weights staged, one tile's dependent
-// loads): 10 + 13 + 15 us at B = 1.
-// Per workgroup (16 waves): waves 1..15 gather the 32 nodes of a tile into an LDS row buffer (two buffers: the next tile is
-// gathered while wave 0 runs chain + score head of this one).
+// k_scored_tail: the end of a forward in ONE launch instead of three (k_gather_scored, the restricted k_node_update, k_score).  After
+// the last backward sweep mu[1] is read by the score head only, at the scored nodes, so their transposed aggregate, the folded node
+// update (q_chain: the arithmetic of k_node_update) and the score head (score_rows) run back to back per tile of 32 scored nodes (the
+// rows are still written to mu[1], as the three kernels did: inspection reads them, the score head does not); the scored nodes of the
+// other layers go through the score head as in k_score, and the workgroup that finishes last turns the per-sample keys into
+// decisions.  Same arithmetic per node as the three kernels: bit-identical scores (tests).
+// Round 3's form (one wave per node, wave 0 alone running chain + score head) only paid up to B = 8: each launch of the three was
+// its own ramp there, but at B = 256 it took 76 us against 61.  This form scales with the batch:
+//   * a workgroup takes contiguous SEGMENTS of the scored list (16 .. 64 nodes; a sample's scored nodes are neighbours in the list, and
+//     the segments of the workgroups of one XCD are neighbours: window rows shared by scored nodes are re-read in one L2), as many
+//     rounds of equal segments as the batch needs;
+//   * waves 0 / 1 are CHAIN waves: one 32-node tile of the segment each (chain + score head); the other 14 are GATHER waves that take
+//     FOUR scored nodes at a time (gather_scored_multi: lane = (node, channel quad): one 16-B piece of a 256-B row per lane, 16 rows in
+//     flight per node), so that a CU keeps 56 nodes' loads in flight at 4 waves per SIMD -- what k_gather_scored needed 8 waves per SIMD for;
+//   * the rows go through an LDS buffer (two: round r + 1 is gathered while the chain waves work on round r); after its last round
+//     a gather wave goes straight to its share of the other layers' score tiles.
 // ------------------------------------------------------------------------------------------
-struct TailArgs { GSArgs g; FArgs f; ScoreArgs s; };
-#define TAIL_WAVES 16
-#define TAIL_TILE 16          // scored nodes of layer 1 per tile: half-filled MFMA tiles, but twice the workgroups gather in parallel and
-                              // a wave gathers one node, not two or three in a row (B = 1: 38 -> see DESIGN 5.3)
-#define TAIL_LDS_FLOATS (PackUpdL3::FLOATS + PackScore::FLOATS + 2 * TAIL_TILE * QROW + TAIL_WAVES * GS_MAXSLOTS * 2 + 16)
+struct TailArgs { GSArgs g; FArgs f; ScoreArgs s; int sp; };      // sp: entries per node in the gather waves' slot lists (tail_slots_pad)
+#ifndef TAIL_WAVES
+#define TAIL_WAVES 12          // 3 per SIMD: 168 registers (the chain's pipelined blocks and 64 registers of rows in flight per gather lane without spills)
+#endif
+#define TAIL_SEG 48           // scored nodes of layer 1 per workgroup and round at most: two chain tiles (32 + 16)
+#ifndef TAIL_PIPE
+#define TAIL_PIPE true
+#endif
+#ifndef TAIL_INF_REGS
+#define TAIL_INF_REGS 64
+#endif
+#define TAIL_FIXED_FLOATS (PackUpdL3::FLOATS + PackScore::FLOATS + 2 * TAIL_SEG * QROW + 16)
+// slot-list entries per node (window slots + padding to whole rounds of GS_INFLIGHT) and nodes per gather wave (4, or 2 when four lists
+// per wave do not fit beside the weights: windows of more than 96 slots)
+__host__ __device__ inline int tail_slots_pad(int nslots) { return ((nslots + GS_INFLIGHT - 1) / GS_INFLIGHT) * GS_INFLIGHT + GS_INFLIGHT; }
+__host__ __device__ inline int tail_npw(int nslots) { return (size_t)TAIL_FIXED_FLOATS * 4 + (size_t)(TAIL_WAVES - 1) * 4 * tail_slots_pad(nslots) * 6 + 64 <= 160 * 1024 - 256 ? 4 : 2; }
+__host__ __device__ inline size_t tail_lds_bytes(int nslots) {
+  return (size_t)TAIL_FIXED_FLOATS * 4 + (size_t)(TAIL_WAVES - 1) * tail_npw(nslots) * tail_slots_pad(nslots) * 6 + 64;
+}
+static_assert(TAIL_FIXED_FLOATS * 4 + (TAIL_WAVES - 1) * 2 * (GS_SLOT_LIMIT + GS_INFLIGHT) * 6 + 64 <= 160 * 1024 - 256, "k_scored_tail: LDS (two nodes per wave)");
 
+// NPW (4 or 2) scored nodes at once by one wave.  Lane (g = lane / LPN, c = lane % LPN): node gcs[g] (wave-uniform ids, -1: none),
+// channels NPW c .. NPW c + NPW - 1 (LPN = 64 / NPW lanes per node hold its 64 channels: a 16-B or 8-B piece of a 256-B row per lane).
+// Per node exactly gather_scored_node's evaluation: window slots in slot order, liveness of the source node, tap weight, compaction
+// into an LDS list, then acc = fma(w, row, acc) over the live slots in slot order and division by the tap count -- the same value
+// per channel bit for bit.  s_row / s_w: this wave's [NPW][sp] lists (16-bit row indices: the host checks Ns < 65536).
+template <int NPW>
+__device__ __forceinline__ void gather_scored_multi(const GSArgs& a, const int (&gcs)[NPW], int lane, unsigned short* s_row, float* s_w, int sp,
+                                                    float (&acc_out)[NPW], float& ssum_out) {
+  constexpr int LPN = 64 / NPW, CPL = NPW;
+  typedef float vec_t __attribute__((ext_vector_type(CPL)));
+  const int Ns = a.Co * a.Ho * a.Wo;
+  const int ty_n = (a.kh + a.stride - 1) / a.stride, tx_n = (a.kw + a.stride - 1) / a.stride;
+  const int nslots = a.Co * ty_n * tx_n;
+  const int npass = (nslots + 63) >> 6;                       // <= 2 (GS_SLOT_LIMIT)
+  // ---- every load of the table builds first (independent), then the ballots
+  float lbv[NPW][2], ubv[NPW][2], wvv[NPW][2];
+  int rowv[NPW][2];
+  bool hitv[NPW][2];
+  int freq[NPW], nlive[NPW];
+#pragma unroll
+  for (int g = 0; g < NPW; ++g) {
+    const int gc = gcs[g] < 0 ? 0 : gcs[g];
+    const int b = gc / a.N, n = gc - b * a.N;
+    const int ci = n / (a.H * a.W), y = (n / a.W) % a.H, x = n % a.W;
+    const float* slb = a.src_lb + (long)b * Ns;
+    const float* sub = a.src_ub + (long)b * Ns;
+    const int ky0 = (y + a.pad) % a.stride, kx0 = (x + a.pad) % a.stride;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int sl = 64 * p + lane;
+      const int co = sl / (ty_n * tx_n), dy = (sl / tx_n) % ty_n, dx = sl % tx_n;
+      const int ky = ky0 + a.stride * dy, kx = kx0 + a.stride * dx;
+      const int ty = y + a.pad - ky, tx = x + a.pad - kx;              // multiples of the stride by construction
+      const int oy = ty / a.stride, ox = tx / a.stride;
+      const bool hit = p < npass && gcs[g] >= 0 && sl < nslots && ky < a.kh && kx < a.kw && ty >= 0 && tx >= 0 && oy < a.Ho && ox < a.Wo;
+      const int row = hit ? (co * a.Ho + oy) * a.Wo + ox : 0;
+      hitv[g][p] = hit; rowv[g][p] = row;
+      lbv[g][p] = hit ? slb[row] : 0.0f;
+      ubv[g][p] = hit ? sub[row] : 0.0f;
+      wvv[g][p] = hit ? a.w[((co * a.kh + ky) * a.kw + kx) * a.C + ci] : 0.0f;
+      if (p == 0) freq[g] = __popcll(__ballot(hit && co == 0));        // taps that touch this pixel (the reference's `freq`)
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < NPW; ++g) {
+    unsigned short* sr = s_row + g * sp;
+    float* sw = s_w + g * sp;
+    int nl = 0;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const bool live = hitv[g][p] && node_is_live(lbv[g][p], ubv[g][p]);
+      const unsigned long long bal = __ballot(live);
+      if (live) {
+        const int q = nl + __popcll(bal & ((1ull << lane) - 1ull));
+        sr[q] = (unsigned short)rowv[g][p];
+        sw[q] = wvv[g][p];
+      }
+      nl += __popcll(bal);
+    }
+    nlive[g] = nl;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // ---- the walks of the nodes side by side
+  const int g = lane / LPN, c = lane % LPN;
+  int mygc = gcs[0], myn = nlive[0], myf = freq[0], nmax = nlive[0];
+#pragma unroll
+  for (int g2 = 1; g2 < NPW; ++g2) {
+    mygc = g == g2 ? gcs[g2] : mygc;
+    myn = g == g2 ? nlive[g2] : myn;
+    myf = g == g2 ? freq[g2] : myf;
+    nmax = nmax > nlive[g2] ? nmax : nlive[g2];
+  }
+  const int b = (mygc < 0 ? 0 : mygc) / a.N;
+  const float* src = a.mu_src + (long)b * Ns * 64 + CPL * c;
+  const unsigned short* sr = s_row + g * sp;
+  const float* sw = s_w + g * sp;
+  float acc[CPL];
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) acc[k] = 0.0f;
+  float ssum = 0.0f;
+  constexpr int INF = TAIL_INF_REGS / NPW;      // rows in flight per node: TAIL_INF_REGS registers of row data per lane either way
+  for (int q = 0; q < nmax; q += INF) {
+    vec_t v[INF];
+    float wq[INF];
+#pragma unroll
+    for (int u = 0; u < INF; ++u) {
+      const bool in = q + u < myn;
+      wq[u] = in ? sw[q + u] : 0.0f;
+      // (a slot beyond this node's list must not touch memory: it may be a dead node's never-written row)
+      vec_t z;
+#pragma unroll
+      for (int k = 0; k < CPL; ++k) z[k] = 0.0f;
+      v[u] = in ? *reinterpret_cast<const vec_t*>(src + (long)sr[q + u] * 64) : z;
+    }
+#pragma unroll
+    for (int u = 0; u < INF; ++u) {
+#pragma unroll
+      for (int k = 0; k < CPL; ++k) acc[k] = fmaf(wq[u], v[u][k], acc[k]);
+      ssum += wq[u];
+    }
+  }
+  if (a.normalise) {
+    const float f = (float)(myf > 0 ? myf : 1);
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) acc[k] = acc[k] / f;
+    ssum = ssum / f;
+  }
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) acc_out[k] = acc[k];
+  ssum_out = ssum;
+  __builtin_amdgcn_wave_barrier();
+}
+
+// the gather waves' part of one segment: groups of NPW nodes qd, qd + ngw, ... of the segment -> rows of the LDS buffer rb.
+// The aggregate of a dead node marked undecided is gathered like any other (its source rows are live rows) and zeroed at the end: the
+// table build then does not wait for the destination's bounds (one memory round trip less per group).
+template <int NPW>
+__device__ __forceinline__ void tail_gather_segment(const TailArgs& a, float* rb, int sg, int seg, int total, int first, int ngw, int lane,
+                                                    unsigned short* s_row, float* s_w) {
+  constexpr int LPN = 64 / NPW, CPL = NPW;
+  typedef float vec_t __attribute__((ext_vector_type(CPL)));
+  for (int qd = first; NPW * qd < seg; qd += ngw) {
+    const int i0 = sg * seg + NPW * qd;
+    if (i0 >= total) break;
+    int gcs[NPW];
+#pragma unroll
+    for (int g = 0; g < NPW; ++g) gcs[g] = i0 + g < total ? __builtin_amdgcn_readfirstlane(a.g.list[i0 + g]) : -1;
+    const int g = lane / LPN;
+    int mygc = gcs[0];
+#pragma unroll
+    for (int g2 = 1; g2 < NPW; ++g2) mygc = g == g2 ? gcs[g2] : mygc;
+    const int gcl = mygc < 0 ? 0 : mygc;
+    const float dlb = a.f.u.lb[gcl], dub = a.f.u.ub[gcl];      // (requested here, used after the gather)
+    float acc[CPL];
+    float ssum;
+    gather_scored_multi<NPW>(a.g, gcs, lane, s_row, s_w, a.sp, acc, ssum);
+    const Ratio rt = compute_ratio(dlb, dub);
+    if (mygc >= 0) {
+      float* row = rb + (NPW * qd + g) * QROW;
+      const bool dead = rt.live == 0.0f;
+      vec_t o;
+#pragma unroll
+      for (int k = 0; k < CPL; ++k) o[k] = dead ? 0.0f : acc[k];
+      *reinterpret_cast<vec_t*>(row + CPL * (lane % LPN)) = o;
+      if (lane % LPN == 0)
+        *reinterpret_cast<f32x4*>(row + 64) = f32x4{__int_as_float(mygc | (rt.amb != 0.0f ? (int)0x80000000 : 0)), rt.r0, rt.r1, dead ? 0.0f : ssum};
+    }
+  }
+}
+
+#if defined(FUSED_TIMING) && FUSED_TIMING == 5      // dev: per-phase cycle sums of k_scored_tail (slots 0-4: first gather wave, 5-9: chain wave 0)
+#define TT_DECL unsigned long long tt_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tt_last = __builtin_readcyclecounter()
+#define TT_MARK(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); tt_[i] += n_ - tt_last; tt_last = n_; } while (0)
+#define TT_FLUSH(c) do { if ((c) && (threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&g_fused_t[i_], tt_[i_]); atomicAdd(&g_fused_t[15], 1ull); } } while (0)
+#else
+#define TT_DECL
+#define TT_MARK(i)
+#define TT_FLUSH(c)
+#endif
 __global__ __launch_bounds__(TAIL_WAVES * 64, 1) void k_scored_tail(TailArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lds_sc = lds + PackUpdL3::FLOATS;
-  float* rows = lds_sc + PackScore::FLOATS;                       // [2][TAIL_TILE][QROW]
-  int* s_row = reinterpret_cast<int*>(rows + 2 * TAIL_TILE * QROW);      // [TAIL_WAVES][GS_MAXSLOTS]
-  float* s_w = reinterpret_cast<float*>(s_row + TAIL_WAVES * GS_MAXSLOTS);
+  float* rows = lds_sc + PackScore::FLOATS;                       // [2][TAIL_SEG][QROW]
+  const int npw = tail_npw(a.g.Co * ((a.g.kh + a.g.stride - 1) / a.g.stride) * ((a.g.kw + a.g.stride - 1) / a.g.stride));
+  float* s_w_all = rows + 2 * TAIL_SEG * QROW;                     // [TAIL_WAVES - 1][npw][sp] tap weights, then as many 16-bit row indices
+  unsigned short* s_row_all = reinterpret_cast<unsigned short*>(s_w_all + (TAIL_WAVES - 1) * npw * a.sp);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  copy_to_lds(lds + PackUpdL3::BA, a.f.u.pack + PackUpd::BA, 64);
-  copy_to_lds(lds + PackUpdL3::BCB, a.f.u.pack + PackUpd::BCB, 64 + 64 + 128);
-  copy_to_lds(lds + PackUpdL3::WAS3, a.f.u.pack + PackUpd::WAS3, 3 * 6144);
-  copy_to_lds(lds_sc, a.s.pack, PackScore::FLOATS);
+  TT_DECL;
   const int total = *a.g.cnt;                                      // scored nodes of layer 1
-  const int T1 = (total + TAIL_TILE - 1) / TAIL_TILE;
-  // ---- layer 1: gather -> chain -> score, tile by tile
-  int buf = 0;
-  for (int tile = blockIdx.x; tile < T1; tile += gridDim.x, buf ^= 1) {
-    float* rb = rows + buf * TAIL_TILE * QROW;
-    if (wave >= 1) {
-      for (int l = wave - 1; l < TAIL_TILE; l += TAIL_WAVES - 1) {
-        const int idx = tile * TAIL_TILE + l;
-        float* row = rb + l * QROW;
-        if (idx < total) {
-          const int gc = a.g.list[idx];
-          const float lb = a.f.u.lb[gc], ub = a.f.u.ub[gc];
-          const Ratio rt = compute_ratio(lb, ub);
-          float acc = 0.0f, ssum = 0.0f;
-          if (rt.live != 0.0f) gather_scored_node(a.g, gc, lane, s_row + wave * GS_MAXSLOTS, s_w + wave * GS_MAXSLOTS, acc, ssum);
-          row[lane] = acc;
-          if (lane == 0) *reinterpret_cast<f32x4*>(row + 64) = f32x4{__int_as_float(gc | (rt.amb != 0.0f ? (int)0x80000000 : 0)), rt.r0, rt.r1, ssum};
-        }
-      }
-    }
-    __syncthreads();                          // (first pass: also the weights; every pass: this tile's rows are in LDS, the previous tile's chain is done)
-    if (wave == 0) {
-      const int nvalid = total - tile * TAIL_TILE < TAIL_TILE ? total - tile * TAIL_TILE : TAIL_TILE;
-      Frag E;
-      q_chain<false>(a.f, lds, rb, nvalid, lane, [] {}, &E);
-      const int j = lane & 31;
-      const bool valid = j < nvalid;
-      const int gc = valid ? (__float_as_int(rb[j * QROW + 64]) & 0x7fffffff) : 0;
-      const float live = valid && node_is_live(a.f.u.lb[gc], a.f.u.ub[gc]) ? 1.0f : 0.0f;
-      if (live == 0.0f) {                     // a dead node marked undecided: its row is zero by definition
-#pragma unroll
-        for (int R = 0; R < 32; ++R) FRAG_AT(E, R) = 0.0f;
-      }
-      score_rows(a.s, lds_sc, 0, gc, valid, live, E, lane);
+  int wg = blockIdx.x;
+  const int nwg = gridDim.x;
+  if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);      // the workgroups of one XCD (blockIdx % 8) take neighbouring segments
+  // rounds of equal segments: as few rounds as TAIL_SEG allows, every workgroup the same share (a multiple of 16 nodes)
+  const int rounds = total > 0 ? (total + TAIL_SEG * nwg - 1) / (TAIL_SEG * nwg) : 0;
+  int seg = rounds ? (total + rounds * nwg - 1) / (rounds * nwg) : npw;
+  seg = (seg + npw - 1) / npw * npw;                               // whole groups of npw nodes
+  if (seg < 16 && total >= 16) seg = 16;                           // (small batches: at least half a chain tile per workgroup)
+  const int nseg = (total + seg - 1) / seg;
+  const int nchain = (seg + 31) >> 5;                              // chain waves: one 32-node tile of the segment each (1 or 2)
+  const int ngw = TAIL_WAVES - nchain;
+  // The weights (92 KB) are staged by the waves that have no group of nodes to gather in the first round -- the chain waves and the
+  // gather waves beyond the segment's groups (a segment has at most 12 groups) -- while the others already gather;
+  // the barrier behind the first round (or the one below, for a workgroup without a segment) publishes them.
+  {
+    const int ngroups = wg < nseg ? (seg + npw - 1) / npw : 0;
+    const int nbusy = ngroups < ngw ? ngroups : ngw;               // gather waves nchain .. nchain + nbusy - 1 have a group
+    const int nst = TAIL_WAVES - nbusy;
+    if (wave < nchain || wave >= nchain + nbusy) {
+      const int si = wave < nchain ? wave : wave - nbusy;
+      const int ct = si * 64 + lane, cn = nst * 64;
+      copy_to_lds_part(lds + PackUpdL3::BA, a.f.u.pack + PackUpd::BA, 64, ct, cn);
+      copy_to_lds_part(lds + PackUpdL3::BCB, a.f.u.pack + PackUpd::BCB, 64 + 64 + 128, ct, cn);
+      copy_to_lds_part(lds + PackUpdL3::WAS3, a.f.u.pack + PackUpd::WAS3, 3 * 6144, ct, cn);
+      copy_to_lds_part(lds_sc, a.s.pack, PackScore::FLOATS, ct, cn);
     }
   }
-  __syncthreads();
+  TT_MARK(wave < nchain ? 5 : 0);             // staging (chain / idle waves) or nothing
+  // ---- layer 1: gather -> chain -> score, segment by segment
+  int buf = 0;
+  for (int sg = wg; sg < nseg; sg += nwg, buf ^= 1) {
+    float* rb = rows + buf * TAIL_SEG * QROW;
+    if (wave >= nchain) {
+      const int gw = wave - nchain;
+      if (npw == 4) tail_gather_segment<4>(a, rb, sg, seg, total, gw, ngw, lane, s_row_all + gw * 4 * a.sp, s_w_all + gw * 4 * a.sp);
+      else tail_gather_segment<2>(a, rb, sg, seg, total, gw, ngw, lane, s_row_all + gw * 2 * a.sp, s_w_all + gw * 2 * a.sp);
+    }
+    TT_MARK(wave < nchain ? 5 : 1);           // gather of this segment (gather waves); chain waves: idle
+    __syncthreads();                          // (first pass: also the weights; every pass: this segment's rows are in LDS, the previous segment's chains are done)
+    TT_MARK(wave < nchain ? 6 : 2);           // barrier wait
+    if (wave < nchain) {
+      const int left = total - sg * seg - 32 * wave;
+      const int lim = seg - 32 * wave < 32 ? seg - 32 * wave : 32;
+      const int nvalid = left < lim ? left : lim;
+      if (nvalid > 0) {
+        const float* rt_ = rb + 32 * wave * QROW;
+        Frag E;
+        q_chain<false, TAIL_PIPE>(a.f, lds, rt_, nvalid, lane, [] {}, &E);
+        const int j = lane & 31;
+        const bool valid = j < nvalid;
+        const int gc = valid ? (__float_as_int(rt_[j * QROW + 64]) & 0x7fffffff) : 0;
+        const float live = valid && node_is_live(a.f.u.lb[gc], a.f.u.ub[gc]) ? 1.0f : 0.0f;
+        if (live == 0.0f) {                     // a dead node marked undecided: its row is zero by definition
+#pragma unroll
+          for (int R = 0; R < 32; ++R) FRAG_AT(E, R) = 0.0f;
+        }
+        score_rows(a.s, lds_sc, 0, gc, valid, live, E, lane);
+      }
+    }
+  }
+  TT_MARK(wave < nchain ? 7 : 0);             // chain + score head of the last segment (chain waves)
+  if (wg >= nseg) __syncthreads();            // a workgroup without a segment: the staged weights become visible here
   // ---- the scored nodes of the other layers: the score head on their rows in memory (k_score's tiles), dealt from the LAST
-  // workgroup backwards -- those have no layer-1 tile and start here at once
+  // workgroup backwards -- those have the fewest layer-1 segments -- and to the gather waves first (they are free while the chain
+  // waves finish the last segment: no barrier in front of this phase)
   long ntiles = 0;
   for (int k = 1; k < a.s.L; ++k) ntiles += (a.s.cnt[4 * k + 2] + 31) / 32;
-  for (long tile = (long)(gridDim.x - 1 - blockIdx.x) * TAIL_WAVES + wave; tile < ntiles; tile += (long)gridDim.x * TAIL_WAVES) {
+  const int slot = wave >= nchain ? wave - nchain : ngw + wave;
+  for (long tile = (long)(gridDim.x - 1 - blockIdx.x) * TAIL_WAVES + slot; tile < ntiles; tile += (long)gridDim.x * TAIL_WAVES) {
     int k = 1, count = 0;
     long t = tile;
     for (; k < a.s.L; ++k) {
@@ -452,5 +668,8 @@ __global__ __launch_bounds__(TAIL_WAVES * 64, 1) void k_scored_tail(TailArgs a) 
     }
     score_tile(a.s, lds_sc, k, a.s.list[k], count, t, lane);
   }
+  TT_MARK(wave < nchain ? 8 : 3);             // the other layers' score tiles
   score_finish(a.s);
+  TT_MARK(wave < nchain ? 9 : 4);             // finish
+  TT_FLUSH(wave == 0 || wave == nchain);
 }

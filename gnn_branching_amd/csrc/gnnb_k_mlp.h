@@ -199,6 +199,10 @@ struct PreAllArgs {       // hoisted feature chains of every ReLU layer, forward
 // one tile (32 ambiguous nodes `list[32 t ..]` of layer k) of the hoisted chains; lds / lds_b: PackPreFwd / PackPreBwd in LDS
 // BF3: the 64x64 blocks (W2 forward; W2, W3, W5 backward) on the bf16 matrix rate with three-piece operands (LDS images
 // PackPreFwdL3 / PackPreBwdL3); the 192-wide W4 and the feature layers stay on the fp32 MFMA
+// (k_pre's 16 waves sit at the 128-register step with the sequential blocks: the pipelined form spills 16 registers there)
+#ifndef PRE_PIPE
+#define PRE_PIPE false
+#endif
 template <bool BF3>
 __device__ __forceinline__ void pre_tile(const PreAllArgs& a, const float* lds, const float* lds_b, int k, bool bwd, const int* list, int count,
                                          long t, int lane) {
@@ -232,7 +236,7 @@ __device__ __forceinline__ void pre_tile(const PreAllArgs& a, const float* lds, 
       frag_relu(H);
       Frag Pf;                                   // fc1_1 and the first half of fc4 are one folded 64x64 map
       frag_bias(Pf, lds + F_B2, h);
-      if (BF3) gemm_w64_bf3<1>(lds + PackPreFwdL3::W23, lane, Pf, [&](int s) { return FRAG_AT(H, s); });
+      if (BF3) gemm_w64_bf3<1, PRE_PIPE>(lds + PackPreFwdL3::W23, lane, Pf, [&](int s) { return FRAG_AT(H, s); });
       else gemm_w64<32>(lds + PackPreFwd::W2, lane, Pf, [&](int s) { return FRAG_AT(H, s); });
       if (valid) frag_store_rows(Pf, a.Pf[k], gc, h);
     } else {
@@ -247,12 +251,12 @@ __device__ __forceinline__ void pre_tile(const PreAllArgs& a, const float* lds, 
       frag_relu(H1);
       Frag H2;
       frag_bias(H2, lds_b + B_B2, h);
-      if (BF3) gemm_w64_bf3<1>(lds_b + PackPreBwdL3::W23, lane, H2, [&](int s) { return FRAG_AT(H1, s); });
+      if (BF3) gemm_w64_bf3<1, PRE_PIPE>(lds_b + PackPreBwdL3::W23, lane, H2, [&](int s) { return FRAG_AT(H1, s); });
       else gemm_w64<32>(lds_b + PackPreBwd::W2, lane, H2, [&](int s) { return FRAG_AT(H1, s); });
       frag_relu(H2);
       Frag S;
       frag_bias(S, lds_b + B_B3, h);
-      if (BF3) gemm_w64_bf3<1>(lds_b + PackPreBwdL3::W33, lane, S, [&](int s) { return FRAG_AT(H2, s); });
+      if (BF3) gemm_w64_bf3<1, PRE_PIPE>(lds_b + PackPreBwdL3::W33, lane, S, [&](int s) { return FRAG_AT(H2, s); });
       else gemm_w64<32>(lds_b + PackPreBwd::W3, lane, S, [&](int s) { return FRAG_AT(H2, s); });
       // bc2 on [s, s*(-d2), s*d1]  (:287-291)
       const float nd2 = -d2;
@@ -262,12 +266,12 @@ __device__ __forceinline__ void pre_tile(const PreAllArgs& a, const float* lds, 
         const float v = FRAG_AT(S, s & 31);
         return s < 32 ? v : (s < 64 ? v * nd2 : v * d1);
       };
-      if (BF3) gemm_w64_bf3<3>(lds_b + PackPreBwdL3::W43, lane, H4, in4);
+      if (BF3) gemm_w64_bf3<3, PRE_PIPE>(lds_b + PackPreBwdL3::W43, lane, H4, in4);
       else gemm_w64<96>(lds_b + B_W4, lane, H4, in4);
       frag_relu(H4);
       Frag Pb;                                   // bc2_1 and the first half of bc4 are one folded 64x64 map
       frag_bias(Pb, lds_b + B_B5, h);
-      if (BF3) gemm_w64_bf3<1>(lds_b + PackPreBwdL3::W53, lane, Pb, [&](int s) { return FRAG_AT(H4, s); });
+      if (BF3) gemm_w64_bf3<1, PRE_PIPE>(lds_b + PackPreBwdL3::W53, lane, Pb, [&](int s) { return FRAG_AT(H4, s); });
       else gemm_w64<32>(lds_b + PackPreBwd::W5, lane, Pb, [&](int s) { return FRAG_AT(H4, s); });
       if (valid) frag_store_rows(Pb, a.Pb[k], gc, h);
     }

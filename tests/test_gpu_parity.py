@@ -462,12 +462,16 @@ def test_large_batch_equals_its_samples_scored_alone():
             assert torch.equal(one[0], full[b])
 
 
-@pytest.mark.parametrize("net,B", [("cifar_base_kw", 1), ("cifar_base_kw", 2), ("cifar_base_kw", 8), ("cifar_deep_kw", 1), ("cifar_deep_kw", 5)])
+@pytest.mark.parametrize("net,B", [("cifar_base_kw", 1), ("cifar_base_kw", 2), ("cifar_base_kw", 8), ("cifar_base_kw", 37), ("cifar_base_kw", 256),
+                                   ("cifar_deep_kw", 1), ("cifar_deep_kw", 5), ("cifar_deep_kw", 128), ("cifar_wide_kw", 1), ("cifar_wide_kw", 3),
+                                   ("cifar_wide_kw", 200)])
 @pytest.mark.parametrize("fam", ["shipped", "random"])
 def test_small_batch_tail_kernel_is_bit_identical(monkeypatch, net, B, fam):
-    """Batches up to 8 end in ONE launch, k_scored_tail (the restricted last step's scored gather + node update of layer 1 + the
+    """A forward ends in ONE launch, k_scored_tail (the restricted last step's scored gather + node update of layer 1 + the
     score head + the decision), instead of three; GNNB_TAIL_MAX_B=0 keeps the three kernels.  Same arithmetic per node: identical
-    scores and decisions -- also with some dead nodes marked undecided and with a sample that has nothing to score."""
+    scores and decisions -- also with some dead nodes marked undecided and with a sample that has nothing to score.  Round 4: every
+    batch size (segments of 16 .. 48 scored nodes, one and several rounds per workgroup), cifar_wide_kw's 128-slot window (two nodes per
+    gather wave instead of four)."""
     from gnn_branching_amd import synth
     batch = synth.make_batch(net, B, seed=40 + B)
     args = list(batch.forward_args())
@@ -478,7 +482,7 @@ def test_small_batch_tail_kernel_is_bit_identical(monkeypatch, net, B, fam):
         args[6][B - 1] = 0
     out, dec, launches = {}, {}, {}
     for knob in ("0", "8"):
-        monkeypatch.setenv("GNNB_TAIL_MAX_B", knob)
+        monkeypatch.setenv("GNNB_TAIL_MAX_B", "0" if knob == "0" else "1000000")
         model = make_model(fam)
         eng = model.engine()
         with torch.no_grad():
@@ -529,12 +533,13 @@ def test_small_batch_classify_pre_kernel_is_bit_identical(monkeypatch, net, B, f
 @pytest.mark.gpu
 def test_profile_trace_lists_the_launches_of_a_forward_in_order():
     """gnnb_profile_trace: class and duration of every launch gnnb_profile_read resolved, in launch order (bench.py prices single launches
-    of the stand-alone aggregation class with it).  One forward of the default path: 13 launches at B = 40, 10 for a single subproblem,
+    of the stand-alone aggregation class with it).  One forward of the default path: 11 launches at B = 40 (13 before round 4's k_scored_tail
+    served every batch size), 10 for a single subproblem,
     the classification first and the score head last, the per-class sums equal to what profile_read returned."""
     from gnn_branching_amd import synth
     model = make_model("shipped")
     eng = model.engine()
-    for B, want in ((40, 13), (1, 10)):
+    for B, want in ((40, 11), (1, 10)):
         batch = synth.make_batch("cifar_base_kw", B, seed=5)
         with torch.no_grad():
             model.forward_device(*batch.forward_args()).check()
