@@ -92,6 +92,7 @@ struct DevGather {          // one conv edge in one direction, as MFMA gather ta
   bool ok = false;
   GatherGeom g;
   float* cmat = nullptr;
+  uint32_t* taps3 = nullptr;   // 32-node tiles: the taps in three bf16 pieces (GatherHost::taps3)
   int* koff = nullptr;
   int* ttab = nullptr;
 };
@@ -123,6 +124,8 @@ struct gnnb_handle {
   int clspre_max_b = 1;         // GNNB_CLSPRE_MAX_B: batches up to it classify and run the hoisted feature chains in one launch (k_classify_pre);
                                 // measured (base, us): B = 1 27.5 vs 7.6 + 22.1, B = 2 34.0 vs 30.0, B = 8 42.5 vs 31.8 -- a block's share of
                                 // the ambiguous nodes is uneven, so beyond one subproblem the two kernels' even dealing wins
+  bool gather_bf3 = false;      // GNNB_GATHER_BF3=1: the input update's aggregate on the bf16 matrix rate (the rows F of layer 1 written as three bf16 pieces,
+                                // gather_tile_sparse_bf3).  Measured SLOWER (base B=256: k_gather_input_update 115 -> 140 us): off by default, kept as the A/B
   int tail_max_b = 1 << 30;     // GNNB_TAIL_MAX_B: batches up to it end in k_scored_tail (scored gather + restricted update + score head in one launch); 0: three kernels
   bool top_fuse_upd = true;     // GNNB_TOP_FUSE_UPD=0: the backward node update of layer L-1 as its own launch behind k_top (it runs inside k_top otherwise)
   int top_split_max = 4;        // GNNB_TOP_SPLIT: 4 (default) = four workgroups per sample while B <= n_cu / 4, two while B <= n_cu / 2; 2 = two at most; 1 = never
@@ -293,15 +296,16 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
 #endif
   HIPCHK(hipFuncSetAttribute((const void*)k_gather16<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   if (const char* e = getenv("GNNB_NO_EMBED_FUSE")) h->embed_fuse = !(e[0] == '1');      // (bench.py's aggregate-only leg: round 0's rows from k_embed)
-  HIPCHK(hipFuncSetAttribute((const void*)k_livesum, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));      // (the kernel also has a few static words)
+  HIPCHK(hipFuncSetAttribute((const void*)k_livesum, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #ifdef GNNB_DEV
   if (const char* e = getenv("GNNB_NO_RESTRICT")) h->restrict_last = !(e[0] == '1');
 #endif
   if (const char* e = getenv("GNNB_NO_DENSE_LDS")) h->dense_lds = !(e[0] == '1');
-  HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));      // (the kernel also has a few static words)
-  HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));      // (the kernel also has a few static words)
-  HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));      // (the kernel also has a few static words)
-  HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));      // (the kernel also has a few static words)
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_gather<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   if (const char* e = getenv("GNNB_NO_GATHER")) h->use_gather = !(e[0] == '1');
   if (const char* e = getenv("GNNB_NO_TOP")) h->use_top = !(e[0] == '1');
@@ -316,6 +320,7 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
 #undef FUSEDQ_ATTR
   if (const char* e = getenv("GNNB_PER_SAMPLE_MIN_B")) h->per_sample_min_b = atoi(e);
   if (const char* e = getenv("GNNB_TAIL_MAX_B")) h->tail_max_b = atoi(e);
+  if (const char* e = getenv("GNNB_GATHER_BF3")) h->gather_bf3 = e[0] == '1';
   if (const char* e = getenv("GNNB_CLSPRE_MAX_B")) h->clspre_max_b = atoi(e);
   if (const char* e = getenv("GNNB_TOP_FUSE_UPD")) h->top_fuse_upd = !(e[0] == '0');
   if (const char* e = getenv("GNNB_TOP_SPLIT")) h->top_split_max = atoi(e) >= 4 ? 4 : (atoi(e) >= 2 ? 2 : 1);
@@ -357,6 +362,7 @@ static void free_network(gnnb_t* h) {
   for (auto* v : {&h->gf, &h->gb})
     for (auto& d : *v) {
       if (d.cmat) (void)hipFree(d.cmat);
+      if (d.taps3) (void)hipFree(d.taps3);
       if (d.koff) (void)hipFree(d.koff);
       if (d.ttab) (void)hipFree(d.ttab);
     }
@@ -545,6 +551,10 @@ extern "C" int gnnb_bind_network(gnnb_t* h, const gnnb_layer_desc* L, int n, int
         DevGather& d = dir == 0 ? h->gf[k] : h->gb[k];
         d.g = gh.g;
         if (int rc = upload(&d.cmat, gh.cmat.data(), gh.cmat.size())) return rc;
+        if (!gh.taps3.empty()) {
+          HIPCHK(hipMalloc((void**)&d.taps3, gh.taps3.size() * sizeof(uint32_t)));
+          HIPCHK(hipMemcpy(d.taps3, gh.taps3.data(), gh.taps3.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
         HIPCHK(hipMalloc((void**)&d.koff, gh.koff.size() * sizeof(int)));
         HIPCHK(hipMemcpy(d.koff, gh.koff.data(), gh.koff.size() * sizeof(int), hipMemcpyHostToDevice));
         {
@@ -587,7 +597,7 @@ static DTileMap to_dtm(const TileMap& t) {
 static DGather to_dg(const DevGather& d, const float* zero) {
   const GatherGeom& g = d.g;
   return DGather{d.cmat, reinterpret_cast<const int2*>(d.koff), d.ttab, zero, g.K2, g.tm.NCG * g.K2, g.Hs, g.Ws, g.Ns, g.ystep, g.ybase,
-                 g.xstep, g.xbase, g.WY, g.WX, g.normalise, g.kh, g.kw, g.stride, g.pad, g.lanes};
+                 g.xstep, g.xbase, g.WY, g.WX, g.normalise, g.kh, g.kw, g.stride, g.pad, g.lanes, reinterpret_cast<const uint2*>(d.taps3)};
 }
 static size_t gather_lds_bytes(const DevGather& d, size_t pack_floats) {
   return (pack_floats + (size_t)d.g.tm.NCG * d.g.K2 * 64) * 4 + (size_t)gather_slots(d.g.K2, d.g.lanes) * 12 + (size_t)((d.g.tm.TPS + 3) & ~3) * 4;
@@ -699,6 +709,7 @@ struct WsLayout {                // plain arrays: gnnb_forward computes it on it
   size_t lf[MAXL + 2];          // live flags (B, N_k) as floats
   size_t sf[MAXL + 2], sb[MAXL + 2];   // k_livesum outputs: sf[k] (B, N_k) over edge k, sb[k] (B, N_k) over edge k+1 transposed
   size_t F1 = 0;                // rows of layer 1 after the producer-side map of the input update (PackPostInp)
+  size_t F3 = 0;                // the same as three bf16 pieces (rows3): what the input update's bf16 x 3 aggregate reads
   size_t cnt = 0, best = 0, nb = 0, Q = 0, total = 0;     // best: B 64-bit decision keys + the finished-workgroup counter of k_score
   size_t topflag = 0, topx = 0;                           // k_top's workgroup split: arrival counters, (B, 8, 64) exchange buffer
 };
@@ -728,6 +739,7 @@ static WsLayout ws_layout(const gnnb_t* h, int B) {
   for (int k = 1; k < K; ++k) { w.sf[k] = off; off += align64((size_t)B * h->N[k]); }
   for (int k = 0; k < K - 1; ++k) { w.sb[k] = off; off += align64((size_t)B * h->N[k]); }
   w.F1 = off; off += align64((size_t)B * h->N[1] * 64);
+  w.F3 = off; off += align64((size_t)B * h->N[1] * ROW3_FLOATS);
   w.Q = off; off += (size_t)map_tiles(bwd_map(h, 0), B) * 2048;
   w.total = off;
   return w;
@@ -909,6 +921,9 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   // in mu[1] (whose dead rows k_classify already zeroed); inspection runs keep both, the mapped ones in F1.
   float* const rows1_for_input = debug_full ? ws + w.F1 : mu(1);
 
+  // the input update's aggregate on the bf16 matrix rate: needs the sparse 32-node walk, the bf16 x 3 blocks and a producer that writes F as
+  // three pieces (the POST block of layer 1's backward update); inspection runs keep fp32 rows
+  const bool input_rows3 = h->gather_bf3 && h->bf3 && !debug_full && h->gb[1].ok && h->gb[1].taps3 && h->gb[1].g.lanes == 32 && (h->gather_sparse & 4);
   const bool embed_in_gather = h->embed_fuse && !debug_full && h->gf[1].ok;
   const bool top_fused = h->use_top && h->top_ok && !debug_full && per_sample;
   // The rows of dead nodes are zero by definition (mu = (.) * live).  Every default consumer of a layer's rows walks only the
@@ -1162,7 +1177,8 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     // normal: list0 = live non-ambiguous nodes (short chain), list1 = ambiguous nodes; restricted: the scored nodes, general chain
     UpdArgs a{h->d_pack[pack], in->lb[k], in->ub[k], nb, ws + (fwd ? w.Pf[k] : w.Pb[k]), (post_input && !debug_full) ? nullptr : mu(k), status,
               ilist(w.live[k]), cnt + 4 * k + (scored ? 3 : 0), ilist(scored ? w.score[k] : w.amb[k]), cnt + 4 * k + (scored ? 2 : 1), sarr, smod,
-              post_input ? rows1_for_input : nullptr, nullptr};
+              post_input ? rows1_for_input : nullptr, nullptr, nullptr};
+    if (post_input && input_rows3) a.post3 = ws + w.F3;
     a.wp = h->d_pack[PK_POST_INP] + (h->bf3 ? (h->gb[1].ok ? PackPostInp::WPG3 : PackPostInp::WPN3) : (h->gb[1].ok ? PackPostInp::WPG : PackPostInp::WPN));
     return a;
   };
@@ -1238,12 +1254,16 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       const long nt = map_tiles(d.g.tm, B);
       const bool sparse = (h->gather_sparse & 4) != 0;
       GIArgs a{h->d_pack[PK_PRE_INP], h->d_pack[PK_UPD_INP], in->lb[0], in->ub[0], rows1_for_input, ws + w.sb[0], mu(0), nt, to_dtm(d.g.tm), to_dg(d, h->d_zero),
-               in->lb[1], in->ub[1], sparse && h->s_in_gather ? 1 : 0};
-      const size_t lds = gather_lds_bytes(d, PackUpdInp::FLOATS + PackPreInp::FLOATS) + (sparse ? sparse_tab_bytes(d) : 0);
-      long giu_grid = (nt + WAVES_MLP - 1) / WAVES_MLP;
-      if (giu_grid > (long)h->n_cu * h->giu_occ) giu_grid = (long)h->n_cu * h->giu_occ;
+               in->lb[1], in->ub[1], sparse && h->s_in_gather ? 1 : 0, (sparse && input_rows3) ? (const void*)(ws + w.F3) : nullptr};
+      const bool r3 = a.mu_src3 != nullptr;
+      const int nw = r3 ? GIU_R3_WAVES : WAVES_MLP;
+      const size_t lds = gather_lds_bytes(d, PackUpdInp::FLOATS + PackPreInp::FLOATS) +
+                         (sparse ? 8 + (size_t)nw * (2 * d.g.K2 + 32) * 8 : 0) + (r3 ? (size_t)d.g.tm.NCG * d.g.K2 * 128 * 4 : 0);
+      long giu_grid = (nt + nw - 1) / nw;
+      if (giu_grid > (long)h->n_cu * (r3 ? 1 : h->giu_occ)) giu_grid = (long)h->n_cu * (r3 ? 1 : h->giu_occ);
       lz.run(PC_GATHER_INPUT, [&] {
-        if (sparse && h->bf3) hipLaunchKernelGGL((k_gather_input_update<true, true>), dim3(giu_grid), dim3(WG_MLP), lds, st, a);
+        if (r3) hipLaunchKernelGGL((k_gather_input_update<true, true, true>), dim3(giu_grid), dim3(GIU_R3_WAVES * 64), lds, st, a);
+        else if (sparse && h->bf3) hipLaunchKernelGGL((k_gather_input_update<true, true>), dim3(giu_grid), dim3(WG_MLP), lds, st, a);
         else if (sparse) hipLaunchKernelGGL((k_gather_input_update<true, false>), dim3(giu_grid), dim3(WG_MLP), lds, st, a);
         else if (h->bf3) hipLaunchKernelGGL((k_gather_input_update<false, true>), dim3(giu_grid), dim3(WG_MLP), lds, st, a);
         else hipLaunchKernelGGL((k_gather_input_update<false, false>), dim3(giu_grid), dim3(WG_MLP), lds, st, a);

@@ -78,6 +78,26 @@ __device__ __forceinline__ void split_bf3(GetB& getB, int fk, u32x4& p1, u32x4& 
   }
 }
 
+// ---- rows in three bf16 pieces ("rows3"): what a conv edge's aggregate reads when it runs on the bf16 matrix rate -------------------
+// v_mfma_f32_32x32x2_f32 / _16x16x4_f32 run on the VECTOR pipe: while a wave's fp32 MFMAs execute, no other wave of the SIMD issues a
+// vector instruction (tools/micro/mfma_valu_overlap.hip: a partner wave's v_fma stream makes NO progress beside them and 89 % of its
+// progress beside v_mfma_f32_32x32x16_bf16).  So the fp32 tap MFMAs of the gathers and the operand splits of the chains add up on one
+// pipe.  A gather on the bf16 rate needs its source rows as bf16 pieces WITHOUT splitting them per read (a row is read by 2-4 tiles):
+// the producer of the rows writes the pieces once.  Layout: a row of 64 values = 32 pairs x 3 pieces, pair u (values 2u, 2u + 1) =
+// 12 bytes at 12 u: {p1 | p2 | p3}, each a dword with the even value in its low half.  x = p1 + p2 + p3 to 24 bits (round to nearest
+// each time, as the activations of gemm_w64_bf3).
+#define ROW3_BYTES 384
+#define ROW3_FLOATS 96
+__device__ __forceinline__ void split_pair_bf3(float a, float b, unsigned& u1, unsigned& u2, unsigned& u3) {
+  u1 = pk_bf16(a, b);
+  const float ra = a - __uint_as_float(u1 << 16), rb = b - __uint_as_float(u1 & 0xffff0000u);
+  u2 = pk_bf16(ra, rb);
+  const float sa = ra - __uint_as_float(u2 << 16), sb = rb - __uint_as_float(u2 & 0xffff0000u);
+  u3 = pk_bf16(sa, sb);
+}
+// fragment -> rows3: lane (j, h) owns values [8q + 4h, 8q + 4h + 4) of its row = pairs 4q + 2h, 4q + 2h + 1: 24 contiguous bytes per q
+__device__ __forceinline__ void frag_store_rows3(const Frag& x, void* base, long row, int h);
+
 // GEMM_BF3_PIPE (default 1): software-pipelined form -- the split of k-step s + 1 (~56 vector instructions) is issued BETWEEN the 12
 // MFMAs of k-step s (sched_group_barrier: one MFMA, then up to five vector instructions, twelve times), so a wave keeps the matrix
 // pipe fed while it splits (an MFMA holds the vector issue for 8 of its 32 cycles: five 4-cycle instructions fit each gap).  The
@@ -221,6 +241,20 @@ __device__ __forceinline__ void frag_store_tiled(const Frag& x, float* base, lon
 #pragma unroll
     for (int c = 0; c < 4; ++c) v[c] = FRAG_AT(x, 4 * q + c);
     p[q * 64] = v;
+  }
+}
+
+__device__ __forceinline__ void frag_store_rows3(const Frag& x, void* base, long row, int h) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  u32x2* p = reinterpret_cast<u32x2*>(reinterpret_cast<char*>(base) + row * ROW3_BYTES + 24 * h);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    unsigned a1, a2, a3, b1, b2, b3;
+    split_pair_bf3(FRAG_AT(x, 4 * q), FRAG_AT(x, 4 * q + 1), a1, a2, a3);
+    split_pair_bf3(FRAG_AT(x, 4 * q + 2), FRAG_AT(x, 4 * q + 3), b1, b2, b3);
+    p[6 * q + 0] = u32x2{a1, a2};
+    p[6 * q + 1] = u32x2{a3, b1};
+    p[6 * q + 2] = u32x2{b2, b3};
   }
 }
 

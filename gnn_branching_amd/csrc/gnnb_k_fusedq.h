@@ -90,7 +90,10 @@ __device__ __forceinline__ void upd_chain_frag(const UpdArgs& u, const float* ld
 #pragma unroll
     for (int R = 0; R < 32; ++R) FRAG_AT(H, R) = 0.0f;
     gemm_w64_bf3<1, PIPE>(lds + PackUpdL3::FLOATS, lane, H, [&](int s) { return FRAG_AT(H2, s); });
-    if (valid) frag_store_rows(H, u.post, gc, h);
+    if (valid) {
+      if (u.post3) frag_store_rows3(H, u.post3, gc, h);
+      else frag_store_rows(H, u.post, gc, h);
+    }
   }
 }
 
@@ -134,14 +137,24 @@ __global__ __launch_bounds__((QG_WAVES + QC_WAVES) * 64, 4) void k_gather_update
   __syncthreads();
   if (threadIdx.x < QTILES) q->free_id[threadIdx.x] = threadIdx.x;
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, hwave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // Q_ROLE_BY_SIMD (dev): the waves w, w + 4, w + 8, w + 12 of a workgroup share a SIMD; gather waves = those with (w & 3) < 2, so that
+  // two SIMDs run only gathers (fp32 MFMAs: they hold the SIMD's vector issue for their whole duration, tools/micro/mfma_valu_overlap.hip)
+  // and two only chains
+#if defined(Q_ROLE_BY_SIMD) && QG_WAVES == 8
+  const bool chain_role = (hwave & 3) >= 2;
+  const int wave = chain_role ? QG_WAVES + ((hwave >> 2) * 2 + (hwave & 1)) : ((hwave >> 2) * 2 + (hwave & 1));
+#else
+  const int wave = hwave;
+  const bool chain_role = wave >= QG_WAVES;
+#endif
 
-  if (wave >= QG_WAVES) {
+  if (chain_role) {
     // ---------------- chain wave ----------------
     // The node-update weights (74 KB + 24 KB of POST) are staged by the chain waves alone while the gather waves, which only need the
     // gather's tables, already walk their first tiles; `staged` counts the chain waves whose part is in LDS.
     {
-      const int ct = threadIdx.x - QG_WAVES * 64, cn = QC_WAVES * 64;
+      const int ct = (wave - QG_WAVES) * 64 + lane, cn = QC_WAVES * 64;
       copy_to_lds_part(lds + PackUpdL3::BA, a.u.pack + PackUpd::BA, 64, ct, cn);
       copy_to_lds_part(lds + PackUpdL3::BCB, a.u.pack + PackUpd::BCB, 64 + 64 + 128, ct, cn);          // BCB, BCBROW, VAW
       copy_to_lds_part(lds + PackUpdL3::WAS3, a.u.pack + PackUpd::WAS3, 6144, ct, cn);

@@ -16,6 +16,7 @@ struct DGather {
   const float* zero;     // 64 zero floats
   int K2, ncg_k2, Hs, Ws, Ns, ystep, ybase, xstep, xbase, WY, WX, normalise, kh, kw, stride, pad;
   int lanes;             // dst nodes per tile: 32 (32x32x2 MFMA, 2 window slots per k-step) or 16 (16x16x4, 4 slots per k-step)
+  const uint2* taps3;    // 32-node tiles: the tap matrix in three bf16 pieces, [NCG][2 K2 slots][32 dst] x {p1 | p2 << 16, p3} (fill_gather_tables)
 };
 
 #define STAGE16_FLOATS (16 * 68 + 16)      // per-wave LDS image of the gathers' row stores (store_tile16 / frag_store_rows_*_staged<16>)
@@ -166,6 +167,96 @@ __device__ __forceinline__ void gather_tile_sparse(Frag& X, const float* cm, con
     __builtin_amdgcn_sched_barrier(0);
   }
   if (K2e & GATHER_CHS) mma(cur, s0);
+  if (ssum) *ssum = sacc + __shfl_xor(sacc, 32);
+}
+
+
+// The sparse walk on the bf16 matrix rate: the source rows come as three bf16 pieces (rows3, gnnb_dev.h), the taps too (DGather::taps3),
+// and a group of 16 live window slots is ONE k-step of v_mfma_f32_32x32x16_bf16 per channel tile and product -- six products
+// x1 w3 + x2 w2 + x3 w1 + x1 w2 + x2 w1 + x1 w1 as in gemm_w64_bf3 (fp32-grade sums): 12 MFMAs of 32 matrix-pipe cycles per 16 slots
+// instead of 16 fp32 MFMAs of 64 VECTOR-pipe cycles.  Lane (m = lane & 31, kg = lane >> 5) takes table entries 16 G + 8 kg .. + 7: one
+// 12-byte load per slot brings the three pieces of channels 2m, 2m + 1 (the fp32 form: 8 bytes per slot), four v_perm per operand
+// put 8 slots of one channel and piece side by side.  Result layout = gather_tile_sparse's (X.t[t][r] = channel 2 k + t, k = (r & 3) + 8 (r >> 2) + 4 h).
+// taps3: this channel group's [slot][32 dst] uint2 in LDS; cm: the fp32 tap matrix (bias sums only).
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+#define PERM_LO 0x05040100u      // v_perm_b32(hi_src, lo_src): {lo_src.lo16, hi_src.lo16}
+#define PERM_HI 0x07060302u      //                              {lo_src.hi16, hi_src.hi16}
+__device__ __forceinline__ void gather_tile_sparse_bf3(Frag& X, const float* cm, const uint2* taps3, const int2* ko, uint2* tab, int K2,
+                                                       __amdgpu_buffer_rsrc_t rsrc3, const float* slb, const float* sub, int j, int wy0, int wx0,
+                                                       int Hs, int Ws, int lane, bool keep = false, float* ssum = nullptr) {
+  const int h = lane >> 5;
+  float sacc = 0.0f;
+  if (!keep) {
+#pragma unroll
+    for (int R = 0; R < 32; ++R) FRAG_AT(X, R) = 0.0f;
+  }
+  const int origin = wy0 * Ws + wx0;
+  int n = 0;
+  for (int base = 0; base < 2 * K2; base += 64) {
+    const int sl = base + lane;
+    const unsigned long long ev = reinterpret_cast<const unsigned long long*>(ko)[sl];
+    const int ex = (int)(unsigned)ev, ey = (int)(unsigned)(ev >> 32);
+    const int wy = wy0 + (ey & 0xffff), wx = wx0 + (ey >> 16);
+    const bool inb = sl < 2 * K2 && (unsigned)wy < (unsigned)Hs && (unsigned)wx < (unsigned)Ws;      // (table padding: 0x7fff, never in range)
+    const int row = inb ? origin + ex : 0;
+    const bool live = inb && node_is_live(slb[row], sub[row]);
+    const unsigned long long bal = __ballot(live);
+    if (live) tab[n + __popcll(bal & ((1ull << lane) - 1ull))] = make_uint2((unsigned)row * ROW3_BYTES, (unsigned)sl * 32u);
+    n += __popcll(bal);
+  }
+  const int npad = (n + 15) & ~15;
+  for (int q = n + lane; q < npad + 16; q += 64) tab[q] = make_uint2(BUF_OOB, 0u);       // out-of-range offset: the load returns 0
+  const int ng = npad >> 4;
+  const unsigned lane_off = 12u * (unsigned)j;
+  u32x3 v[8];
+  auto load = [&](int G) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const unsigned o = tab[16 * G + 8 * h + u].x;
+      v[u] = __builtin_amdgcn_raw_buffer_load_b96(rsrc3, o == BUF_OOB ? BUF_OOB : o + lane_off, 0, 0);
+    }
+  };
+  load(0);
+  for (int G = 0; G < ng; ++G) {
+    // the taps of this lane's 8 slots for dst node j: B operands (three pieces); the fp32 taps for the bias sum
+    u32x4 b1, b2, b3;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned c0 = tab[16 * G + 8 * h + 2 * q].y, c1 = tab[16 * G + 8 * h + 2 * q + 1].y;
+      const uint2 t0 = taps3[c0 + j], t1 = taps3[c1 + j];
+      if (ssum) {        // (padding entries point at tap row 0)
+        sacc += 16 * G + 8 * h + 2 * q < n ? cm[c0 + j] : 0.0f;
+        sacc += 16 * G + 8 * h + 2 * q + 1 < n ? cm[c1 + j] : 0.0f;
+      }
+      b1[q] = __builtin_amdgcn_perm(t1.x, t0.x, PERM_LO);
+      b2[q] = __builtin_amdgcn_perm(t1.x, t0.x, PERM_HI);
+      b3[q] = __builtin_amdgcn_perm(t1.y, t0.y, PERM_LO);
+    }
+    const bf16x8 w1 = __builtin_bit_cast(bf16x8, b1), w2 = __builtin_bit_cast(bf16x8, b2), w3 = __builtin_bit_cast(bf16x8, b3);
+    // A operands: channel 2m + t of the 8 slots, piece p (the loads of group G are waited for here); one channel tile at a time, the
+    // next group's loads are issued as soon as the second tile's operands are built: they fly under its MFMAs
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      u32x4 a[3];
+#pragma unroll
+      for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[pp][q] = __builtin_amdgcn_perm(v[2 * q + 1][pp], v[2 * q][pp], t2 ? PERM_HI : PERM_LO);
+      if (t2 == 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        load(G + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const bf16x8 x1 = __builtin_bit_cast(bf16x8, a[0]), x2 = __builtin_bit_cast(bf16x8, a[1]), x3 = __builtin_bit_cast(bf16x8, a[2]);
+      X.t[t2] = mfma_bf16(x1, w3, X.t[t2]);
+      X.t[t2] = mfma_bf16(x2, w2, X.t[t2]);
+      X.t[t2] = mfma_bf16(x3, w1, X.t[t2]);
+      X.t[t2] = mfma_bf16(x1, w2, X.t[t2]);
+      X.t[t2] = mfma_bf16(x2, w1, X.t[t2]);
+      X.t[t2] = mfma_bf16(x1, w1, X.t[t2]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
   if (ssum) *ssum = sacc + __shfl_xor(sacc, 32);
 }
 
@@ -737,10 +828,12 @@ __device__ __forceinline__ void gather_process_tile16(const GArgs& a, const Tile
 }
 
 // LDS image of a gather's tables: tap matrix, window offsets (two forms), tile table
-struct GatherLds { float* cm; int2* ko; int* tt; unsigned* kvo; };
-__device__ __forceinline__ GatherLds gather_lds(float* base, const DGather& g, int TPS) {
+struct GatherLds { float* cm; int2* ko; int* tt; unsigned* kvo; uint2* t3; };
+// with3: the bf16 x 3 tap matrix (DGather::taps3, twice the bytes of cm) sits in front of the fp32 one
+__device__ __forceinline__ GatherLds gather_lds(float* base, const DGather& g, int TPS, bool with3 = false) {
   GatherLds l;
-  l.cm = base;
+  l.t3 = reinterpret_cast<uint2*>(base);
+  l.cm = base + (with3 ? g.ncg_k2 * 128 : 0);
   l.ko = reinterpret_cast<int2*>(l.cm + g.ncg_k2 * 64);
   l.tt = reinterpret_cast<int*>(l.ko + gather_slots(g.K2, g.lanes));
   l.kvo = reinterpret_cast<unsigned*>(l.tt + ((TPS + 3) & ~3));
@@ -858,13 +951,14 @@ struct GIArgs {
   const float* mu_src; const float* sarr; float* mu; long ntiles; DTileMap tm; DGather g;
   const float *src_lb, *src_ub;     // SPARSE: bounds of ReLU layer 1 (the rows of its dead nodes are zero and skipped)
   int s_from_gather;                // SPARSE: the bias-sum scalar comes out of this kernel's own gather instead of sarr (k_livesum)
+  const void* mu_src3;              // SPARSE: the source rows as three bf16 pieces (rows3) -> the aggregate runs on the bf16 matrix rate; null: fp32 rows, fp32 MFMAs
 };
 
 // input layer: E_0 = relu(Q + inp_b2[:, 64:] . (A_1^T mu_1)),  Q = inp_b2[:, :64] . inp_b_1(relu(inp_b([l0,u0]))) + b;
 // mu_0 = inp_b2_2(E_0) is deferred into the next round's forward update of ReLU layer 1 (gnnb_pack.h).
 // graph_conv.py:361-385; the aggregate, the feature chain and the update stay in registers.
 // one tile of the fused input-layer update; lds_upd / lds_pre: PackUpdInp / PackPreInp in LDS
-template <bool SPARSE, bool BF3>
+template <bool SPARSE, bool BF3, bool R3 = false>
 __device__ __forceinline__ void input_update_tile(const GIArgs& a, const TileCtx& tc, int sample, const float* lds_upd, const float* lds_pre,
                                                   const GatherLds& gl, uint2* tab, int lane) {
   const int h = lane >> 5, j = lane & 31;
@@ -895,7 +989,14 @@ __device__ __forceinline__ void input_update_tile(const GIArgs& a, const TileCtx
 #if defined(GIU_ABL) && (GIU_ABL & 4)      // dev, timing only: no gather
   if (wy0 > 100000)
 #endif
-  if (SPARSE)
+  if (SPARSE && R3) {
+    const int uy = __builtin_amdgcn_readfirstlane(wy0), ux = __builtin_amdgcn_readfirstlane(wx0);
+    const __amdgpu_buffer_rsrc_t rsrc3 = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(a.mu_src3) + (long)sample * a.g.Ns * ROW3_BYTES),
+                                                                           0, a.g.Ns * ROW3_BYTES, 0x00020000);
+    gather_tile_sparse_bf3(H, gl.cm + tc.cg * a.g.K2 * 64, gl.t3 + (long)tc.cg * a.g.K2 * 64, gl.ko, tab, a.g.K2, rsrc3,
+                           a.src_lb + (long)sample * a.g.Ns, a.src_ub + (long)sample * a.g.Ns, j, uy, ux, a.g.Hs, a.g.Ws, lane, true,
+                           own_s ? &ssum : nullptr);
+  } else if (SPARSE)
     gather_dispatch(H, gl.cm + tc.cg * a.g.K2 * 64, gl.ko, gl.kvo, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane, tab,
                     a.src_lb + (long)sample * a.g.Ns, a.src_ub + (long)sample * a.g.Ns, true, own_s ? &ssum : nullptr);
   else
@@ -913,29 +1014,35 @@ __device__ __forceinline__ void input_update_tile(const GIArgs& a, const TileCtx
 #endif
 }
 
-template <bool SPARSE, bool BF3>
-__global__ __launch_bounds__(WG_MLP, 2) void k_gather_input_update(GIArgs a) {
+// R3: the source rows are three bf16 pieces (GIArgs::mu_src3) and the aggregate runs on the bf16 matrix rate (gather_tile_sparse_bf3); its
+// 24-byte loads and operand pieces need ~165 registers: 12 waves per workgroup (3 per SIMD), one workgroup per CU.  !R3: fp32 rows,
+// fp32 MFMAs, two 8-wave workgroups per CU (128 registers).
+#define GIU_R3_WAVES 12
+template <bool SPARSE, bool BF3, bool R3 = false>
+__global__ __launch_bounds__(R3 ? GIU_R3_WAVES * 64 : WG_MLP, R3 ? 3 : 2) void k_gather_input_update(GIArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NW = R3 ? GIU_R3_WAVES : WAVES_MLP;
   float* lds_pre = lds + PackUpdInp::FLOATS;
-  const GatherLds gl = gather_lds(lds_pre + PackPreInp::FLOATS, a.g, a.tm.TPS);
+  const GatherLds gl = gather_lds(lds_pre + PackPreInp::FLOATS, a.g, a.tm.TPS, R3);
   stage_gather(gl.cm, gl.ko, gl.tt, gl.kvo, a.g, a.tm.TPS);
+  if (R3) copy_to_lds(reinterpret_cast<float*>(gl.t3), reinterpret_cast<const float*>(a.g.taps3), a.g.ncg_k2 * 128);
   copy_to_lds(lds_pre, a.pack_pre, PackPreInp::FLOATS);
   stage_pack(lds, a.pack, PackUpdInp::FLOATS);
   const int lane = threadIdx.x & 63, j = lane & 31, wave = threadIdx.x >> 6;
   uint2* tab = reinterpret_cast<uint2*>(gl.kvo + ((gather_slots(a.g.K2, 32) + 1) & ~1)) + wave * (2 * a.g.K2 + 32);      // SPARSE
-  // rounds of 8 tiles round-robin over the workgroups, XCD-grouped (see k_gather / k_gather16): an XCD keeps a handful of samples
+  // rounds of NW tiles round-robin over the workgroups, XCD-grouped (see k_gather / k_gather16): an XCD keeps a handful of samples
   // open instead of 32 (contiguous chunks: the counters saw the rows of layer 1 fetched 2.2 times, profiles/r04a_base_aggonly_*)
   int wg = blockIdx.x;
   const int nwg = gridDim.x;
   if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
-  const long nrounds = (a.ntiles + WAVES_MLP - 1) / WAVES_MLP;
+  const long nrounds = (a.ntiles + NW - 1) / NW;
   for (long r = wg; r < nrounds; r += nwg) {
-    const long tile = r * WAVES_MLP + wave;
+    const long tile = r * NW + wave;
     if (tile >= a.ntiles) break;
     const int sample = __builtin_amdgcn_readfirstlane((int)(tile / a.tm.TPS));
     const int t = __builtin_amdgcn_readfirstlane((int)(tile - (long)sample * a.tm.TPS));
     const TileCtx tc = block_decode(a.tm, gl.tt, sample, t, j);
-    input_update_tile<SPARSE, BF3>(a, tc, sample, lds, lds_pre, gl, tab, lane);
+    input_update_tile<SPARSE, BF3, R3>(a, tc, sample, lds, lds_pre, gl, tab, lane);
   }
 }
 

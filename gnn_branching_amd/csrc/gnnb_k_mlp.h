@@ -407,6 +407,7 @@ struct UpdArgs {
   // on the ~3x fewer producer nodes: F = WP.E goes to `post` (rows by node id), and `mu` may be null (nothing else reads E)
   float* post;
   const float* wp;          // PackPostInp block (WPN or WPG), staged behind the update pack
+  void* post3;              // POST: F is written as three bf16 pieces (rows3: the input update's aggregate runs on the bf16 matrix rate) instead of `post`
 };
 
 // folded node update (gnnb_pack.h PackUpd):  E_g = relu(P'_g + Wcb.h) [r0 != 0],  h = relu(Wa.[r0 nb_g, r1 nb_g] + ba);
@@ -518,7 +519,10 @@ __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, i
       for (int R = 0; R < 32; ++R) FRAG_AT(H, R) = 0.0f;
       if (BF3) gemm_w64_bf3<1>(lds + O_END, lane, H, [&](int s) { return FRAG_AT(H2, s); });
       else gemm_w64<32>(lds + O_END, lane, H, [&](int s) { return FRAG_AT(H2, s); });
-      if (valid) frag_store_rows(H, a.post, gc, h);
+      if (valid) {
+        if (a.post3) frag_store_rows3(H, a.post3, gc, h);
+        else frag_store_rows(H, a.post, gc, h);
+      }
     }
     FT_MARK(4);                                // stores (+ POST block)
     if (!has_next) break;

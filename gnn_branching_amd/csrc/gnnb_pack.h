@@ -556,6 +556,7 @@ struct GatherHost {
   GatherGeom g;
   std::vector<float> cmat;       // [NCG][K2][64]: column of slot k, dst lane j: (k / spk) * 64 + (k % spk) * lanes + j, spk = 64 / lanes
   std::vector<int32_t> koff;     // [spk*K2 + pad][2]: {row offset relative to the window origin, wy | wx << 16}
+  std::vector<uint32_t> taps3;   // 32-node tiles: [NCG][2 K2 slots][32 dst][2]: the taps in three bf16 pieces {p1 | p2 << 16, p3} (the bf16 x 3 gathers)
   long mfma_per_sample = 0;      // in units of one 32x32x2 MFMA (64 cycles): 2 per k-step
 };
 
@@ -627,6 +628,24 @@ inline void fill_gather_tables(const Edge& e, int dir, GatherHost& out) {
         out.cmat[((size_t)cg * g.K2 + sidx) * 64 + h * g.lanes + j] = w;
       }
     }
+  // the same taps as three bf16 pieces (w = p1 + p2 + p3 to 24 bits, round to nearest each time: pack_w64_bf3's split), by window slot:
+  // entry (cg, slot, dst j) sits where the sparse walk's table points with the offset it uses for cmat (slot * 32 + j)
+  out.taps3.clear();
+  if (g.lanes == 32) {
+    out.taps3.assign((size_t)g.tm.NCG * g.K2 * 64 * 2, 0u);
+    for (int cg = 0; cg < g.tm.NCG; ++cg)
+      for (int sl = 0; sl < 2 * g.K2; ++sl)
+        for (int j = 0; j < 32; ++j) {
+          const float w = out.cmat[((size_t)cg * g.K2 + sl / 2) * 64 + (sl % 2) * 32 + j];
+          const unsigned short p1 = bf16_rne(w);
+          const float r1 = w - bf16_f32(p1);
+          const unsigned short p2 = bf16_rne(r1);
+          const unsigned short p3 = bf16_rne(r1 - bf16_f32(p2));
+          const size_t o = (((size_t)cg * 2 * g.K2 + sl) * 32 + j) * 2;
+          out.taps3[o] = (uint32_t)p1 | ((uint32_t)p2 << 16);
+          out.taps3[o + 1] = (uint32_t)p3;
+        }
+  }
 }
 
 // pick the tile shape with the fewest MFMAs per sample

@@ -245,6 +245,26 @@ def test_round0_rows_from_the_embedding_kernel_match(monkeypatch, case, fuse):
         assert model.engine().describe()["embed_fused"] == 0
 
 
+@pytest.mark.parametrize("case", ["cifar_base_kw_B3", "cifar_wide_kw_B2", "cifar_deep_kw_B2"])
+@pytest.mark.parametrize("fuse", ["0", "1"])
+def test_input_update_aggregate_on_the_bf16_rate_matches(monkeypatch, case, fuse):
+    """GNNB_GATHER_BF3=1 (round 4's A/B, off by default because it measured slower): the backward update of layer 1 writes the rows the
+    input update aggregates as three bf16 pieces (rows3) and the input update's sparse walk runs on v_mfma_f32_32x32x16_bf16 with six
+    products per k-step (gather_tile_sparse_bf3) instead of fp32 MFMAs on fp32 rows.  fp32-grade sums: the same parity bar, the
+    reference's decisions -- through the fused half-pass kernel and through k_node_update (GNNB_FUSE=0), which share the row store."""
+    monkeypatch.setenv("GNNB_GATHER_BF3", "1")
+    monkeypatch.setenv("GNNB_FUSE", fuse)
+    g, batch = load_golden(case)
+    for fam in FAMILIES:
+        model = make_model(fam)
+        with torch.no_grad():
+            res = model.forward_device(*batch.forward_args()).check()
+        want = g[f"{fam}_scores"]
+        fin = np.isfinite(want)
+        assert np.abs(res.scores.cpu().numpy()[fin] - want[fin]).max() <= score_tol(fam, want[fin])
+        assert res.decisions.cpu().tolist() == g[f"{fam}_decisions"].tolist()
+
+
 def test_per_tile_dense_kernel_path_matches(monkeypatch):
     """GNNB_NO_DENSE_LDS=1 selects the per-tile dense edge kernels (the fallback for Linear layers whose source does
     not fit the LDS-staged kernels): same scores."""
