@@ -290,6 +290,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-fp32", action="store_true", help="skip the GNNB_BF3=0 comparison leg (exact_fp32_ms_per_step, bf3_max_abs_delta)")
     ap.add_argument("--no-aggregate-only", action="store_true", help="skip the GNNB_FUSE=0 leg (roofline_aggregate_only: the stand-alone edge-aggregation kernel)")
+    ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed leg (host_fed_ms_per_step: the same batch from pinned / pageable host tensors through engine.HostFedPipeline)")
     ap.add_argument("--cpu-budget", type=float, default=75.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--dist", action="store_true",
                     help="run through torch.distributed even with --gpus 1: the process starts its rank(s) with torch.distributed.run exactly as "
@@ -530,6 +531,14 @@ def main():
             except Exception as e:      # noqa: BLE001
                 side_errors["aggregate_only"] = f"{type(e).__name__}: {e}"
                 agg_only = {"error": side_errors["aggregate_only"]}
+        # ---- the same batch arriving as HOST tensors (the reference pays its H2D copies inside the call, graph_score.py:26-30): the copies of
+        # batch i + 1 under the forward of batch i (engine.HostFedPipeline).  Never `value`: reported beside it.
+        host_fed = None
+        if not args.no_host_fed:
+            try:
+                host_fed = host_fed_leg(eng, batch, args.steps, round(1e3 * elapsed / args.steps, 4), res)
+            except Exception as e:      # noqa: BLE001
+                side_errors["host_fed"] = f"{type(e).__name__}: {e}"
         cpu = None
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(sd, args.net, args.cpu_budget)
@@ -558,6 +567,7 @@ def main():
             "plan": plan["updates"],
             "node_classes": {str(k): v for k, v in stats.items()},
             "instrumented_ms_per_step": round(1e3 * instrumented / args.steps, 4),
+            "host_fed_ms_per_step": host_fed,
             "dist": dist_record,
             "side_leg_errors": side_errors or None,
         }
@@ -606,6 +616,37 @@ def exact_fp32_leg(sd, d_args, res, steps):
     if not np.array_equal(fin, np.isfinite(a16)):
         raise RuntimeError("exact-fp32 leg: different set of scored nodes")
     return exact_ms, (float(np.abs(a32[fin] - a16[fin]).max()) if fin.any() else 0.0)
+
+
+def host_fed_leg(eng, batch, steps, device_resident_ms, res):
+    """ms per step with the batch arriving as host tensors every step, copies overlapped with the previous step's forward
+    (engine.HostFedPipeline: two device buffer sets, a copy stream): once from pinned host tensors, once from pageable ones."""
+    from gnn_branching_amd.engine import HostFedPipeline
+    args = list(batch.forward_args())
+    nbytes = 4 * sum(t.numel() for g in args if isinstance(g, list) for t in g) + 4 * (args[4].numel() + args[6].numel())
+    out = {"device_resident": device_resident_ms, "bytes_per_batch": int(nbytes)}
+    for kind in ("pinned", "pageable"):
+        a = [[t.float().contiguous() for t in g] if isinstance(g, list) else g for g in args]
+        a[4], a[6] = args[4].float().contiguous(), args[6].float().contiguous()
+        if kind == "pinned":
+            a = [[t.pin_memory() for t in g] if isinstance(g, list) else g for g in a]
+            a[4], a[6] = a[4].pin_memory(), a[6].pin_memory()
+        pipe = HostFedPipeline(eng)
+        for _ in range(4):
+            r = pipe.submit(*a)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = pipe.submit(*a)
+        torch.cuda.synchronize()
+        out[kind] = round(1e3 * (time.perf_counter() - t0) / steps, 4)
+        r.check()
+        if not torch.equal(r.scores, res.scores):
+            raise RuntimeError(f"host-fed ({kind}) scores differ from the device-resident forward")
+    out["pinned_over_device_resident"] = round(out["pinned"] / device_resident_ms, 3)
+    out["note"] = ("one step = submit(batch from host tensors): H2D of batch i+1 (2 MB pieces) on a copy stream under the forward of batch i; pageable "
+                   "inputs go through the runtime's staging")
+    return out
 
 
 def restricted_source_rows(batch, k):

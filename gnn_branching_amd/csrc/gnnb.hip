@@ -33,6 +33,8 @@
 #include <string>
 #include <vector>
 #include <chrono>
+#include <thread>
+#include <atomic>
 
 #include "../../include/gnnb.h"
 #include "gnnb_pack.h"
@@ -1468,7 +1470,28 @@ extern "C" int gnnb_forward_host(gnnb_t* h, const gnnb_batch* in, int B, float* 
     h->hs_out_B = B;
   }
   // ---- stage, one transfer, forward
-  for (const Slot& sl : slots) memcpy(h->hs_pinned + sl.off, sl.src, sl.n * sizeof(float));
+  // staging: one memcpy per input tensor; big batches (36.5 MB at base B = 256: 2.3 ms on one thread) are split over a few helper threads
+  if (total * sizeof(float) < (size_t)4 << 20) {
+    for (const Slot& sl : slots) memcpy(h->hs_pinned + sl.off, sl.src, sl.n * sizeof(float));
+  } else {
+    const int nthr = 8;
+    const size_t chunk = (size_t)1 << 18;                 // floats (1 MB) per work item
+    std::vector<std::pair<size_t, size_t>> items;         // (slot, first float)
+    for (size_t i = 0; i < slots.size(); ++i)
+      for (size_t o = 0; o < slots[i].n; o += chunk) items.emplace_back(i, o);
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+      for (size_t it = next.fetch_add(1); it < items.size(); it = next.fetch_add(1)) {
+        const Slot& sl = slots[items[it].first];
+        const size_t o = items[it].second, n = std::min(chunk, sl.n - o);
+        memcpy(h->hs_pinned + sl.off + o, sl.src + o, n * sizeof(float));
+      }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthr; ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+  }
   HIPCHK(hipMemcpyAsync(h->hs_dev, h->hs_pinned, total * sizeof(float), hipMemcpyHostToDevice, st));
   std::vector<const float*> lb(K + 1), ub(K + 1), dual(L), prim(in->n_primal);
   for (int k = 0; k <= K; ++k) { lb[k] = h->hs_dev + slots[i_lb[k]].off; ub[k] = h->hs_dev + slots[i_ub[k]].off; }

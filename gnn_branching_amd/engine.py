@@ -90,6 +90,75 @@ class ForwardResult:
         return [self.scores[b][self.masks[b] != 0] for b in range(self.scores.shape[0])]
 
 
+class HostFedPipeline:
+    """Cross-batch double buffering for batches that arrive as HOST tensors (the reference pays its host->device copies inside the
+    call, graph_score.py:26-30; SURVEY 8(d): "H2D reported separately").
+
+    ``submit(*forward_args)`` enqueues the copies of batch i + 1 on a COPY stream while the forward of batch i runs on the caller's
+    stream, and returns that batch's ForwardResult without synchronising: `depth` (2) sets of device input buffers, each guarded by
+    two events -- the copy stream waits for the forward that last read a set before overwriting it, the compute stream waits for the
+    set's copies before its forward.  Host tensors are copied straight from where they are, in pieces of 2 MB (see `submit`): from
+    pinned memory the copies are asynchronous DMA that hides under the running forward; from pageable memory the runtime stages them
+    (the host blocks per piece, the GPU still overlaps them with the previous forward).
+    Scores are bit-identical to ``engine.forward`` on device-resident inputs (tests/test_gpu_hostfed.py)."""
+
+    PIECE = int(os.environ.get("GNNB_H2D_PIECE_FLOATS", str(1 << 19)))            # floats per copy (2 MB)
+
+    def __init__(self, engine, depth=2):
+        self.eng, self.depth = engine, max(2, int(depth))
+        self.copy_stream = torch.cuda.Stream(device=engine.device)
+        self.slots = [None] * self.depth          # per slot: dict(key=shape signature, dev=[tensors], pin=[tensors or None], ev_copy, ev_done)
+        self.i = 0
+
+    @staticmethod
+    def _flat_inputs(lower_bounds_all, upper_bounds_all, dual_vars, primals, primal_inputs, masks):
+        ts = list(lower_bounds_all) + list(upper_bounds_all) + list(dual_vars) + list(primals) + [primal_inputs, masks]
+        out = []
+        for t in ts:
+            if not torch.is_tensor(t):
+                t = torch.tensor(t, dtype=torch.float32)
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                t = t.to(torch.float32).contiguous()
+            out.append(t)
+        return out
+
+    def submit(self, lower_bounds_all, upper_bounds_all, dual_vars, primals, primal_inputs, layers, masks):
+        eng = self.eng
+        host = self._flat_inputs(lower_bounds_all, upper_bounds_all, dual_vars, primals, primal_inputs, masks)
+        key = tuple((tuple(t.shape)) for t in host)
+        k = self.i % self.depth
+        self.i += 1
+        sl = self.slots[k]
+        with torch.cuda.device(eng.device):
+            cur = torch.cuda.current_stream()
+            if sl is None or sl["key"] != key:
+                if sl is not None:
+                    sl["ev_done"].synchronize()
+                sl = {"key": key, "dev": [torch.empty(t.shape, dtype=torch.float32, device=eng.device) for t in host],
+                      "ev_copy": torch.cuda.Event(), "ev_done": torch.cuda.Event(), "used": False}
+                self.slots[k] = sl
+            if sl["used"]:
+                sl["ev_copy"].synchronize()          # the staging blocks of this set are free again (its last copies have left the host)
+            self.copy_stream.wait_event(sl["ev_done"]) if sl["used"] else None      # the forward that last read this set has finished
+            with torch.cuda.stream(self.copy_stream):
+                for j, t in enumerate(host):
+                    # pieces of at most 2 MB: measured on MI355X / ROCm 7.2 (tools/hostfed_probe.py), 21 pinned copies of 1.7 MB on a side
+                    # stream hide completely under the forward (0.85 ms with or without them), ONE 36.5 MB copy beside the same forward
+                    # takes 3.1 ms.  Pageable tensors go through the runtime's own staging (synchronous for the host, still beside the
+                    # previous forward on the GPU); packing them into pinned memory here first cost 10 ms per batch.
+                    dv, sv = sl["dev"][j].view(-1), t.reshape(-1)
+                    for o in range(0, sv.numel(), self.PIECE):
+                        dv[o:o + self.PIECE].copy_(sv[o:o + self.PIECE], non_blocking=True)
+                sl["ev_copy"].record(self.copy_stream)
+            cur.wait_event(sl["ev_copy"])
+            nb, nd, npr = len(lower_bounds_all), len(dual_vars), len(primals)
+            d = sl["dev"]
+            res = eng.forward(d[:nb], d[nb:2 * nb], d[2 * nb:2 * nb + nd], d[2 * nb + nd:2 * nb + nd + npr], d[-2], layers, d[-1])
+            sl["ev_done"].record(cur)
+            sl["used"] = True
+        return res
+
+
 class ScorerEngine:
     def __init__(self, state_dict, T=2, p=64, device=None):
         self.lib = _lib.load()
