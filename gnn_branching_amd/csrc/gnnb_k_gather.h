@@ -995,10 +995,10 @@ __device__ __forceinline__ void input_update_tile(const GIArgs& a, const TileCtx
                                                                            0, a.g.Ns * ROW3_BYTES, 0x00020000);
     gather_tile_sparse_bf3(H, gl.cm + tc.cg * a.g.K2 * 64, gl.t3 + (long)tc.cg * a.g.K2 * 64, gl.ko, tab, a.g.K2, rsrc3,
                            a.src_lb + (long)sample * a.g.Ns, a.src_ub + (long)sample * a.g.Ns, j, uy, ux, a.g.Hs, a.g.Ws, lane, true,
-                           own_s ? &ssum : nullptr);
+                           &ssum);
   } else if (SPARSE)
     gather_dispatch(H, gl.cm + tc.cg * a.g.K2 * 64, gl.ko, gl.kvo, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane, tab,
-                    a.src_lb + (long)sample * a.g.Ns, a.src_ub + (long)sample * a.g.Ns, true, own_s ? &ssum : nullptr);
+                    a.src_lb + (long)sample * a.g.Ns, a.src_ub + (long)sample * a.g.Ns, true, &ssum /* (always: a pointer chosen at run time would pin `ssum` to the stack; it is only used when own_s) */);
   else
     gather_dispatch(H, gl.cm + tc.cg * a.g.K2 * 64, gl.ko, gl.kvo, a.g, a.mu_src + (long)sample * a.g.Ns * 64, j, wy0, wx0, lane, nullptr,
                     nullptr, nullptr, true);

@@ -408,7 +408,7 @@ struct TailArgs { GSArgs g; FArgs f; ScoreArgs s; int sp; };      // sp: entries
 #define TAIL_PIPE true
 #endif
 #ifndef TAIL_INF_REGS
-#define TAIL_INF_REGS 64
+#define TAIL_INF_REGS 48      // (64: three registers spilled)
 #endif
 #define TAIL_FIXED_FLOATS (PackUpdL3::FLOATS + PackScore::FLOATS + 2 * TAIL_SEG * QROW + 16)
 // slot-list entries per node (window slots + padding to whole rounds of GS_INFLIGHT) and nodes per gather wave (4, or 2 when four lists

@@ -357,8 +357,9 @@ __global__ __launch_bounds__(CLS_THREADS) void k_classify_pre(ClassifyArgs ca, P
     copy_to_lds(lds + PackPreBwdL3::W43, a.pack_b + PackPreBwd::W43, 18432);
     copy_to_lds(lds + PackPreBwdL3::W53, a.pack_b + PackPreBwd::W53, 6144);
   }
-  int k = 0;
-  const int count = classify_block(ca, amb_local, &k);
+  int k_ = 0;
+  const int count = __builtin_amdgcn_readfirstlane(classify_block(ca, amb_local, &k_));      // (block-uniform: scalar registers, not a spilled vector pair)
+  const int k = __builtin_amdgcn_readfirstlane(k_);
   __syncthreads();                                   // the block's list and the images are in LDS
   const long nt = (count + 31) / 32;
   for (long t = wave; t < nt; t += PRE_WAVES) pre_tile<true>(a, lds, lds, k, false, amb_local, count, t, lane);
@@ -427,6 +428,7 @@ __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, i
   constexpr int O_WA = (int)PackUpd::WA, O_BA = BF3 ? (int)PackUpdL3::BA : (int)PackUpd::BA;
   constexpr int O_BCB = BF3 ? (int)PackUpdL3::BCB : (int)PackUpd::BCB, O_VAW = BF3 ? (int)PackUpdL3::VAW : (int)PackUpd::VAW;
   constexpr int O_END = BF3 ? (int)PackUpdL3::FLOATS : (int)PackUpd::FLOATS;
+  constexpr bool NU_PIPE = (GEMM_BF3_PIPE != 0) && !(DEFERRED && POST);      // (the pipelined blocks spill two registers in the DEFERRED + POST instantiation)
   const int h = lane >> 5, j = lane & 31;
   // the general tiles (1.5-3x the work of a short-chain tile) come FIRST in the tile order, so they are never a SIMD's tail
   const long n1 = (c1 + 31) / 32, n0 = (c0 + 31) / 32, ntiles = n0 + n1;
@@ -480,7 +482,7 @@ __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, i
         const float x[1] = {r0 * sw};
         gemm_small<1>(lds + O_VAW, lane, H, x);
       }
-      if (BF3) gemm_w64_bf3<1>(lds + PackUpdL3::WAS3, lane, H, [&](int s) { return FRAG_AT(X, s) * r0; });
+      if (BF3) gemm_w64_bf3<1, NU_PIPE>(lds + PackUpdL3::WAS3, lane, H, [&](int s) { return FRAG_AT(X, s) * r0; });
       else gemm_w64<32>(lds + PackUpd::WAS, lane, H, [&](int s) { return FRAG_AT(X, s) * r0; });
       frag_bias(H2, lds + O_BCB, h);
     } else {
@@ -493,8 +495,8 @@ __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, i
       }
       if (BF3) {                             // Wa.[r0 x, r1 x] = WAS.(r0 x) + Wa[:, 64:].((r1 - r0) x), both blocks bf16 x 3 (PackUpdL3)
         const float dr = r1 - r0;
-        gemm_w64_bf3<1>(lds + PackUpdL3::WAS3, lane, H, [&](int s) { return FRAG_AT(X, s) * r0; });
-        gemm_w64_bf3<1>(lds + PackUpdL3::WA1S3, lane, H, [&](int s) { return FRAG_AT(X, s) * dr; });
+        gemm_w64_bf3<1, NU_PIPE>(lds + PackUpdL3::WAS3, lane, H, [&](int s) { return FRAG_AT(X, s) * r0; });
+        gemm_w64_bf3<1, NU_PIPE>(lds + PackUpdL3::WA1S3, lane, H, [&](int s) { return FRAG_AT(X, s) * dr; });
       } else gemm_w64<64>(lds + O_WA, lane, H, [&](int s) { return FRAG_AT(X, s & 31) * (s < 32 ? r0 : r1); });
     }
     FT_MARK(1);                                // wait for this tile's rows + first GEMM
@@ -503,7 +505,7 @@ __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, i
     __builtin_amdgcn_sched_barrier(0);
     FT_MARK(2);                                // wait for the next tile's list entry / scalars + issue of its row loads
     frag_relu(H);
-    if (BF3) gemm_w64_bf3<1>(lds + PackUpdL3::WCB3, lane, H2, [&](int s) { return FRAG_AT(H, s); });
+    if (BF3) gemm_w64_bf3<1, NU_PIPE>(lds + PackUpdL3::WCB3, lane, H2, [&](int s) { return FRAG_AT(H, s); });
     else gemm_w64<32>(lds + PackUpd::WCB, lane, H2, [&](int s) { return FRAG_AT(H, s); });
     frag_relu(H2);
     FT_MARK(3);                                // second GEMM
@@ -517,7 +519,7 @@ __device__ __forceinline__ void node_update_loop(const UpdArgs& a, float* lds, i
     if (post) {
 #pragma unroll
       for (int R = 0; R < 32; ++R) FRAG_AT(H, R) = 0.0f;
-      if (BF3) gemm_w64_bf3<1>(lds + O_END, lane, H, [&](int s) { return FRAG_AT(H2, s); });
+      if (BF3) gemm_w64_bf3<1, NU_PIPE>(lds + O_END, lane, H, [&](int s) { return FRAG_AT(H2, s); });
       else gemm_w64<32>(lds + O_END, lane, H, [&](int s) { return FRAG_AT(H2, s); });
       if (valid) {
         if (a.post3) frag_store_rows3(H, a.post3, gc, h);

@@ -371,14 +371,16 @@ __global__ __launch_bounds__(256) void k_tlin_bwd_w_all(const TLin* ops, const i
   __shared__ __attribute__((aligned(16))) float Xs[TL_CHUNK * 64];
   __shared__ int Rs[TL_CHUNK];
   __shared__ int s_op;
+  __shared__ TLin s_a;            // the op's descriptor in LDS: as a private copy its run-time indexed segment table lived in scratch (248 B per lane)
   const int tid = threadIdx.x;
   if (tid == 0) {
     int o = 0;
     while (o + 1 < nops && first[o + 1] <= (int)blockIdx.x) ++o;
     s_op = o;
+    s_a = ops[o];
   }
   __syncthreads();
-  const TLin a = ops[s_op];
+  const TLin& a = s_a;
   const int chunk = (int)blockIdx.x - first[s_op];
   const long n = tl_rows(a), row0 = (long)chunk * TL_CHUNK;
   const int j = blockIdx.y;

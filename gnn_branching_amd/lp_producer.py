@@ -355,13 +355,17 @@ class LayerGraphLP:
         return Subproblem(float(res.fun), float(act.reshape(-1)[0]), x0[None], lower_all, upper_all, duals, primals, mask, (lbs, ubs))
 
 
-def branch_and_bound(lp, scorer, layers, eps=1e-4, max_nodes=200, decision_bound=None, log=print):
+def branch_and_bound(lp, scorer, layers, eps=1e-4, max_nodes=200, decision_bound=None, log=print, dump=None):
     """The BaB loop of plnn/relu_conv_gnnkwthreshold.py:120-262 in its plain form: pick the domain with the lowest bound,
     split the ReLU the scorer names, bound both children, keep those that can still improve the answer.
 
     ``scorer(sub, layers_dict) -> [layer, idx]`` (gnn_scorer / babsr_scorer below).  ``decision_bound``: stop as soon as the
     sign of (minimum - decision_bound) is known (the reference verifies with decision_bound = 0, :257-262); None: minimise
-    to ``eps``.  Returns (global_lb, global_ub, visited LP solves)."""
+    to ``eps``.  ``dump``: a callable that receives the run's trace in the format the reference writes to
+    ``./gnn_dump_files/<trace_name>`` (relu_conv_gnnkwthreshold.py:75-79): per branch the line of :201-202 (``kw: improvement -1
+    decision None``: this plain loop never bounds the KW fall-back's children) and the global lower bound of :256-257 -- the file a
+    Gurobi owner can diff against a ``--bab_gnn`` run's dump.  Returns (global_lb, global_ub, visited LP solves)."""
+    from .bab_caller import gnn_improvement, trace_line
     fixed = {"fixed_layers": list(layers[:-1]), "prop_layers": [layers[-1]]}
     root_mask = [torch.full((int(np.prod(lp.shapes[i + 1])),), -1, dtype=torch.long) for i in lp.pre_relu_indices]
     root = lp.solve(root_mask)
@@ -396,6 +400,11 @@ def branch_and_bound(lp, scorer, layers, eps=1e-4, max_nodes=200, decision_bound
             else:
                 closed_lb = min(closed_lb, c.lb)
         global_lb = min([d.lb for d in domains] + [closed_lb, global_ub])
+        if dump is not None:
+            lbs = [c.lb for c in children] + [float("inf")] * (2 - len(children))      # an infeasible child cannot contain a counter-example
+            imp = gnn_improvement(lbs[0], lbs[1], dom.lb) if dom.lb < 0 else 0.0
+            dump(trace_line(visited, decision, imp, decision))
+            dump(f"{global_lb}\n")
     return global_lb, global_ub, visited
 
 

@@ -99,8 +99,8 @@ def run_trace(name, gt, cls, seed, eps, max_nodes):
         trace_a.append(dec)
         nodes_a.append((sub, scores[0].copy()))
         return dec
-    lines_a = []
-    res_a = lp_producer.branch_and_bound(lp, hip_scorer, layers, max_nodes=max_nodes, log=lines_a.append)
+    lines_a, dump_a = [], []
+    res_a = lp_producer.branch_and_bound(lp, hip_scorer, layers, max_nodes=max_nodes, log=lines_a.append, dump=dump_a.append)
 
     # ---- run B: the oracle as the scorer
     trace_b, gaps_b = [], []
@@ -127,12 +127,20 @@ def run_trace(name, gt, cls, seed, eps, max_nodes):
         d = torch.cat([t[:, 1:].reshape(-1) for t in sub.dual_vars])
         stats.append((int(m.sum()), sum(int((t == 0).sum()) + int((t == 1).sum()) for t in sub.mask), float(d.min()), float(d.max())))
     return dict(trace_a=trace_a, trace_b=trace_b, gaps_b=gaps_b, worst=worst, worst_node=worst_node, stats=stats, res_a=res_a, res_b=res_b,
-                lines_a=lines_a, lines_b=lines_b, lp=lp)
+                lines_a=lines_a, lines_b=lines_b, lp=lp, dump_a=dump_a)
 
 
-@pytest.mark.parametrize("name,gt,cls,seed,eps", [("cifar_base_kw", 3, 5, 4, 0.02), ("cifar_deep_kw", 3, 5, 4, 0.02)])
-def test_decision_trace_on_lp_inputs(name, gt, cls, seed, eps):
-    r = run_trace(name, gt, cls, seed, eps, max_nodes=2 * MIN_NODES + 4)
+# (network, property gt vs cls, input seed, eps, branching decisions asked for): round 4 adds cifar_wide_kw (fewer nodes: its LPs are 4x
+# base's) and a second property / input on base
+@pytest.mark.parametrize("name,gt,cls,seed,eps,min_nodes", [("cifar_base_kw", 3, 5, 4, 0.02, MIN_NODES), ("cifar_deep_kw", 3, 5, 4, 0.02, MIN_NODES),
+                                                             ("cifar_base_kw", 7, 2, 11, 0.02, 24), ("cifar_wide_kw", 3, 5, 4, 0.02, 12)])
+def test_decision_trace_on_lp_inputs(name, gt, cls, seed, eps, min_nodes):
+    r = run_trace(name, gt, cls, seed, eps, max_nodes=2 * min_nodes + 4)
+    # the run's trace in the reference's dump format (relu_conv_gnnkwthreshold.py:75-79, :201-202, :256-257), for a Gurobi owner to diff
+    out_dir = os.path.join(os.path.dirname(__file__), "..", "gpurun_out", "bab_traces")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, f"{name}_gt{gt}_cls{cls}_seed{seed}_eps{eps}.trace"), "w") as f:
+        f.writelines(r["dump_a"])
     ta, tb = r["trace_a"], r["trace_b"]
     n = min(len(ta), len(tb))
     first_diff = next((i for i in range(n) if ta[i] != tb[i]), None)
@@ -143,7 +151,7 @@ def test_decision_trace_on_lp_inputs(name, gt, cls, seed, eps):
           f"LP solves {r['lp'].solves}, cache hits {r['lp'].hits}); undecided ReLUs per node {min(amb)}..{max(amb)}, decided (0/1) {min(decided)}..{max(decided)}; "
           f"duals in [{dmin:.4g}, {dmax:.4g}]; max |HIP score - oracle| over all nodes = {r['worst']:.3e} (node {r['worst_node']}); "
           f"smallest oracle top-2 gap {min(r['gaps_b']):.3e}; traces " + ("identical" if first_diff is None and len(ta) == len(tb) else f"differ at node {first_diff}"))
-    assert len(ta) >= MIN_NODES, f"the run ended after {len(ta)} decisions: pick a harder property"
+    assert len(ta) >= min_nodes, f"the run ended after {len(ta)} decisions: pick a harder property"
     assert dmin < 0 < dmax, "LP duals of both signs are the point of this test"
     assert max(decided) > min(decided), "masks must gain decided nodes along the run"
     assert r["worst"] <= 1e-4, (r["worst"], r["worst_node"])

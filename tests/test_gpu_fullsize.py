@@ -118,3 +118,32 @@ def test_top_kernel_at_size(monkeypatch, net, B, weights):
     for s in torch.nonzero(differ).flatten().tolist():        # a different argmax is only acceptable between scores closer than the bar
         row_a, row_b = a[s], b[s]
         assert abs(row_a[torch.isfinite(row_a)].max().item() - row_b[torch.isfinite(row_b)].max().item()) <= tol
+
+
+# The three-piece bf16 blocks against the exact-fp32 MFMA path AT BENCH SIZES (round 3 quoted these figures in DESIGN.md; round 4 asserts
+# them).  Both are fp32-grade evaluations that add in different orders; the bound is what two such evaluations differ by on the shipped
+# checkpoint: scores of magnitude 5..50 on base / wide (measured 1.7-1.9e-5), up to 70 on deep (measured 5.1e-5) -- always inside the
+# 1e-4 budget, with the same decisions wherever the exact path's top-2 gap exceeds the delta.
+@pytest.mark.parametrize("net,B,bound", [("cifar_base_kw", 256, 3e-5), ("cifar_wide_kw", 256, 3e-5), ("cifar_deep_kw", 128, 7e-5)])
+def test_bf16x3_delta_at_bench_size(monkeypatch, net, B, bound):
+    from gnn_branching_amd import synth
+    state = shipped_state()
+    batch = synth.make_batch(net, B, seed=1234)
+    out = {}
+    for bf3 in ("1", "0"):
+        monkeypatch.setenv("GNNB_BF3", bf3)
+        model = model_for(state)                     # a new engine: the knob is read by gnnb_create
+        with torch.no_grad():
+            res = model.forward_device(*batch.forward_args()).check()
+        out[bf3] = (res.scores.cpu().numpy(), res.decisions.cpu().numpy())
+    a, b = out["1"][0], out["0"][0]
+    fin = np.isfinite(b)
+    assert np.array_equal(fin, np.isfinite(a))
+    delta = float(np.abs(a[fin] - b[fin]).max())
+    top2 = np.sort(np.where(fin, b, -np.inf), axis=1)[:, -2:]
+    differ = np.nonzero((out["1"][1] != out["0"][1]).any(axis=1))[0]
+    print(f"{net} B={B}: max |bf16x3 - exact fp32| = {delta:.3e} (bound {bound:.0e}, max |score| {np.abs(b[fin]).max():.1f}); "
+          f"{len(differ)} of {B} decisions differ")
+    assert delta <= bound
+    for i in differ:                                 # a decision may only flip at a near tie of the exact path
+        assert top2[i, 1] - top2[i, 0] <= 2 * delta, (i, top2[i])
