@@ -33,13 +33,14 @@ def test_message_passing_bytes_follow_survey_8d():
 
 
 def test_committed_counter_summaries_cover_the_half_pass_kernels():
-    mp_names = ("k_gather", "k_gather_update", "k_gather_input_update", "k_top", "k_node_update")
+    # (round 4: the restricted last half-pass runs inside k_scored_tail on the default path: no stand-alone k_gather / k_node_update launch)
+    mp_names = ("k_gather", "k_gather_update", "k_gather_input_update", "k_top", "k_node_update", "k_scored_tail")
     for net, B in (("cifar_base_kw", 256), ("cifar_wide_kw", 256), ("cifar_deep_kw", 128)):
         path = os.path.join(ROOT, "profiles", f"pmc_latest_{net}_B{B}.json")
         assert os.path.exists(path), path
         pmc = json.load(open(path))
         for cls in mp_names:
             rows = bench.pmc_rows(pmc, cls)
-            if cls == "k_gather" and not rows:
-                continue                                             # a configuration may not launch a stand-alone gather at all
+            if cls in ("k_gather", "k_node_update") and not rows:
+                continue                                             # a configuration may not launch a stand-alone gather / node update at all
             assert rows and all(r["hbm_bytes_per_launch"] > 0 for r in rows), (net, cls)

@@ -1,10 +1,10 @@
 #!/bin/bash
-# dev helper (GPU box): the stand-alone edge-aggregation leg (GNNB_FUSE=0 GNNB_NO_EMBED_FUSE=1) of one configuration ->
+# dev helper (GPU box): the stand-alone edge-aggregation leg (GNNB_FUSE=0 GNNB_NO_EMBED_FUSE=1 GNNB_TAIL_MAX_B=0) of one configuration ->
 # gpurun_out/prof_<tag>/: bench JSON of that path, rocprofv3 kernel stats, FETCH / WRITE counter passes per kernel template
 #   tools/profile_aggonly.sh <tag> [bench.py args, e.g. --config 3]
 R=$GRAFT_REPO_ROOT; TAG=${1:-r04_aggonly}; shift
 O=$R/gpurun_out/prof_$TAG; mkdir -p $O
-export GNNB_FUSE=0 GNNB_NO_EMBED_FUSE=1
+export GNNB_FUSE=0 GNNB_NO_EMBED_FUSE=1 GNNB_TAIL_MAX_B=0
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline --no-exact-fp32 --no-aggregate-only "$@" > $O/bench.json 2> $O/stats.log || { echo "stats failed"; tail -5 $O/stats.log; exit 1; }
 cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv
