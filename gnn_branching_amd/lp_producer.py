@@ -84,6 +84,7 @@ class LayerGraphLP:
     """LP relaxation of ``layers`` (net.layers with the folded Linear(., 1) property layer last) over an input box."""
 
     def __init__(self, layers, input_lb, input_ub, bounds="kw", lp_method="highs-ipm"):
+        self.retry_stats = {"infeasible_first": 0, "flipped_to_feasible": 0}      # see solve(): the widened re-solve of an 'infeasible' IPM answer
         self.lp_method = lp_method
         if bounds not in ("kw", "interval"):
             raise ValueError(bounds)
@@ -322,10 +323,15 @@ class LayerGraphLP:
         # ends in a basic solution, so the marginals are vertex duals like the simplex's (and Gurobi's)
         res = linprog(c, method=self.lp_method, **args)
         if res.status == 2 and self.lp_method != "highs":
-            # "infeasible" from the clean-up simplex can still be rounding: once more with 1e-6 of slack on every free box
+            # "infeasible" from the clean-up simplex can still be rounding: once more with 1e-6 of slack on every free box (a relaxation: a
+            # child it turns feasible is kept and bounded, which is sound; one that stays infeasible is pruned).  `retry_stats` counts how
+            # often that happens and how often it flips the verdict (tests/test_gpu_bab_trace.py prints it per run)
+            self.retry_stats["infeasible_first"] += 1
             free = width > 0
             args["bounds"] = np.stack([np.where(free, lo_v - 1e-6, lo_v), np.where(free, up_v + 1e-6, up_v)], 1)
             res = linprog(c, method=self.lp_method, **args)
+            if res.status == 0:
+                self.retry_stats["flipped_to_feasible"] += 1
         if res.status not in (0, 2):         # HiGHS' presolve sometimes ends without a model status on an infeasible child
             res = linprog(c, method="highs", options={"presolve": False}, **args)
         if res.status == 2:

@@ -150,7 +150,7 @@ def test_decision_trace_on_lp_inputs(name, gt, cls, seed, eps, min_nodes):
     print(f"\n{name}: {len(ta)} branching decisions on LP inputs (HIP run: bounds {r['res_a'][0]:.5f} / {r['res_a'][1]:.5f}, {r['res_a'][2]} LPs; "
           f"LP solves {r['lp'].solves}, cache hits {r['lp'].hits}); undecided ReLUs per node {min(amb)}..{max(amb)}, decided (0/1) {min(decided)}..{max(decided)}; "
           f"duals in [{dmin:.4g}, {dmax:.4g}]; max |HIP score - oracle| over all nodes = {r['worst']:.3e} (node {r['worst_node']}); "
-          f"smallest oracle top-2 gap {min(r['gaps_b']):.3e}; traces " + ("identical" if first_diff is None and len(ta) == len(tb) else f"differ at node {first_diff}"))
+          f"smallest oracle top-2 gap {min(r['gaps_b']):.3e}; LP 'infeasible' answers re-solved with slack: {r['lp'].retry_stats}; traces " + ("identical" if first_diff is None and len(ta) == len(tb) else f"differ at node {first_diff}"))
     assert len(ta) >= min_nodes, f"the run ended after {len(ta)} decisions: pick a harder property"
     assert dmin < 0 < dmax, "LP duals of both signs are the point of this test"
     assert max(decided) > min(decided), "masks must gain decided nodes along the run"
