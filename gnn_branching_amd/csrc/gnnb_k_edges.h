@@ -601,6 +601,11 @@ __device__ __forceinline__ void dense_fwd_sample_bf3(const DenseLArgs& a, int b,
 // memory), epi(arow, in_range, X, s, what node() returned) when its MFMAs are done; mid() runs once behind the barrier that ends the
 // image build (Cr is dead from there on).  `store` is unused.
 struct NoHook { __device__ void operator()() const {} };
+// k_top keeps the rows of layer L in LDS as C[row][64]: a row is 64 banks, and the update phases put node 4 j + t on lane j, so the 16
+// lanes of a ds_read_b128 group all hit the same four banks (F2 + B1: 1.1 M conflict cycles per launch, profiles/r04_k_top_lds_conflicts_by_phase.txt).
+// The column index of row n is therefore XOR-ed with 4 ((n >> 2) & 15): 16-byte pieces stay whole, the 16 lanes of a group spread over
+// all 64 banks.  Every access to C goes through csw().
+__device__ __forceinline__ int csw(int row) { return ((row >> 2) & 15) << 2; }
 template <bool FUSE = false, class Store, class Mid = NoHook, class Node = NoHook, class Epi = NoHook>
 __device__ __forceinline__ void dense_bwd_sample_bf3(const DenseLArgs& a, const float* Cr, float* img, Store store, const top_idx_t* rlist,
                                                      int n_rows, float* sout, const float* Wk, int ldK, const float* livek,
@@ -634,11 +639,12 @@ __device__ __forceinline__ void dense_bwd_sample_bf3(const DenseLArgs& a, const 
     const int k0 = st * 16 + kg * 8 + 2 * q;
     float2 v0, v1;                                   // .x / .y: channel tile 0 / 1 of column n (plain: channels 2 n, 2 n + 1; FUSE: n, 32 + n)
     if (FUSE) {
-      v0 = make_float2(Cr[k0 * 64 + n], Cr[k0 * 64 + 32 + n]);
-      v1 = make_float2(Cr[(k0 + 1) * 64 + n], Cr[(k0 + 1) * 64 + 32 + n]);
+      const int s0 = csw(k0), s1 = csw(k0 + 1);
+      v0 = make_float2(Cr[k0 * 64 + (n ^ s0)], Cr[k0 * 64 + ((32 + n) ^ s0)]);
+      v1 = make_float2(Cr[(k0 + 1) * 64 + (n ^ s1)], Cr[(k0 + 1) * 64 + ((32 + n) ^ s1)]);
     } else {
-      v0 = *reinterpret_cast<const float2*>(Cr + k0 * 64 + 2 * n);
-      v1 = *reinterpret_cast<const float2*>(Cr + (k0 + 1) * 64 + 2 * n);
+      v0 = *reinterpret_cast<const float2*>(Cr + k0 * 64 + ((2 * n) ^ csw(k0)));
+      v1 = *reinterpret_cast<const float2*>(Cr + (k0 + 1) * 64 + ((2 * n) ^ csw(k0 + 1)));
     }
     const Split3 sx = split3(v0.x, v1.x), sy = split3(v0.y, v1.y);
     const unsigned u[2][3] = {{sx.u1, sx.u2, sx.u3}, {sy.u1, sy.u2, sy.u3}};
@@ -930,10 +936,10 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, const 
 #if defined(TOP_ABL) && (TOP_ABL & 2)     // dev, timing only: no F1
   if (K_eff < 0)
 #endif
-  dense_fwd_sample_bf3<TS>(a.df, b, A, part_, [&](int row, int ch, float v) { Cr[row * 64 + ch] = v; }, compact ? klist : nullptr, K_eff,
+  dense_fwd_sample_bf3<TS>(a.df, b, A, part_, [&](int row, int ch, float v) { Cr[row * 64 + (ch ^ csw(row))] = v; }, compact ? klist : nullptr, K_eff,
                            own_s ? xs : nullptr, t0);
 #if defined(TOP_STOP) && TOP_STOP == 2
-  if (a.N > 0) { if (Cr[tid] == 12345.0f) a.mu_prop[0] = 1.0f; return; }
+  if (a.N > 0) { if (Cr[tid] == 12345.0f) a.mu_prop[0] = 1.0f; return; }      // (dev stop: any read of C keeps F1 alive)
 #endif
   FT_MARK(1);        // F1 dense forward edge
 
@@ -946,23 +952,23 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, const 
   const float s_own = (own_s && valid) ? xs[n] : 0.0f;      // (xs is rewritten in F3, behind a barrier)
   Ratio r{};
   if (upd_wave) r = compute_ratio(a.lb[g], a.ub[g]);
-  auto load_row = [&](Frag& x_, int row) {       // fragment <- LDS row (row-major 64 floats)
-    const f32x4* p = reinterpret_cast<const f32x4*>(Cr + row * 64 + 4 * h);
+  auto load_row = [&](Frag& x_, int row) {       // fragment <- row of C in LDS (columns swizzled: csw)
+    const float* p = Cr + row * 64;
+    const int sw = csw(row);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const f32x4 v = p[2 * q];
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p + ((8 * q + 4 * h) ^ sw));
 #pragma unroll
       for (int c = 0; c < 4; ++c) FRAG_AT(x_, 4 * q + c) = v[c];
     }
   };
-  auto store_row = [&](const Frag& x_, float* base) {
-    f32x4* p = reinterpret_cast<f32x4*>(base + 4 * h);
+  auto store_row = [&](const Frag& x_, float* base, int sw = 0) {      // sw: csw(row) for a row of C, 0 for a row in memory
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       f32x4 v;
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[c] = FRAG_AT(x_, 4 * q + c);
-      p[2 * q] = v;
+      *reinterpret_cast<f32x4*>(base + ((8 * q + 4 * h) ^ sw)) = v;
     }
   };
   // general folded node chain on fragment X, the arithmetic of k_node_update / k_gather_update_q (bf16 x 3 blocks, LDS image
@@ -1058,7 +1064,7 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, const 
     chain(X, r.amb != 0.0f ? a.Pf + g * 64 : a.pack_f + PackUpd::BCBROW, true, (h ? r.r1 : r.r0) * (a.sf ? a.sf[g] : s_own), E);
     if (valid) {
       if (frag_has_nan(E)) atomicOr(a.status, 1);
-      store_row(E, Cr + n * 64);
+      store_row(E, Cr + n * 64, csw(n));
     }
   }
   __syncthreads();
@@ -1075,7 +1081,7 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, const 
     const bool mine = (wave & 3) >= t0 && (wave & 3) < t0 + TS;
     if (mine) {
       float acc = 0.0f;
-      for (int m = wave; m < N; m += 8) acc = fmaf(pw[m], Cr[m * 64 + lane], acc);
+      for (int m = wave; m < N; m += 8) acc = fmaf(pw[m], Cr[m * 64 + (lane ^ csw(m))], acc);
       if (S == 1) part_[wave * 64 + lane] = acc;
       else __hip_atomic_store(a.xbuf + ((long)b * 8 + wave) * 64 + lane, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1158,7 +1164,7 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, const 
     chain(X, r.amb != 0.0f ? a.Pb + g * 64 : a.pack_b + PackUpd::BCBROW, false, 0.0f, E);
     if (valid) {
       if (frag_has_nan(E)) atomicOr(a.status, 1);
-      store_row(E, Cr + n * 64);
+      store_row(E, Cr + n * 64, csw(n));
       if (S == 1) store_row(E, a.mu + g * 64);
       else {                                           // the other workgroups of the sample read these rows: write-through stores
         float* base = a.mu + g * 64 + 4 * h;
@@ -1180,7 +1186,7 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, const 
     if (!await(a.xbase + 2 * S)) return;
     for (int e = tid; e < N * 32; e += 512) {          // the rows the other workgroups own -> C (8 bytes per load)
       const int t = (e >> 5) & 3;
-      if (t < t0 || t >= t0 + TS) reinterpret_cast<float2*>(Cr)[e] = ld_sc1(a.mu + (long)b * N * 64 + 2 * e);
+      if (t < t0 || t >= t0 + TS) *reinterpret_cast<float2*>(Cr + (e >> 5) * 64 + ((2 * (e & 31)) ^ csw(e >> 5))) = ld_sc1(a.mu + (long)b * N * 64 + 2 * e);
     }
   }
   __syncthreads();

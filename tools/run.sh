@@ -42,5 +42,33 @@ d=json.loads(sys.stdin.readline()); k=d['kernels']
 print('$L', d['ms_per_step'], {n: v['avg_us'] for n, v in k.items()})" || exit 1
     done; done
     ;;
+  top_phases)
+    # LDS bank conflicts of k_top by phase: libraries tools/ablate/r4top{1,2,6,7,8}.so (tools/mklib.sh WORK r4topN -DTOP_STOP=N: k_top leaves
+    # before F1 / after F1 / after F2 / after F3 / after B1) and the shipped one; counters of the k_top dispatches under each
+    O=$R/gpurun_out/top_phases; mkdir -p $O; cd /tmp && export TMPDIR=/tmp
+    for L in r4top1 r4top2 r4top6 r4top7 r4top8 full; do
+      [ $L = full ] && unset GNNB_LIB || export GNNB_LIB=$R/tools/ablate/$L.so
+      timeout -k 10 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/$L -- python3 $R/tools/top_phases.py "$@" > $O/$L.log 2>&1 || { echo "$L failed"; tail -3 $O/$L.log; exit 1; }
+    done
+    python3 - <<PY
+import csv, glob, collections
+prev = None
+print("%-8s %10s %14s %14s %12s %12s" % ("stop", "k_top us", "bank_conflict", "active_lds", "insts_lds", "insts_valu"))
+for L, name in (("r4top1", "lists"), ("r4top2", "+F1"), ("r4top6", "+F2"), ("r4top7", "+F3"), ("r4top8", "+B1"), ("full", "+B2+upd")):
+    vals = collections.defaultdict(list)
+    for f in glob.glob("$O/%s/*/*_counter_collection.csv" % L):
+        for r in csv.DictReader(open(f)):
+            if r["Kernel_Name"].startswith(("void k_top", "k_top")): vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    dur = []
+    for f in glob.glob("$O/%s/*/*_kernel_trace.csv" % L):
+        for r in csv.DictReader(open(f)):
+            if r["Kernel_Name"].startswith(("void k_top", "k_top")): dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    m = {k: sum(v) / len(v) for k, v in vals.items()}
+    row = (sum(dur[2:]) / max(1, len(dur[2:])), m.get("SQ_LDS_BANK_CONFLICT", 0), m.get("SQ_ACTIVE_INST_LDS", 0), m.get("SQ_INSTS_LDS", 0), m.get("SQ_INSTS_VALU", 0))
+    d = tuple(a - b for a, b in zip(row, prev)) if prev else row
+    print("%-8s %10.1f %14.0f %14.0f %12.0f %12.0f   (this phase: %.1f us, %.0f conflict cycles, %.0f LDS instructions)" % ((name,) + row + (d[0], d[1], d[3])))
+    prev = row
+PY
+    ;;
   *) echo "unknown recipe $recipe"; exit 2;;
 esac
