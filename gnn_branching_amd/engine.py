@@ -103,6 +103,7 @@ class HostFedPipeline:
     Scores are bit-identical to ``engine.forward`` on device-resident inputs (tests/test_gpu_hostfed.py)."""
 
     PIECE = int(os.environ.get("GNNB_H2D_PIECE_FLOATS", str(1 << 19)))            # floats per copy (2 MB)
+    SMALL = 1 << 20            # bytes: tensors below it are staged together
 
     def __init__(self, engine, depth=2):
         self.eng, self.depth = engine, max(2, int(depth))
@@ -134,14 +135,38 @@ class HostFedPipeline:
             if sl is None or sl["key"] != key:
                 if sl is not None:
                     sl["ev_done"].synchronize()
-                sl = {"key": key, "dev": [torch.empty(t.shape, dtype=torch.float32, device=eng.device) for t in host],
+                # tensors below SMALL bytes share ONE pinned staging block and ONE device block (a copy of a few KB costs ~10 us of the copy
+                # queue's time each, tools/hostfed_probe.py: a batch has a dozen of them); the big ones get their own device tensors
+                small = [j for j, t in enumerate(host) if t.numel() * 4 < self.SMALL]
+                offs, tot = {}, 0
+                for j in small:
+                    offs[j] = tot
+                    tot += (host[j].numel() + 63) & ~63
+                dev_small = torch.empty(max(tot, 1), dtype=torch.float32, device=eng.device)
+                pin_small = torch.empty(max(tot, 1), dtype=torch.float32, pin_memory=True)
+                dev = [dev_small[offs[j]:offs[j] + t.numel()].view(t.shape) if j in offs else torch.empty(t.shape, dtype=torch.float32, device=eng.device)
+                       for j, t in enumerate(host)]
+                sl = {"key": key, "dev": dev, "offs": offs, "dev_small": dev_small, "pin_small": pin_small, "pin_np": pin_small.numpy(),
                       "ev_copy": torch.cuda.Event(), "ev_done": torch.cuda.Event(), "used": False}
                 self.slots[k] = sl
             if sl["used"]:
-                sl["ev_copy"].synchronize()          # the staging blocks of this set are free again (its last copies have left the host)
+                sl["ev_copy"].synchronize()          # the staging block of this set is free again (its last copies have left the host)
             self.copy_stream.wait_event(sl["ev_done"]) if sl["used"] else None      # the forward that last read this set has finished
+            offs, pin_np = sl["offs"], sl["pin_np"]
+            for j, o in offs.items():                # (host memcpy of the small tensors into the shared staging block: < 1 MB in all)
+                t = host[j]
+                if t.device.type == "cpu":
+                    pin_np[o:o + t.numel()] = t.reshape(-1).numpy()
             with torch.cuda.stream(self.copy_stream):
+                if offs:
+                    if any(host[j].device.type != "cpu" for j in offs):
+                        for j, o in offs.items():
+                            sl["dev"][j].copy_(host[j], non_blocking=True)
+                    else:
+                        sl["dev_small"].copy_(sl["pin_small"], non_blocking=True)
                 for j, t in enumerate(host):
+                    if j in offs:
+                        continue
                     # pieces of at most 2 MB: measured on MI355X / ROCm 7.2 (tools/hostfed_probe.py), 21 pinned copies of 1.7 MB on a side
                     # stream hide completely under the forward (0.85 ms with or without them), ONE 36.5 MB copy beside the same forward
                     # takes 3.1 ms.  Pageable tensors go through the runtime's own staging (synchronous for the host, still beside the

@@ -53,3 +53,32 @@ def both21():
             a.copy_(b, non_blocking=True)
     eng.forward(*d)
 print("21 copies (side) + fwd   %.3f ms" % timeit(both21))
+tiny = [torch.empty(256, dtype=torch.float32, pin_memory=True) for _ in range(8)]
+dtiny = [torch.empty(256, dtype=torch.float32, device=dev) for _ in range(8)]
+def both21_tiny():
+    with torch.cuda.stream(cs):
+        for a, b in zip(dchunks, chunks):
+            a.copy_(b, non_blocking=True)
+        for a, b in zip(dtiny, tiny):
+            a.copy_(b, non_blocking=True)
+    eng.forward(*d)
+print("21 copies + 8 tiny + fwd %.3f ms" % timeit(both21_tiny))
+mid = [torch.empty(25600, dtype=torch.float32, pin_memory=True) for _ in range(4)]
+dmid = [torch.empty(25600, dtype=torch.float32, device=dev) for _ in range(4)]
+def both21_mid():
+    with torch.cuda.stream(cs):
+        for a, b in zip(dchunks, chunks):
+            a.copy_(b, non_blocking=True)
+        for a, b in zip(dmid, mid):
+            a.copy_(b, non_blocking=True)
+    eng.forward(*d)
+print("21 copies + 4 x 100 KB + fwd %.3f ms" % timeit(both21_mid))
+ev = torch.cuda.Event()
+def both21_events():
+    with torch.cuda.stream(cs):
+        for a, b in zip(dchunks, chunks):
+            a.copy_(b, non_blocking=True)
+        ev.record(cs)
+    torch.cuda.current_stream().wait_event(ev)
+    eng.forward(*d)
+print("21 copies, forward waits for them (no overlap by construction) %.3f ms" % timeit(both21_events))
