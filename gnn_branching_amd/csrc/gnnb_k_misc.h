@@ -403,7 +403,8 @@ struct TailArgs { GSArgs g; FArgs f; ScoreArgs s; int sp; };      // sp: entries
 #ifndef TAIL_WAVES
 #define TAIL_WAVES 12          // 3 per SIMD: 168 registers (the chain's pipelined blocks and 64 registers of rows in flight per gather lane without spills)
 #endif
-#define TAIL_SEG 48           // scored nodes of layer 1 per workgroup and round at most: two chain tiles (32 + 16)
+#define TAIL_SEG 40           // scored nodes of layer 1 per workgroup and round at most: two chain tiles (32 + 8) and ONE group of four per gather wave
+                              // (10 gather waves; with 48 two waves gathered two groups in a row and every round took twice as long: wide 163 us)
 #ifndef TAIL_PIPE
 #define TAIL_PIPE true
 #endif
