@@ -102,7 +102,7 @@ class HostFedPipeline:
     (the host blocks per piece, the GPU still overlaps them with the previous forward).
     Scores are bit-identical to ``engine.forward`` on device-resident inputs (tests/test_gpu_hostfed.py)."""
 
-    PIECE = int(os.environ.get("GNNB_H2D_PIECE_FLOATS", str(1 << 19)))            # floats per copy (2 MB)
+    PIECE = 1 << 19            # floats per copy (2 MB)
     SMALL = 1 << 20            # bytes: tensors below it are staged together
 
     def __init__(self, engine, depth=2):
