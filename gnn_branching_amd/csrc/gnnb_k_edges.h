@@ -990,13 +990,7 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, const 
     frag_scale(H2, r.live);
   };
   // the bf16 x 3 image of a node-update pack -> W, by threads t0 .. t0 + nthr - 1 (no barrier)
-  auto stage_l3 = [&](const float* pack, int th0, int nthr) {
-    copy_to_lds_part(A + PackUpdL3::BA, pack + PackUpd::BA, 64, tid - th0, nthr);
-    copy_to_lds_part(A + PackUpdL3::BCB, pack + PackUpd::BCB, 64 + 64 + 128, tid - th0, nthr);        // BCB, BCBROW, VAW
-    copy_to_lds_part(A + PackUpdL3::WAS3, pack + PackUpd::WAS3, 6144, tid - th0, nthr);
-    copy_to_lds_part(A + PackUpdL3::WCB3, pack + PackUpd::WCB3, 6144, tid - th0, nthr);
-    copy_to_lds_part(A + PackUpdL3::WA1S3, pack + PackUpd::WA1S3, 6144, tid - th0, nthr);
-  };
+  auto stage_l3 = [&](const float* pack, int th0, int nthr) { stage_updl3(A, pack, nullptr, tid - th0, nthr); };
   // Hand-off between the S workgroups of this sample WITHOUT cache maintenance (MI355X_MICROARCH.md "Valid forms", first row of
   // its table): every handed-off byte is stored write-through (`sc1`: relaxed agent-scope atomic stores) and loaded `sc1`; every
   // storing wave drains its stores (vmcnt(0)), the workgroup meets at a barrier, ONE lane adds to the sample's counter; the

@@ -29,6 +29,39 @@
 // the fused and the two-kernel half-pass are bit-identical and which one runs is a pure scheduling decision.
 #pragma once
 
+// The bf16 x 3 image of a node-update pack (PackUpd -> PackUpdL3: BA | BCB, BCBROW, VAW | WAS3, WCB3, WA1S3, contiguous in both; plus the
+// POST block `wp` behind it) into LDS by threads ct of cn, EVERY load requested before the first LDS write: one memory round trip for the
+// 75-98 KB instead of one per piece (five or six copy_to_lds_part calls in a row cost a chain wave 17.7 k cycles = 9 us at the start
+// of k_gather_update_q, tools/fusedq_timing.py).  Batches of UPDL3_BATCH 16-byte pieces per lane (512 threads: one batch).
+#define UPDL3_BATCH 13
+__device__ __forceinline__ void stage_updl3(float* lds, const float* pack, const float* wp, int ct, int cn) {
+  constexpr int NSMALL = 16 + 64, NBIG = 3 * 6144 / 4;
+  const int n4 = NSMALL + NBIG + (wp ? 6144 / 4 : 0);
+  for (int i0 = ct; i0 < n4; i0 += UPDL3_BATCH * cn) {
+    f32x4 v[UPDL3_BATCH];
+#pragma unroll
+    for (int u = 0; u < UPDL3_BATCH; ++u) {
+      const int i = i0 + u * cn;
+      const float* src = pack + PackUpd::BA + 4 * i;                                              // i < 16
+      if (i >= 16) src = pack + PackUpd::BCB + 4 * (i - 16);
+      if (i >= NSMALL) src = pack + PackUpd::WAS3 + 4 * (i - NSMALL);
+      if (i >= NSMALL + NBIG) src = wp + 4 * (i - NSMALL - NBIG);
+      v[u] = *reinterpret_cast<const f32x4*>(i < n4 ? src : pack);
+    }
+#pragma unroll
+    for (int u = 0; u < UPDL3_BATCH; ++u) {
+      const int i = i0 + u * cn;
+      float* dst = lds + PackUpdL3::BA + 4 * i;
+      if (i >= 16) dst = lds + PackUpdL3::BCB + 4 * (i - 16);
+      if (i >= NSMALL) dst = lds + PackUpdL3::WAS3 + 4 * (i - NSMALL);
+      if (i >= NSMALL + NBIG) dst = lds + PackUpdL3::FLOATS + 4 * (i - NSMALL - NBIG);
+      if (i < n4) *reinterpret_cast<f32x4*>(dst) = v[u];
+    }
+  }
+}
+static_assert(PackUpdL3::BCB == PackUpdL3::BA + 64 && PackUpdL3::WAS3 == PackUpdL3::BCB + 256 && PackUpdL3::FLOATS == PackUpdL3::WAS3 + 3 * 6144,
+              "stage_updl3: layout of the LDS image");
+
 struct FArgs {
   GArgs g;             // the gather (k_gather / k_gather16 arguments; g.nb is unused; g.sout != null: the sparse walk computes the bias sums)
   UpdArgs u;           // the node update (k_node_update arguments; list0 / list1 / cnt0 / cnt1, nb are unused)
@@ -121,12 +154,28 @@ __device__ __forceinline__ void q_chain(const FArgs& a, const float* lds, const 
   upd_chain_frag<POST, PIPE>(a.u, lds, X, gc, r0, r1, amb, sw, valid, lane, keep);
 }
 
+#if defined(FUSED_TIMING) && FUSED_TIMING == 6      // dev: per-phase cycle sums of ONE k_gather_update_q template (Q_TIME_LANES / _SRC / _POST); slots 0-4 gather waves, 5-9 chain waves
+#ifndef Q_TIME_LANES
+#define Q_TIME_LANES 32
+#define Q_TIME_SRC 1
+#define Q_TIME_POST true
+#endif
+#define QT_ON (LANES == Q_TIME_LANES && SRC == Q_TIME_SRC && POST == Q_TIME_POST)
+#define QT_DECL unsigned long long qt_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long qt_last = __builtin_readcyclecounter()
+#define QT_MARK(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); qt_[i] += n_ - qt_last; qt_last = n_; } while (0)
+#define QT_FLUSH() do { if (QT_ON && (threadIdx.x & 63) == 0 && (blockIdx.x & 31) == 5) {      /* (a sample of the workgroups: 40 k atomics on ten words cost 0.7 ms) */ for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&g_fused_t[i_], qt_[i_]); atomicAdd(&g_fused_t[chain_role ? 14 : 15], 1ull); } } while (0)
+#else
+#define QT_DECL
+#define QT_MARK(i)
+#define QT_FLUSH()
+#endif
 // LANES: dst nodes per gather tile (16: forward edges, 32: transposed edges).  SRC: 0 dense source rows, 1 sparse walk (the source
 // is a ReLU layer), 2 round-0 embedding computed in the gather (16-node tiles only).  POST: see UpdArgs.
 template <int LANES, int SRC, bool POST>
 __global__ __launch_bounds__((QG_WAVES + QC_WAVES) * 64, 4) void k_gather_update_q(FArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr bool SPARSE = SRC == 1, EMBED = SRC == 2;
+  QT_DECL;
   float* qbase = lds + PackUpdL3::FLOATS + (POST ? 6144 : 0);
   const int NQ = a.qtiles;
   QHdr* q = reinterpret_cast<QHdr*>(qbase + (size_t)NQ * 32 * QROW);
@@ -149,18 +198,14 @@ __global__ __launch_bounds__((QG_WAVES + QC_WAVES) * 64, 4) void k_gather_update
   const bool chain_role = wave >= QG_WAVES;
 #endif
 
+  QT_MARK(chain_role ? 5 : 0);                      // gather tables staged, queue header zeroed (both roles)
   if (chain_role) {
     // ---------------- chain wave ----------------
     // The node-update weights (74 KB + 24 KB of POST) are staged by the chain waves alone while the gather waves, which only need the
     // gather's tables, already walk their first tiles; `staged` counts the chain waves whose part is in LDS.
     {
       const int ct = (wave - QG_WAVES) * 64 + lane, cn = QC_WAVES * 64;
-      copy_to_lds_part(lds + PackUpdL3::BA, a.u.pack + PackUpd::BA, 64, ct, cn);
-      copy_to_lds_part(lds + PackUpdL3::BCB, a.u.pack + PackUpd::BCB, 64 + 64 + 128, ct, cn);          // BCB, BCBROW, VAW
-      copy_to_lds_part(lds + PackUpdL3::WAS3, a.u.pack + PackUpd::WAS3, 6144, ct, cn);
-      copy_to_lds_part(lds + PackUpdL3::WCB3, a.u.pack + PackUpd::WCB3, 6144, ct, cn);
-      copy_to_lds_part(lds + PackUpdL3::WA1S3, a.u.pack + PackUpd::WA1S3, 6144, ct, cn);
-      if (POST) copy_to_lds_part(lds + PackUpdL3::FLOATS, a.u.wp, 6144, ct, cn);
+      stage_updl3(lds, a.u.pack, POST ? a.u.wp : nullptr, ct, cn);
       __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): this wave's part is in LDS before it is counted
       if (lane == 0) __hip_atomic_fetch_add(&q->staged, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       bool ok = false;
@@ -170,6 +215,7 @@ __global__ __launch_bounds__((QG_WAVES + QC_WAVES) * 64, 4) void k_gather_update
       }
       if (!ok) { if (lane == 0) atomicOr(a.u.status, 2); return; }
     }
+    QT_MARK(6);                                     // node-update weights staged (all chain waves)
     // claims the next tile, copies it out of its ring slot, releases the slot, runs the chain
     for (;;) {
       int T = 0;
@@ -188,7 +234,8 @@ __global__ __launch_bounds__((QG_WAVES + QC_WAVES) * 64, 4) void k_gather_update
         __builtin_amdgcn_s_sleep(8);
       }
       if (nvalid < 0) { if (lane == 0) atomicOr(a.u.status, 2); return; }
-      if (nvalid == 0) return;
+      QT_MARK(7);                                   // waiting for a tile of rows
+      if (nvalid == 0) { QT_FLUSH(); return; }
       q_chain<POST>(a, lds, ring, nvalid, lane, [&]() {
         // (called once the rows are in registers) hand the slot back before the chain runs: the ring only has to cover the
         // time a tile takes to fill and to be copied out, not the ~10 us of its chain
@@ -197,7 +244,8 @@ __global__ __launch_bounds__((QG_WAVES + QC_WAVES) * 64, 4) void k_gather_update
           __hip_atomic_store(&q->free_id[s], T + NQ, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       });
-      if (nvalid < 32) return;                       // the last, partly filled tile
+      QT_MARK(8);                                   // rows -> registers, chain, row stores
+      if (nvalid < 32) { QT_FLUSH(); return; }      // the last, partly filled tile
     }
   }
 
@@ -243,6 +291,7 @@ __global__ __launch_bounds__((QG_WAVES + QC_WAVES) * 64, 4) void k_gather_update
     const float lb = nx.lb, ub = nx.ub;
     fetch(r + nwg);
     const bool need = tc.valid && node_is_live(lb, ub);
+    QT_MARK(1);                                     // tile decode, its bounds (requested one tile ahead)
     if (!__any(need)) continue;
     const Ratio rt = compute_ratio(lb, ub);
     float ssum = 0.0f;
@@ -251,6 +300,7 @@ __global__ __launch_bounds__((QG_WAVES + QC_WAVES) * 64, 4) void k_gather_update
     if (LANES == 32) gather_compute_tile<false, SPARSE>(a.g, tc, sample, gl.cm, gl.ko, gl.kvo, tab, el, lane, X, ssum);
     else gather_compute_tile16<EMBED, SPARSE>(a.g, tc, sample, gl.cm, gl.ko, gl.kvo, tab, ew, eb, lane, acc, ssum);
 
+    QT_MARK(2);                                     // table build + walk
     // ---- the live nodes of the tile -> consecutive rows of the ring ----
     const unsigned long long bal = __ballot(need) & (LANES == 16 ? 0xffffull : 0xffffffffull);
     const int n = __popcll(bal);
@@ -267,6 +317,7 @@ __global__ __launch_bounds__((QG_WAVES + QC_WAVES) * 64, 4) void k_gather_update
         __builtin_amdgcn_s_sleep(4);
       }
       if (!ok) { if (lane == 0) atomicOr(a.u.status, 2); stuck = true; break; }
+      QT_MARK(3);                                   // waiting for the ring slot
       const bool mine = need && (pos >> 5) == T;
       if (mine) {
         float* row = qbase + ((size_t)s * 32 + (pos & 31)) * QROW;
@@ -289,9 +340,11 @@ __global__ __launch_bounds__((QG_WAVES + QC_WAVES) * 64, 4) void k_gather_update
       const int lo = T * 32 > base ? T * 32 : base, hi = (T + 1) * 32 < base + n ? (T + 1) * 32 : base + n;
       __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the rows are in LDS before their count is
       if (lane == 0) __hip_atomic_fetch_add(&q->filled[s], hi - lo, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      QT_MARK(4);                                   // rows -> ring
     }
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);
   if (lane == 0) __hip_atomic_fetch_add(&q->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  QT_FLUSH();
 }
 

@@ -611,9 +611,7 @@ __global__ __launch_bounds__(TAIL_WAVES * 64, 1) void k_scored_tail(TailArgs a) 
     if (wave < nchain || wave >= nchain + nbusy) {
       const int si = wave < nchain ? wave : wave - nbusy;
       const int ct = si * 64 + lane, cn = nst * 64;
-      copy_to_lds_part(lds + PackUpdL3::BA, a.f.u.pack + PackUpd::BA, 64, ct, cn);
-      copy_to_lds_part(lds + PackUpdL3::BCB, a.f.u.pack + PackUpd::BCB, 64 + 64 + 128, ct, cn);
-      copy_to_lds_part(lds + PackUpdL3::WAS3, a.f.u.pack + PackUpd::WAS3, 3 * 6144, ct, cn);
+      stage_updl3(lds, a.f.u.pack, nullptr, ct, cn);
       copy_to_lds_part(lds_sc, a.s.pack, PackScore::FLOATS, ct, cn);
     }
   }
