@@ -521,7 +521,8 @@ def main():
         side_errors = {}
         # ---- the same batch arriving as HOST tensors (the reference pays its H2D copies inside the call, graph_score.py:26-30): the copies of
         # batch i + 1 under the forward of batch i (engine.HostFedPipeline).  Never `value`: reported beside it.
-        # First of the side legs: measured behind the two legs below (second and third handles, their workspaces) the same copies took 1.26 ms instead of 0.95.
+        # First of the side legs: a pipeline built right after other handles and their workspaces were released runs its first ~100 steps at 1.3-2.3 ms
+        # (tools/hostfed_repeat.py: the first pipeline after gc.collect() + empty_cache() 1.69 ms, the next one 0.92 again) -- allocation churn, not the copies.
         host_fed = None
         if not args.no_host_fed:
             try:
