@@ -610,6 +610,12 @@ static size_t sparse_tab_bytes(const DevGather& d) {
   return 8 + (size_t)WAVES_MLP * ((d.g.lanes == 16 ? 4 : 2) * d.g.K2 + 32) * 8;
 }
 
+#if defined(FUSED_TIMING) && FUSED_TIMING == 6
+// dev: start / end (100 MHz chip-wide clock) of every wave of the instrumented k_gather_update_q launch: 2 x 16 x gridDim words
+extern "C" int gnnb_debug_wall(unsigned long long* out, int nwords) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qt_wall), (size_t)nwords * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef FUSED_TIMING
 // dev: cycle sums of k_gather_update's phases over every wave since the last reset (index 15: number of waves)
 extern "C" int gnnb_debug_read(unsigned long long* out, int reset) {

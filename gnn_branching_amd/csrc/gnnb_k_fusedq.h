@@ -161,9 +161,11 @@ __device__ __forceinline__ void q_chain(const FArgs& a, const float* lds, const 
 #define Q_TIME_POST true
 #endif
 #define QT_ON (LANES == Q_TIME_LANES && SRC == Q_TIME_SRC && POST == Q_TIME_POST)
-#define QT_DECL unsigned long long qt_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long qt_last = __builtin_readcyclecounter()
+__device__ unsigned long long g_qt_wall[2 * 16 * 1024];
+#define QT_DECL unsigned long long qt_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long qt_last = __builtin_readcyclecounter(); const unsigned long long qt_w0 = wall_clock64()
 #define QT_MARK(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); qt_[i] += n_ - qt_last; qt_last = n_; } while (0)
-#define QT_FLUSH() do { if (QT_ON && (threadIdx.x & 63) == 0 && (blockIdx.x & 31) == 5) {      /* (a sample of the workgroups: 40 k atomics on ten words cost 0.7 ms) */ for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&g_fused_t[i_], qt_[i_]); atomicAdd(&g_fused_t[chain_role ? 14 : 15], 1ull); } } while (0)
+#define QT_FLUSH() do { if (QT_ON && (threadIdx.x & 63) == 0) { const int w_ = blockIdx.x * 16 + (threadIdx.x >> 6); g_qt_wall[2 * w_] = qt_w0; g_qt_wall[2 * w_ + 1] = wall_clock64(); }      /* start / end of EVERY wave, 100 MHz chip-wide clock */ \
+  if (QT_ON && (threadIdx.x & 63) == 0 && (blockIdx.x & 31) == 5) {      /* (a sample of the workgroups: 40 k atomics on ten words cost 0.7 ms) */ for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&g_fused_t[i_], qt_[i_]); atomicAdd(&g_fused_t[chain_role ? 14 : 15], 1ull); } } while (0)
 #else
 #define QT_DECL
 #define QT_MARK(i)

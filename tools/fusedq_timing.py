@@ -32,6 +32,27 @@ for _ in range(n):
     m.forward_device(*args)
 torch.cuda.synchronize()
 lib.gnnb_debug_read(out, 1)
+# one more forward alone: start / end of every wave of the instrumented launch on the chip-wide 100 MHz clock, beside its HIP-event duration
+eng = m.engine()
+eng.profile_enable(True)
+eng.profile_read(reset=True)
+eng.profile_trace(65536)
+m.forward_device(*args)
+torch.cuda.synchronize()
+eng.profile_read(reset=True)
+trace = eng.profile_trace(65536)
+eng.profile_enable(False)
+wall = (C.c_ulonglong * (2 * 16 * 256))()
+lib.gnnb_debug_wall(wall, 2 * 16 * 256)
+w = np.array(wall[:], dtype=np.uint64).reshape(-1, 2).astype(np.int64)
+wg_end = (w[:, 1].reshape(-1, 16).max(1) - w[:, 0].min()) * 0.01          # (rows are written per workgroup: 16 waves each)
+g_end = (w[:, 1].reshape(-1, 16)[:, :8].max(1) - w[:, 0].min()) * 0.01
+print("per workgroup, us after the first wave's start: last chain wave ends min / 10 % / median / 90 % / max = " +
+      " / ".join(f"{np.percentile(wg_end, q):.1f}" for q in (0, 10, 50, 90, 100)) + "; last gather wave ends " +
+      " / ".join(f"{np.percentile(g_end, q):.1f}" for q in (0, 10, 50, 90, 100)))
+print("median / max end of the last chain wave by XCD (blockIdx % 8): " + "  ".join(f"{x}: {np.median(wg_end[x::8]):.1f} / {wg_end[x::8].max():.1f}" for x in range(8)))
+print(f"instrumented launch: first wave start -> last wave end {(w[:, 1].max() - w[:, 0].min()) * 0.01:.1f} us; starts spread over {(w[:, 0].max() - w[:, 0].min()) * 0.01:.1f} us, "
+      f"ends over {(w[:, 1].max() - w[:, 1].min()) * 0.01:.1f} us; HIP-event durations of this forward's launches: {[(nm, round(1e3 * ms, 1)) for nm, ms in trace]}")
 names = ["G tables staged, header", "G tile decode + bounds", "G table build + walk", "G wait for ring slot", "G rows -> ring",
          "C tables staged, header", "C weights staged (all)", "C wait for a tile", "C rows->regs, chain, stores", "-"]
 ng, nc = out[15], out[14]
