@@ -292,6 +292,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-fp32", action="store_true", help="skip the GNNB_BF3=0 comparison leg (exact_fp32_ms_per_step, bf3_max_abs_delta)")
     ap.add_argument("--no-aggregate-only", action="store_true", help="skip the GNNB_FUSE=0 leg (roofline_aggregate_only: the stand-alone edge-aggregation kernel)")
+    ap.add_argument("--no-two-in-flight", action="store_true", help="skip the two-batches-in-flight leg (two_batches_in_flight: engine.BatchPipeline, throughput only)")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed leg (host_fed_ms_per_step: the same batch from pinned / pageable host tensors through engine.HostFedPipeline)")
     ap.add_argument("--cpu-budget", type=float, default=75.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--dist", action="store_true",
@@ -529,6 +530,12 @@ def main():
                 host_fed = host_fed_leg(eng, batch, args.steps, round(1e3 * elapsed / args.steps, 4), res)
             except Exception as e:      # noqa: BLE001
                 side_errors["host_fed"] = f"{type(e).__name__}: {e}"
+        two_in_flight = None
+        if not args.no_two_in_flight and not use_dist:
+            try:
+                two_in_flight = two_in_flight_leg(sd, d_args, res, args.steps, 1e3 * elapsed / args.steps, total_amb)
+            except Exception as e:      # noqa: BLE001
+                side_errors["two_in_flight"] = f"{type(e).__name__}: {e}"
         exact_ms = bf3_delta = None
         if plan.get("bf3") and not args.no_exact_fp32:
             try:
@@ -576,6 +583,7 @@ def main():
             "node_classes": {str(k): v for k, v in stats.items()},
             "instrumented_ms_per_step": round(1e3 * instrumented / args.steps, 4),
             "host_fed_ms_per_step": host_fed,
+            "two_batches_in_flight": two_in_flight,
             "dist": dist_record,
             "side_leg_errors": side_errors or None,
         }
@@ -669,6 +677,29 @@ def host_fed_leg(eng, batch, steps, device_resident_ms, res):
                    "inputs go through the runtime's staging.  The copies hide completely only where the link sustains h2d_GBps_needed_to_hide "
                    "(bytes_per_batch / device-resident step); below it the step is the copy time")
     return out
+
+
+def two_in_flight_leg(sd, d_args, res, steps, one_ms, n_amb):
+    """Throughput with TWO independent batches in flight (engine.BatchPipeline: two handles, two streams, the same batch shape dealt to
+    them in turn) -- never `value`: SURVEY 8(d) defines the metric on the wall time of ONE batched forward."""
+    from gnn_branching_amd.engine import BatchPipeline
+    pipe = BatchPipeline(sd, depth=2)
+    for _ in range(8):
+        r = pipe.submit(*d_args)
+    pipe.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rs = [pipe.submit(*d_args) for _ in range(steps)]
+    pipe.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    for r in rs[-2:]:
+        r.check()
+        if not torch.equal(r.scores, res.scores):
+            raise RuntimeError("scores of the two-in-flight pipeline differ from the plain forward")
+    return {"ms_per_batch": round(ms, 4), "scores_per_s": round(n_amb / (ms * 1e-3), 1), "over_one_in_flight": round(ms / one_ms, 3),
+            "note": "two independent batches in flight on two streams (two handles: own workspaces; k_top's workgroup split off): the ramps, tails "
+                    "and launch gaps of one batch's dependent launches fill with the other's kernels.  Throughput only -- a batch takes longer "
+                    "from submit to ready; `value` stays one batched forward at a time"}
 
 
 def restricted_source_rows(batch, k):

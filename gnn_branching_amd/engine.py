@@ -73,15 +73,26 @@ def _raise_for_status(st):
 
 
 class ForwardResult:
-    """Device outputs of one batched forward."""
-    __slots__ = ("scores", "decisions", "status", "masks")
+    """Device outputs of one batched forward.  `ready` (BatchPipeline only): the event behind the forward on the side stream it ran on."""
+    __slots__ = ("scores", "decisions", "status", "masks", "ready")
 
-    def __init__(self, scores, decisions, status, masks):
-        self.scores, self.decisions, self.status, self.masks = scores, decisions, status, masks
+    def __init__(self, scores, decisions, status, masks, ready=None):
+        self.scores, self.decisions, self.status, self.masks, self.ready = scores, decisions, status, masks, ready
+
+    def wait(self):
+        """Order the caller's current stream behind the forward (a no-op for a forward that ran on that stream)."""
+        if self.ready is not None:
+            cur = torch.cuda.current_stream(self.scores.device)
+            cur.wait_event(self.ready)
+            for t in (self.scores, self.decisions, self.status):
+                t.record_stream(cur)          # (allocated on the side stream: keep the allocator from recycling them under the caller)
+        return self
 
     def check(self):
         """Synchronises.  Raises like the reference would stop (it enters pdb on NaN embeddings,
         graph_conv.py:184-186, :339-341)."""
+        if self.ready is not None:
+            self.ready.synchronize()
         _raise_for_status(_or_reduce(self.status))
         return self
 
@@ -182,6 +193,49 @@ class HostFedPipeline:
             sl["ev_done"].record(cur)
             sl["used"] = True
         return res
+
+
+class BatchPipeline:
+    """`depth` (2) INDEPENDENT batches in flight: one handle (own workspace, own control blocks) and one HIP stream per slot, batches
+    dealt to the slots in turn.  A forward is a chain of 11-19 dependent launches; while one batch's kernel drains or its next one
+    ramps up, the other batch's kernel fills the CUs: measured per batch on MI355X (tools/two_batches_probe.py) base B=256 0.769 ->
+    0.728 ms, deep B=128 0.911 -> 0.785 ms.  Throughput, not latency: a batch takes longer from submit to ready.  Scores are bit-identical to
+    ``ScorerEngine.forward`` (tests/test_gpu_pipeline.py).  The handles are created with k_top's workgroup split off (GNNB_TOP_SPLIT=1):
+    with a second batch's kernels on the chip the partner workgroups of a split sample are not guaranteed to be resident together.
+
+    ``submit(*forward_args)`` returns the batch's ForwardResult at once; ``result.wait()`` orders the caller's stream behind it,
+    ``result.check()`` synchronises on it; ``synchronize()`` waits for everything submitted."""
+
+    def __init__(self, state_dict, depth=2, T=2, p=64, device=None):
+        self.depth = max(1, int(depth))
+        prev = os.environ.get("GNNB_TOP_SPLIT")
+        os.environ["GNNB_TOP_SPLIT"] = "1"
+        try:
+            self.engines = [ScorerEngine(state_dict, T, p, device) for _ in range(self.depth)]
+        finally:
+            if prev is None:
+                del os.environ["GNNB_TOP_SPLIT"]
+            else:
+                os.environ["GNNB_TOP_SPLIT"] = prev
+        self.device = self.engines[0].device
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
+        self.i = 0
+
+    def submit(self, lower_bounds_all, upper_bounds_all, dual_vars, primals, primal_inputs, layers, masks):
+        k = self.i % self.depth
+        self.i += 1
+        eng, st = self.engines[k], self.streams[k]
+        with torch.cuda.device(self.device):
+            st.wait_stream(torch.cuda.current_stream())          # the inputs were produced on the caller's stream
+            with torch.cuda.stream(st):
+                res = eng.forward(lower_bounds_all, upper_bounds_all, dual_vars, primals, primal_inputs, layers, masks)
+                res.ready = torch.cuda.Event()
+                res.ready.record(st)
+        return res
+
+    def synchronize(self):
+        for st in self.streams:
+            st.synchronize()
 
 
 class ScorerEngine:
