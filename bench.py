@@ -357,14 +357,32 @@ def main():
     loop = StepLoop(lambda: eng.forward(*d_args), use_dist, world * B)
     step, drain = loop.step, loop.drain
 
-    # Untimed pre-warm (allocator, clocks, caches), then the W warm-up steps the contract asks for.
-    for _ in range(int(os.environ.get("BENCH_PREWARM", "32"))):
+    # Untimed pre-warm (allocator, caches, the first status read), the collector's pause, a second pre-warm (clocks), then the W
+    # warm-up steps the contract asks for.
+    for _ in range(4):
         res = step()
     torch.cuda.synchronize()
     res.check()                 # (its device->host copy sits before the warm-up steps: the first launch after one has been seen to stall)
     sizes = eng.sizes
+    # The host only enqueues (0.2 ms per step against ~1 ms of GPU work), but a full collection of Python's cyclic GC walks
+    # every object torch and numpy created at import -- 35-100 ms, i.e. several times the whole K-step region -- and fires at
+    # an allocation count, i.e. at a fixed step index (tools/host_stall2.py: step 52 for base, 7 and 99 for deep).  Standard
+    # benchmarking hygiene: collect now, keep the collector off while the K steps are timed.  The collection comes BEFORE the W
+    # warm-up steps: behind them its 35-100 ms of idle GPU let the clocks drop, and the first timed steps paid for ramping them
+    # up again (base: 0.789 ms per step at K = 100 against 0.774 at K = 1000 on one box; the default K is 20).
+    import gc
+    late = bool(os.environ.get("BENCH_GC_LATE"))       # dev A/B: the earlier order (collect between the warm-up steps and the timed region)
+    if not late:
+        gc.collect()
+        gc.disable()
+    for _ in range(int(os.environ.get("BENCH_PREWARM", "64"))):
+        res = step()
     for _ in range(args.warmup):
         res = step()
+    if late:
+        torch.cuda.synchronize()
+        gc.collect()
+        gc.disable()
 
     def sync():
         drain()
@@ -374,13 +392,6 @@ def main():
             torch.cuda.synchronize()
 
     sync()
-    # The host only enqueues (0.2 ms per step against ~1 ms of GPU work), but a full collection of Python's cyclic GC walks
-    # every object torch and numpy created at import -- 35-100 ms, i.e. several times the whole K-step region -- and fires at
-    # an allocation count, i.e. at a fixed step index (tools/host_stall2.py: step 52 for base, 7 and 99 for deep).  Standard
-    # benchmarking hygiene: collect now, keep the collector off while the K steps are timed.
-    import gc
-    gc.collect()
-    gc.disable()
     trace = [] if os.environ.get("BENCH_TRACE") else None      # dev: host time of every timed step() call
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -688,10 +699,16 @@ def two_in_flight_leg(sd, d_args, res, steps, one_ms, n_amb):
         r = pipe.submit(*d_args)
     pipe.synchronize()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    rs = [pipe.submit(*d_args) for _ in range(steps)]
-    pipe.synchronize()
-    ms = 1e3 * (time.perf_counter() - t0) / steps
+    import gc
+    gc.collect()
+    gc.disable()                  # (as in the headline's timed region: a full collection costs tens of ms)
+    try:
+        t0 = time.perf_counter()
+        rs = [pipe.submit(*d_args) for _ in range(steps)]
+        pipe.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+    finally:
+        gc.enable()
     for r in rs[-2:]:
         r.check()
         if not torch.equal(r.scores, res.scores):
