@@ -538,20 +538,20 @@ def main():
         host_fed = None
         if not args.no_host_fed:
             try:
-                host_fed = host_fed_leg(eng, batch, args.steps, round(1e3 * elapsed / args.steps, 4), res)
+                host_fed = host_fed_leg(eng, batch, max(args.steps, 100), round(1e3 * elapsed / args.steps, 4), res)
             except Exception as e:      # noqa: BLE001
                 side_errors["host_fed"] = f"{type(e).__name__}: {e}"
         two_in_flight = None
         if not args.no_two_in_flight and not use_dist:
             try:
-                two_in_flight = two_in_flight_leg(sd, d_args, res, args.steps, 1e3 * elapsed / args.steps, total_amb)
+                two_in_flight = two_in_flight_leg(sd, d_args, res, max(args.steps, 200), 1e3 * elapsed / args.steps, total_amb)
             except Exception as e:      # noqa: BLE001
                 side_errors["two_in_flight"] = f"{type(e).__name__}: {e}"
         exact_ms = bf3_delta = None
         if plan.get("bf3") and not args.no_exact_fp32:
             try:
                 with _env(GNNB_BF3="0"):
-                    exact_ms, bf3_delta = exact_fp32_leg(sd, d_args, res, args.steps)
+                    exact_ms, bf3_delta = exact_fp32_leg(sd, d_args, res, max(args.steps, 100))
             except Exception as e:      # noqa: BLE001
                 side_errors["exact_fp32"] = f"{type(e).__name__}: {e}"
         # ---- the edge aggregation ALONE ("standalone message-passing (aggregate-only) kernel for the HBM-roofline
@@ -629,7 +629,7 @@ def exact_fp32_leg(sd, d_args, res, steps):
     model32 = GraphNet(2, 64)
     model32.load_state_dict(sd)
     eng32 = model32.eval().engine()
-    for _ in range(5):
+    for _ in range(40):           # (a new handle: bind, allocations -- the GPU idled meanwhile and its clocks dropped)
         r32 = eng32.forward(*d_args)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
@@ -659,7 +659,7 @@ def host_fed_leg(eng, batch, steps, device_resident_ms, res):
             a = [[t.pin_memory() for t in g] if isinstance(g, list) else g for g in a]
             a[4], a[6] = a[4].pin_memory(), a[6].pin_memory()
         pipe = HostFedPipeline(eng)
-        for _ in range(4):
+        for _ in range(24):
             r = pipe.submit(*a)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -695,16 +695,18 @@ def two_in_flight_leg(sd, d_args, res, steps, one_ms, n_amb):
     them in turn) -- never `value`: SURVEY 8(d) defines the metric on the wall time of ONE batched forward."""
     from gnn_branching_amd.engine import BatchPipeline
     pipe = BatchPipeline(sd, depth=2)
-    for _ in range(8):
+    import gc
+    gc.collect()
+    gc.disable()                  # (as for the headline's timed region: a full collection costs tens of ms -- and BEFORE the warm-up, see there)
+    for _ in range(48):
         r = pipe.submit(*d_args)
     pipe.synchronize()
     torch.cuda.synchronize()
-    import gc
-    gc.collect()
-    gc.disable()                  # (as in the headline's timed region: a full collection costs tens of ms)
     try:
         t0 = time.perf_counter()
-        rs = [pipe.submit(*d_args) for _ in range(steps)]
+        rs = []
+        for _ in range(steps):
+            rs = (rs + [pipe.submit(*d_args)])[-2:]       # (only the last result of each slot is kept: holding all of them makes every submit a fresh device allocation)
         pipe.synchronize()
         ms = 1e3 * (time.perf_counter() - t0) / steps
     finally:

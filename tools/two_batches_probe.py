@@ -43,3 +43,72 @@ for name, f in (("one batch at a time", one_stream), ("two batches in flight", t
     torch.cuda.synchronize()
     print(f"{net} B={B}: {name:24s} {1e3 * (time.perf_counter() - t0) / K:.4f} ms per batch", flush=True)
 r0 = engs[0][1].forward(*argsets[0]); torch.cuda.synchronize(); r0.check()
+
+# ---- the same through engine.BatchPipeline (what bench.py's side leg runs)
+from gnn_branching_amd.engine import BatchPipeline
+pipe = BatchPipeline(engs[0][0].state_dict(), depth=2)
+
+
+def piped(sets):
+    def f():
+        keep = []
+        for i in range(K):
+            keep = (keep + [pipe.submit(*sets[i % len(sets)])])[-2:]
+        pipe.synchronize()
+    return f
+
+
+for name, f in (("BatchPipeline, two different batches", piped(argsets)), ("BatchPipeline, the same batch twice", piped(argsets[:1])),
+                ("two batches in flight (plain)", two_streams)):
+    f()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    f()
+    torch.cuda.synchronize()
+    print(f"{net} B={B}: {name:40s} {1e3 * (time.perf_counter() - t0) / K:.4f} ms per batch", flush=True)
+
+# ---- bisect: the pipeline's handles in the plain loop; the plain loop with an event per forward
+def plain_with(engines, events):
+    def f():
+        for i in range(K):
+            with torch.cuda.stream(streams[i & 1]):
+                r = engines[i & 1].forward(*argsets[i & 1])
+                if events:
+                    e = torch.cuda.Event()
+                    e.record(streams[i & 1])
+    return f
+
+
+for name, f in (("plain loop, the pipeline's handles", plain_with(pipe.engines, False)), ("plain loop, own handles, event per forward", plain_with([e[1] for e in engs], True)),
+                ("plain loop, pipeline's handles and streams", None)):
+    if f is None:
+        def f():
+            for i in range(K):
+                with torch.cuda.stream(pipe.streams[i & 1]):
+                    pipe.engines[i & 1].forward(*argsets[i & 1])
+    f()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    f()
+    torch.cuda.synchronize()
+    print(f"{net} B={B}: {name:46s} {1e3 * (time.perf_counter() - t0) / K:.4f} ms per batch", flush=True)
+
+# ---- which PAIRS of streams overlap?
+more = streams + list(pipe.streams) + [torch.cuda.Stream() for _ in range(4)] + [torch.cuda.Stream(priority=-1)]
+own = [e[1] for e in engs]
+for a in range(len(more)):
+    for b in range(a + 1, len(more)):
+        if not (b == a + 1 or a == 0):
+            continue
+        pair = (more[a], more[b])
+
+        def f():
+            for i in range(K):
+                with torch.cuda.stream(pair[i & 1]):
+                    own[i & 1].forward(*argsets[i & 1])
+        f()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        f()
+        torch.cuda.synchronize()
+        print(f"streams #{a} + #{b}{' (high priority)' if b == len(more) - 1 else ''}: {1e3 * (time.perf_counter() - t0) / K:.4f} ms per batch", flush=True)
