@@ -228,6 +228,9 @@ class BatchPipeline:
         one run their kernels in order (measured on MI355X / ROCm 7.2, tools/two_batches_probe.py: of the first nine streams torch hands out
         the pairs (#2, #3) and (#0, #5) serialise, every other pair overlaps) -- so candidates are timed against the streams already
         chosen with two 0.3-ms spin kernels and taken only if the pair finishes in well under twice one kernel's time."""
+        if not hasattr(torch.cuda, "_sleep"):                   # (no spin kernel to time with: take the streams as they come)
+            return [torch.cuda.Stream(device=device) for _ in range(n)]
+
         def spin(st):
             with torch.cuda.stream(st):
                 torch.cuda._sleep(700000)
