@@ -112,3 +112,19 @@ for a in range(len(more)):
         f()
         torch.cuda.synchronize()
         print(f"streams #{a} + #{b}{' (high priority)' if b == len(more) - 1 else ''}: {1e3 * (time.perf_counter() - t0) / K:.4f} ms per batch", flush=True)
+
+# ---- the DEFAULT stream against side streams (what the RCCL all-gather of bench.py --gpus N meets: forwards on the default stream)
+for b in range(len(more)):
+    def f():
+        for i in range(K):
+            if i & 1:
+                with torch.cuda.stream(more[b]):
+                    own[1].forward(*argsets[1])
+            else:
+                own[0].forward(*argsets[0])
+    f()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    f()
+    torch.cuda.synchronize()
+    print(f"default stream + #{b}: {1e3 * (time.perf_counter() - t0) / K:.4f} ms per batch", flush=True)
