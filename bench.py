@@ -79,6 +79,8 @@ def plan_flops(plan, B, stats, restrict_last=True, per_launch=None):
     bf3 = bool(plan.get("bf3", 0))
     W64 = 24 if bf3 else 64           # one 64x64 block: 48 bf16 MFMAs of 32 cycles, or 64 fp32 MFMAs of 64 cycles
     alg, issued, agg_bytes = {}, {}, {}
+    survey = plan.setdefault("_survey_bytes", {})     # per aggregation class: SURVEY 8(d)'s letter 4 p (N_src + N_dst) per half-pass, dead rows included
+    survey.clear()
 
     def add(d, k, v):
         d[k] = d.get(k, 0.0) + v
@@ -114,6 +116,7 @@ def plan_flops(plan, B, stats, restrict_last=True, per_launch=None):
             # (round 0 with the embedding fused into the first gather reads three scalars per source node, not a 256-B row)
             src_row_bytes = 12.0 if (plan.get("embed_fused") and u["update"] == "fwd" and k == 1 and t == 0) else 4.0 * 64
             add(agg_bytes, agg, src_row_bytes * B * u["n_src"] + 4.0 * 64 * n_upd)
+            add(survey, agg, 4.0 * 64 * B * (u["n_src"] + u["nodes"]))
             if per_launch is not None:       # (bench.py's aggregate-only leg prices single launches: half-pass, its aggregation kernel class, its bytes)
                 per_launch.append({"t": t, "update": u["update"], "layer": k, "agg": agg, "restricted": bool(restricted),
                                    "embed_in_gather": src_row_bytes == 12.0,
@@ -226,9 +229,16 @@ class StepLoop:
         self.pending = None
         self.last_gathered = None
         self.gathers_completed = 0
+        self.status_acc = None          # set to an empty int tensor by a caller that wants the steps' status words OR-ed (bench.py --dist)
 
     def step(self):
         res = self.forward_fn()
+        if self.status_acc is not None and hasattr(res, "status"):
+            # the OR of every step's status words, kept on the device (no sync): what the forwards that ran beside a collective reported
+            word = res.status[0:1]
+            for c in range(1, res.status.numel()):
+                word = word | res.status[c:c + 1]
+            self.status_acc = word if not self.status_acc.numel() else (self.status_acc | word)
         if self.use_dist:
             from gnn_branching_amd import parallel
             nxt = parallel.gather_scores_async(res.scores, self.total_batch)
@@ -355,6 +365,8 @@ def main():
     d_args = (dev_list(batch.lower_bounds_all), dev_list(batch.upper_bounds_all), dev_list(batch.dual_vars),
               dev_list(batch.primals), batch.primal_inputs.to(dev), batch.layers, batch.masks.to(dev))
     loop = StepLoop(lambda: eng.forward(*d_args), use_dist, world * B)
+    if use_dist:
+        loop.status_acc = torch.empty(0, dtype=torch.int32, device=dev)
     step, drain = loop.step, loop.drain
 
     # Untimed pre-warm (allocator, caches, the first status read), the collector's pause, a second pre-warm (clocks), then the W
@@ -375,7 +387,8 @@ def main():
     if not late:
         gc.collect()
         gc.disable()
-    for _ in range(int(os.environ.get("BENCH_PREWARM", "64"))):
+    prewarm = int(os.environ.get("BENCH_PREWARM", "64"))
+    for _ in range(prewarm):
         res = step()
     for _ in range(args.warmup):
         res = step()
@@ -429,7 +442,9 @@ def main():
         assert loop.gathers_completed >= args.steps, (loop.gathers_completed, args.steps)
         dist_record = {"backend": dist.get_backend(), "world_size": world, "gathers_completed": loop.gathers_completed,
                        "gathered_rows": int(loop.last_gathered.shape[0]), "gathered_equals_plain_forward_bitwise": same,
-                       "status_word": int(_status_word(plain)), "self_launched": bool(os.environ.get("BENCH_SELF_LAUNCHED"))}
+                       # the OR over every step of the run -- the forwards that overlapped an all-gather -- and the plain forward's
+                       "status_word": int(_status_word(plain)) | (int(loop.status_acc.cpu()[0]) if loop.status_acc is not None and loop.status_acc.numel() else 0),
+                       "self_launched": bool(os.environ.get("BENCH_SELF_LAUNCHED"))}
 
     # ---- per-kernel durations with HIP events on the launch stream (same K steps, instrumented) ----
     eng.profile_enable(True)
@@ -472,8 +487,12 @@ def main():
             # an edge-aggregation (message-passing) kernel: HBM-bound by SURVEY 8(d).  Algorithmic bytes per launch =
             # 4*p*(source rows read once + updated destination rows written once), averaged over the class's launches.
             ach_gbs = agg_bytes.get(dom, 0.0) / dom_s / 1e9 if dom_s > 0 else 0.0
+            sv_gbs = plan.get("_survey_bytes", {}).get(dom, 0.0) / dom_s / 1e9 if dom_s > 0 else 0.0
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(ach_gbs / PEAK_HBM_GBS, 4), "traffic": traffic,
+                        # frac: bytes the launch must move (live source rows + updated rows; round 0 reads 12 B per source node);
+                        # frac_survey_bytes: SURVEY 8(d)'s letter, 4 p (N_src + N_dst) per half-pass with dead rows counted, over the same time
+                        "frac_survey_bytes": round(sv_gbs / PEAK_HBM_GBS, 4),
                         "avg_launch_us": kern[dom]["avg_us"], "launches_per_step": launches,
                         "algorithmic_bytes_per_launch": round(agg_bytes.get(dom, 0.0) / max(launches, 1)),
                         "issued_mfma_tflops": round(iss_tf, 2), "issued_mfma_frac": round(iss_tf / PEAK_F32_MFMA_TFLOPS, 4)}
@@ -573,6 +592,9 @@ def main():
             "value": round(total_amb * args.steps / elapsed, 1),
             "unit": "scores/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            # what ran, untimed, before the K timed steps besides the W warm-up steps the contract asks for: 4 steps (allocator, first status
+            # read) + BENCH_PREWARM steps (clocks); Python's cyclic collector is run once before them and kept off while the K steps are timed
+            "prewarm_steps": 4 + prewarm, "gc_disabled": True,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (bf16x3-split 64x64 blocks)" if plan.get("bf3") else "f32", "data": "synthetic",
@@ -766,6 +788,10 @@ def aggregate_only_leg(sd, d_args, res, args, batch, stats, B):
     same_set = bool(torch.equal(finA, torch.isfinite(rA.scores)))
     agg_delta = float((rA.scores[finA] - res.scores[finA]).abs().max()) if (same_set and finA.any()) else None
     same_dec = bool(torch.equal(rA.decisions, res.decisions))
+    # parity of this leg against the default path is asserted here (into side_leg_errors / the leg's "error" field, never into `value`):
+    # the same scored set, the same decisions, scores within the 2e-5 two fp32-grade evaluations of the same sums differ by
+    if not same_set or not same_dec or agg_delta is None or agg_delta > 2e-5:
+        raise RuntimeError(f"aggregate-only leg disagrees with the default path: same scored set {same_set}, same decisions {same_dec}, max |delta| {agg_delta}")
     planA = engA.describe()
     launchesA = []
     plan_flops(planA, B, stats, per_launch=launchesA)

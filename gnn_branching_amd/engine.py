@@ -94,6 +94,9 @@ class ForwardResult:
         graph_conv.py:184-186, :339-341)."""
         if self.ready is not None:
             self.ready.synchronize()
+            cur = torch.cuda.current_stream(self.scores.device)
+            for t in (self.scores, self.decisions, self.status):
+                t.record_stream(cur)          # (as wait(): allocated on the side stream, from here on used by the caller's)
         _raise_for_status(_or_reduce(self.status))
         return self
 
@@ -169,6 +172,13 @@ class HostFedPipeline:
                 t = host[j]
                 if t.device.type == "cpu":
                     pin_np[o:o + t.numel()] = t.reshape(-1).numpy()
+            dev_src = [t for t in host if t.device.type != "cpu"]
+            if dev_src:
+                # sources that already live on the device (or temporaries _flat_inputs made from them) were produced on the caller's
+                # stream: the copy stream must not read them before that work is done, nor may the allocator recycle them under it
+                self.copy_stream.wait_stream(cur)
+                for t in dev_src:
+                    t.record_stream(self.copy_stream)
             with torch.cuda.stream(self.copy_stream):
                 if offs:
                     if any(host[j].device.type != "cpu" for j in offs):
@@ -191,6 +201,10 @@ class HostFedPipeline:
             nb, nd, npr = len(lower_bounds_all), len(dual_vars), len(primals)
             d = sl["dev"]
             res = eng.forward(d[:nb], d[nb:2 * nb], d[2 * nb:2 * nb + nd], d[2 * nb + nd:2 * nb + nd + npr], d[-2], layers, d[-1])
+            # the result outlives the slot: its mask must not be a view of the slot's device buffer, which the submit `depth` calls
+            # later overwrites (a held result's ragged() would then be cut with another batch's mask).  Cloned on the compute stream,
+            # behind the copies it waited for and in front of ev_done.
+            res.masks = res.masks.clone()
             sl["ev_done"].record(cur)
             sl["used"] = True
         return res
@@ -270,6 +284,13 @@ class BatchPipeline:
             if not cur.query():                                  # the inputs were produced on the caller's stream: wait for it -- unless it is idle:
                 st.wait_stream(cur)                              # an event recorded on the default stream orders it against every other stream's
                                                                  # work, and the two batches then run one after the other (0.94 instead of 0.78 ms)
+            # Lifetime contract: the caller may drop or overwrite-by-reallocation its inputs as soon as submit returns -- every device
+            # input is marked as in use by the side stream, so the caching allocator will not hand its memory out again before the
+            # forward has read it.  (Writing INTO an input tensor in place before result.wait() / check() is still a race.)
+            for grp in (lower_bounds_all, upper_bounds_all, dual_vars, primals, [primal_inputs, masks]):
+                for t in grp:
+                    if torch.is_tensor(t) and t.device.type == "cuda":
+                        t.record_stream(st)
             with torch.cuda.stream(st):
                 res = eng.forward(lower_bounds_all, upper_bounds_all, dual_vars, primals, primal_inputs, layers, masks)
                 res.ready = torch.cuda.Event()

@@ -23,7 +23,7 @@ def test_host_fed_pipeline_is_bit_identical_and_reuses_its_buffers(pinned):
             d = [[t.to(dev) for t in g] if isinstance(g, list) else g for g in args]
             d[4], d[6] = args[4].to(dev), args[6].to(dev)
             r = eng.forward(*d).check()
-            want.append((r.scores.cpu().numpy(), r.decisions.cpu().numpy()))
+            want.append((r.scores.cpu().numpy(), r.decisions.cpu().numpy(), [t.cpu().numpy() for t in r.ragged()]))
     pipe = E.HostFedPipeline(eng)
     results = []
     with torch.no_grad():
@@ -33,7 +33,11 @@ def test_host_fed_pipeline_is_bit_identical_and_reuses_its_buffers(pinned):
                 args = [[t.pin_memory() for t in g] if isinstance(g, list) else g for g in args]
                 args[4], args[6] = b.forward_args()[4].pin_memory(), b.forward_args()[6].pin_memory()
             results.append(pipe.submit(*args))              # no synchronisation between submissions
-    for r, (ws, wd) in zip(results, want):
+    for r, (ws, wd, wr) in zip(results, want):
         r.check()
         assert np.array_equal(r.scores.cpu().numpy(), ws, equal_nan=True)
         assert np.array_equal(r.decisions.cpu().numpy(), wd)
+        # results held across more than `depth` submits keep their OWN mask (it used to be a view of the slot's buffer, which the
+        # submit two calls later overwrites): the ragged score lists are cut with it
+        got = [t.cpu().numpy() for t in r.ragged()]
+        assert len(got) == len(wr) and all(np.array_equal(g, w) for g, w in zip(got, wr))
