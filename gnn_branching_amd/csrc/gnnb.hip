@@ -116,6 +116,10 @@ struct gnnb_handle {
                                 // gathers, bit 1 = 32-node gathers, bit 2 = the input-layer gather
   bool gather16 = true;         // forward conv edges: 16-node tiles on the 16x16x4 MFMA when their window is smaller
   bool embed_fuse = true;       // round 0: the first forward gather computes the input embedding itself (no k_embed, no mu[0] rows)
+  int owned = 0;                // dev A/B (GNNB_OWNED=1): k_gather_update_q with sample-owned tiles when the batch is a multiple of the grid
+  int sweep = 0;                // GNNB_SWEEP=1: consecutive fused conv half-passes as ONE launch (k_sweep: sample-owned tiles, a workgroup barrier between
+                                // phases) when the batch is a multiple of the CU count.  Bit-identical; measured (profiles/r05_sweep_ab.txt) -1 % per step on
+                                // cifar_deep_kw B = 256 and +1.4 % on cifar_base_kw B = 256: off by default
   int fuse = 1;                 // conv half-passes as ONE kernel (k_gather_update_q: the aggregate never reaches HBM) wherever that kernel
                                 // exists (measured faster at every batch size and on all three networks: base B = 256 0.975 vs 1.014 ms,
                                 // deep B = 1024 6.59 vs 7.31 ms, B = 1 0.344 vs 0.359 ms); GNNB_FUSE=0: always two kernels.  Both forms
@@ -317,6 +321,9 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
 #endif
 
   if (const char* e = getenv("GNNB_FUSE")) h->fuse = e[0] - '0';
+  if (const char* e = getenv("GNNB_OWNED")) h->owned = e[0] == '1';
+  if (const char* e = getenv("GNNB_SWEEP")) h->sweep = e[0] != '0';
+  HIPCHK(hipFuncSetAttribute((const void*)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #define FUSEDQ_ATTR(L, S, P) HIPCHK(hipFuncSetAttribute((const void*)k_gather_update_q<L, S, P>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
   FUSEDQ_ATTR(16, 0, false); FUSEDQ_ATTR(16, 1, false); FUSEDQ_ATTR(16, 2, false); FUSEDQ_ATTR(32, 1, false); FUSEDQ_ATTR(32, 1, true);
 #undef FUSEDQ_ATTR
@@ -616,6 +623,12 @@ extern "C" int gnnb_debug_wall(unsigned long long* out, int nwords) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qt_wall), (size_t)nwords * 8) == hipSuccess ? 0 : -1;
 }
 #endif
+#ifdef SWEEP_TIMING
+// dev: the stamps of the last k_sweep launch (see gnnb_k_fusedq.h)
+extern "C" int gnnb_debug_sweep_wall(unsigned long long* out, int nwords) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sw_wall), (size_t)nwords * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef FUSED_TIMING
 // dev: cycle sums of k_gather_update's phases over every wave since the last reset (index 15: number of waves)
 extern "C" int gnnb_debug_read(unsigned long long* out, int reset) {
@@ -826,10 +839,30 @@ extern "C" int gnnb_profile_trace(gnnb_t* h, int* cls, double* ms, int cap) {
   return n;
 }
 
+// the fused conv half-passes enqueued since the last launch of anything else: they go out together as one k_sweep (Launcher::run flushes)
+struct SweepQueue {
+  SweepArgs sa;
+  size_t lds = 0;
+  unsigned grid = 0;
+  int launches = 0;
+  bool busy = false;
+  SweepQueue() { sa.nphase = 0; }
+};
+
 struct Launcher {
   gnnb_t* h;
   hipStream_t st;
   int rc = 0;
+  SweepQueue* sq = nullptr;
+  void flush() {
+    if (!sq || sq->busy || sq->sa.nphase == 0) return;
+    sq->busy = true;
+    sq->sa.ordinal = sq->launches++;
+    run(PC_GATHER_UPDATE, [&] { hipLaunchKernelGGL(k_sweep, dim3(sq->grid), dim3((QG_WAVES + QC_WAVES) * 64), sq->lds, st, sq->sa); });
+    sq->sa.nphase = 0;
+    sq->lds = 0;
+    sq->busy = false;
+  }
   hipEvent_t get_event() {
     if (!h->pool.empty()) { hipEvent_t e = h->pool.back(); h->pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
@@ -838,6 +871,7 @@ struct Launcher {
   }
   template <class F>
   void run(int cls, F&& f) {
+    flush();                       // (whatever is launched next may read what the queued half-passes write)
     if (rc) return;
     if (h->prof) {
       gnnb_handle::Ev ev{cls, get_event(), get_event()};
@@ -895,6 +929,9 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   float* ws = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
   Launcher lz{h, st};
+  SweepQueue sweepq;
+  const bool sweep_on = h->sweep && h->fuse != 0 && B % h->n_cu == 0;      // sample-owned tiles need an even deal of the samples over the workgroups
+  if (sweep_on) lz.sq = &sweepq;
   auto mu = [&](int k) { return ws + w.mu[k]; };
   float* nb = ws + w.nb;
 
@@ -1241,8 +1278,17 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
                   a.sw_from_gather ? sout : nullptr};
       a.u = upd_args(k, fwd, false, post_input);
       a.qtiles = nq;
+      a.owned = ((h->owned || sweep_on) && B % h->n_cu == 0) ? B : 0;
       const long nrounds = (nt + QG_WAVES - 1) / QG_WAVES;
       const dim3 g((unsigned)std::max<long>(1, std::min<long>(nrounds, h->n_cu))), b((QG_WAVES + QC_WAVES) * 64);
+      if (sweep_on) {
+        if (sweepq.sa.nphase == SWEEP_MAX) lz.flush();
+        const int i = sweepq.sa.nphase++;
+        sweepq.sa.kind[i] = d.g.lanes == 16 ? (embed_src ? 2 : (sparse ? 1 : 0)) : (post_input ? 4 : 3);
+        sweepq.sa.ph[i] = a;
+        sweepq.lds = std::max(sweepq.lds, ldsq);
+        sweepq.grid = g.x;
+      } else
       lz.run(PC_GATHER_UPDATE, [&] {
         if (d.g.lanes == 16) {
           if (embed_src) hipLaunchKernelGGL((k_gather_update_q<16, 2, false>), g, b, ldsq, st, a);
@@ -1387,6 +1433,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     ++done;
   }
 
+  lz.flush();
   // scores (graph_conv.py:442-450) and decision (graph_score.py:41-47)
   {
     ScoreArgs a{};

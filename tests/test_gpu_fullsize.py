@@ -88,6 +88,37 @@ def test_fused_halfpass_kernel_at_size(monkeypatch, net, B):
     assert out["0"][1] == out["1"][1]
 
 
+@pytest.mark.parametrize("net,B", [("cifar_base_kw", 256), ("cifar_deep_kw", 256), ("cifar_wide_kw", 256), ("cifar_base_kw", 512)])
+def test_sweep_kernel_is_bit_identical_to_one_launch_per_halfpass(monkeypatch, net, B):
+    """GNNB_SWEEP=1, for batches that are a multiple of the CU count: consecutive fused conv half-passes go out as ONE launch (k_sweep: every
+    workgroup owns whole samples, a workgroup barrier between phases; graph_conv.py:107-192 / :222-385 are loops over layers inside one
+    call) -- against GNNB_SWEEP=0 (one k_gather_update_q launch per half-pass, tiles dealt across all samples): the same arithmetic per
+    node, so identical scores and decisions bit for bit, on the shipped checkpoint and on a seeded random weight set; fewer launches."""
+    from gnn_branching_amd import synth
+    from oracle.gnn_oracle import random_gnn_state
+    for state in (shipped_state(), random_gnn_state(20240917)):
+        batch = synth.make_batch(net, B, seed=77)
+        out, launches = {}, {}
+        for sweep in ("0", "1"):
+            monkeypatch.setenv("GNNB_SWEEP", sweep)          # (default 0: opt-in, see DESIGN.md section 5)
+            model = model_for(state)
+            eng = model.engine()
+            with torch.no_grad():
+                model.forward_device(*batch.forward_args()).check()
+                eng.profile_enable(True)
+                eng.profile_read(reset=True)
+                res = model.forward_device(*batch.forward_args()).check()
+                torch.cuda.synchronize()
+                launches[sweep] = sum(v[1] for v in eng.profile_read(reset=True).values())
+                eng.profile_enable(False)
+                again = model.forward_device(*batch.forward_args()).check()        # a second forward on the same workspace
+            out[sweep] = (res.scores.cpu(), res.decisions.cpu().tolist())
+            assert torch.equal(again.scores.cpu(), out[sweep][0])
+        assert torch.equal(out["0"][0], out["1"][0])
+        assert out["0"][1] == out["1"][1]
+        assert launches["1"] < launches["0"], launches
+
+
 @pytest.mark.parametrize("net,B", [("cifar_base_kw", 256), ("cifar_wide_kw", 256), ("cifar_deep_kw", 128)])
 @pytest.mark.parametrize("weights", ["shipped", "random"])
 def test_top_kernel_at_size(monkeypatch, net, B, weights):
