@@ -414,6 +414,88 @@ def branch_and_bound(lp, scorer, layers, eps=1e-4, max_nodes=200, decision_bound
     return global_lb, global_ub, visited
 
 
+def branch_and_bound_threshold(lp, scorer, kw_scorer, layers, eps=1e-4, max_branches=50, decision_bound=None, branching_threshold=0.2,
+                               kwbd_threshold=10, sparsest_layer=0, log=print, dump=None):
+    """The BaB loop of plnn/relu_conv_gnnkwthreshold.py:126-262 WITH its control flow (the loop `bab_mip.py --bab_gnn` runs): branch on the
+    GNN's decision and bound its two children (:143-146); when the GNN's improvement of the bound (:151) is below ``branching_threshold``
+    (:155) ask the BaBSR heuristic (``choose_node_conv``, :157), skip a KW point that was inefficient ``kwbd_threshold`` times (:160-167),
+    else bound ITS two children too (:168-173) and keep the better pair: a KW point that improves less than the GNN's and less than 0.05
+    is counted as inefficient, one that improves more replaces the GNN's decision (:176-192, ``bab_caller.resolve_branching``).
+
+    ``scorer(sub, layers_dict) -> [layer, idx]`` (the GNN); ``kw_scorer(sub, icp_score, random_order, sparsest_layer) -> (decision,
+    icp_score)`` (BaBSR; the counter is the loop's state as at :119, :157).  ``log`` receives the per-branch line of :204 (= the line
+    of :201-202 in the dump), ``dump`` the dump file's lines (:201-202, :256-257).  A domain's GNN decision is computed when the domain
+    is picked (the reference computes it when the domain is created, :230 / :239: the same function of the same domain).
+    Returns (global_lb, global_ub, LP solves, branches, branches that bounded a KW decision, branches that used it)."""
+    from .bab_caller import gnn_improvement, resolve_branching, trace_line
+    fixed = {"fixed_layers": list(layers[:-1]), "prop_layers": [layers[-1]]}
+    n_relu = len(lp.pre_relu_indices)
+    root_mask = [torch.full((int(np.prod(lp.shapes[i + 1])),), -1, dtype=torch.long) for i in lp.pre_relu_indices]
+    root = lp.solve(root_mask)
+    if root is None:
+        raise RuntimeError("infeasible root domain")
+    random_order = [l for l in range(n_relu) if l != sparsest_layer]
+    random_order = ([sparsest_layer] if 0 <= sparsest_layer < n_relu else []) + random_order      # :97-103
+    global_lb, global_ub, domains = root.lb, root.ub, [root]
+    solves, nb_states, icp, n_kw, n_kw_used = 0, 0, 0, 0, 0
+    ineff_kw_dc, closed_lb = {}, float("inf")
+
+    def bound_children(dom, decision):
+        out = []
+        for choice in (0, 1):
+            m = [t.clone() for t in dom.mask]
+            m[decision[0]][decision[1]] = choice
+            out.append(lp.solve(m, parent=dom, split_layer=decision[0]))
+        return out
+
+    def child_lb(c):                          # an infeasible child cannot contain a counter-example
+        return float("inf") if c is None else c.lb
+
+    while domains and global_ub - global_lb > eps and nb_states < 2 * max_branches:
+        if decision_bound is not None and (global_lb >= decision_bound or global_ub < decision_bound):
+            break
+        domains.sort(key=lambda d: d.lb)
+        dom = domains.pop(0)
+        if not any(bool((m == -1).any()) for m in dom.mask):
+            closed_lb = min(closed_lb, dom.lb)
+            global_lb = min([d.lb for d in domains] + [closed_lb])
+            continue
+        gnn_decision = scorer(dom, fixed)                                                                  # :117 / :230 / :239
+        nb_states += 2                                                                                     # :138
+        children = bound_children(dom, gnn_decision)                                                       # :143-146
+        solves += 2
+        gnn_imp = gnn_improvement(child_lb(children[0]), child_lb(children[1]), dom.lb) if dom.lb < 0 else 1.0     # :151
+        decision, kw_decision, kw_imp = gnn_decision, None, -1
+        if gnn_imp < branching_threshold:                                                                  # :155
+            kw_decision, icp = kw_scorer(dom, icp, random_order, sparsest_layer)                           # :157
+            if ineff_kw_dc.get(f"{kw_decision[0]}-{kw_decision[1]}", 0) < kwbd_threshold:                  # :160-167
+                kw_children = bound_children(dom, kw_decision)                                             # :168-171
+                solves += 2
+                n_kw += 1
+                kw_imp = gnn_improvement(child_lb(kw_children[0]), child_lb(kw_children[1]), dom.lb)       # :173
+                decision, used_kw = resolve_branching(gnn_decision, gnn_imp, kw_decision, kw_imp, ineff_kw_dc)     # :176-192
+                if used_kw:
+                    children = kw_children
+                    n_kw_used += 1
+        line = trace_line(nb_states, decision, gnn_imp, gnn_decision, kw_imp, kw_decision)                 # :201-204
+        log(line.rstrip())
+        for c in children:
+            if c is not None:
+                global_ub = min(global_ub, c.ub)                                                           # :209-214
+        for c in children:
+            if c is None:
+                continue
+            if c.lb < global_ub - eps and (decision_bound is None or c.lb < decision_bound):               # :226, :235
+                domains.append(c)
+            else:
+                closed_lb = min(closed_lb, c.lb)
+        global_lb = min([d.lb for d in domains] + [closed_lb, global_ub])
+        if dump is not None:
+            dump(line)
+            dump(f"{global_lb}\n")                                                                         # :256-257
+    return global_lb, global_ub, solves, nb_states // 2, n_kw, n_kw_used
+
+
 def branch_and_bound_online(lp, graph, layers, eps=1e-4, max_nodes=200, decision_bound=None, branching_threshold=0.2,
                             online_threshold=5, sparsest_layer=0, log=print):
     """The BaB loop of plnn/relu_conv_online.py:126-276: branch on the GNN's decision; when its improvement of the bound

@@ -132,14 +132,19 @@ def run_trace(name, gt, cls, seed, eps, max_nodes):
 
 # (network, property gt vs cls, input seed, eps, branching decisions asked for): round 4 adds cifar_wide_kw (fewer nodes: its LPs are 4x
 # base's) and a second property / input on base
-@pytest.mark.parametrize("name,gt,cls,seed,eps,min_nodes", [("cifar_base_kw", 3, 5, 4, 0.02, MIN_NODES), ("cifar_deep_kw", 3, 5, 4, 0.02, MIN_NODES),
-                                                             ("cifar_base_kw", 7, 2, 11, 0.02, 24), ("cifar_wide_kw", 3, 5, 4, 0.02, 12)])
+# Default `-m gpu` run (the driver's step has a time limit; the LP solves on the host are what these tests cost): base 16 / deep 8 / wide 3
+# decisions.  The round-4 lengths (40 / 40 / 24 / 12 decisions, 330 s) carry the `slow` marker: GNNB_RUN_SLOW=1 python -m pytest -m "gpu and slow".
+SLOW = pytest.mark.slow
+@pytest.mark.parametrize("name,gt,cls,seed,eps,min_nodes", [
+    ("cifar_base_kw", 3, 5, 4, 0.02, 16), ("cifar_deep_kw", 3, 5, 4, 0.02, 8), ("cifar_wide_kw", 3, 5, 4, 0.02, 3),
+    pytest.param("cifar_base_kw", 3, 5, 4, 0.02, MIN_NODES, marks=SLOW), pytest.param("cifar_deep_kw", 3, 5, 4, 0.02, MIN_NODES, marks=SLOW),
+    pytest.param("cifar_base_kw", 7, 2, 11, 0.02, 24, marks=SLOW), pytest.param("cifar_wide_kw", 3, 5, 4, 0.02, 12, marks=SLOW)])
 def test_decision_trace_on_lp_inputs(name, gt, cls, seed, eps, min_nodes):
     r = run_trace(name, gt, cls, seed, eps, max_nodes=2 * min_nodes + 4)
     # the run's trace in the reference's dump format (relu_conv_gnnkwthreshold.py:75-79, :201-202, :256-257), for a Gurobi owner to diff
     out_dir = os.path.join(os.path.dirname(__file__), "..", "gpurun_out", "bab_traces")
     os.makedirs(out_dir, exist_ok=True)
-    with open(os.path.join(out_dir, f"{name}_gt{gt}_cls{cls}_seed{seed}_eps{eps}.trace"), "w") as f:
+    with open(os.path.join(out_dir, f"{name}_gt{gt}_cls{cls}_seed{seed}_eps{eps}_n{min_nodes}.trace"), "w") as f:
         f.writelines(r["dump_a"])
     ta, tb = r["trace_a"], r["trace_b"]
     n = min(len(ta), len(tb))
@@ -162,3 +167,89 @@ def test_decision_trace_on_lp_inputs(name, gt, cls, seed, eps, min_nodes):
     else:
         assert len(ta) == len(tb) and r["lines_a"] == r["lines_b"]           # same tree, same bounds, line by line
         assert r["res_a"] == r["res_b"]
+
+
+# ---- the reference loop's OWN control flow (round 5): GNN decision -> improvement below the branching threshold -> BaBSR decision -> two more
+# LPs -> keep the better pair (plnn/relu_conv_gnnkwthreshold.py:150-199), with both scorers on the device against an oracle twin ------------
+def run_threshold_trace(name, gt, cls, seed, eps, max_branches, branching_threshold=0.2):
+    from gnn_branching_amd.graphnet.graph_score import GraphChoice
+    from gnn_branching_amd.plnn import kw_score_conv as kw
+    from oracle import babsr_oracle, gnn_oracle
+    from tests.common import shipped_state
+    layers = nets.load_verified_net(name, gt, cls)
+    rng = np.random.RandomState(seed)
+    x = torch.from_numpy(rng.standard_normal((3, 32, 32)).astype(np.float32))
+    lp = CachedLP(lp_producer.LayerGraphLP(layers, x - eps, x + eps))
+    sizes = [int(np.prod(lp.shapes[i + 1])) for i in lp.pre_relu_indices]
+    state = shipped_state()
+    dev_layers = {"fixed_layers": [copy.deepcopy(l).cuda() for l in layers[:-1]], "prop_layers": [copy.deepcopy(layers[-1]).cuda()]}
+    host_layers = {"fixed_layers": list(layers[:-1]), "prop_layers": [layers[-1]]}
+    graph = GraphChoice([torch.full((n,), -1, dtype=torch.long) for n in sizes], CKPT)
+    graph.verbose = False
+
+    # ---- run A: both scorers on the MI355X, called the way the reference driver calls them
+    def hip_gnn(sub, _layers):
+        lbg, ubg = sub.graph_bounds(lp.pre_relu_indices, len(lp.layers))
+        return graph.decision(lbg, ubg, sub.dual_vars, sub.ub_point, sub.primals, dev_layers, sub.mask)
+
+    def hip_kw(sub, icp, random_order, sparsest_layer):
+        return kw.choose_node_conv(sub.lower_all, sub.upper_all, sub.mask, lp.layers, lp.pre_relu_indices, icp, random_order, sparsest_layer)
+    lines_a, dump_a = [], []
+    res_a = lp_producer.branch_and_bound_threshold(lp, hip_gnn, hip_kw, layers, max_branches=max_branches, branching_threshold=branching_threshold,
+                                                   decision_bound=0.0, log=lines_a.append, dump=dump_a.append)
+
+    # ---- run B: the oracle twin (gnn_oracle + babsr_oracle, both pinned by the reference's own outputs) -- test side only
+    gaps = []
+
+    def oracle_gnn(sub, _layers):
+        lbg, ubg = sub.graph_bounds(lp.pre_relu_indices, len(lp.layers))
+        with torch.no_grad():
+            s = gnn_oracle.oracle_forward(state, lbg, ubg, sub.dual_vars, sub.primals, sub.ub_point, host_layers, mask_1d(sub))[0]
+        top = torch.sort(s, descending=True)[0]
+        gaps.append(float(top[0] - top[1]) if len(top) > 1 else float("inf"))
+        return gnn_oracle.decision_from_scores(s, mask_1d(sub)[0], sizes)
+
+    def oracle_kw(sub, icp, random_order, sparsest_layer):
+        lbs = [sub.lower_all[i].unsqueeze(0) for i in lp.pre_relu_indices]
+        ubs = [sub.upper_all[i].unsqueeze(0) for i in lp.pre_relu_indices]
+        masks = [(m == -1).float().reshape(1, -1) for m in sub.mask]
+        with torch.no_grad():
+            score, icpt = babsr_oracle.babsr_scores(lbs, ubs, masks, list(layers[:-1]), layers[-1].weight.detach().reshape(1, -1))
+        return babsr_oracle.decide([t[0] for t in score], [t[0] for t in icpt], [m[0] for m in masks], icp, random_order, sparsest_layer)
+    lines_b = []
+    res_b = lp_producer.branch_and_bound_threshold(lp, oracle_gnn, oracle_kw, layers, max_branches=max_branches, branching_threshold=branching_threshold,
+                                                   decision_bound=0.0, log=lines_b.append)
+    return dict(lines_a=lines_a, lines_b=lines_b, dump_a=dump_a, res_a=res_a, res_b=res_b, gaps=gaps, lp=lp)
+
+
+# eps chosen so that the ROOT is undecided (lower bound < 0 < upper bound: at eps = 0.02 these properties hold at the root and the reference loop would
+# not branch at all): base 0.09 (root -0.19 / 0.05), deep 0.05 (root -0.035 / 0.007); decision_bound = 0 as the reference verifies (:257-262)
+@pytest.mark.parametrize("name,gt,cls,seed,eps,branches", [("cifar_base_kw", 3, 5, 4, 0.09, 12), ("cifar_deep_kw", 3, 5, 4, 0.05, 6),
+                                                            pytest.param("cifar_base_kw", 3, 5, 4, 0.09, 30, marks=pytest.mark.slow),
+                                                            pytest.param("cifar_deep_kw", 3, 5, 4, 0.05, 16, marks=pytest.mark.slow)])
+def test_threshold_loop_trace_with_the_kw_fallback(name, gt, cls, seed, eps, branches):
+    """BASELINE config 5's stand-in with the reference loop's control flow: `gnn_improvement < branching_threshold` -> `choose_node_conv` on
+    the device (gnnb_babsr) -> two more LPs -> keep the better pair (relu_conv_gnnkwthreshold.py:150-199).  The HIP run's trace LINES
+    (branch count, decision kept, GNN improvement and decision, KW improvement and decision: the line of :201-202) equal the oracle
+    twin's, and at least one branch bounded a KW decision."""
+    r = run_threshold_trace(name, gt, cls, seed, eps, max_branches=branches)
+    out_dir = os.path.join(os.path.dirname(__file__), "..", "gpurun_out", "bab_traces")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, f"{name}_gt{gt}_cls{cls}_seed{seed}_eps{eps}_threshold0.2_n{branches}.trace"), "w") as f:
+        f.writelines(r["dump_a"])
+    la, lb = r["lines_a"], r["lines_b"]
+    n_kw = sum("kw: improvement -1 decision None" not in l for l in la)
+    print(f"\n{name}: {len(la)} branches with the KW fall-back (threshold 0.2): {r['res_a'][4]} bounded a KW decision, {r['res_a'][5]} kept it; "
+          f"{r['res_a'][2]} LPs posed (LP solves {r['lp'].solves}, cache hits {r['lp'].hits}); bounds {r['res_a'][0]:.5f} / {r['res_a'][1]:.5f}; "
+          f"smallest oracle top-2 GNN gap {min(r['gaps']):.3e}")
+    for l in la:
+        print("   ", l)
+    assert len(la) >= min(branches, 4), f"the run ended after {len(la)} branches"
+    assert n_kw >= 1 and r["res_a"][4] >= 1, "no branch fell below the branching threshold: nothing exercised the KW fall-back"
+    first_diff = next((i for i in range(min(len(la), len(lb))) if la[i] != lb[i]), None)
+    if first_diff is not None:
+        # a different line is only acceptable where the oracle's GNN scores were a near tie the 1e-4 parity budget cannot order
+        print(f"{name}: line {first_diff} differs\n  HIP    {la[first_diff]}\n  oracle {lb[first_diff]}")
+        assert min(r["gaps"]) < 1e-3, (la[first_diff], lb[first_diff])
+    else:
+        assert la == lb and r["res_a"] == r["res_b"]            # same tree, same bounds, same counters, line by line
