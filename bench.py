@@ -446,6 +446,13 @@ def main():
                        "status_word": int(_status_word(plain)) | (int(loop.status_acc.cpu()[0]) if loop.status_acc is not None and loop.status_acc.numel() else 0),
                        "self_launched": bool(os.environ.get("BENCH_SELF_LAUNCHED"))}
 
+        if not args.no_two_in_flight:
+            try:
+                dist_record["dist_two_in_flight"] = dist_two_in_flight_leg(sd, d_args, plain, max(args.steps, 100), world * B, rank, B,
+                                                                           round(1e3 * elapsed / args.steps, 4))
+            except Exception as e:      # noqa: BLE001
+                dist_record["dist_two_in_flight"] = {"error": f"{type(e).__name__}: {e}"}
+
     # ---- per-kernel durations with HIP events on the launch stream (same K steps, instrumented) ----
     eng.profile_enable(True)
     eng.profile_read(reset=True)
@@ -741,6 +748,70 @@ def two_in_flight_leg(sd, d_args, res, steps, one_ms, n_amb):
             "note": "two independent batches in flight on two streams (two handles: own workspaces; k_top's workgroup split off): the ramps, tails "
                     "and launch gaps of one batch's dependent launches fill with the other's kernels.  Throughput only -- a batch takes longer "
                     "from submit to ready; `value` stays one batched forward at a time"}
+
+
+def dist_two_in_flight_leg(sd, d_args, plain, steps, total_batch, rank, B, one_handle_ms):
+    """The multi-GPU path with TWO handles in flight (engine.BatchPipeline: two handles, two streams) and the score all-gather of every
+    batch launched behind its forward on that batch's OWN stream -- so forward i + 1 (other handle, other stream) and the collective of
+    batch i overlap, and the caller's stream stays idle.  Never `value` (SURVEY 8(d): the metric is one batched forward at a time);
+    reported in `dist` beside the one-handle figure.  Asserts the gathered rows of this rank's shard == the plain forward bitwise and
+    a clean status word over every forward of the leg."""
+    import gc
+    from gnn_branching_amd import parallel
+    from gnn_branching_amd.engine import BatchPipeline
+    pipe = BatchPipeline(sd, depth=2)
+    pend = [None, None]
+    state = {"done": 0, "last": None, "status": None}
+
+    def step():
+        k = pipe.i % pipe.depth
+        st = pipe.streams[k]
+        if pend[k] is not None:
+            with torch.cuda.stream(st):
+                state["last"] = pend[k].wait()          # the slot's stream waits for its previous collective (bounds what is in flight)
+            state["done"] += 1
+        res = pipe.submit(*d_args)
+        with torch.cuda.stream(st):
+            pend[k] = parallel.gather_scores_async(res.scores, total_batch)      # ordered behind THIS forward on its stream
+            word = res.status[0:1]
+            for c in range(1, res.status.numel()):
+                word = word | res.status[c:c + 1]
+            state["status"] = word.clone() if state["status"] is None else (state["status"] | word.to(state["status"].device))
+        return res
+
+    def drain():
+        for k in range(pipe.depth):
+            if pend[k] is not None:
+                with torch.cuda.stream(pipe.streams[k]):
+                    state["last"] = pend[k].wait()
+                state["done"] += 1
+                pend[k] = None
+        pipe.synchronize()
+        torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()
+    try:
+        for _ in range(48):
+            step()
+        drain()
+        state["status"] = None
+        n0 = state["done"]
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        drain()
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+    finally:
+        gc.enable()
+    got = state["last"][rank * B:(rank + 1) * B]
+    same = bool(torch.equal(got, plain.scores))
+    status = int(state["status"].cpu()[0]) if state["status"] is not None else 0
+    if not same or status != 0:
+        raise RuntimeError(f"two handles in flight + all-gather: gathered == plain forward {same}, status word {status}")
+    return {"ms_per_batch": round(ms, 4), "one_handle_ms_per_step": one_handle_ms, "over_one_handle": round(ms / one_handle_ms, 3),
+            "gathers_completed": state["done"] - n0, "gathered_equals_plain_forward_bitwise": same, "status_word": status,
+            "note": "engine.BatchPipeline (two handles, two streams, k_top's workgroup split off) with each batch's all-gather launched behind its "
+                    "forward on that batch's own stream; throughput only, never `value`"}
 
 
 def restricted_source_rows(batch, k):

@@ -9,7 +9,7 @@ R=$GRAFT_REPO_ROOT; cd $R
 recipe=$1; shift
 case $recipe in
   dist)
-    TAG=${1:-r04}; O=$R/gpurun_out/dist_$TAG; mkdir -p $O
+    TAG=${1:-r05}; O=$R/gpurun_out/dist_$TAG; mkdir -p $O
     timeout -k 10 400 python3 bench.py --gpus 1 --dist --config 4 --no-cpu-baseline --no-exact-fp32 --no-aggregate-only > $O/deep_B128_dist.json 2> $O/deep_B128_dist.log || { echo "dist deep failed"; tail -20 $O/deep_B128_dist.log; exit 1; }
     timeout -k 10 400 python3 bench.py --gpus 1 --dist --config 2 --no-cpu-baseline --no-exact-fp32 --no-aggregate-only > $O/base_B256_dist.json 2> $O/base_B256_dist.log || { echo "dist base failed"; tail -20 $O/base_B256_dist.log; exit 1; }
     python3 - <<PY
@@ -17,6 +17,7 @@ import json
 for n in ("deep_B128_dist", "base_B256_dist"):
     d = json.loads(open("$O/" + n + ".json").read().strip().splitlines()[-1])
     print(n, d["ms_per_step"], d["value"], d["dist"])
+    print(n, "two handles in flight + all-gather:", d["dist"].get("dist_two_in_flight"))
 PY
     ;;
   aggonly)
