@@ -41,6 +41,9 @@ SYMBOLS = [
     ("gnnb_forward", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_size_t, C.c_void_p]),
     ("gnnb_forward_host", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("gnnb_amb_records_bytes", C.c_size_t, [C.c_void_p, C.c_int]),
+    ("gnnb_pack_amb_records", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("gnnb_scatter_amb_records", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
     ("gnnb_babsr", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p,
                              C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("gnnb_mu_projection", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),

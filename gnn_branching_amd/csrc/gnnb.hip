@@ -35,6 +35,9 @@
 #include <chrono>
 #include <thread>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 
 #include "../../include/gnnb.h"
 #include "gnnb_pack.h"
@@ -99,7 +102,60 @@ struct DevGather {          // one conv edge in one direction, as MFMA gather ta
   int* ttab = nullptr;
 };
 
+// Host helper threads of a handle, created on the first call that wants them (gnnb_pack_amb_records) and joined by gnnb_destroy: creating
+// and joining threads per call cost 0.25 ms of a 0.65-ms pack.  Idle workers sleep on a condition variable.  (A handle is created in the
+// process that uses it -- the BaB harness forks first, bab_mip.py:244-249 -- so no thread ever has to survive a fork.)
+struct WorkPool {
+  std::vector<std::thread> th;
+  std::mutex m;
+  std::condition_variable cv, done_cv;
+  const std::function<void()>* job = nullptr;
+  long gen = 0;
+  int busy = 0;
+  bool stop = false;
+  explicit WorkPool(int n) {
+    for (int i = 0; i < n; ++i)
+      th.emplace_back([this] {
+        long seen = 0;
+        for (;;) {
+          const std::function<void()>* f;
+          {
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&] { return stop || gen != seen; });
+            if (stop) return;
+            seen = gen;
+            f = job;
+          }
+          (*f)();
+          {
+            std::lock_guard<std::mutex> lk(m);
+            if (--busy == 0) done_cv.notify_one();
+          }
+        }
+      });
+  }
+  void run(const std::function<void()>& f) {      // f on every worker and on the caller; returns when all are done
+    {
+      std::lock_guard<std::mutex> lk(m);
+      job = &f; ++gen; busy = (int)th.size();
+    }
+    cv.notify_all();
+    f();
+    std::unique_lock<std::mutex> lk(m);
+    done_cv.wait(lk, [&] { return busy == 0; });
+  }
+  ~WorkPool() {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      stop = true;
+    }
+    cv.notify_all();
+    for (auto& t : th) t.join();
+  }
+};
+
 struct gnnb_handle {
+  WorkPool* work_pool = nullptr;      // see WorkPool
   int T = 2, p = 64, device = 0, n_cu = 256;
   bool use_gather = true;       // MFMA gather for conv edges (false: VALU gather kernels)
   // (k_node_update: 12 waves per workgroup = 3 per SIMD with the bf16x3 blocks (142-152 VGPRs, no scratch); the fp32-MFMA-only
@@ -400,6 +456,7 @@ extern "C" int gnnb_destroy(gnnb_t* h) {
   if (h->hs_scores) (void)hipFree(h->hs_scores);
   if (h->hs_dec) (void)hipFree(h->hs_dec);
   free_trainer(h);
+  delete h->work_pool;
   for (auto& ev : h->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
   for (auto& ev : h->pool) (void)hipEventDestroy(ev);
   delete h;
@@ -1562,6 +1619,111 @@ extern "C" int gnnb_forward_host(gnnb_t* h, const gnnb_batch* in, int B, float* 
   memcpy(decisions, out_i, (size_t)B * 2 * sizeof(int32_t));
   *status = out_i[(size_t)B * 2];
   if (scores) memcpy(scores, out_s, (size_t)B * R * sizeof(float));
+  return GNNB_OK;
+}
+
+// ---- host-fed batches: compact records of the ambiguous nodes instead of whole dual / primal tensors (include/gnnb.h) --------------------
+extern "C" size_t gnnb_amb_records_bytes(const gnnb_t* h, int B) {
+  if (!h || !h->bound || B < 1) return 0;
+  const int L = (int)h->N.size() - 2;
+  size_t words = 16 + (size_t)((B + 3) & ~3);
+  for (int k = 1; k <= L; ++k) words += (size_t)AMBREC_WORDS * B * h->N[k];
+  return words * 4;
+}
+
+extern "C" int gnnb_pack_amb_records(const gnnb_t* hc, const gnnb_batch* in, int B, void* dst, size_t cap, size_t* used) {
+  gnnb_t* h = const_cast<gnnb_t*>(hc);                  // (the helper threads live in the handle)
+  if (!h || !in || !dst || !used) return fail(GNNB_E_INVALID, "gnnb_pack_amb_records: null argument");
+  if (!h->bound) return fail(GNNB_E_STATE, "gnnb_pack_amb_records: call gnnb_bind_network first");
+  const int K = (int)h->N.size() - 1, L = K - 1;
+  if (B < 1 || L > MAXL || in->n_graph != K + 1 || in->n_relu != L || in->n_primal != h->n_fixed + 1)
+    return fail(GNNB_E_INVALID, "gnnb_pack_amb_records: batch does not match the bound network");
+  for (int k = 1; k <= L; ++k) {
+    const int q = h->relu_q[k];
+    if (!in->lb[k] || !in->ub[k] || !in->dual[k - 1] || !in->primal[q - 1] || !in->primal[q])
+      return fail(GNNB_E_INVALID, "gnnb_pack_amb_records: null input pointer (layer %d)", k);
+    if ((long)B * h->N[k] > 0x7fffffffL) return fail(GNNB_E_INVALID, "gnnb_pack_amb_records: batch too large");
+  }
+  if (!in->primal[in->n_primal - 1]) return fail(GNNB_E_INVALID, "gnnb_pack_amb_records: null primals[-1]");
+  const size_t zwords = (size_t)((B + 3) & ~3);
+  if (cap < (16 + zwords) * 4) return fail(GNNB_E_NOMEM, "gnnb_pack_amb_records: buffer of %zu bytes is too small", cap);
+  const size_t max_rec = (cap / 4 - 16 - zwords) / AMBREC_WORDS;
+  // ONE pass: work items = contiguous node ranges of a layer; a thread collects the records of its range in a local block and copies
+  // the block behind an atomic cursor.  The order of the records in the image is whatever the threads make it: the scatter does not care.
+  struct Item { int k; long lo, hi; };
+  std::vector<Item> items;
+  const long chunk = 1L << 15;
+  for (int k = 1; k <= L; ++k) {
+    const long G = (long)B * h->N[k];
+    for (long lo = 0; lo < G; lo += chunk) items.push_back(Item{k, lo, std::min(G, lo + chunk)});
+  }
+  int32_t* img = reinterpret_cast<int32_t*>(dst);
+  int32_t* recs = img + 16;
+  std::atomic<size_t> next{0}, cursor{0};
+  std::atomic<int> overflow{0};
+  const std::function<void()> work = [&]() {
+    constexpr int BLK = 1024;
+    int32_t local[BLK * AMBREC_WORDS];
+    for (size_t it = next.fetch_add(1); it < items.size(); it = next.fetch_add(1)) {
+      const Item& w = items[it];
+      const int k = w.k, q = h->relu_q[k];
+      const float *lb = in->lb[k], *ub = in->ub[k], *du = in->dual[k - 1], *zp = in->primal[q - 1], *zq = in->primal[q];
+      int n = 0;
+      auto flush = [&]() {
+        if (!n) return;
+        const size_t at = cursor.fetch_add((size_t)n);
+        if (at + n > max_rec) overflow.store(1);
+        else memcpy(recs + at * AMBREC_WORDS, local, (size_t)n * AMBREC_WORDS * 4);
+        n = 0;
+      };
+      for (long g = w.lo; g < w.hi; ++g) {
+        if (!(lb[g] < 0.0f && ub[g] > 0.0f)) continue;
+        int32_t* r = local + n * AMBREC_WORDS;
+        r[0] = k - 1; r[1] = (int32_t)g;
+        memcpy(r + 2, du + g * 3 + 1, 8);
+        memcpy(r + 4, zp + g, 4);
+        memcpy(r + 5, zq + g, 4);
+        if (++n == BLK) flush();
+      }
+      flush();
+    }
+  };
+  if (items.size() >= 8) {
+    if (!h->work_pool) h->work_pool = new WorkPool(11);
+    h->work_pool->run(work);
+  } else {
+    work();
+  }
+  const size_t total = cursor.load();
+  if (overflow.load() || total > max_rec) return fail(GNNB_E_NOMEM, "gnnb_pack_amb_records: %zu records do not fit a buffer of %zu bytes", total, cap);
+  memset(img, 0, 64);
+  img[0] = AMBREC_MAGIC; img[1] = L; img[2] = (int32_t)total; img[3] = B;
+  memcpy(recs + total * AMBREC_WORDS, in->primal[in->n_primal - 1], (size_t)B * sizeof(float));
+  *used = (16 + total * AMBREC_WORDS + zwords) * 4;
+  return GNNB_OK;
+}
+
+extern "C" int gnnb_scatter_amb_records(gnnb_t* h, const void* dev_image, int B, float* const* dual, int n_relu, float* const* primal, int n_primal,
+                                        void* stream) {
+  if (!h || !dev_image || !dual || !primal) return fail(GNNB_E_INVALID, "gnnb_scatter_amb_records: null argument");
+  if (!h->bound) return fail(GNNB_E_STATE, "gnnb_scatter_amb_records: call gnnb_bind_network first");
+  const int L = (int)h->N.size() - 2;
+  if (B < 1 || L > MAXL || n_relu != L || n_primal != h->n_fixed + 1) return fail(GNNB_E_INVALID, "gnnb_scatter_amb_records: arrays do not match the bound network");
+  ScatterArgs a{};
+  a.image = reinterpret_cast<const int*>(dev_image); a.L = L; a.B = B;
+  long total = B;
+  for (int k = 1; k <= L; ++k) {
+    const int q = h->relu_q[k];
+    if (!dual[k - 1] || !primal[q - 1] || !primal[q]) return fail(GNNB_E_INVALID, "gnnb_scatter_amb_records: null array (layer %d)", k);
+    a.dual[k - 1] = dual[k - 1]; a.z_pre[k - 1] = primal[q - 1]; a.z_post[k - 1] = primal[q];
+    total += (long)B * h->N[k];                          // (upper bound: the kernel reads the real counts from the image)
+  }
+  if (!primal[n_primal - 1]) return fail(GNNB_E_INVALID, "gnnb_scatter_amb_records: null primals[-1]");
+  a.z_out = primal[n_primal - 1];
+  // (grid-stride: sized for an eighth of the nodes being ambiguous, correct for any share)
+  hipLaunchKernelGGL(k_scatter_amb, dim3((unsigned)std::min<long>(1024, (total / 8 + 255) / 256 + 1)), dim3(256), 0, (hipStream_t)stream, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(GNNB_E_HIP, "launch of k_scatter_amb failed: %s", hipGetErrorString(e));
   return GNNB_OK;
 }
 

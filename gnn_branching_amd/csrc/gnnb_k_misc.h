@@ -672,3 +672,33 @@ __global__ __launch_bounds__(TAIL_WAVES * 64, 1) void k_scored_tail(TailArgs a) 
   TT_MARK(wave < nchain ? 9 : 4);             // finish
   TT_FLUSH(wave == 0 || wave == nchain);
 }
+
+// ---- k_scatter_amb: the compact records of a host-fed batch (gnnb_pack_amb_records) -> full-size dual / primal arrays --------------------
+// image (32-bit words): hdr[16] = {magic, L, n_records, B, 0 ..}; n_records x {layer k - 1, flat node index b N_k + n, dual[:, 1], dual[:, 2],
+// primal_pre, primal_post} in any order; then zout[B] = primals[-1].  One thread per record / per z_out entry, grid-stride (the record count
+// is only known on the device).
+#define AMBREC_MAGIC 0x414d4252
+#define AMBREC_WORDS 6
+struct ScatterArgs {
+  const int* image;
+  float* dual[MAXL]; float* z_pre[MAXL]; float* z_post[MAXL]; float* z_out;
+  int L, B;
+};
+__global__ void k_scatter_amb(ScatterArgs a) {
+  const int* hdr = a.image;
+  const long nrec = hdr[2];
+  const long total = nrec + a.B;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    if (i < nrec) {
+      const int* r = a.image + 16 + i * AMBREC_WORDS;
+      const int k = r[0], g = r[1];
+      if ((unsigned)k >= (unsigned)a.L) continue;         // (a corrupt image must not write out of bounds)
+      a.dual[k][(long)g * 3 + 1] = __int_as_float(r[2]);
+      a.dual[k][(long)g * 3 + 2] = __int_as_float(r[3]);
+      a.z_pre[k][g] = __int_as_float(r[4]);
+      a.z_post[k][g] = __int_as_float(r[5]);
+    } else {
+      a.z_out[i - nrec] = __int_as_float(a.image[16 + nrec * AMBREC_WORDS + (i - nrec)]);
+    }
+  }
+}

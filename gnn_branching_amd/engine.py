@@ -115,13 +115,20 @@ class HostFedPipeline:
     set's copies before its forward.  Host tensors are copied straight from where they are, in pieces of 2 MB (see `submit`): from
     pinned memory the copies are asynchronous DMA that hides under the running forward; from pageable memory the runtime stages them
     (the host blocks per piece, the GPU still overlaps them with the previous forward).
+    ``compact`` (default): of ``dual_vars`` and ``primals`` the forward reads only the entries of AMBIGUOUS nodes (and primals[-1]), so those
+    tensors do not cross the link whole: ``gnnb_pack_amb_records`` gathers, on a few host threads, {index, dual[:, 1], dual[:, 2],
+    primal_pre, primal_post} of the nodes with lb < 0 < ub into a pinned image (base B = 256: 1.2 MB instead of 17 MB), the image is
+    copied, and one launch (``gnnb_scatter_amb_records``) writes the records into the slot's full-size device tensors in front of the
+    forward.  36.5 -> 21 MB per base batch: the copies hide under the forward again.
     Scores are bit-identical to ``engine.forward`` on device-resident inputs (tests/test_gpu_hostfed.py)."""
 
     PIECE = 1 << 19            # floats per copy (2 MB)
     SMALL = 1 << 20            # bytes: tensors below it are staged together
 
-    def __init__(self, engine, depth=2):
+    def __init__(self, engine, depth=2, compact=True):
         self.eng, self.depth = engine, max(2, int(depth))
+        self.compact = bool(compact)
+        self.link_bytes = 0
         self.copy_stream = torch.cuda.Stream(device=engine.device)
         self.slots = [None] * self.depth          # per slot: dict(key=shape signature, dev=[tensors], pin=[tensors or None], ev_copy, ev_done)
         self.i = 0
@@ -141,7 +148,10 @@ class HostFedPipeline:
     def submit(self, lower_bounds_all, upper_bounds_all, dual_vars, primals, primal_inputs, layers, masks):
         eng = self.eng
         host = self._flat_inputs(lower_bounds_all, upper_bounds_all, dual_vars, primals, primal_inputs, masks)
-        key = tuple((tuple(t.shape)) for t in host)
+        nb, nd, npr = len(lower_bounds_all), len(dual_vars), len(primals)
+        compact = self.compact and all(t.device.type == "cpu" for t in host)
+        skip = set(range(2 * nb, 2 * nb + nd + npr)) if compact else set()      # dual_vars / primals: records instead of whole tensors
+        key = (compact,) + tuple((tuple(t.shape)) for t in host)
         k = self.i % self.depth
         self.i += 1
         sl = self.slots[k]
@@ -152,7 +162,7 @@ class HostFedPipeline:
                     sl["ev_done"].synchronize()
                 # tensors below SMALL bytes share ONE pinned staging block and ONE device block (a copy of a few KB costs ~10 us of the copy
                 # queue's time each, tools/hostfed_probe.py: a batch has a dozen of them); the big ones get their own device tensors
-                small = [j for j, t in enumerate(host) if t.numel() * 4 < self.SMALL]
+                small = [j for j, t in enumerate(host) if t.numel() * 4 < self.SMALL and j not in skip]
                 offs, tot = {}, 0
                 for j in small:
                     offs[j] = tot
@@ -163,10 +173,28 @@ class HostFedPipeline:
                        for j, t in enumerate(host)]
                 sl = {"key": key, "dev": dev, "offs": offs, "dev_small": dev_small, "pin_small": pin_small, "pin_np": pin_small.numpy(),
                       "ev_copy": torch.cuda.Event(), "ev_done": torch.cuda.Event(), "used": False}
+                if compact:
+                    eng.bind(layers["fixed_layers"], tuple(host[0].shape[1:]))
+                    for j in skip:
+                        dev[j].zero_()                # (entries of nodes that are never ambiguous are never read: zero, not garbage)
+                    cap = int(eng.lib.gnnb_amb_records_bytes(eng.h, int(host[0].shape[0])))
+                    sl["img_cap"] = cap
+                    sl["pin_img"] = torch.empty(cap // 4, dtype=torch.int32, pin_memory=True)
+                    sl["dev_img"] = torch.empty(cap // 4, dtype=torch.int32, device=eng.device)
                 self.slots[k] = sl
             if sl["used"]:
                 sl["ev_copy"].synchronize()          # the staging block of this set is free again (its last copies have left the host)
             self.copy_stream.wait_event(sl["ev_done"]) if sl["used"] else None      # the forward that last read this set has finished
+            used_words = 0
+            if compact:
+                B = int(host[0].shape[0])
+                tabs = [(C.c_void_p * n)(*[t.data_ptr() for t in g]) for n, g in
+                        ((nb, host[:nb]), (nb, host[nb:2 * nb]), (nd, host[2 * nb:2 * nb + nd]), (npr, host[2 * nb + nd:2 * nb + nd + npr]))]
+                hb = _lib.Batch(tabs[0], tabs[1], tabs[2], tabs[3], host[-2].data_ptr(), None, None, host[-1].data_ptr(), nb, nd, npr)
+                used = C.c_size_t(0)
+                _lib.check(eng.lib.gnnb_pack_amb_records(eng.h, C.byref(hb), B, sl["pin_img"].data_ptr(), sl["img_cap"], C.byref(used)),
+                           "gnnb_pack_amb_records")
+                used_words = (used.value + 3) // 4
             offs, pin_np = sl["offs"], sl["pin_np"]
             for j, o in offs.items():                # (host memcpy of the small tensors into the shared staging block: < 1 MB in all)
                 t = host[j]
@@ -186,8 +214,10 @@ class HostFedPipeline:
                             sl["dev"][j].copy_(host[j], non_blocking=True)
                     else:
                         sl["dev_small"].copy_(sl["pin_small"], non_blocking=True)
+                for o in range(0, used_words, self.PIECE):                 # the record image of the ambiguous nodes
+                    sl["dev_img"][o:min(o + self.PIECE, used_words)].copy_(sl["pin_img"][o:min(o + self.PIECE, used_words)], non_blocking=True)
                 for j, t in enumerate(host):
-                    if j in offs:
+                    if j in offs or j in skip:
                         continue
                     # pieces of at most 2 MB: measured on MI355X / ROCm 7.2 (tools/hostfed_probe.py), 21 pinned copies of 1.7 MB on a side
                     # stream hide completely under the forward (0.85 ms with or without them), ONE 36.5 MB copy beside the same forward
@@ -198,8 +228,13 @@ class HostFedPipeline:
                         dv[o:o + self.PIECE].copy_(sv[o:o + self.PIECE], non_blocking=True)
                 sl["ev_copy"].record(self.copy_stream)
             cur.wait_event(sl["ev_copy"])
-            nb, nd, npr = len(lower_bounds_all), len(dual_vars), len(primals)
+            self.link_bytes = 4 * (used_words + sum(t.numel() for j, t in enumerate(host) if j not in skip))      # what this submit sent over the link
             d = sl["dev"]
+            if compact:                              # records -> the slot's full-size dual / primal tensors, one launch in front of the forward
+                dptr = (C.c_void_p * nd)(*[t.data_ptr() for t in d[2 * nb:2 * nb + nd]])
+                pptr = (C.c_void_p * npr)(*[t.data_ptr() for t in d[2 * nb + nd:2 * nb + nd + npr]])
+                _lib.check(eng.lib.gnnb_scatter_amb_records(eng.h, sl["dev_img"].data_ptr(), int(host[0].shape[0]), dptr, nd, pptr, npr,
+                                                            C.c_void_p(cur.cuda_stream)), "gnnb_scatter_amb_records")
             res = eng.forward(d[:nb], d[nb:2 * nb], d[2 * nb:2 * nb + nd], d[2 * nb + nd:2 * nb + nd + npr], d[-2], layers, d[-1])
             # the result outlives the slot: its mask must not be a view of the slot's device buffer, which the submit `depth` calls
             # later overwrites (a held result's ragged() would then be cut with another batch's mask).  Cloned on the compute stream,

@@ -100,6 +100,24 @@ int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* scores_padded, i
  * memory; the call returns after synchronising `stream`.  Staging buffers and the workspace belong to the handle. */
 int gnnb_forward_host(gnnb_t* h, const gnnb_batch* in, int B, float* scores, int32_t* decisions, int32_t* status, void* stream);
 
+/* Host-fed batches, fewer bytes over the link (reference graph_score.py:26-30 moves EVERY tensor whole).  Of `dual_vars` and `primals` the
+ * forward reads only the entries of AMBIGUOUS ReLU nodes (the relaxation terms of graph_conv.py:153-161 and :273-293 are multiplied by
+ * amb = 0 everywhere else) and the network output primals[-1]: 4 floats for ~7 % of the nodes instead of 5 for all of them.
+ *   gnnb_amb_records_bytes   upper bound of the record image of a batch of B (every node ambiguous)
+ *   gnnb_pack_amb_records    HOST: `in` holds HOST pointers laid out as for gnnb_forward (only lb / ub of the ReLU layers, dual, primal
+ *                            are read).  Writes to `dst` (host memory, e.g. pinned; >= cap bytes) for every ReLU layer the nodes with
+ *                            lb < 0 < ub -- a superset of the nodes the device classifies as ambiguous -- as records {layer, flat index
+ *                            b N_k + n, dual[:, 1], dual[:, 2], primal_pre, primal_post} in no particular order, then primals[-1];
+ *                            *used = bytes written.  Runs on a dozen helper threads that belong to the handle (created on first use,
+ *                            joined by gnnb_destroy).
+ *   gnnb_scatter_amb_records DEVICE: one launch on `stream` that writes the records of an image copied to device memory into full-size
+ *                            device arrays dual[k] (B N_k, 3) / primal[m] laid out as gnnb_forward expects them; entries of other nodes
+ *                            are left as they are (the forward never reads them).  Then call gnnb_forward on those arrays: scores are
+ *                            the bits of a forward on the whole tensors. */
+size_t gnnb_amb_records_bytes(const gnnb_t* h, int B);
+int gnnb_pack_amb_records(const gnnb_t* h, const gnnb_batch* in, int B, void* dst, size_t cap, size_t* used);
+int gnnb_scatter_amb_records(gnnb_t* h, const void* dev_image, int B, float* const* dual, int n_relu, float* const* primal, int n_primal, void* stream);
+
 /* BaBSR ("KW") branching heuristic for a batch -- the fallback scorer of the BaB loop (reference
  * plnn/kw_score_conv.py choose_node_conv :41-113, called at plnn/relu_conv_gnnkwthreshold.py:157).  lb/ub: HOST tables of
  * n_graph DEVICE pointers laid out like struct gnnb_batch.lb, .ub -- only the ReLU layers 1..L are read; prop_w (B, N_L); mask (B, R) 1.0 where the

@@ -9,8 +9,9 @@ from tests.test_gpu_parity import make_model
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("compact", [True, False])
 @pytest.mark.parametrize("pinned", [False, True])
-def test_host_fed_pipeline_is_bit_identical_and_reuses_its_buffers(pinned):
+def test_host_fed_pipeline_is_bit_identical_and_reuses_its_buffers(pinned, compact):
     from gnn_branching_amd import engine as E, synth
     model = make_model("shipped")
     eng = model.engine()
@@ -24,7 +25,7 @@ def test_host_fed_pipeline_is_bit_identical_and_reuses_its_buffers(pinned):
             d[4], d[6] = args[4].to(dev), args[6].to(dev)
             r = eng.forward(*d).check()
             want.append((r.scores.cpu().numpy(), r.decisions.cpu().numpy(), [t.cpu().numpy() for t in r.ragged()]))
-    pipe = E.HostFedPipeline(eng)
+    pipe = E.HostFedPipeline(eng, compact=compact)       # compact: dual_vars / primals cross the link as records of the ambiguous nodes only
     results = []
     with torch.no_grad():
         for b in batches:
@@ -41,3 +42,68 @@ def test_host_fed_pipeline_is_bit_identical_and_reuses_its_buffers(pinned):
         # submit two calls later overwrites): the ragged score lists are cut with it
         got = [t.cpu().numpy() for t in r.ragged()]
         assert len(got) == len(wr) and all(np.array_equal(g, w) for g, w in zip(got, wr))
+
+
+@pytest.mark.parametrize("net,B", [("cifar_base_kw", 40), ("cifar_deep_kw", 9)])
+def test_amb_record_image_and_scatter(net, B):
+    """gnnb_pack_amb_records / gnnb_scatter_amb_records (include/gnnb.h): the image holds exactly the nodes with lb < 0 < ub of every ReLU
+    layer, in index order, with dual[:, 1], dual[:, 2] and the two primals of the node -- and primals[-1]; scattered into poisoned
+    full-size arrays, those entries (and only those) carry the batch's values.  LP-like signed duals and decided nodes included."""
+    import ctypes as C
+    from gnn_branching_amd import _lib, synth
+    model = make_model("shipped")
+    eng = model.engine()
+    batch = synth.make_batch(net, B, seed=21)
+    rng = np.random.RandomState(3)
+    args = list(batch.forward_args())
+    args[2] = [torch.from_numpy(rng.standard_normal(tuple(t.shape)).astype(np.float32)) for t in args[2]]      # duals of either sign
+    lbs, ubs, duals, prims, x, layers, mask = args
+    eng.bind(layers["fixed_layers"], tuple(lbs[0].shape[1:]))
+    nb, nd, npr = len(lbs), len(duals), len(prims)
+    host = [t.float().contiguous() for t in list(lbs) + list(ubs) + list(duals) + list(prims)]
+    tabs = [(C.c_void_p * n)(*[t.data_ptr() for t in g]) for n, g in ((nb, host[:nb]), (nb, host[nb:2 * nb]), (nd, host[2 * nb:2 * nb + nd]), (npr, host[2 * nb + nd:]))]
+    hb = _lib.Batch(tabs[0], tabs[1], tabs[2], tabs[3], None, None, None, None, nb, nd, npr)
+    cap = int(eng.lib.gnnb_amb_records_bytes(eng.h, B))
+    img = torch.zeros(cap // 4, dtype=torch.int32)
+    used = C.c_size_t(0)
+    _lib.check(eng.lib.gnnb_pack_amb_records(eng.h, C.byref(hb), B, img.data_ptr(), cap, C.byref(used)), "gnnb_pack_amb_records")
+    words = img.numpy()
+    L = nd
+    nrec = int(words[2])
+    assert words[1] == L and words[3] == B and used.value == 4 * (16 + 6 * nrec + ((B + 3) & ~3)) <= cap
+    rec = words[16:16 + 6 * nrec].reshape(nrec, 6)
+    relu_q = [i for i, l in enumerate(layers["fixed_layers"]) if isinstance(l, torch.nn.ReLU)]
+    total = 0
+    for k in range(L):
+        lb, ub = lbs[k + 1].reshape(-1).numpy(), ubs[k + 1].reshape(-1).numpy()
+        want = np.flatnonzero((lb < 0) & (ub > 0))
+        mine = rec[rec[:, 0] == k]
+        mine = mine[np.argsort(mine[:, 1], kind="stable")]        # (the records come in whatever order the packer's threads finished)
+        assert np.array_equal(mine[:, 1], want)
+        vals = mine[:, 2:].copy().view(np.float32)
+        d = duals[k].numpy().reshape(-1, 3)
+        assert np.array_equal(vals[:, 0], d[want, 1]) and np.array_equal(vals[:, 1], d[want, 2])
+        assert np.array_equal(vals[:, 2], prims[relu_q[k] - 1].numpy()[want]) and np.array_equal(vals[:, 3], prims[relu_q[k]].numpy()[want])
+        total += len(want)
+    assert total == nrec
+    assert np.array_equal(words[16 + 6 * nrec:16 + 6 * nrec + B].view(np.float32), prims[-1].numpy())
+    # ---- scatter into NaN-poisoned arrays on the device
+    dev = eng.device
+    d_img = img[:used.value // 4].to(dev)
+    d_dual = [torch.full(tuple(t.shape), float("nan"), device=dev) for t in duals]
+    d_prim = [torch.full(tuple(t.shape), float("nan"), device=dev) for t in prims]
+    dptr = (C.c_void_p * nd)(*[t.data_ptr() for t in d_dual])
+    pptr = (C.c_void_p * npr)(*[t.data_ptr() for t in d_prim])
+    _lib.check(eng.lib.gnnb_scatter_amb_records(eng.h, d_img.data_ptr(), B, dptr, nd, pptr, npr, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+               "gnnb_scatter_amb_records")
+    torch.cuda.synchronize()
+    for k in range(L):
+        lb, ub = lbs[k + 1].reshape(-1), ubs[k + 1].reshape(-1)
+        amb = (lb < 0) & (ub > 0)
+        got = d_dual[k].cpu().reshape(-1, 3)
+        assert torch.equal(got[amb][:, 1:], duals[k].reshape(-1, 3)[amb][:, 1:])
+        assert torch.isnan(got[~amb]).all() and torch.isnan(got[:, 0]).all()
+        for m in (relu_q[k] - 1, relu_q[k]):
+            gp = d_prim[m].cpu().reshape(-1)
+            assert torch.equal(gp[amb], prims[m].reshape(-1)[amb]) and torch.isnan(gp[~amb]).all()
+    assert torch.equal(d_prim[-1].cpu().reshape(-1), prims[-1].reshape(-1))
