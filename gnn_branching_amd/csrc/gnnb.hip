@@ -183,6 +183,9 @@ struct gnnb_handle {
   bool scored_gather = true;    // the restricted last step's aggregate one wave per scored node (k_gather_scored); GNNB_DEV: GNNB_NO_SCORED_GATHER=1
   bool use_top = true;          // fuse the top of the network (last Linear edge, last ReLU layer, property node) into k_top
   bool top_ok = false;          // ... which the bound network allows (set by gnnb_bind_network)
+  int clspre_b = 0;             // GNNB_CLSPRE_B=1: batches of 2 and more classify and run the hoisted feature chains in ONE launch (k_classify_pre_b: every
+                                // block takes a slice of every layer) instead of two (k_classify, k_pre).  Bit-identical, one launch less, and measured a
+                                // wash (profiles/r05_classify_pre_merged_ab.txt: base B=256 58.1 us against 14.2 + 40.5): off by default
   int clspre_max_b = 1;         // GNNB_CLSPRE_MAX_B: batches up to it classify and run the hoisted feature chains in one launch (k_classify_pre);
                                 // measured (base, us): B = 1 27.5 vs 7.6 + 22.1, B = 2 34.0 vs 30.0, B = 8 42.5 vs 31.8 -- a block's share of
                                 // the ambiguous nodes is uneven, so beyond one subproblem the two kernels' even dealing wins
@@ -387,6 +390,8 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   if (const char* e = getenv("GNNB_TAIL_MAX_B")) h->tail_max_b = atoi(e);
   if (const char* e = getenv("GNNB_GATHER_BF3")) h->gather_bf3 = e[0] == '1';
   if (const char* e = getenv("GNNB_CLSPRE_MAX_B")) h->clspre_max_b = atoi(e);
+  if (const char* e = getenv("GNNB_CLSPRE_B")) h->clspre_b = e[0] != '0';
+  HIPCHK(hipFuncSetAttribute((const void*)k_classify_pre_b, hipFuncAttributeMaxDynamicSharedMemorySize, (size_t)PackPreBwdL3::FLOATS * 4));
   if (const char* e = getenv("GNNB_TOP_FUSE_UPD")) h->top_fuse_upd = !(e[0] == '0');
   if (const char* e = getenv("GNNB_TOP_SPLIT")) h->top_split_max = atoi(e) >= 4 ? 4 : (atoi(e) >= 2 ? 2 : 1);
   HIPCHK(hipFuncSetAttribute((const void*)k_classify_pre, hipFuncAttributeMaxDynamicSharedMemorySize, CLSPRE_LDS_BYTES));
@@ -1069,6 +1074,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   }
   // a single subproblem: k_classify and k_pre in one launch (k_classify_pre; GNNB_CLSPRE_MAX_B, default 1)
   const bool cls_pre = h->bf3 && B <= h->clspre_max_b;
+  bool cls_pre_b = false;
   {
     ClassifyArgs a{};
     a.L = L; a.mask = in->mask; a.scores = scores; a.cnt = cnt + 4; a.R = h->R;
@@ -1086,7 +1092,16 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       blk += (int)((a.G[i] + CLS_BLOCK - 1) / CLS_BLOCK);
     }
     a.blk0[L] = blk;
-    if (cls_pre) lz.run(PC_CLASSIFY, [&] { hipLaunchKernelGGL(k_classify_pre, dim3((unsigned)blk), dim3(CLS_THREADS), CLSPRE_LDS_BYTES, st, a, pre); });
+    // batches: one launch too, every block a slice of every layer (k_classify_pre_b) -- while a block's passes x layers fit its segment table
+    if (!cls_pre && h->bf3 && h->clspre_b && !debug_full) {
+      const int grid = h->n_cu;
+      long slots = 0;
+      for (int k = 1; k <= L; ++k) slots += ((((long)B * h->N[k] + grid - 1) / grid + 63) & ~63L) / 64;
+      cls_pre_b = (slots + CLSM_SLOTS - 1) / CLSM_SLOTS + L <= CLSM_SEGS;
+      for (int k = 1; k <= L; ++k) cls_pre_b = cls_pre_b && (long)B * h->N[k] < (1L << 31);
+    }
+    if (cls_pre_b) lz.run(PC_CLASSIFY, [&] { hipLaunchKernelGGL(k_classify_pre_b, dim3((unsigned)h->n_cu), dim3(CLS_THREADS), (size_t)PackPreBwdL3::FLOATS * 4, st, a, pre); });
+    else if (cls_pre) lz.run(PC_CLASSIFY, [&] { hipLaunchKernelGGL(k_classify_pre, dim3((unsigned)blk), dim3(CLS_THREADS), CLSPRE_LDS_BYTES, st, a, pre); });
     else lz.run(PC_CLASSIFY, [&] { hipLaunchKernelGGL(k_classify, dim3((unsigned)blk), dim3(CLS_THREADS), 0, st, a); });
   }
 
@@ -1144,7 +1159,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     if (!embed_in_gather) lz.run(PC_EMBED, [&] { hipLaunchKernelGGL(k_embed, dim3((unsigned)grid), dim3(256), 0, st, a); });
     proj[0] = L_INP_F_1;
   }
-  if (!cls_pre) {
+  if (!cls_pre && !cls_pre_b) {
     long nt = 0;                                      // upper bound: the kernel reads the real counts on the device
     for (int k = 1; k <= L; ++k) nt += (((long)B * h->N[k] + 31) / 32) * 2;
     const PreAllArgs& a = pre;

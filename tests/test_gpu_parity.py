@@ -550,6 +550,37 @@ def test_small_batch_classify_pre_kernel_is_bit_identical(monkeypatch, net, B, f
     print(f"{net} B={B} {fam}: {launches['8']} launches per forward")
 
 
+@pytest.mark.parametrize("net,B", [("cifar_base_kw", 2), ("cifar_base_kw", 37), ("cifar_base_kw", 256), ("cifar_deep_kw", 128), ("cifar_wide_kw", 200),
+                                   ("cifar_deep_kw", 700)])
+@pytest.mark.parametrize("fam", ["shipped", "random"])
+def test_batch_classify_pre_kernel_is_bit_identical(monkeypatch, net, B, fam):
+    """GNNB_CLSPRE_B=1, for batches (B >= 2): classification and the hoisted feature chains in ONE launch, every block a slice of every layer
+    (k_classify_pre_b; opt-in: measured a wash) -- against the default (k_classify + k_pre).  Same lists up to order, P' rows addressed by node id, every
+    node's chain its own column of an MFMA tile: identical scores and decisions, one launch less; workspace NaN-poisoned in between.
+    (cifar_wide_kw B = 200 and cifar_deep_kw B = 700 need several classification passes per block.)"""
+    from gnn_branching_amd import synth
+    batch = synth.make_batch(net, B, seed=80 + B)
+    out, launches = {}, {}
+    for knob in ("0", "1"):
+        monkeypatch.setenv("GNNB_CLSPRE_B", knob)
+        model = make_model(fam)
+        eng = model.engine()
+        with torch.no_grad():
+            model.forward_device(*batch.forward_args()).check()
+            eng.workspace(B).view(torch.float32).fill_(float("nan"))
+            eng.profile_enable(True)
+            eng.profile_read(reset=True)
+            res = model.forward_device(*batch.forward_args()).check()
+            prof = eng.profile_read(reset=True)
+            eng.profile_enable(False)
+            again = model.forward_device(*batch.forward_args()).check()
+        out[knob] = (res.scores.cpu().numpy(), res.decisions.cpu().tolist())
+        assert np.array_equal(again.scores.cpu().numpy(), out[knob][0], equal_nan=True)
+        launches[knob] = sum(v[1] for v in prof.values())
+    assert np.array_equal(out["0"][0], out["1"][0], equal_nan=True) and out["0"][1] == out["1"][1]
+    assert launches["1"] == launches["0"] - 1, launches
+
+
 @pytest.mark.gpu
 def test_profile_trace_lists_the_launches_of_a_forward_in_order():
     """gnnb_profile_trace: class and duration of every launch gnnb_profile_read resolved, in launch order (bench.py prices single launches
