@@ -12,6 +12,6 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_REQ_sum" ; do
   i=$((i+1))
   if [ -n "$PMC_PASSES" ] && ! echo " $PMC_PASSES " | grep -q " $i "; then continue; fi
-  timeout -k 10 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$TAG/p$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-fp32 --no-aggregate-only "$@" > $R/gpurun_out/pmc_$TAG/p$i.log 2>&1 || { echo "pass $i failed"; tail -3 $R/gpurun_out/pmc_$TAG/p$i.log; break; }
+  timeout -k 10 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$TAG/p$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-fp32 --no-aggregate-only --no-two-in-flight --no-host-fed "$@" > $R/gpurun_out/pmc_$TAG/p$i.log 2>&1 || { echo "pass $i failed"; tail -3 $R/gpurun_out/pmc_$TAG/p$i.log; break; }
 done
 ls -R $R/gpurun_out/pmc_$TAG | head -30

@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT; TAG=${1:-r02}; shift
 O=$R/gpurun_out/prof_$TAG; mkdir -p $O
 cd $R && timeout -k 10 500 python3 bench.py "$@" > $O/bench.json 2> $O/bench.err || { echo "bench failed"; tail -5 $O/bench.err; exit 1; }
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline --no-exact-fp32 --no-aggregate-only "$@" > $O/stats.log 2>&1 || { echo "stats failed"; tail -5 $O/stats.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline --no-exact-fp32 --no-aggregate-only --no-two-in-flight --no-host-fed "$@" > $O/stats.log 2>&1 || { echo "stats failed"; tail -5 $O/stats.log; exit 1; }
 cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv
 cd $R && bash tools/pmc.sh $TAG "$@" > $O/pmc.log 2>&1
 python3 tools/pmc_table.py $TAG $O/pmc_summary.json > $O/pmc_table.txt 2>&1
