@@ -34,6 +34,7 @@
 #include <vector>
 #include <chrono>
 #include <thread>
+#include <unistd.h>
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -113,6 +114,7 @@ struct WorkPool {
   long gen = 0;
   int busy = 0;
   bool stop = false;
+  pid_t owner = getpid();             // a forked child inherits the object but not the threads: it makes a pool of its own (gnnb_pack_amb_records)
   explicit WorkPool(int n) {
     for (int i = 0; i < n; ++i)
       th.emplace_back([this] {
@@ -461,7 +463,7 @@ extern "C" int gnnb_destroy(gnnb_t* h) {
   if (h->hs_scores) (void)hipFree(h->hs_scores);
   if (h->hs_dec) (void)hipFree(h->hs_dec);
   free_trainer(h);
-  delete h->work_pool;
+  if (h->work_pool && h->work_pool->owner == getpid()) delete h->work_pool;
   for (auto& ev : h->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
   for (auto& ev : h->pool) (void)hipEventDestroy(ev);
   delete h;
@@ -822,7 +824,7 @@ static WsLayout ws_layout(const gnnb_t* h, int B) {
   for (int k = 1; k < K; ++k) { w.sf[k] = off; off += align64((size_t)B * h->N[k]); }
   for (int k = 0; k < K - 1; ++k) { w.sb[k] = off; off += align64((size_t)B * h->N[k]); }
   w.F1 = off; off += align64((size_t)B * h->N[1] * 64);
-  w.F3 = off; off += align64((size_t)B * h->N[1] * ROW3_FLOATS);
+  w.F3 = off; off += h->gather_bf3 ? align64((size_t)B * h->N[1] * ROW3_FLOATS) : 0;      // rows3 of layer 1: only the opt-in GNNB_GATHER_BF3=1 path writes / reads them (base B=256: 400 MB)
   w.Q = off; off += (size_t)map_tiles(bwd_map(h, 0), B) * 2048;
   w.total = off;
   return w;
@@ -1704,6 +1706,7 @@ extern "C" int gnnb_pack_amb_records(const gnnb_t* hc, const gnnb_batch* in, int
     }
   };
   if (items.size() >= 8) {
+    if (h->work_pool && h->work_pool->owner != getpid()) h->work_pool = nullptr;      // (after a fork: the parent's threads are not here; its object is left alone)
     if (!h->work_pool) h->work_pool = new WorkPool(11);
     h->work_pool->run(work);
   } else {

@@ -216,6 +216,11 @@ __device__ __forceinline__ bool fusedq_body(const FArgs& a, float* lds, int tpha
 #endif
 
   QT_MARK(chain_role ? 5 : 0);                      // gather tables staged, queue header zeroed (both roles)
+#if defined(Q_PRIO) && Q_PRIO == 1                  // dev A/B: static priority for one role (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+  if (chain_role) __builtin_amdgcn_s_setprio(1);
+#elif defined(Q_PRIO) && Q_PRIO == 2
+  if (!chain_role) __builtin_amdgcn_s_setprio(1);
+#endif
   if (chain_role) {
     // ---------------- chain wave ----------------
     // The node-update weights (74 KB + 24 KB of POST) are staged by the chain waves alone while the gather waves, which only need the
