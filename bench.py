@@ -123,7 +123,7 @@ def plan_flops(plan, B, stats, restrict_last=True, per_launch=None):
                                    "bytes": src_row_bytes * B * u["n_src"] + 4.0 * 64 * n_upd,
                                    "survey_bytes": 4.0 * 64 * B * (u["n_src"] + u["nodes"])})
             # folded chains, last layer deferred.  bf16x3 (default): a tile of nodes with r0 == r1 runs 2 blocks of 48 bf16 MFMAs (+2 small),
-            # a tile that holds an ambiguous node 3; fp32 MFMA only (GNNB_BF3=0): 130 / 194 fp32 MFMAs
+            # a tile that holds an ambiguous node 3; fp32 MFMA only (option bf3=0): 130 / 194 fp32 MFMAs
             live, amb = stats[k]["live"], stats[k]["amb"]
             post = u["update"] == "bwd" and k == 1 and t < T - 1 and upd in ("k_node_update", "k_gather_update")
             if upd == "k_top" and k == len(plan["sizes"]) - 2:      # layer L: one workgroup per sample, every node of the layer through the general chain
@@ -255,6 +255,23 @@ class StepLoop:
             self.pending = None
 
 
+def dist_run_description(dist, elapsed, steps, local_scores, gathered, top_split):
+    """What a multi-GPU run says about itself in the `dist` record (all ranks must call it: one small all-gather of every rank's own wall
+    time): the process group's world size as the backend reports it, each rank's ms per step (`value` uses the maximum), the bytes ONE
+    score all-gather moves per rank, and which k_top mode the handles ran in.  tests/test_parallel_gloo.py runs it under gloo."""
+    world = int(dist.get_world_size())
+    t = torch.tensor([elapsed], dtype=torch.float64, device=local_scores.device)
+    every = torch.empty(world, dtype=torch.float64, device=local_scores.device)
+    dist.all_gather_into_tensor(every, t)
+    rank_ms = [round(1e3 * float(x) / steps, 4) for x in every.cpu().tolist()]
+    return {"process_group_world_size": world, "backend": dist.get_backend(),
+            "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
+            "gather_bytes_per_step": {"sent_per_rank": int(local_scores.numel() * local_scores.element_size()),
+                                      "received_per_rank": int(gathered.numel() * gathered.element_size())},
+            "k_top_split": int(top_split),
+            "k_top_split_note": "1 = k_top never waits for a partner workgroup: the rule for handles that run beside a collective (DESIGN.md section 6)"}
+
+
 def _status_word(res):
     v = 0
     for x in res.status.cpu().tolist():
@@ -300,8 +317,8 @@ def parse_args(argv=None):
     ap.add_argument("--net", default=None)
     ap.add_argument("--batch", type=int, default=None, help="subproblems per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-exact-fp32", action="store_true", help="skip the GNNB_BF3=0 comparison leg (exact_fp32_ms_per_step, bf3_max_abs_delta)")
-    ap.add_argument("--no-aggregate-only", action="store_true", help="skip the GNNB_FUSE=0 leg (roofline_aggregate_only: the stand-alone edge-aggregation kernel)")
+    ap.add_argument("--no-exact-fp32", action="store_true", help="skip the exact-fp32 comparison leg (handle option bf3=0: exact_fp32_ms_per_step, bf3_max_abs_delta)")
+    ap.add_argument("--no-aggregate-only", action="store_true", help="skip the fuse=0 leg (roofline_aggregate_only: the stand-alone edge-aggregation kernel)")
     ap.add_argument("--no-two-in-flight", action="store_true", help="skip the two-batches-in-flight leg (two_batches_in_flight: engine.BatchPipeline, throughput only)")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed leg (host_fed_ms_per_step: the same batch from pinned / pageable host tensors through engine.HostFedPipeline)")
     ap.add_argument("--cpu-budget", type=float, default=75.0, help="seconds of CPU work for the cpu_baseline leg")
@@ -354,6 +371,12 @@ def main():
     model = GraphNet(2, 64)
     model.load_state_dict(sd)
     model.eval()
+    if use_dist:
+        # whenever a collective can be in flight beside a forward (StepLoop overlaps the all-gather of batch i with
+        # forward i + 1, and RCCL's kernel holds CUs), the handle is created with k_top's workgroup split OFF -- its split workgroups
+        # spin-wait on partner workgroups that must all be resident (parallel.DIST_ENGINE_OPTIONS)
+        from gnn_branching_amd import parallel
+        model.engine_options = dict(parallel.DIST_ENGINE_OPTIONS)
     eng = model.engine()
 
     B = args.batch
@@ -418,7 +441,9 @@ def main():
     gc.enable()
     if trace is not None:
         print("host ms per timed step():", trace, file=sys.stderr)
+    run_desc = None
     if use_dist:
+        run_desc = dist_run_description(dist, elapsed, args.steps, res.scores, loop.last_gathered, eng.get_option("top_split"))
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -440,7 +465,8 @@ def main():
         same = bool(torch.equal(got, plain.scores))
         assert same, "all-gathered scores differ from the non-distributed forward"
         assert loop.gathers_completed >= args.steps, (loop.gathers_completed, args.steps)
-        dist_record = {"backend": dist.get_backend(), "world_size": world, "gathers_completed": loop.gathers_completed,
+        dist_record = {"world_size": world, **run_desc,      # (what the first real multi-GPU run needs to be self-describing)
+                       "gathers_completed": loop.gathers_completed,
                        "gathered_rows": int(loop.last_gathered.shape[0]), "gathered_equals_plain_forward_bitwise": same,
                        # the OR over every step of the run -- the forwards that overlapped an all-gather -- and the plain forward's
                        "status_word": int(_status_word(plain)) | (int(loop.status_acc.cpu()[0]) if loop.status_acc is not None and loop.status_acc.numel() else 0),
@@ -553,7 +579,7 @@ def main():
                        "bytes_per_subproblem": message_passing_bytes(sizes, 1, T),
                        "note": "achieved = SURVEY 8(d) algorithmic bytes 4*p*(N_src + N_dst) per half-pass / time of all half-pass kernels; "
                                "frac_counter = HBM bytes the counters saw (dead rows are skipped, round 0 computes its source rows) / the same time"}
-        # ---- the same batch with every block on the exact-fp32 MFMA (GNNB_BF3=0 is read by gnnb_create: a second handle),
+        # ---- the same batch with every block on the exact-fp32 MFMA (handle option bf3=0 on a second handle),
         # outside the timed region of the headline: what the three-piece bf16 blocks buy, and how far their scores are from it.
         # A side leg never takes the headline down with it: a failure is recorded in the JSON (`side_leg_errors`).
         side_errors = {}
@@ -576,18 +602,16 @@ def main():
         exact_ms = bf3_delta = None
         if plan.get("bf3") and not args.no_exact_fp32:
             try:
-                with _env(GNNB_BF3="0"):
-                    exact_ms, bf3_delta = exact_fp32_leg(sd, d_args, res, max(args.steps, 100))
+                exact_ms, bf3_delta = exact_fp32_leg(sd, d_args, res, max(args.steps, 100))
             except Exception as e:      # noqa: BLE001
                 side_errors["exact_fp32"] = f"{type(e).__name__}: {e}"
         # ---- the edge aggregation ALONE ("standalone message-passing (aggregate-only) kernel for the HBM-roofline
-        # measurement, plus the fused production variant"): the same batch through a second handle with GNNB_FUSE=0, where every conv
+        # measurement, plus the fused production variant"): the same batch through a second handle with option fuse=0, where every conv
         # half-pass is k_gather (aggregate rows -> HBM) + k_node_update; identical scores.  Outside the timed region of the headline.
         agg_only = None
         if not args.no_aggregate_only:
             try:
-                with _env(GNNB_FUSE="0", GNNB_NO_EMBED_FUSE="1", GNNB_TAIL_MAX_B="0"):      # (the restricted last step's aggregate as its own launch too)
-                    agg_only = aggregate_only_leg(sd, d_args, res, args, batch, stats, B)
+                agg_only = aggregate_only_leg(sd, d_args, res, args, batch, stats, B)
             except Exception as e:      # noqa: BLE001
                 side_errors["aggregate_only"] = f"{type(e).__name__}: {e}"
                 agg_only = {"error": side_errors["aggregate_only"]}
@@ -633,30 +657,11 @@ def main():
         dist.destroy_process_group()
 
 
-class _env:
-    """Set environment variables for the duration of a side leg and put back what was there (a value the user exported survives)."""
-
-    def __init__(self, **kv):
-        self.kv, self.old = kv, {}
-
-    def __enter__(self):
-        for k, v in self.kv.items():
-            self.old[k] = os.environ.get(k)
-            os.environ[k] = v
-
-    def __exit__(self, *exc):
-        for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-        return False
-
-
 def exact_fp32_leg(sd, d_args, res, steps):
     from gnn_branching_amd.graphnet.graph_conv import GraphNet
     model32 = GraphNet(2, 64)
     model32.load_state_dict(sd)
+    model32.engine_options = {"bf3": 0}           # a second handle with every block on the exact-fp32 MFMA
     eng32 = model32.eval().engine()
     for _ in range(40):           # (a new handle: bind, allocations -- the GPU idled meanwhile and its clocks dropped)
         r32 = eng32.forward(*d_args)
@@ -766,7 +771,7 @@ def dist_two_in_flight_leg(sd, d_args, plain, steps, total_batch, rank, B, one_h
     from gnn_branching_amd.engine import BatchPipeline
     pipe = BatchPipeline(sd, depth=2)
     pend = [None, None]
-    state = {"done": 0, "last": None, "status": None}
+    state = {"done": 0, "last": None, "status": [None] * pipe.depth}      # one status accumulator per slot: each is only touched on its slot's stream
 
     def step():
         k = pipe.i % pipe.depth
@@ -781,7 +786,7 @@ def dist_two_in_flight_leg(sd, d_args, plain, steps, total_batch, rank, B, one_h
             word = res.status[0:1]
             for c in range(1, res.status.numel()):
                 word = word | res.status[c:c + 1]
-            state["status"] = word.clone() if state["status"] is None else (state["status"] | word.to(state["status"].device))
+            state["status"][k] = word.clone() if state["status"][k] is None else (state["status"][k] | word)
         return res
 
     def drain():
@@ -799,7 +804,7 @@ def dist_two_in_flight_leg(sd, d_args, plain, steps, total_batch, rank, B, one_h
         for _ in range(48):
             step()
         drain()
-        state["status"] = None
+        state["status"] = [None] * pipe.depth
         n0 = state["done"]
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -810,7 +815,10 @@ def dist_two_in_flight_leg(sd, d_args, plain, steps, total_batch, rank, B, one_h
         gc.enable()
     got = state["last"][rank * B:(rank + 1) * B]
     same = bool(torch.equal(got, plain.scores))
-    status = int(state["status"].cpu()[0]) if state["status"] is not None else 0
+    status = 0
+    for acc in state["status"]:        # (after drain(): every stream is synchronised, the accumulators are final)
+        if acc is not None:
+            status |= int(acc.cpu()[0])
     if not same or status != 0:
         raise RuntimeError(f"two handles in flight + all-gather: gathered == plain forward {same}, status word {status}")
     return {"ms_per_batch": round(ms, 4), "one_handle_ms_per_step": one_handle_ms, "over_one_handle": round(ms / one_handle_ms, 3),
@@ -846,6 +854,9 @@ def aggregate_only_leg(sd, d_args, res, args, batch, stats, B):
     from gnn_branching_amd.graphnet.graph_conv import GraphNet
     modelA = GraphNet(2, 64)
     modelA.load_state_dict(sd)
+    # every conv half-pass as k_gather (aggregate rows -> HBM) + k_node_update, round 0's rows from k_embed, and the restricted last
+    # step's aggregate as its own launch too
+    modelA.engine_options = {"fuse": 0, "embed_fuse": 0, "tail_max_b": 0}
     engA = modelA.eval().engine()
     for _ in range(40):           # (a new handle: the GPU idled while it was built and its clocks dropped)
         rA = engA.forward(*d_args)
@@ -914,11 +925,11 @@ def aggregate_only_leg(sd, d_args, res, args, batch, stats, B):
                         "counter_over_rows_moved": round(counter / moved, 3) if counter else None})
     msA, nA = profA.get("k_gather", (0.0, 0))
     if not nA:
-        return {"error": "no k_gather launch in the GNNB_FUSE=0 run"}
+        return {"error": "no k_gather launch in the fuse=0 run"}
     strict = sum(planA["T"] * 4.0 * 64 * B * (u["n_src"] + u["nodes"]) for u in planA["updates"]
                  if u["update"] != "input" and u["kernel"].split("+")[0] == "k_gather")
     sA = msA * 1e-3 / args.steps
-    return {"kernel": "k_gather (edge aggregate alone: GNNB_FUSE=0 GNNB_NO_EMBED_FUSE=1 GNNB_TAIL_MAX_B=0 -- rows to HBM, node update, input embedding and score head in their own launches)",
+    return {"kernel": "k_gather (edge aggregate alone: handle options fuse=0 embed_fuse=0 tail_max_b=0 -- rows to HBM, node update, input embedding and score head in their own launches)",
             "bound": "hbm", "same_scored_set_as_default_path": same_set, "same_decisions_as_default_path": same_dec,
             "max_abs_score_delta_vs_default_path": agg_delta,
             "avg_launch_us": round(1e3 * msA / nA, 2), "launches_per_step": int(nA // args.steps), "peak": PEAK_HBM_GBS, "unit": "GB/s",

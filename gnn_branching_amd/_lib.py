@@ -43,7 +43,12 @@ SYMBOLS = [
     ("gnnb_forward_host", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("gnnb_amb_records_bytes", C.c_size_t, [C.c_void_p, C.c_int]),
     ("gnnb_pack_amb_records", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
-    ("gnnb_scatter_amb_records", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
+    ("gnnb_scatter_amb_records", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_void_p,
+                                           C.c_void_p]),
+    ("gnnb_set_option", C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    ("gnnb_get_option", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
+    ("gnnb_option_count", C.c_int, []),
+    ("gnnb_option_name", C.c_char_p, [C.c_int]),
     ("gnnb_babsr", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p,
                              C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("gnnb_mu_projection", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
@@ -60,12 +65,43 @@ SYMBOLS = [
     ("gnnb_describe", C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     ("gnnb_mu_location", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     ("gnnb_set_halfpass_limit", C.c_int, [C.c_void_p, C.c_int]),
+    ("gnnb_debug_occupy", C.c_int, [C.c_int, C.c_int, C.c_size_t, C.c_double, C.c_void_p]),
     ("gnnb_profile_enable", C.c_int, [C.c_void_p, C.c_int]),
     ("gnnb_profile_classes", C.c_int, []),
     ("gnnb_profile_class_name", C.c_char_p, [C.c_int]),
     ("gnnb_profile_read", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int, C.c_int]),
     ("gnnb_profile_trace", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int]),
 ]
+
+
+# Handle options (gnnb_set_option) and the environment names the PYTHON host accepts for them.  libgnnb.so reads no environment
+# variable; `ScorerEngine(options=...)` is the interface.  The environment names exist for the parity tests and bench.py's side legs,
+# which select an implementation per test with monkeypatch.setenv: they are read once, when an engine is created, and go through
+# gnnb_set_option like any other option (never written by this package).  value = (option, transform of the variable's integer).
+OPTION_ENV = {
+    "GNNB_BF3": ("bf3", lambda v: int(v != 0)),
+    "GNNB_FUSE": ("fuse", lambda v: int(v != 0)),
+    "GNNB_NO_TOP": ("top", lambda v: int(v == 0)),
+    "GNNB_NO_GATHER": ("gather", lambda v: int(v == 0)),
+    "GNNB_NO_EMBED_FUSE": ("embed_fuse", lambda v: int(v == 0)),
+    "GNNB_NO_DENSE_LDS": ("dense_lds", lambda v: int(v == 0)),
+    "GNNB_TAIL_MAX_B": ("tail_max_b", lambda v: max(0, min(v, 1 << 30))),
+    "GNNB_TOP_SPLIT": ("top_split", lambda v: 4 if v >= 4 else (2 if v >= 2 else 1)),
+    "GNNB_TOP_FUSE_UPD": ("top_fuse_upd", lambda v: int(v != 0)),
+    "GNNB_CLSPRE_MAX_B": ("clspre_max_b", lambda v: max(0, min(v, 1 << 30))),
+}
+OPTIONS = tuple(sorted({o for o, _ in OPTION_ENV.values()}))
+
+
+def options_from_env(env=None):
+    """{option: value} for the OPTION_ENV variables that are set (read-only view of the environment)."""
+    env = os.environ if env is None else env
+    out = {}
+    for name, (opt, f) in OPTION_ENV.items():
+        v = env.get(name)
+        if v is not None and v.strip() != "":
+            out[opt] = f(int(v))
+    return out
 
 
 BUILD_ID_MARK = b"GNNB_BUILD_ID:"

@@ -35,6 +35,7 @@
 #include <chrono>
 #include <thread>
 #include <unistd.h>
+#include <sched.h>
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -136,7 +137,9 @@ struct WorkPool {
         }
       });
   }
+  std::mutex callers;                 // one run() at a time: `job` points into the caller's frame (two pipelines on one engine, ctypes drops the GIL)
   void run(const std::function<void()>& f) {      // f on every worker and on the caller; returns when all are done
+    std::lock_guard<std::mutex> one(callers);
     {
       std::lock_guard<std::mutex> lk(m);
       job = &f; ++gen; busy = (int)th.size();
@@ -174,10 +177,6 @@ struct gnnb_handle {
                                 // gathers, bit 1 = 32-node gathers, bit 2 = the input-layer gather
   bool gather16 = true;         // forward conv edges: 16-node tiles on the 16x16x4 MFMA when their window is smaller
   bool embed_fuse = true;       // round 0: the first forward gather computes the input embedding itself (no k_embed, no mu[0] rows)
-  int owned = 0;                // dev A/B (GNNB_OWNED=1): k_gather_update_q with sample-owned tiles when the batch is a multiple of the grid
-  int sweep = 0;                // GNNB_SWEEP=1: consecutive fused conv half-passes as ONE launch (k_sweep: sample-owned tiles, a workgroup barrier between
-                                // phases) when the batch is a multiple of the CU count.  Bit-identical; measured (profiles/r05_sweep_ab.txt) -1 % per step on
-                                // cifar_deep_kw B = 256 and +1.4 % on cifar_base_kw B = 256: off by default
   int fuse = 1;                 // conv half-passes as ONE kernel (k_gather_update_q: the aggregate never reaches HBM) wherever that kernel
                                 // exists (measured faster at every batch size and on all three networks: base B = 256 0.975 vs 1.014 ms,
                                 // deep B = 1024 6.59 vs 7.31 ms, B = 1 0.344 vs 0.359 ms); GNNB_FUSE=0: always two kernels.  Both forms
@@ -185,14 +184,11 @@ struct gnnb_handle {
   bool scored_gather = true;    // the restricted last step's aggregate one wave per scored node (k_gather_scored); GNNB_DEV: GNNB_NO_SCORED_GATHER=1
   bool use_top = true;          // fuse the top of the network (last Linear edge, last ReLU layer, property node) into k_top
   bool top_ok = false;          // ... which the bound network allows (set by gnnb_bind_network)
-  int clspre_b = 0;             // GNNB_CLSPRE_B=1: batches of 2 and more classify and run the hoisted feature chains in ONE launch (k_classify_pre_b: every
-                                // block takes a slice of every layer) instead of two (k_classify, k_pre).  Bit-identical, one launch less, and measured a
-                                // wash (profiles/r05_classify_pre_merged_ab.txt: base B=256 58.1 us against 14.2 + 40.5): off by default
   int clspre_max_b = 1;         // GNNB_CLSPRE_MAX_B: batches up to it classify and run the hoisted feature chains in one launch (k_classify_pre);
                                 // measured (base, us): B = 1 27.5 vs 7.6 + 22.1, B = 2 34.0 vs 30.0, B = 8 42.5 vs 31.8 -- a block's share of
                                 // the ambiguous nodes is uneven, so beyond one subproblem the two kernels' even dealing wins
-  bool gather_bf3 = false;      // GNNB_GATHER_BF3=1: the input update's aggregate on the bf16 matrix rate (the rows F of layer 1 written as three bf16 pieces,
-                                // gather_tile_sparse_bf3).  Measured SLOWER (base B=256: k_gather_input_update 115 -> 140 us): off by default, kept as the A/B
+  bool gather_bf3 = false;      // GNNB_DEV builds only (GNNB_GATHER_BF3=1): the input update's aggregate on the bf16 matrix rate (rows of layer 1 as three bf16
+                                // pieces, gather_tile_sparse_bf3).  Measured SLOWER (base B=256: 115 -> 140 us, docs/DESIGN_HISTORY.md): not instantiated in the shipped library
   int tail_max_b = 1 << 30;     // GNNB_TAIL_MAX_B: batches up to it end in k_scored_tail (scored gather + restricted update + score head in one launch); 0: three kernels
   bool top_fuse_upd = true;     // GNNB_TOP_FUSE_UPD=0: the backward node update of layer L-1 as its own launch behind k_top (it runs inside k_top otherwise)
   int top_split_max = 4;        // GNNB_TOP_SPLIT: 4 (default) = four workgroups per sample while B <= n_cu / 4, two while B <= n_cu / 2; 2 = two at most; 1 = never
@@ -253,7 +249,11 @@ static int upload(float** d, const float* h, size_t n) {
 
 // (re)build the operand packs of the scorer from a parameter blob and put them on the device
 static int load_weights(gnnb_t* h, const float* w_blob, hipStream_t st) {
+#ifdef GNNB_DEV
   static const bool timing = std::getenv("GNNB_PACK_TIMING") != nullptr;       // dev aid: where the time of this call goes, to stderr
+#else
+  constexpr bool timing = false;
+#endif
   const auto t_start = std::chrono::steady_clock::now();
   h->blob.assign(w_blob, w_blob + blob_floats());
   build_packs(h->blob.data(), h->packs);
@@ -304,6 +304,90 @@ static const char g_build_id[] = "GNNB_BUILD_ID:" GNNB_SRC_HASH;
 extern "C" const char* gnnb_build_id(void) { return g_build_id + 14; }
 extern "C" const char* gnnb_last_error(void) { return g_err.c_str(); }
 
+
+// ---- handle options (include/gnnb.h gnnb_set_option) ---------------------------------------------------------------------------------
+// The shipped library reads NO environment variable: every switch a caller, a test or bench.py can flip goes through this table.  Each
+// option selects between implementations that compute the same scores (bit-identical unless the comment says otherwise), so the parity
+// tests use them as independent implementations of one another (INTEGRATION.md lists the test of each).
+struct OptDesc { const char* name; int lo, hi; bool before_bind; };
+static const OptDesc kOptions[] = {
+    {"bf3", 0, 1, false},             // 1: 64x64 blocks on the bf16 matrix rate with three-piece operands; 0: every block exact fp32 MFMA (and no k_top)
+    {"fuse", 0, 1, false},            // 1: a conv half-pass is ONE kernel (k_gather_update_q); 0: k_gather + k_node_update
+    {"top", 0, 1, false},             // 1: the top of the network in k_top; 0: separate kernels (fp32 MFMA edges)
+    {"gather", 0, 1, true},           // 1: MFMA gathers for conv edges; 0: the VALU conv kernels + flat node update
+    {"embed_fuse", 0, 1, false},      // 1: round 0's input embedding computed inside the first gather; 0: k_embed writes the rows
+    {"dense_lds", 0, 1, true},        // 1: Linear edges one workgroup per sample out of LDS; 0: the per-tile dense kernel (the fallback of wide layers)
+    {"tail_max_b", 0, 1 << 30, false},    // batches up to it end in k_scored_tail; 0: k_gather_scored + k_node_update + k_score
+    {"top_split", 1, 4, false},       // most workgroups k_top spreads one sample over (1, 2 or 4); 1 = never wait for a partner workgroup
+    {"top_fuse_upd", 0, 1, false},    // 1: the backward update of layer L-1 inside k_top; 0: its own launch behind it
+    {"clspre_max_b", 0, 1 << 30, false},  // batches up to it classify and run the hoisted feature chains in one launch (k_classify_pre)
+};
+static int* opt_field(gnnb_t* h, int i, bool** bf) {
+  *bf = nullptr;
+  switch (i) {
+    case 0: *bf = &h->bf3; return nullptr;
+    case 1: return &h->fuse;
+    case 2: *bf = &h->use_top; return nullptr;
+    case 3: *bf = &h->use_gather; return nullptr;
+    case 4: *bf = &h->embed_fuse; return nullptr;
+    case 5: *bf = &h->dense_lds; return nullptr;
+    case 6: return &h->tail_max_b;
+    case 7: return &h->top_split_max;
+    case 8: *bf = &h->top_fuse_upd; return nullptr;
+    default: return &h->clspre_max_b;
+  }
+}
+static int opt_index(const char* name) {
+  if (!name) return -1;
+  for (int i = 0; i < (int)(sizeof kOptions / sizeof kOptions[0]); ++i)
+    if (!strcmp(name, kOptions[i].name)) return i;
+  return -1;
+}
+extern "C" int gnnb_option_count(void) { return (int)(sizeof kOptions / sizeof kOptions[0]); }
+extern "C" const char* gnnb_option_name(int i) { return i >= 0 && i < gnnb_option_count() ? kOptions[i].name : ""; }
+extern "C" int gnnb_set_option(gnnb_t* h, const char* name, int value) {
+  if (!h) return fail(GNNB_E_INVALID, "gnnb_set_option: null handle");
+  const int i = opt_index(name);
+  if (i < 0) return fail(GNNB_E_INVALID, "gnnb_set_option: unknown option '%s'", name ? name : "(null)");
+  const OptDesc& d = kOptions[i];
+  if (value < d.lo || value > d.hi) return fail(GNNB_E_INVALID, "gnnb_set_option: %s = %d outside [%d, %d]", d.name, value, d.lo, d.hi);
+  if (d.before_bind && h->bound) return fail(GNNB_E_STATE, "gnnb_set_option: %s must be set before gnnb_bind_network (it shapes the tables built there)", d.name);
+  bool* bf = nullptr;
+  int* f = opt_field(h, i, &bf);
+  if (bf) *bf = value != 0;
+  else *f = (i == 7) ? (value >= 4 ? 4 : (value >= 2 ? 2 : 1)) : value;
+  return GNNB_OK;
+}
+extern "C" int gnnb_get_option(const gnnb_t* h, const char* name, int* value) {
+  if (!h || !value) return fail(GNNB_E_INVALID, "gnnb_get_option: null argument");
+  const int i = opt_index(name);
+  if (i < 0) return fail(GNNB_E_INVALID, "gnnb_get_option: unknown option '%s'", name ? name : "(null)");
+  bool* bf = nullptr;
+  int* f = opt_field(const_cast<gnnb_t*>(h), i, &bf);
+  *value = bf ? (*bf ? 1 : 0) : *f;
+  return GNNB_OK;
+}
+#ifdef GNNB_DEV
+// development builds (-DGNNB_DEV: tools/ablate) keep environment overrides for A/B runs of paths the shipped library does not expose
+static void dev_env_overrides(gnnb_t* h) {
+  if (const char* e = getenv("GNNB_ZERO_DEAD")) h->zero_dead = e[0] == '1';
+  if (const char* e = getenv("GNNB_S_IN_GATHER")) h->s_in_gather = e[0] != '0';
+  if (const char* e = getenv("GNNB_GIU_OCC")) h->giu_occ = atoi(e) < 1 ? 1 : atoi(e);
+  if (const char* e = getenv("GNNB_GATHER_OCC")) h->gather_occ = atoi(e) < 1 ? 1 : atoi(e);
+  if (const char* e = getenv("GNNB_NO_GATHER16")) h->gather16 = !(e[0] == '1');
+  if (const char* e = getenv("GNNB_SPARSE")) h->gather_sparse = atoi(e);
+  if (const char* e = getenv("GNNB_NO_RESTRICT")) h->restrict_last = !(e[0] == '1');
+  if (const char* e = getenv("GNNB_NO_SCORED_GATHER")) h->scored_gather = !(e[0] == '1');
+  if (const char* e = getenv("GNNB_PER_SAMPLE_MIN_B")) h->per_sample_min_b = atoi(e);
+  if (const char* e = getenv("GNNB_GATHER_BF3")) h->gather_bf3 = e[0] == '1';
+  for (int i = 0; i < gnnb_option_count(); ++i) {      // GNNB_OPT_<NAME>=<int> for every option of the table
+    std::string k = std::string("GNNB_OPT_") + kOptions[i].name;
+    for (auto& c : k) c = (char)toupper((unsigned char)c);
+    if (const char* e = getenv(k.c_str())) (void)gnnb_set_option(h, kOptions[i].name, atoi(e));
+  }
+}
+#endif
+
 extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, int T, int p) {
   if (!out || !w_blob) return fail(GNNB_E_INVALID, "gnnb_create: null argument");
   if (p != P) return fail(GNNB_E_INVALID, "gnnb_create: embedding size %d unsupported (kernels are built for p=64)", p);
@@ -336,71 +420,34 @@ extern "C" int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, i
   HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpdL3::FLOATS + 6144) * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpdL3::FLOATS + 6144) * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_node_update<12, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (PackUpdL3::FLOATS + 6144) * 4));
-  if (const char* e = getenv("GNNB_BF3")) h->bf3 = e[0] == '1';
-#ifdef GNNB_DEV
-  if (const char* e = getenv("GNNB_ZERO_DEAD")) h->zero_dead = e[0] == '1';
-#endif
-#ifdef GNNB_DEV
-  if (const char* e = getenv("GNNB_S_IN_GATHER")) h->s_in_gather = e[0] != '0';
-#endif
-#ifdef GNNB_DEV
-  if (const char* e = getenv("GNNB_GIU_OCC")) h->giu_occ = atoi(e) < 1 ? 1 : atoi(e);
-#endif
-#ifdef GNNB_DEV
-  if (const char* e = getenv("GNNB_GATHER_OCC")) h->gather_occ = atoi(e) < 1 ? 1 : atoi(e);
-#endif
   HIPCHK(hipFuncSetAttribute((const void*)k_input_update, hipFuncAttributeMaxDynamicSharedMemorySize, PackUpdInp::FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_score, hipFuncAttributeMaxDynamicSharedMemorySize, PackScore::FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_gather<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_gather<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_gather16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_gather16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-#ifdef GNNB_DEV
-  if (const char* e = getenv("GNNB_NO_GATHER16")) h->gather16 = !(e[0] == '1');
-#endif
-#ifdef GNNB_DEV
-  if (const char* e = getenv("GNNB_SPARSE")) h->gather_sparse = atoi(e);
-#endif
   HIPCHK(hipFuncSetAttribute((const void*)k_gather16<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-  if (const char* e = getenv("GNNB_NO_EMBED_FUSE")) h->embed_fuse = !(e[0] == '1');      // (bench.py's aggregate-only leg: round 0's rows from k_embed)
   HIPCHK(hipFuncSetAttribute((const void*)k_livesum, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-#ifdef GNNB_DEV
-  if (const char* e = getenv("GNNB_NO_RESTRICT")) h->restrict_last = !(e[0] == '1');
-#endif
-  if (const char* e = getenv("GNNB_NO_DENSE_LDS")) h->dense_lds = !(e[0] == '1');
   HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void*)k_gather<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-  if (const char* e = getenv("GNNB_NO_GATHER")) h->use_gather = !(e[0] == '1');
-  if (const char* e = getenv("GNNB_NO_TOP")) h->use_top = !(e[0] == '1');
-  if (!h->bf3) h->use_top = false;      // k_top's edges and chains only exist on the bf16 x 3 rate: GNNB_BF3=0 (every block exact fp32) takes the separate kernels
 #ifdef GNNB_DEV
-  if (const char* e = getenv("GNNB_NO_SCORED_GATHER")) h->scored_gather = !(e[0] == '1');
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather_input_update<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #endif
+  HIPCHK(hipFuncSetAttribute((const void*)k_gather<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
 
-  if (const char* e = getenv("GNNB_FUSE")) h->fuse = e[0] - '0';
-  if (const char* e = getenv("GNNB_OWNED")) h->owned = e[0] == '1';
-  if (const char* e = getenv("GNNB_SWEEP")) h->sweep = e[0] != '0';
-  HIPCHK(hipFuncSetAttribute((const void*)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #define FUSEDQ_ATTR(L, S, P) HIPCHK(hipFuncSetAttribute((const void*)k_gather_update_q<L, S, P>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
   FUSEDQ_ATTR(16, 0, false); FUSEDQ_ATTR(16, 1, false); FUSEDQ_ATTR(16, 2, false); FUSEDQ_ATTR(32, 1, false); FUSEDQ_ATTR(32, 1, true);
 #undef FUSEDQ_ATTR
-  if (const char* e = getenv("GNNB_PER_SAMPLE_MIN_B")) h->per_sample_min_b = atoi(e);
-  if (const char* e = getenv("GNNB_TAIL_MAX_B")) h->tail_max_b = atoi(e);
-  if (const char* e = getenv("GNNB_GATHER_BF3")) h->gather_bf3 = e[0] == '1';
-  if (const char* e = getenv("GNNB_CLSPRE_MAX_B")) h->clspre_max_b = atoi(e);
-  if (const char* e = getenv("GNNB_CLSPRE_B")) h->clspre_b = e[0] != '0';
-  HIPCHK(hipFuncSetAttribute((const void*)k_classify_pre_b, hipFuncAttributeMaxDynamicSharedMemorySize, (size_t)PackPreBwdL3::FLOATS * 4));
-  if (const char* e = getenv("GNNB_TOP_FUSE_UPD")) h->top_fuse_upd = !(e[0] == '0');
-  if (const char* e = getenv("GNNB_TOP_SPLIT")) h->top_split_max = atoi(e) >= 4 ? 4 : (atoi(e) >= 2 ? 2 : 1);
   HIPCHK(hipFuncSetAttribute((const void*)k_classify_pre, hipFuncAttributeMaxDynamicSharedMemorySize, CLSPRE_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void*)k_scored_tail, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));      // (the kernel also has a few static words)
   HIPCHK(hipFuncSetAttribute((const void*)k_top<4>, hipFuncAttributeMaxDynamicSharedMemorySize, TOP_LDS_FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_top<2>, hipFuncAttributeMaxDynamicSharedMemorySize, TOP_LDS_FLOATS * 4));
   HIPCHK(hipFuncSetAttribute((const void*)k_top<1>, hipFuncAttributeMaxDynamicSharedMemorySize, TOP_LDS_FLOATS * 4));
+#ifdef GNNB_DEV
+  dev_env_overrides(h);
+#endif
   *out = h;
   return GNNB_OK;
 }
@@ -687,12 +734,6 @@ extern "C" int gnnb_debug_wall(unsigned long long* out, int nwords) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qt_wall), (size_t)nwords * 8) == hipSuccess ? 0 : -1;
 }
 #endif
-#ifdef SWEEP_TIMING
-// dev: the stamps of the last k_sweep launch (see gnnb_k_fusedq.h)
-extern "C" int gnnb_debug_sweep_wall(unsigned long long* out, int nwords) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sw_wall), (size_t)nwords * 8) == hipSuccess ? 0 : -1;
-}
-#endif
 #ifdef FUSED_TIMING
 // dev: cycle sums of k_gather_update's phases over every wave since the last reset (index 15: number of waves)
 extern "C" int gnnb_debug_read(unsigned long long* out, int reset) {
@@ -765,7 +806,7 @@ extern "C" int gnnb_describe(const gnnb_t* h, char* buf, size_t cap) {
     }
     o += t;
   };
-  const bool top = h->use_top && h->top_ok;     // k_top covers the edge into layer L, both updates of layer L and the edge back
+  const bool top = h->use_top && h->bf3 && h->top_ok;     // k_top covers the edge into layer L, both updates of layer L and the edge back
   bool first = true;
   for (int k = 1; k <= L; ++k) {
     if (!first) o += ", ";
@@ -859,6 +900,19 @@ extern "C" int gnnb_set_halfpass_limit(gnnb_t* h, int n) {
   return GNNB_OK;
 }
 
+// Inspection: occupy `n_workgroups` CUs (one workgroup each when lds_bytes > 80 KiB) for `ms` milliseconds (<= 500) on `stream` with a kernel that
+// only spins on the clock -- the stand-in for "something else holds CUs" (an RCCL kernel, a second batch) in tests/test_gpu_dist_safety.py.
+extern "C" int gnnb_debug_occupy(int n_workgroups, int threads, size_t lds_bytes, double ms, void* stream) {
+  if (n_workgroups < 1 || n_workgroups > 4096 || threads < 64 || threads > 1024 || lds_bytes > 160 * 1024 || !(ms > 0.0) || ms > 500.0)
+    return fail(GNNB_E_INVALID, "gnnb_debug_occupy: bad arguments");
+  static bool attr = false;
+  if (!attr) { HIPCHK(hipFuncSetAttribute((const void*)k_occupy, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+  hipLaunchKernelGGL(k_occupy, dim3((unsigned)n_workgroups), dim3((unsigned)threads), lds_bytes, (hipStream_t)stream, (unsigned long long)(ms * 1e5));
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(GNNB_E_HIP, "launch of k_occupy failed: %s", hipGetErrorString(e));
+  return GNNB_OK;
+}
+
 // ---- profiling ----
 extern "C" int gnnb_profile_enable(gnnb_t* h, int on) {
   if (!h) return fail(GNNB_E_INVALID, "null handle");
@@ -903,30 +957,10 @@ extern "C" int gnnb_profile_trace(gnnb_t* h, int* cls, double* ms, int cap) {
   return n;
 }
 
-// the fused conv half-passes enqueued since the last launch of anything else: they go out together as one k_sweep (Launcher::run flushes)
-struct SweepQueue {
-  SweepArgs sa;
-  size_t lds = 0;
-  unsigned grid = 0;
-  int launches = 0;
-  bool busy = false;
-  SweepQueue() { sa.nphase = 0; }
-};
-
 struct Launcher {
   gnnb_t* h;
   hipStream_t st;
   int rc = 0;
-  SweepQueue* sq = nullptr;
-  void flush() {
-    if (!sq || sq->busy || sq->sa.nphase == 0) return;
-    sq->busy = true;
-    sq->sa.ordinal = sq->launches++;
-    run(PC_GATHER_UPDATE, [&] { hipLaunchKernelGGL(k_sweep, dim3(sq->grid), dim3((QG_WAVES + QC_WAVES) * 64), sq->lds, st, sq->sa); });
-    sq->sa.nphase = 0;
-    sq->lds = 0;
-    sq->busy = false;
-  }
   hipEvent_t get_event() {
     if (!h->pool.empty()) { hipEvent_t e = h->pool.back(); h->pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
@@ -935,7 +969,6 @@ struct Launcher {
   }
   template <class F>
   void run(int cls, F&& f) {
-    flush();                       // (whatever is launched next may read what the queued half-passes write)
     if (rc) return;
     if (h->prof) {
       gnnb_handle::Ev ev{cls, get_event(), get_event()};
@@ -993,9 +1026,6 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   float* ws = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
   Launcher lz{h, st};
-  SweepQueue sweepq;
-  const bool sweep_on = h->sweep && h->fuse != 0 && B % h->n_cu == 0;      // sample-owned tiles need an even deal of the samples over the workgroups
-  if (sweep_on) lz.sq = &sweepq;
   auto mu = [&](int k) { return ws + w.mu[k]; };
   float* nb = ws + w.nb;
 
@@ -1034,7 +1064,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   // three pieces (the POST block of layer 1's backward update); inspection runs keep fp32 rows
   const bool input_rows3 = h->gather_bf3 && h->bf3 && !debug_full && h->gb[1].ok && h->gb[1].taps3 && h->gb[1].g.lanes == 32 && (h->gather_sparse & 4);
   const bool embed_in_gather = h->embed_fuse && !debug_full && h->gf[1].ok;
-  const bool top_fused = h->use_top && h->top_ok && !debug_full && per_sample;
+  const bool top_fused = h->use_top && h->bf3 && h->top_ok && !debug_full && per_sample;      // (k_top only exists on the bf16 x 3 rate)
   // The rows of dead nodes are zero by definition (mu = (.) * live).  Every default consumer of a layer's rows walks only the
   // live ones (sparse gathers, the compacted Linear edges of k_top, the score head), so nothing needs them in memory; they
   // are written (k_classify) only for a layer with a consumer that reads every row: VALU / non-sparse gathers, the
@@ -1076,7 +1106,6 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
   }
   // a single subproblem: k_classify and k_pre in one launch (k_classify_pre; GNNB_CLSPRE_MAX_B, default 1)
   const bool cls_pre = h->bf3 && B <= h->clspre_max_b;
-  bool cls_pre_b = false;
   {
     ClassifyArgs a{};
     a.L = L; a.mask = in->mask; a.scores = scores; a.cnt = cnt + 4; a.R = h->R;
@@ -1094,16 +1123,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       blk += (int)((a.G[i] + CLS_BLOCK - 1) / CLS_BLOCK);
     }
     a.blk0[L] = blk;
-    // batches: one launch too, every block a slice of every layer (k_classify_pre_b) -- while a block's passes x layers fit its segment table
-    if (!cls_pre && h->bf3 && h->clspre_b && !debug_full) {
-      const int grid = h->n_cu;
-      long slots = 0;
-      for (int k = 1; k <= L; ++k) slots += ((((long)B * h->N[k] + grid - 1) / grid + 63) & ~63L) / 64;
-      cls_pre_b = (slots + CLSM_SLOTS - 1) / CLSM_SLOTS + L <= CLSM_SEGS;
-      for (int k = 1; k <= L; ++k) cls_pre_b = cls_pre_b && (long)B * h->N[k] < (1L << 31);
-    }
-    if (cls_pre_b) lz.run(PC_CLASSIFY, [&] { hipLaunchKernelGGL(k_classify_pre_b, dim3((unsigned)h->n_cu), dim3(CLS_THREADS), (size_t)PackPreBwdL3::FLOATS * 4, st, a, pre); });
-    else if (cls_pre) lz.run(PC_CLASSIFY, [&] { hipLaunchKernelGGL(k_classify_pre, dim3((unsigned)blk), dim3(CLS_THREADS), CLSPRE_LDS_BYTES, st, a, pre); });
+    if (cls_pre) lz.run(PC_CLASSIFY, [&] { hipLaunchKernelGGL(k_classify_pre, dim3((unsigned)blk), dim3(CLS_THREADS), CLSPRE_LDS_BYTES, st, a, pre); });
     else lz.run(PC_CLASSIFY, [&] { hipLaunchKernelGGL(k_classify, dim3((unsigned)blk), dim3(CLS_THREADS), 0, st, a); });
   }
 
@@ -1161,7 +1181,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     if (!embed_in_gather) lz.run(PC_EMBED, [&] { hipLaunchKernelGGL(k_embed, dim3((unsigned)grid), dim3(256), 0, st, a); });
     proj[0] = L_INP_F_1;
   }
-  if (!cls_pre && !cls_pre_b) {
+  if (!cls_pre) {
     long nt = 0;                                      // upper bound: the kernel reads the real counts on the device
     for (int k = 1; k <= L; ++k) nt += (((long)B * h->N[k] + 31) / 32) * 2;
     const PreAllArgs& a = pre;
@@ -1352,17 +1372,8 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
                   a.sw_from_gather ? sout : nullptr};
       a.u = upd_args(k, fwd, false, post_input);
       a.qtiles = nq;
-      a.owned = ((h->owned || sweep_on) && B % h->n_cu == 0) ? B : 0;
       const long nrounds = (nt + QG_WAVES - 1) / QG_WAVES;
       const dim3 g((unsigned)std::max<long>(1, std::min<long>(nrounds, h->n_cu))), b((QG_WAVES + QC_WAVES) * 64);
-      if (sweep_on) {
-        if (sweepq.sa.nphase == SWEEP_MAX) lz.flush();
-        const int i = sweepq.sa.nphase++;
-        sweepq.sa.kind[i] = d.g.lanes == 16 ? (embed_src ? 2 : (sparse ? 1 : 0)) : (post_input ? 4 : 3);
-        sweepq.sa.ph[i] = a;
-        sweepq.lds = std::max(sweepq.lds, ldsq);
-        sweepq.grid = g.x;
-      } else
       lz.run(PC_GATHER_UPDATE, [&] {
         if (d.g.lanes == 16) {
           if (embed_src) hipLaunchKernelGGL((k_gather_update_q<16, 2, false>), g, b, ldsq, st, a);
@@ -1390,8 +1401,10 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
       long giu_grid = (nt + nw - 1) / nw;
       if (giu_grid > (long)h->n_cu * (r3 ? 1 : h->giu_occ)) giu_grid = (long)h->n_cu * (r3 ? 1 : h->giu_occ);
       lz.run(PC_GATHER_INPUT, [&] {
-        if (r3) hipLaunchKernelGGL((k_gather_input_update<true, true, true>), dim3(giu_grid), dim3(GIU_R3_WAVES * 64), lds, st, a);
-        else if (sparse && h->bf3) hipLaunchKernelGGL((k_gather_input_update<true, true>), dim3(giu_grid), dim3(WG_MLP), lds, st, a);
+#ifdef GNNB_DEV
+        if (r3) { hipLaunchKernelGGL((k_gather_input_update<true, true, true>), dim3(giu_grid), dim3(GIU_R3_WAVES * 64), lds, st, a); return; }
+#endif
+        if (sparse && h->bf3) hipLaunchKernelGGL((k_gather_input_update<true, true>), dim3(giu_grid), dim3(WG_MLP), lds, st, a);
         else if (sparse) hipLaunchKernelGGL((k_gather_input_update<true, false>), dim3(giu_grid), dim3(WG_MLP), lds, st, a);
         else if (h->bf3) hipLaunchKernelGGL((k_gather_input_update<false, true>), dim3(giu_grid), dim3(WG_MLP), lds, st, a);
         else hipLaunchKernelGGL((k_gather_input_update<false, false>), dim3(giu_grid), dim3(WG_MLP), lds, st, a);
@@ -1507,7 +1520,6 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     ++done;
   }
 
-  lz.flush();
   // scores (graph_conv.py:442-450) and decision (graph_score.py:41-47)
   {
     ScoreArgs a{};
@@ -1707,7 +1719,13 @@ extern "C" int gnnb_pack_amb_records(const gnnb_t* hc, const gnnb_batch* in, int
   };
   if (items.size() >= 8) {
     if (h->work_pool && h->work_pool->owner != getpid()) h->work_pool = nullptr;      // (after a fork: the parent's threads are not here; its object is left alone)
-    if (!h->work_pool) h->work_pool = new WorkPool(11);
+    if (!h->work_pool) {                                 // helpers: what the machine (or the cgroup's CPU set) offers, a dozen threads with the caller at most
+      const unsigned hc = std::thread::hardware_concurrency();
+      cpu_set_t set;
+      int avail = (sched_getaffinity(0, sizeof set, &set) == 0) ? CPU_COUNT(&set) : (int)hc;
+      if (avail < 1) avail = hc ? (int)hc : 1;
+      h->work_pool = new WorkPool(std::max(0, std::min(avail, 12) - 1));
+    }
     h->work_pool->run(work);
   } else {
     work();
@@ -1722,7 +1740,7 @@ extern "C" int gnnb_pack_amb_records(const gnnb_t* hc, const gnnb_batch* in, int
 }
 
 extern "C" int gnnb_scatter_amb_records(gnnb_t* h, const void* dev_image, int B, float* const* dual, int n_relu, float* const* primal, int n_primal,
-                                        void* stream) {
+                                        int32_t* status, void* stream) {
   if (!h || !dev_image || !dual || !primal) return fail(GNNB_E_INVALID, "gnnb_scatter_amb_records: null argument");
   if (!h->bound) return fail(GNNB_E_STATE, "gnnb_scatter_amb_records: call gnnb_bind_network first");
   const int L = (int)h->N.size() - 2;
@@ -1734,8 +1752,11 @@ extern "C" int gnnb_scatter_amb_records(gnnb_t* h, const void* dev_image, int B,
     const int q = h->relu_q[k];
     if (!dual[k - 1] || !primal[q - 1] || !primal[q]) return fail(GNNB_E_INVALID, "gnnb_scatter_amb_records: null array (layer %d)", k);
     a.dual[k - 1] = dual[k - 1]; a.z_pre[k - 1] = primal[q - 1]; a.z_post[k - 1] = primal[q];
+    a.G[k - 1] = (long)B * h->N[k];
     total += (long)B * h->N[k];                          // (upper bound: the kernel reads the real counts from the image)
   }
+  a.max_rec = total - B;
+  a.status = status;
   if (!primal[n_primal - 1]) return fail(GNNB_E_INVALID, "gnnb_scatter_amb_records: null primals[-1]");
   a.z_out = primal[n_primal - 1];
   // (grid-stride: sized for an eighth of the nodes being ambiguous, correct for any share)

@@ -67,7 +67,6 @@ struct FArgs {
   UpdArgs u;           // the node update (k_node_update arguments; list0 / list1 / cnt0 / cnt1, nb are unused)
   int sw_from_gather;  // 1: the bias-sum scalar of a node comes out of its (sparse) gather; 0: u.sarr holds it (table / k_livesum)
   int qtiles;          // ring slots (2..QTILES): as many as fit beside the weights and the gather's tables in LDS
-  int owned;           // > 0: sample-owned tiles -- workgroup w takes ALL tiles of samples w, w + gridDim, ... (`owned` = samples in the batch); 0: rounds of tiles dealt across all samples
 };
 
 #ifndef QG_WAVES
@@ -174,20 +173,11 @@ __device__ unsigned long long g_qt_wall[2 * 16 * 1024];
 #endif
 // LANES: dst nodes per gather tile (16: forward edges, 32: transposed edges).  SRC: 0 dense source rows, 1 sparse walk (the source
 // is a ReLU layer), 2 round-0 embedding computed in the gather (16-node tiles only).  POST: see UpdArgs.
-#ifdef SWEEP_TIMING      // dev: wall-clock stamps (100 MHz chip-wide clock) of every wave in every phase of k_sweep: [workgroup][phase][wave][4] =
-                         // {phase entered (behind the barrier), tables / weights staged, -, this wave's part done}, tphase = (sweep launch of the forward & 3) * 8 + phase; tools/sweep_timing.py
-__device__ unsigned long long g_sw_wall[4 * 256 * 8 * 16 * 4];      // [sweep launch of the forward (SweepArgs.ordinal & 3)]...
-#define SW_STAMP(slot) do { if (tphase >= 0 && (threadIdx.x & 63) == 0 && blockIdx.x < 256) g_sw_wall[((((tphase >> 3) * 256 + blockIdx.x) * 8 + (tphase & 7)) * 16 + (threadIdx.x >> 6)) * 4 + (slot)] = wall_clock64(); } while (0)
-#else
-#define SW_STAMP(slot)
-#endif
-// fusedq_body: one half-pass by this workgroup (all 16 waves call it; it starts with workgroup barriers).  Returns false when a wait hit its
+// fusedq_body: one half-pass by this workgroup (all 16 waves call it; it starts with workgroup barriers; k_scored_tail shares q_chain).  Returns false when a wait hit its
 // iteration cap (status bit 1 is raised; the caller must leave the kernel), true when this wave's part of the half-pass is done.
 template <int LANES, int SRC, bool POST>
-__device__ __forceinline__ bool fusedq_body(const FArgs& a, float* lds, int tphase = -1) {
+__device__ __forceinline__ bool fusedq_body(const FArgs& a, float* lds) {
   constexpr bool SPARSE = SRC == 1, EMBED = SRC == 2;
-  (void)tphase;
-  SW_STAMP(0);
   QT_DECL;
   float* qbase = lds + PackUpdL3::FLOATS + (POST ? 6144 : 0);
   const int NQ = a.qtiles;
@@ -199,8 +189,8 @@ __device__ __forceinline__ bool fusedq_body(const FArgs& a, float* lds, int tpha
   __syncthreads();
   if (threadIdx.x < QTILES) q->free_id[threadIdx.x] = threadIdx.x;
   __syncthreads();
-  // (the thread index goes through an opaque asm: inside k_sweep's phase loop hipcc otherwise computes every lane-derived address of all five
-  // forms of this body once, in front of the loop, keeps them alive across every phase and spills them)
+  // (the thread index goes through an opaque asm so that hipcc derives the lane addresses here, behind the barriers, not in the prologue: the
+  // form the round-5 measurements were taken with)
   int tidx = threadIdx.x;
   asm volatile("" : "+v"(tidx));
   const int lane = tidx & 63, hwave = __builtin_amdgcn_readfirstlane(tidx >> 6);
@@ -238,7 +228,6 @@ __device__ __forceinline__ bool fusedq_body(const FArgs& a, float* lds, int tpha
       if (!ok) { if (lane == 0) atomicOr(a.u.status, 2); return false; }
     }
     QT_MARK(6);                                     // node-update weights staged (all chain waves)
-    SW_STAMP(1);
     // claims the next tile, copies it out of its ring slot, releases the slot, runs the chain
     for (;;) {
       int T = 0;
@@ -258,7 +247,7 @@ __device__ __forceinline__ bool fusedq_body(const FArgs& a, float* lds, int tpha
       }
       if (nvalid < 0) { if (lane == 0) atomicOr(a.u.status, 2); return false; }
       QT_MARK(7);                                   // waiting for a tile of rows
-      if (nvalid == 0) { QT_FLUSH(); SW_STAMP(3); return true; }
+      if (nvalid == 0) { QT_FLUSH(); return true; }
       q_chain<POST>(a, lds, ring, nvalid, lane, [&]() {
         // (called once the rows are in registers) hand the slot back before the chain runs: the ring only has to cover the
         // time a tile takes to fill and to be copied out, not the ~10 us of its chain
@@ -268,7 +257,7 @@ __device__ __forceinline__ bool fusedq_body(const FArgs& a, float* lds, int tpha
         }
       });
       QT_MARK(8);                                   // rows -> registers, chain, row stores
-      if (nvalid < 32) { QT_FLUSH(); SW_STAMP(3); return true; }      // the last, partly filled tile
+      if (nvalid < 32) { QT_FLUSH(); return true; }      // the last, partly filled tile
     }
   }
 
@@ -289,13 +278,10 @@ __device__ __forceinline__ bool fusedq_body(const FArgs& a, float* lds, int tpha
   }
   int wg = blockIdx.x;
   const int nwg = gridDim.x;
-  const bool owned = a.owned > 0;
-  if (!owned && (nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
-  // owned: this workgroup's private tile space = the TPS tiles of each of its samples, one after the other
-  const int nown = owned ? ((int)blockIdx.x < a.owned ? (a.owned - (int)blockIdx.x + nwg - 1) / nwg : 0) : 0;
-  const long ntl = owned ? (long)nown * a.g.tm.TPS : a.g.ntiles;
+  if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);      // workgroups b, b + 8, ... share an XCD: give them neighbouring rounds of tiles
+  const long ntl = a.g.ntiles;
   const long nrounds = (ntl + QG_WAVES - 1) / QG_WAVES;
-  const long r0 = owned ? 0 : wg, rstep = owned ? 1 : nwg;
+  const long r0 = wg, rstep = nwg;
   bool stuck = false;
   // The bounds of a tile's dst nodes are fetched one tile ahead (they decide which lanes are live: the tile cannot start without
   // them, and a gather wave spent 14 % of its time waiting for them).
@@ -305,14 +291,13 @@ __device__ __forceinline__ bool fusedq_body(const FArgs& a, float* lds, int tpha
     nx.in = r < nrounds && tile < ntl;
     const long tl = nx.in ? tile : 0;
     const int si = __builtin_amdgcn_readfirstlane((int)(tl / a.g.tm.TPS));
-    nx.sample = owned ? (int)blockIdx.x + si * nwg : si;
+    nx.sample = si;
     const int t = __builtin_amdgcn_readfirstlane((int)(tl - (long)si * a.g.tm.TPS));
     nx.tc = block_decode(a.g.tm, gl.tt, nx.sample, t, jn);
     nx.gc = (int)(nx.tc.sample * a.g.tm.N + nx.tc.n);
     nx.lb = a.g.lb[nx.gc];
     nx.ub = a.g.ub[nx.gc];
   };
-  SW_STAMP(1);
   fetch(r0);
   for (long r = r0; r < nrounds && !stuck; r += rstep) {
     if (!nx.in) break;
@@ -376,7 +361,7 @@ __device__ __forceinline__ bool fusedq_body(const FArgs& a, float* lds, int tpha
   __builtin_amdgcn_s_waitcnt(0xc07f);
   if (lane == 0) __hip_atomic_fetch_add(&q->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   QT_FLUSH();
-  SW_STAMP(3);
+ 
   return !stuck;
 }
 
@@ -385,41 +370,3 @@ __global__ __launch_bounds__((QG_WAVES + QC_WAVES) * 64, 4) void k_gather_update
   extern __shared__ __attribute__((aligned(16))) float lds[];
   fusedq_body<LANES, SRC, POST>(a, lds);
 }
-
-// ---- k_sweep: CONSECUTIVE conv half-passes in one launch (round 5) -----------------------------------------------------------------------
-// graph_conv.py:107-192 (forward sweep) and :222-385 (backward sweep) are loops over layers inside one call; as launches every half-pass
-// pays a chip-wide kernel boundary: the slowest workgroup's tail, the launch gap, the ramp.  Subproblems are independent,
-// so with SAMPLE-OWNED tiles (FArgs.owned: workgroup w runs every tile of samples w, w + grid, ...) the rows a half-pass reads were
-// written by the same workgroup one phase earlier: the dependency between consecutive half-passes is workgroup-local.  One workgroup
-// barrier between phases orders them -- on gfx950 the waves of a workgroup share their CU's vector L1, which a store of that CU updates
-// on its way to L2, so workgroup scope needs no cache maintenance (the barrier's fence waits for every wave's outstanding stores) -- and
-// no other workgroup, no other XCD's L2 is involved.  Workgroups drift apart freely: a slow one in phase p can catch up in phase p + 1.
-// Each phase is fusedq_body, i.e. exactly the arithmetic of the per-launch path per node: scores are bit-identical (GNNB_SWEEP=0).
-#define SWEEP_MAX 8
-struct SweepArgs {
-  int nphase;
-  int kind[SWEEP_MAX];       // 0: <16, 0, false>  1: <16, 1, false>  2: <16, 2, false>  3: <32, 1, false>  4: <32, 1, true>
-  int ordinal;               // which sweep launch of its forward this is (dev timing only)
-  FArgs ph[SWEEP_MAX];
-};
-static_assert(sizeof(SweepArgs) <= 4096, "kernel arguments of k_sweep");
-
-__global__ __launch_bounds__((QG_WAVES + QC_WAVES) * 64, 4) void k_sweep(SweepArgs sa) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  for (int p = 0; p < sa.nphase; ++p) {
-    if (p) __syncthreads();        // every wave is done with phase p - 1: its rows are in memory (workgroup-scope release / acquire), LDS is free
-    // (the phase's arguments are COPIED inside its case: every field that form of the half-pass uses is loaded once per phase, as a kernel
-    // loads its arguments; through a reference the tile loops re-read them from memory, and a copy in front of the switch keeps the
-    // union of all five forms' fields alive)
-    bool ok = true;
-    switch (sa.kind[p]) {
-      case 0: { const FArgs a = sa.ph[p]; ok = fusedq_body<16, 0, false>(a, lds, (sa.ordinal & 3) * 8 + p); break; }
-      case 1: { const FArgs a = sa.ph[p]; ok = fusedq_body<16, 1, false>(a, lds, (sa.ordinal & 3) * 8 + p); break; }
-      case 2: { const FArgs a = sa.ph[p]; ok = fusedq_body<16, 2, false>(a, lds, (sa.ordinal & 3) * 8 + p); break; }
-      case 3: { const FArgs a = sa.ph[p]; ok = fusedq_body<32, 1, false>(a, lds, (sa.ordinal & 3) * 8 + p); break; }
-      default: { const FArgs a = sa.ph[p]; ok = fusedq_body<32, 1, true>(a, lds, (sa.ordinal & 3) * 8 + p); break; }
-    }
-    if (!ok) return;
-  }
-}
-

@@ -682,17 +682,28 @@ __global__ __launch_bounds__(TAIL_WAVES * 64, 1) void k_scored_tail(TailArgs a) 
 struct ScatterArgs {
   const int* image;
   float* dual[MAXL]; float* z_pre[MAXL]; float* z_post[MAXL]; float* z_out;
+  long G[MAXL];          // nodes of ReLU layer k in the batch (B N_k): a record's flat index must be below it
+  long max_rec;          // records the image can hold for this binding and B (sum of G)
+  int* status;           // may be null; bit 2 (value 4): the image does not belong to this binding / batch size, or holds a record outside its arrays
   int L, B;
 };
 __global__ void k_scatter_amb(ScatterArgs a) {
   const int* hdr = a.image;
+  // an image packed under another binding or batch size (or a stale device copy) must not be scattered: nothing is written, bit 2 is raised
+  if (hdr[0] != AMBREC_MAGIC || hdr[1] != a.L || hdr[3] != a.B || hdr[2] < 0 || (long)hdr[2] > a.max_rec) {
+    if (a.status && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.status, 4);
+    return;
+  }
   const long nrec = hdr[2];
   const long total = nrec + a.B;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     if (i < nrec) {
       const int* r = a.image + 16 + i * AMBREC_WORDS;
       const int k = r[0], g = r[1];
-      if ((unsigned)k >= (unsigned)a.L) continue;         // (a corrupt image must not write out of bounds)
+      if ((unsigned)k >= (unsigned)a.L || g < 0 || (long)g >= a.G[k]) {      // (a corrupt record must not write out of bounds)
+        if (a.status) atomicOr(a.status, 4);
+        continue;
+      }
       a.dual[k][(long)g * 3 + 1] = __int_as_float(r[2]);
       a.dual[k][(long)g * 3 + 2] = __int_as_float(r[3]);
       a.z_pre[k][g] = __int_as_float(r[4]);
@@ -701,4 +712,15 @@ __global__ void k_scatter_amb(ScatterArgs a) {
       a.z_out[i - nrec] = __int_as_float(a.image[16 + nrec * AMBREC_WORDS + (i - nrec)]);
     }
   }
+}
+
+// ---- k_occupy: inspection hook (gnnb_debug_occupy) -- workgroups that hold their CU (its LDS, through the dynamic allocation) until `ticks`
+// of the chip-wide 100 MHz clock have passed since the first wave looked at it.  tests/test_gpu_dist_safety.py runs forwards beside it to
+// show that no kernel of a forward needs workgroups co-resident once the k_top split is off.  Every wave leaves when the time is up: the
+// grid always drains.
+__global__ void k_occupy(unsigned long long ticks) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (threadIdx.x == 0) lds[0] = 0.0f;                       // (touch the allocation)
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
 }

@@ -372,192 +372,6 @@ __global__ __launch_bounds__(CLS_THREADS) void k_classify_pre(ClassifyArgs ca, P
   for (long t = wave; t < nt; t += PRE_WAVES) pre_tile<true>(a, lds, lds, k, true, amb_local, count, t, lane);
 }
 
-// k_classify_pre_b (round 5): k_classify and k_pre in ONE launch for BATCHES.  k_classify_pre gives a block 2048 consecutive nodes of ONE
-// layer, and the layers' shares of ambiguous nodes differ twenty-fold (3 % of layer 1, 58 % of the last layer: a block's feature-chain work
-// is uneven, which is why that kernel only runs for B = 1).  Here block i takes the i-th slice of EVERY layer -- 1 / gridDim of each: at
-// B = gridDim that is one subproblem -- so every block holds about the same number of ambiguous nodes of every layer.  A block
-//   1. requests its LDS images (they fly under the classification),
-//   2. classifies its slices of all layers in one pass (classify_multi: wave-slots of 64 nodes, one ballot / count / atomic chain for
-//      the lot instead of one per layer), which appends the block's nodes to the global lists as CONTIGUOUS segments,
-//   3. runs the hoisted feature chains on ITS OWN ambiguous segments, read back from the global lists (same CU: a workgroup barrier
-//      orders the stores and the loads) -- P' rows are addressed by node id, so who computes them does not matter.
-// Against k_classify + k_pre: one launch and its gap less, the 150 KB of images staged under the classification instead of behind it.
-#define CLSM_SLOTS 64            // wave-slots (64 nodes) per pass: 4 per wave
-#define CLSM_SEGS 32             // ambiguous segments a block can collect (passes x layers)
-struct ClsSegs { int n; int k[CLSM_SEGS], base[CLSM_SEGS], count[CLSM_SEGS]; };
-__device__ __forceinline__ void classify_multi(const ClassifyArgs& a, ClsSegs* segs) {
-  __shared__ int s_k[CLSM_SLOTS];            // layer of a slot (-1: none)
-  __shared__ long s_g[CLSM_SLOTS], s_e[CLSM_SLOTS];      // first node of the slot, end of the block's slice of that layer
-  __shared__ int s_cnt[3][CLSM_SLOTS], s_base[3][CLSM_SLOTS];
-  __shared__ long s_lo[MAXL], s_hi[MAXL];                // this block's slice of layer k
-  __shared__ int s_pre[MAXL + 1];                        // wave-slots of the layers before k in this block
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  {
-    const long gid = (long)blockIdx.x * CLS_THREADS + threadIdx.x, nthr = (long)gridDim.x * CLS_THREADS;
-    for (long i = gid; i < a.B; i += nthr) a.best[i] = 0ull;
-    for (long i = gid; i < a.nflag; i += nthr) a.topflag[i] = 0;
-    if (gid == 0) { *a.status = 0; *a.done = 0; }
-  }
-  // this block's slice of every layer: a multiple of 64 nodes (whole wave-slots); one thread per layer (a 64-bit division each)
-  if (threadIdx.x < a.L) {
-    const int k = threadIdx.x;
-    const long per = ((a.G[k] + gridDim.x - 1) / gridDim.x + 63) & ~63L;
-    const long lo = (long)blockIdx.x * per;
-    s_lo[k] = lo;
-    s_hi[k] = lo + per < a.G[k] ? lo + per : a.G[k];
-  }
-  if (threadIdx.x == 0) segs->n = 0;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int t = 0;
-    for (int k = 0; k < a.L; ++k) { s_pre[k] = t; t += s_hi[k] > s_lo[k] ? (int)((s_hi[k] - s_lo[k] + 63) >> 6) : 0; }
-    for (int k = a.L; k <= MAXL; ++k) s_pre[k] = t;
-  }
-  __syncthreads();
-  const int total_slots = s_pre[a.L];
-  for (int pass = 0; pass * CLSM_SLOTS < total_slots; ++pass) {
-    if (pass) __syncthreads();                         // (the slot table is rewritten)
-    // ---- the next CLSM_SLOTS wave-slots of this block's slices, layer after layer: one thread per slot
-    if (threadIdx.x < CLSM_SLOTS) {
-      const int idx = pass * CLSM_SLOTS + threadIdx.x;
-      int k = -1;
-      if (idx < total_slots) {
-        k = 0;
-        while (k + 1 < a.L && idx >= s_pre[k + 1]) ++k;
-        s_g[threadIdx.x] = s_lo[k] + ((long)(idx - s_pre[k]) << 6);
-        s_e[threadIdx.x] = s_hi[k];
-      }
-      s_k[threadIdx.x] = k;
-    }
-    __syncthreads();
-    const int nslots = total_slots - pass * CLSM_SLOTS < CLSM_SLOTS ? total_slots - pass * CLSM_SLOTS : CLSM_SLOTS;
-    constexpr int SPW = CLSM_SLOTS / (CLS_THREADS / 64);
-    bool flag[SPW][3], live[SPW], valid[SPW];
-    unsigned long long bal[SPW][3];
-    // every load of the wave's SPW slots is requested before the first one is used: ONE memory round trip per pass (slot by slot -- load,
-    // classify, ballot -- the pass was four dependent round trips).  The slot's layer is wave-uniform: scalar registers pick the pointers.
-    float lbv[SPW], ubv[SPW], mkv[SPW];
-    long sidxv[SPW], gv[SPW];
-    int kv[SPW];
-#pragma unroll
-    for (int i = 0; i < SPW; ++i) {
-      const int sl = wave + i * (CLS_THREADS / 64);
-      const int k = __builtin_amdgcn_readfirstlane(s_k[sl]);
-      const int kk = k < 0 ? 0 : k;
-      const long g = s_g[sl] + lane, e = s_e[sl];
-      valid[i] = k >= 0 && g < e;
-      const long gc = valid[i] ? g : (k >= 0 ? e - 1 : 0);
-      const int N = a.N[kk];
-      const long b = (int)gc / N;                        // (the host only takes this kernel while B N_k < 2^31)
-      sidxv[i] = b * a.R + a.off[kk] + (gc - b * N);
-      lbv[i] = a.lb[kk][gc];
-      ubv[i] = a.ub[kk][gc];
-      mkv[i] = a.mask[sidxv[i]];
-      gv[i] = g; kv[i] = k;
-    }
-#pragma unroll
-    for (int i = 0; i < SPW; ++i) {
-      const int sl = wave + i * (CLS_THREADS / 64);
-      const int k = kv[i];
-      const Ratio r = compute_ratio(lbv[i], ubv[i]);
-      live[i] = valid[i] && r.live != 0.0f;
-      flag[i][1] = valid[i] && r.amb != 0.0f;
-      flag[i][0] = live[i] && !flag[i][1];
-      flag[i][2] = valid[i] && mkv[i] != 0.0f;
-      if (valid[i]) {
-        a.scores[sidxv[i]] = -INFINITY;
-        a.livef[k < 0 ? 0 : k][gv[i]] = live[i] ? 1.0f : 0.0f;
-      }
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        bal[i][c] = __ballot(flag[i][c]);
-        if (lane == 0) s_cnt[c][sl] = __popcll(bal[i][c]);
-      }
-    }
-    __syncthreads();
-    // ---- one thread per (class, layer): positions of the layer's slots, one global atomic for the lot
-    if (threadIdx.x < 3 * MAXL) {
-      const int c = threadIdx.x % 3, k = threadIdx.x / 3;
-      int total = 0;
-      bool any = false;
-      for (int sl = 0; sl < nslots; ++sl)
-        if (s_k[sl] == k) { s_base[c][sl] = total; total += s_cnt[c][sl]; any = true; }
-      if (any) {
-        const int base = total ? atomicAdd(a.cnt + 4 * k + c, total) : 0;
-        for (int sl = 0; sl < nslots; ++sl)
-          if (s_k[sl] == k) s_base[c][sl] += base;
-        if (c == 1 && total > 0 && segs) {
-          const int i = atomicAdd(&segs->n, 1);
-          if (i < CLSM_SEGS) { segs->k[i] = k; segs->base[i] = base; segs->count[i] = total; }
-        }
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < SPW; ++i) {
-      const int sl = wave + i * (CLS_THREADS / 64);
-      const int k = kv[i];
-      if (k < 0) continue;
-      const long g = gv[i];
-      int* lists[3] = {a.live[k], a.amb[k], a.score[k]};
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-        if (flag[i][c]) lists[c][s_base[c][sl] + __popcll(bal[i][c] & ((1ull << lane) - 1ull))] = (int)g;
-      float* mu = a.mu[k];
-      float* mu2 = k == 0 ? a.mu2 : nullptr;
-      unsigned long long dead = a.zero[k] ? __ballot(valid[i] && !live[i]) : 0ull;
-      while (dead) {                       // the whole wave zeroes one dead row per iteration (coalesced 256 B)
-        const int l = __ffsll((long long)dead) - 1;
-        dead &= dead - 1;
-        const long row = g - lane + l;
-        mu[row * 64 + lane] = 0.0f;
-        if (mu2) mu2[row * 64 + lane] = 0.0f;
-      }
-    }
-  }
-}
-
-// the number of passes a block of k_classify_pre_b needs must keep its segments within CLSM_SEGS (the host checks: clspre_b_ok)
-__global__ __launch_bounds__(CLS_THREADS) void k_classify_pre_b(ClassifyArgs ca, PreAllArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ ClsSegs segs;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  copy_to_lds(lds + PackPreFwdL3::W1, a.pack_f + PackPreFwd::W1, 512 + 64);
-  copy_to_lds(lds + PackPreFwdL3::B2, a.pack_f + PackPreFwd::B2, 64);
-  copy_to_lds(lds + PackPreFwdL3::W23, a.pack_f + PackPreFwd::W23, 6144);
-  if (a.do_bwd) {
-    copy_to_lds(lds + PackPreBwdL3::B3, a.pack_b + PackPreBwd::B3, 64);
-    copy_to_lds(lds + PackPreBwdL3::B4, a.pack_b + PackPreBwd::B4, 64);
-    copy_to_lds(lds + PackPreBwdL3::B5, a.pack_b + PackPreBwd::B5, 64);
-    copy_to_lds(lds + PackPreBwdL3::W33, a.pack_b + PackPreBwd::W33, 6144);
-    copy_to_lds(lds + PackPreBwdL3::W43, a.pack_b + PackPreBwd::W43, 18432);
-    copy_to_lds(lds + PackPreBwdL3::W53, a.pack_b + PackPreBwd::W53, 6144);
-  }
-  classify_multi(ca, &segs);
-  __syncthreads();                                   // the block's list segments (global memory, this CU) and the images (LDS) are in place
-  const int nseg = segs.n < CLSM_SEGS ? segs.n : CLSM_SEGS;
-  long nt = 0;
-  for (int i = 0; i < nseg; ++i) nt += (segs.count[i] + 31) / 32;
-  auto run = [&](long t, bool bwd) {                 // tile t of this block: which segment (wave-uniform)
-    int i = 0;
-    for (; i < nseg; ++i) {
-      const long tk = (segs.count[i] + 31) / 32;
-      if (t < tk) break;
-      t -= tk;
-    }
-    const int k = __builtin_amdgcn_readfirstlane(segs.k[i]);
-    pre_tile<true>(a, lds, lds, k, bwd, a.list[k] + segs.base[i], segs.count[i], t, lane);
-  };
-  for (long t = wave; t < nt; t += PRE_WAVES) run(t, false);
-  if (!a.do_bwd) return;
-  __syncthreads();
-  copy_to_lds(lds + PackPreBwdL3::W1, a.pack_b + PackPreBwd::W1, 512 + 64);                      // W1, B1
-  copy_to_lds(lds + PackPreBwdL3::B2, a.pack_b + PackPreBwd::B2, 64);
-  copy_to_lds(lds + PackPreBwdL3::W23, a.pack_b + PackPreBwd::W23, 6144);
-  __syncthreads();
-  for (long t = wave; t < nt; t += PRE_WAVES) run(t, true);
-}
-
 // Q = inp_b2[:, :64] . inp_b_1(relu(inp_b([l0, u0]))) + inp_b2.bias       graph_conv.py:380-384
 __global__ __launch_bounds__(WG_MLP, 2) void k_pre_inp(PreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];

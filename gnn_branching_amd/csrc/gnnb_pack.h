@@ -384,7 +384,11 @@ inline void build_packs(const float* blob, Packs& pk) {
   std::thread helper[2];
   bool threaded[2] = {false, false};
 #ifndef GNNB_PACK_NO_THREADS
+#ifdef GNNB_DEV
   static const bool use_threads = [] { const char* e = std::getenv("GNNB_PACK_THREADS"); return !e || std::atoi(e) != 0; }();
+#else
+  constexpr bool use_threads = true;
+#endif
   if (use_threads) {
     try { helper[0] = std::thread(upd_e_i); threaded[0] = true; } catch (const std::system_error&) {}
     try { helper[1] = std::thread(upd_f_b); threaded[1] = true; } catch (const std::system_error&) {}

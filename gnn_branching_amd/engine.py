@@ -5,7 +5,6 @@ network and a workspace per batch size.  Tensors are only carriers of device
 memory here (``data_ptr()``); all arithmetic of the hot path runs in libgnnb.so.
 """
 import ctypes as C
-import os
 import time
 
 from array import array as _array
@@ -61,10 +60,15 @@ def _raise_for_status(st):
     """status word of gnnb_forward: bit 0 = an embedding was NaN (the reference enters pdb there, graph_conv.py:184-186, :339-341);
     bit 1 = a wait inside a kernel (k_gather_update_q's LDS ring, or k_top's workgroup split waiting for its partner workgroups)
     ran into its iteration cap: a protocol bug, a wedged GPU, or -- for k_top -- partner workgroups kept off the chip by other work
-    (GNNB_TOP_SPLIT=1 turns the split off); results are invalid."""
+    (handle option "top_split" = 1 turns the split off); results are invalid.  bit 2 = gnnb_scatter_amb_records refused a record image
+    (not packed for this binding / batch size, or a record outside its arrays)."""
     if st & 2:
         msg = ("a wait inside a kernel (k_gather_update_q ring or k_top workgroup split) hit its iteration cap (status bit 1); "
-               "results are invalid; GNNB_TOP_SPLIT=1 disables the k_top split")
+               "results are invalid; the handle option top_split=1 disables the k_top split")
+        print(f"[gnn_branching_amd] {msg}", flush=True)
+        raise RuntimeError(msg)
+    if st & 4:
+        msg = "gnnb_scatter_amb_records refused a record image (status bit 2): packed for another network or batch size, or corrupt"
         print(f"[gnn_branching_amd] {msg}", flush=True)
         raise RuntimeError(msg)
     if st & 1:
@@ -145,6 +149,25 @@ class HostFedPipeline:
             out.append(t)
         return out
 
+    @staticmethod
+    def _check_sizes(eng, host, nb, nd, npr):
+        """ValueError (not a segfault in the C packer) for tensors that do not hold what the bound network needs."""
+        B, sizes = int(host[0].shape[0]), eng.sizes
+        if nb != len(sizes) or nd != len(sizes) - 2:
+            raise ValueError(f"{nb} bound tensors / {nd} dual tensors, layer graph has {len(sizes)} layers")
+        for k in range(nb):
+            for t, what in ((host[k], "lower"), (host[nb + k], "upper")):
+                if t.numel() != B * sizes[k]:
+                    raise ValueError(f"{what} bounds of graph layer {k}: {tuple(t.shape)} does not hold {B}x{sizes[k]} values")
+        for k in range(nd):
+            if host[2 * nb + k].numel() != B * sizes[k + 1] * 3:
+                raise ValueError(f"dual_vars[{k}] has {tuple(host[2 * nb + k].shape)}, expected ({B * sizes[k + 1]}, 3)")
+        eng._check_primals(eng._net_keepalive, host[2 * nb + nd:2 * nb + nd + npr], B)
+        if host[-1].numel() != B * eng.R:
+            raise ValueError(f"masks has {tuple(host[-1].shape)}, expected ({B}, {eng.R})")
+        if host[-2].numel() != B * sizes[0]:
+            raise ValueError("primal_inputs has the wrong size")
+
     def submit(self, lower_bounds_all, upper_bounds_all, dual_vars, primals, primal_inputs, layers, masks):
         eng = self.eng
         host = self._flat_inputs(lower_bounds_all, upper_bounds_all, dual_vars, primals, primal_inputs, masks)
@@ -155,6 +178,12 @@ class HostFedPipeline:
         k = self.i % self.depth
         self.i += 1
         sl = self.slots[k]
+        if compact:
+            # the packer walks raw host pointers with the sizes of whatever network the HANDLE is bound to: bind (cached by key) on every
+            # submit -- another pipeline or eng.forward on the shared engine may have rebound it since this slot was shaped -- and check every
+            # element count against that binding before the C side sees a pointer
+            eng.bind(layers["fixed_layers"], tuple(host[0].shape[1:]))
+            self._check_sizes(eng, host, nb, nd, npr)
         with torch.cuda.device(eng.device):
             cur = torch.cuda.current_stream()
             if sl is None or sl["key"] != key:
@@ -174,7 +203,6 @@ class HostFedPipeline:
                 sl = {"key": key, "dev": dev, "offs": offs, "dev_small": dev_small, "pin_small": pin_small, "pin_np": pin_small.numpy(),
                       "ev_copy": torch.cuda.Event(), "ev_done": torch.cuda.Event(), "used": False}
                 if compact:
-                    eng.bind(layers["fixed_layers"], tuple(host[0].shape[1:]))
                     for j in skip:
                         dev[j].zero_()                # (entries of nodes that are never ambiguous are never read: zero, not garbage)
                     cap = int(eng.lib.gnnb_amb_records_bytes(eng.h, int(host[0].shape[0])))
@@ -230,12 +258,14 @@ class HostFedPipeline:
             cur.wait_event(sl["ev_copy"])
             self.link_bytes = 4 * (used_words + sum(t.numel() for j, t in enumerate(host) if j not in skip))      # what this submit sent over the link
             d = sl["dev"]
+            status = None
             if compact:                              # records -> the slot's full-size dual / primal tensors, one launch in front of the forward
                 dptr = (C.c_void_p * nd)(*[t.data_ptr() for t in d[2 * nb:2 * nb + nd]])
                 pptr = (C.c_void_p * npr)(*[t.data_ptr() for t in d[2 * nb + nd:2 * nb + nd + npr]])
+                status = torch.zeros(2, dtype=torch.int32, device=eng.device)      # [forward, scatter]: the scatter raises bit 2 on a foreign / corrupt image
                 _lib.check(eng.lib.gnnb_scatter_amb_records(eng.h, sl["dev_img"].data_ptr(), int(host[0].shape[0]), dptr, nd, pptr, npr,
-                                                            C.c_void_p(cur.cuda_stream)), "gnnb_scatter_amb_records")
-            res = eng.forward(d[:nb], d[nb:2 * nb], d[2 * nb:2 * nb + nd], d[2 * nb + nd:2 * nb + nd + npr], d[-2], layers, d[-1])
+                                                            status[1:].data_ptr(), C.c_void_p(cur.cuda_stream)), "gnnb_scatter_amb_records")
+            res = eng.forward(d[:nb], d[nb:2 * nb], d[2 * nb:2 * nb + nd], d[2 * nb + nd:2 * nb + nd + npr], d[-2], layers, d[-1], status=status)
             # the result outlives the slot: its mask must not be a view of the slot's device buffer, which the submit `depth` calls
             # later overwrites (a held result's ragged() would then be cut with another batch's mask).  Cloned on the compute stream,
             # behind the copies it waited for and in front of ev_done.
@@ -250,23 +280,17 @@ class BatchPipeline:
     dealt to the slots in turn.  A forward is a chain of 11-19 dependent launches; while one batch's kernel drains or its next one
     ramps up, the other batch's kernel fills the CUs: measured per batch on MI355X (tools/two_batches_probe.py) base B=256 0.769 ->
     0.728 ms, deep B=128 0.911 -> 0.785 ms.  Throughput, not latency: a batch takes longer from submit to ready.  Scores are bit-identical to
-    ``ScorerEngine.forward`` (tests/test_gpu_pipeline.py).  The handles are created with k_top's workgroup split off (GNNB_TOP_SPLIT=1):
+    ``ScorerEngine.forward`` (tests/test_gpu_pipeline.py).  The handles are created with k_top's workgroup split off (handle option "top_split" = 1):
     with a second batch's kernels on the chip the partner workgroups of a split sample are not guaranteed to be resident together.
 
     ``submit(*forward_args)`` returns the batch's ForwardResult at once; ``result.wait()`` orders the caller's stream behind it,
     ``result.check()`` synchronises on it; ``synchronize()`` waits for everything submitted."""
 
-    def __init__(self, state_dict, depth=2, T=2, p=64, device=None):
+    def __init__(self, state_dict, depth=2, T=2, p=64, device=None, options=None):
         self.depth = max(1, int(depth))
-        prev = os.environ.get("GNNB_TOP_SPLIT")
-        os.environ["GNNB_TOP_SPLIT"] = "1"
-        try:
-            self.engines = [ScorerEngine(state_dict, T, p, device) for _ in range(self.depth)]
-        finally:
-            if prev is None:
-                del os.environ["GNNB_TOP_SPLIT"]
-            else:
-                os.environ["GNNB_TOP_SPLIT"] = prev
+        opts = dict(options or {})
+        opts["top_split"] = 1             # whatever the caller or the environment says: partner workgroups are not guaranteed to be co-resident here
+        self.engines = [ScorerEngine(state_dict, T, p, device, options=opts) for _ in range(self.depth)]
         self.device = self.engines[0].device
         self.streams = self._overlapping_streams(self.device, self.depth)
         self.i = 0
@@ -338,7 +362,9 @@ class BatchPipeline:
 
 
 class ScorerEngine:
-    def __init__(self, state_dict, T=2, p=64, device=None):
+    def __init__(self, state_dict, T=2, p=64, device=None, options=None):
+        """options: {name: int} of handle options (include/gnnb.h gnnb_set_option; _lib.OPTIONS), applied over the ones the
+        environment names (_lib.OPTION_ENV: the tests' and bench.py's switches; the library itself reads no environment)."""
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("gnn_branching_amd needs an AMD GPU (MI355X / gfx950); there is no CPU path")
@@ -352,6 +378,10 @@ class ScorerEngine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.gnnb_create(C.byref(h), blob.ctypes.data_as(C.c_void_p), blob.size, T, p), "gnnb_create")
         self.h = h
+        self.options = dict(_lib.options_from_env())
+        self.options.update(options or {})
+        for name, value in self.options.items():
+            self.set_option(name, value)
         self._net_key = None
         self._net_keepalive = None
         self.sizes = None
@@ -359,9 +389,9 @@ class ScorerEngine:
         self._ws = {}
         self._prop_cache = {}
         self._prop_host_cache = None
-        # batch pipelining: a large batch is cut into `n_streams` contiguous chunks that run on separate HIP streams,
-        # so the launch ramps and tails of one chunk's ~40 dependent kernels overlap the other chunk's work
-        self.n_streams = int(os.environ.get("GNNB_STREAMS", "1"))   # measured on base B=256 (round 2): 1 stream 0.92 ms, 2 streams 0.97, 3 streams 1.10
+        # a large batch can be cut into `n_streams` contiguous chunks on separate HIP streams; measured slower at every size tried
+        # (base B=256: 1 stream 0.84 ms, 2 streams 0.90: every kernel's fixed part is paid twice), so 1 unless a caller sets the attribute
+        self.n_streams = 1
         self.min_chunk = 64
         self._streams = []
 
@@ -372,6 +402,17 @@ class ScorerEngine:
                 self.lib.gnnb_destroy(h)
             except Exception:
                 pass
+
+    # ---- handle options ---------------------------------------------------------------------
+    def set_option(self, name, value):
+        """gnnb_set_option: see include/gnnb.h for the table.  "gather" and "dense_lds" must be set before the first bind."""
+        _lib.check(self.lib.gnnb_set_option(self.h, name.encode(), int(value)), f"gnnb_set_option({name})")
+        self.options[name] = int(value)
+
+    def get_option(self, name):
+        v = C.c_int(0)
+        _lib.check(self.lib.gnnb_get_option(self.h, name.encode(), C.byref(v)), f"gnnb_get_option({name})")
+        return v.value
 
     # ---- verified network -------------------------------------------------------------------
     def bind(self, fixed_layers, input_shape):
@@ -488,13 +529,18 @@ class ScorerEngine:
         self._last_bounds = list(zip(lbs, ubs))           # for mu() (inspection)
         return B, lbs, ubs, duals, prim, x_lp, mask, pw, pb
 
-    def forward(self, lower_bounds_all, upper_bounds_all, dual_vars, primals, primal_inputs, layers, masks):
+    def forward(self, lower_bounds_all, upper_bounds_all, dual_vars, primals, primal_inputs, layers, masks, status=None):
+        """status: optional preallocated device int32 tensor; the forward's status words go to its first element(s), further elements
+        (HostFedPipeline: the scatter launch's word) are left to the caller and OR-ed in by ForwardResult.check()."""
         B, lbs, ubs, duals, prim, x_lp, mask, pw, pb = self._marshal(lower_bounds_all, upper_bounds_all, dual_vars, primals,
                                                                      primal_inputs, layers, masks)
         scores = torch.empty(B, self.R, dtype=torch.float32, device=self.device)
         dec = torch.empty(B, 2, dtype=torch.int32, device=self.device)
         nchunk = self.n_streams if (self.n_streams > 1 and B >= self.n_streams * self.min_chunk) else 1
-        status = torch.empty(nchunk, dtype=torch.int32, device=self.device)
+        if status is None:
+            status = torch.empty(nchunk, dtype=torch.int32, device=self.device)
+        elif status.numel() < nchunk or status.dtype != torch.int32 or status.device != self.device:
+            raise ValueError("forward: `status` must be a device int32 tensor with one element per chunk")
         mask2 = mask.view(B, self.R)
         bounds = [(B * c) // nchunk for c in range(nchunk + 1)]
 

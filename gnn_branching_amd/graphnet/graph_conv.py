@@ -67,6 +67,7 @@ class GraphNet(nn.Module):
         self.ComputeFinalScore = ComputeFinalScore(p)
         self._engine = None
         self._engine_key = None
+        self.engine_options = {}      # handle options of the HIP engine (include/gnnb.h gnnb_set_option); set before the first forward
 
     def _apply(self, fn, *a, **k):            # .cuda() / .to() / .float(): parameters may be replaced
         self._plist = None
@@ -84,7 +85,7 @@ class GraphNet(nn.Module):
             self._plist = list(self.parameters())
         key = tuple((q.data_ptr(), q._version) for q in self._plist)
         if self._engine is None or key != self._engine_key:
-            self._engine = ScorerEngine(self.state_dict(), T=self.T, p=self.p)
+            self._engine = ScorerEngine(self.state_dict(), T=self.T, p=self.p, options=self.engine_options)
             self._engine_key = key
         return self._engine
 

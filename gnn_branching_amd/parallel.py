@@ -12,6 +12,12 @@ The scorer itself is passed in (``score_fn(shard) -> (B_local, R) tensor``): on 
 import torch
 import torch.distributed as dist
 
+# Handle options (include/gnnb.h gnnb_set_option) of every scorer that runs while a collective may be in flight on the same GPU: k_top must
+# not spread a sample over workgroups that spin-wait on each other -- they need all their partners resident at one per CU, and an RCCL
+# kernel on the communication stream holds CUs for as long as its peers take.  bench.py's multi-GPU path and engine.BatchPipeline (which
+# sets the same option itself) create their handles with it; S = 1 computes the same bits (tests/test_gpu_parity.py, test_gpu_dist_safety.py).
+DIST_ENGINE_OPTIONS = {"top_split": 1}
+
 
 def shard_bounds(batch_size, world_size, rank):
     """Contiguous shard [lo, hi) of rank ``rank``: sizes differ by at most one, earlier ranks take the remainder."""

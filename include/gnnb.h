@@ -10,8 +10,10 @@
  * Conventions: every function returns 0 on success or a negative GNNB_E_* code and never
  * throws; gnnb_last_error() returns a thread-local message for the last failure.
  * gnnb_forward is stream-ordered and asynchronous, allocates nothing and never
- * synchronises; one handle per host thread.  No HIP call happens at library load time
- * (the reference creates its GPU context inside a forked child: experiments/bab_mip.py:244-249).
+ * synchronises; one handle per host thread (no entry point is re-entrant on one handle).  No HIP
+ * call happens at library load time (the reference creates its GPU context inside a forked child:
+ * experiments/bab_mip.py:244-249).  The library reads NO environment variable: every switch is a
+ * handle option (gnnb_set_option).
  */
 #ifndef GNNB_H
 #define GNNB_H
@@ -23,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GNNB_ABI_VERSION 1
+#define GNNB_ABI_VERSION 2
 
 enum {
   GNNB_OK = 0,
@@ -70,6 +72,28 @@ typedef struct {
  * (weight (out,in) row-major, then bias), 117 825 floats for T=2, p=64.  HOST pointer. */
 int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, int T, int p);
 
+/* Handle options.  The reference has one implementation of the path and therefore no switches (graph_conv.py:77-388); here an option
+ * selects between kernels that compute the same scores, which is what lets the parity tests check them against each other and lets a
+ * caller that shares the GPU (two batches in flight, a collective on another stream) turn off what needs co-resident workgroups.
+ * Set options after gnnb_create; the ones marked (*) shape the tables of gnnb_bind_network and return GNNB_E_STATE on a bound handle.
+ *   "bf3"          1 (default): 64x64 node-MLP blocks on the bf16 matrix rate, both operands in three bf16 pieces, fp32 accumulate
+ *                  (fp32-grade); 0: every block on the exact-fp32 MFMA (and the separate kernels instead of k_top)
+ *   "fuse"         1: a conv half-pass (graph_conv.py:110-181, :299-349) is ONE kernel; 0: aggregate kernel + node-update kernel
+ *   "top"          1: last Linear edge, last ReLU layer, property node (graph_conv.py:130-137, :194-210, :320-326) in k_top; 0: separate kernels
+ *   "gather" (*)   1: conv edges as MFMA tap blocks; 0: the scalar conv kernels
+ *   "embed_fuse"   1: round 0's input embedding (graph_conv.py:90-95) computed inside the first aggregate; 0: written by k_embed
+ *   "dense_lds" (*) 1: Linear edges one workgroup per sample out of LDS; 0: the per-tile kernel (what very wide layers fall back to)
+ *   "tail_max_b"   batches up to it run the last restricted update + score head (graph_conv.py:442-470) as ONE launch; 0: three kernels
+ *   "top_split"    1 / 2 / 4: most workgroups k_top spreads one sample over.  2 and 4 make workgroups WAIT for partner workgroups and
+ *                  need all of them resident: set 1 when anything else may occupy CUs while a forward runs (status bit 1 otherwise)
+ *   "top_fuse_upd" 1: the backward update of layer L-1 (graph_conv.py:253-350) inside k_top; 0: its own launch
+ *   "clspre_max_b" batches up to it classify nodes and run the hoisted feature chains in one launch
+ * gnnb_option_count / gnnb_option_name enumerate the table; gnnb_get_option reads a value back. */
+int gnnb_set_option(gnnb_t* h, const char* name, int value);
+int gnnb_get_option(const gnnb_t* h, const char* name, int* value);
+int gnnb_option_count(void);
+const char* gnnb_option_name(int i);
+
 /* The verified network's fixed layers, i.e. the static part of the `layers` argument
  * (reference relu_conv_gnnkwthreshold.py:110-113; graph structure walked at
  * graph_conv.py:107-192 and :222-385).  (c0,h0,w0) = input tensor shape. */
@@ -88,7 +112,7 @@ size_t gnnb_workspace_bytes(const gnnb_t* h, int B);
  * decisions: device (B, 2) int32 [dec_lay, dec_idx], first maximal score; [-1,-1] if a sample
  * has no ambiguous ReLU.  status: device int32[1], bit 0 set if an embedding was NaN (the reference
  * enters pdb, graph_conv.py:184-186, :339-341), bit 1 if a wait inside a kernel (k_gather_update_q's LDS ring; k_top's workgroup
- * split waiting for its partner workgroups -- GNNB_TOP_SPLIT=1 turns that split off) hit its iteration cap (never in a correct run on a
+ * split waiting for its partner workgroups -- option "top_split" = 1 turns that split off) hit its iteration cap (never in a correct run on a
  * GPU the caller does not share with long-running kernels; the results are then invalid).  stream: hipStream_t (NULL = default). */
 int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* scores_padded, int32_t* decisions,
                  int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
@@ -108,15 +132,19 @@ int gnnb_forward_host(gnnb_t* h, const gnnb_batch* in, int B, float* scores, int
  *                            are read).  Writes to `dst` (host memory, e.g. pinned; >= cap bytes) for every ReLU layer the nodes with
  *                            lb < 0 < ub -- a superset of the nodes the device classifies as ambiguous -- as records {layer, flat index
  *                            b N_k + n, dual[:, 1], dual[:, 2], primal_pre, primal_post} in no particular order, then primals[-1];
- *                            *used = bytes written.  Runs on a dozen helper threads that belong to the handle (created on first use,
- *                            joined by gnnb_destroy).
+ *                            *used = bytes written.  Runs on up to a dozen helper threads that belong to the handle (created on first
+ *                            use, joined by gnnb_destroy); calls on one handle are serialised, every tensor's element count is the
+ *                            caller's responsibility (B N_k per bound / primal tensor, 3 B N_k per dual tensor of the BOUND network).
  *   gnnb_scatter_amb_records DEVICE: one launch on `stream` that writes the records of an image copied to device memory into full-size
  *                            device arrays dual[k] (B N_k, 3) / primal[m] laid out as gnnb_forward expects them; entries of other nodes
  *                            are left as they are (the forward never reads them).  Then call gnnb_forward on those arrays: scores are
- *                            the bits of a forward on the whole tensors. */
+ *                            the bits of a forward on the whole tensors.  status: device int32[1] the caller zeroed, or NULL; bit 2
+ *                            (value 4) is set -- and nothing, or not that record, is written -- when the image's header does not match
+ *                            this binding and B, or a record points outside its arrays (a stale or foreign image). */
 size_t gnnb_amb_records_bytes(const gnnb_t* h, int B);
 int gnnb_pack_amb_records(const gnnb_t* h, const gnnb_batch* in, int B, void* dst, size_t cap, size_t* used);
-int gnnb_scatter_amb_records(gnnb_t* h, const void* dev_image, int B, float* const* dual, int n_relu, float* const* primal, int n_primal, void* stream);
+int gnnb_scatter_amb_records(gnnb_t* h, const void* dev_image, int B, float* const* dual, int n_relu, float* const* primal, int n_primal,
+                             int32_t* status, void* stream);
 
 /* BaBSR ("KW") branching heuristic for a batch -- the fallback scorer of the BaB loop (reference
  * plnn/kw_score_conv.py choose_node_conv :41-113, called at plnn/relu_conv_gnnkwthreshold.py:157).  lb/ub: HOST tables of
@@ -176,6 +204,10 @@ int gnnb_mu_projection(const gnnb_t* h, int k, int* linear_id);
 /* Stop after `n` half-passes (1 = round-0 forward sweep, 2 = + round-0 backward sweep, ...;
  * <= 0 = run everything).  With a limit set the scores are computed from the embeddings so far. */
 int gnnb_set_halfpass_limit(gnnb_t* h, int n);
+
+/* Occupy n_workgroups CUs (one workgroup per CU when lds_bytes > 80 KiB) for `ms` (<= 500) milliseconds on `stream` with a kernel that only
+ * watches the clock: the test stand-in for "something else holds CUs while a forward runs" (a collective, a second batch). */
+int gnnb_debug_occupy(int n_workgroups, int threads, size_t lds_bytes, double ms, void* stream);
 
 /* Per-kernel-class timing with HIP events recorded on the launch stream.  When enabled every
  * launch in gnnb_forward is bracketed by a pair of events; gnnb_profile_read synchronises the

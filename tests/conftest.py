@@ -24,6 +24,14 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+def pytest_sessionfinish(session, exitstatus):
+    # the parity margins the GPU tests reported (tests/margins.py) -> profiles/r06_parity_margins.json
+    from tests import margins
+    path = margins.dump(ROOT)
+    if path:
+        print(f"\nparity margins written to {path}")
+
+
 @pytest.fixture(scope="session")
 def shipped_state():
     from tests.common import shipped_state as f

@@ -25,10 +25,55 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_no_device_needed_for_metadata(lib):
-    assert lib.gnnb_abi_version() == 1
+    assert lib.gnnb_abi_version() == 2
     n = lib.gnnb_profile_classes()
     names = [lib.gnnb_profile_class_name(i).decode() for i in range(n)]
     assert "k_node_update" in names and "k_conv_fwd" in names and len(set(names)) == n
+
+
+def test_option_table_is_the_documented_one(lib):
+    """Handle options go through the C-ABI (gnnb_set_option), not the environment: the table the library exports == the names the Python
+    host knows == the table of include/gnnb.h and INTEGRATION.md; ten at most; unknown names and null handles are refused without a GPU."""
+    names = [lib.gnnb_option_name(i).decode() for i in range(lib.gnnb_option_count())]
+    assert sorted(names) == sorted(_lib.OPTIONS) and len(names) <= 10, names
+    header = open(os.path.join(ROOT, "include", "gnnb.h")).read()
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for n in names:
+        assert f'"{n}"' in header, n
+        assert f"`{n}`" in integ, n
+    assert lib.gnnb_set_option(None, b"fuse", 0) != 0
+    assert lib.gnnb_option_name(99) == b""
+
+
+def test_library_and_package_leave_the_environment_alone():
+    """The shipped library reads no environment variable (development builds, -DGNNB_DEV, do); the package never WRITES one: options reach a
+    handle through gnnb_set_option (ScorerEngine(options=...)), the GNNB_* names of _lib.OPTION_ENV are read once per engine for the tests."""
+    csrc = os.path.join(ROOT, "gnn_branching_amd", "csrc")
+    for f in os.listdir(csrc):
+        if not f.endswith((".hip", ".h")):
+            continue
+        depth = 0                                      # nesting depth of #ifdef GNNB_DEV blocks
+        stack = []
+        for line in open(os.path.join(csrc, f)):
+            t = line.strip()
+            if t.startswith(("#if", "#ifdef", "#ifndef")):
+                stack.append("GNNB_DEV" in t and not t.startswith("#ifndef"))
+                depth += stack[-1]
+            elif t.startswith("#else") and stack and stack[-1]:
+                stack[-1] = False
+                depth -= 1
+            elif t.startswith("#endif") and stack:
+                depth -= stack.pop()
+            elif "getenv(" in t and not t.startswith("//"):
+                assert depth > 0, f"{f}: getenv outside #ifdef GNNB_DEV: {t}"
+    pkg = os.path.join(ROOT, "gnn_branching_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(d, f)).read()
+                assert not re.search(r"os\.environ\[[^\]]+\]\s*=|os\.environ\.(setdefault|update|pop)\(|os\.putenv|del os\.environ", src), os.path.join(d, f)
+    assert _lib.options_from_env({"GNNB_NO_TOP": "1", "GNNB_TOP_SPLIT": "3", "GNNB_BF3": "0", "OTHER": "7"}) == {"top": 0, "top_split": 2, "bf3": 0}
+    assert _lib.options_from_env({}) == {}
 
 
 def test_product_path_fails_loudly_without_gpu():
@@ -67,6 +112,8 @@ def test_status_word_maps_to_the_reference_s_failure_modes():
         engine._raise_for_status(2)
     with pytest.raises(RuntimeError):                 # a timed-out wait outranks the NaN check: its rows are garbage anyway
         engine._raise_for_status(3)
+    with pytest.raises(RuntimeError, match="record image"):      # bit 2: gnnb_scatter_amb_records refused a foreign / corrupt image
+        engine._raise_for_status(4)
     res = engine.ForwardResult(None, None, torch.tensor([0, 1], dtype=torch.int32), None)
     with pytest.raises(FloatingPointError):
         res.check()

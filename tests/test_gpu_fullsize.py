@@ -1,10 +1,11 @@
-"""-m gpu: properties at BASELINE.json's full sizes (where the CPU oracle would take minutes):
-batched == re-scored subsets bit for bit, permutation equivariance, decisions == first argmax of the scores,
-plus spot checks of a few samples against the oracle within the 1e-4 budget."""
+"""-m gpu: properties at BASELINE.json's full sizes: batched == re-scored subsets bit for bit, permutation equivariance, decisions ==
+first argmax of the scores, and 64+ samples of every configuration against the CPU oracle within the 1e-4 budget (graph_conv.py:442-470 is
+per sample, so the oracle scores any subset of a batch on its own: ~20 ms per sample) -- the margins go on record (tests/margins.py)."""
 import numpy as np
 import pytest
 import torch
 
+from tests import margins
 from tests.common import SCORE_ATOL, shipped_state
 
 pytestmark = pytest.mark.gpu
@@ -62,11 +63,40 @@ def test_full_size_batch_properties(net, B):
             batch.masks[perm])
         pres = model.forward_device(*pb.forward_args()).check()
         assert torch.equal(pres.scores.cpu(), scores[perm])
-        # 5. a few samples against the CPU oracle
-        for b in (0, B // 2, B - 1):
-            want = gnn_oracle.oracle_forward(state, *batch.slice(b, b + 1).forward_args())[0]
-            got = scores[b][batch.masks[b] != 0]
-            assert (got - want).abs().max().item() <= SCORE_ATOL
+        # 5. 64+ samples against the CPU oracle: a seeded spread, both ends, and the samples with the largest |score|, the most scored
+        #    nodes and the closest decision (smallest top-1 / top-2 gap) -- where an error would show or matter first
+        sc = scores.numpy()
+        fin = np.isfinite(sc)
+        absmax = np.where(fin, np.abs(sc), 0.0).max(1)
+        n_scored = fin.sum(1)
+        top2 = np.sort(np.where(fin, sc, -np.inf), 1)[:, -2:]
+        gap = np.where(n_scored >= 2, top2[:, 1] - top2[:, 0], np.inf)
+        pick = {0, B // 2, B - 1, int(absmax.argmax()), int(n_scored.argmax()), int(gap.argmin())}
+        pick |= set(int(i) for i in np.random.RandomState(6).choice(B, size=min(B, 64), replace=False))
+        pick = sorted(pick)
+        worst, worst_b = 0.0, -1
+        torch.set_num_threads(min(16, torch.get_num_threads()))
+        for c in range(0, len(pick), 16):
+            idx = pick[c:c + 16]
+            it = torch.tensor(idx)
+            sub = synth.SubproblemBatch(
+                [t[it] for t in batch.lower_bounds_all], [t[it] for t in batch.upper_bounds_all],
+                [t.view(B, -1, 3)[it].reshape(-1, 3) for t in batch.dual_vars],
+                [t.view(B, -1)[it].reshape(-1) for t in batch.primals], batch.primal_inputs[it],
+                {"fixed_layers": batch.layers["fixed_layers"], "prop_layers": [batch.layers["prop_layers"][i] for i in idx]},
+                batch.masks[it])
+            want = gnn_oracle.oracle_forward(state, *sub.forward_args())
+            for b, w in zip(idx, want):
+                got = scores[b][batch.masks[b] != 0]
+                err = (got - w).abs().max().item() if w.numel() else 0.0
+                if err > worst:
+                    worst, worst_b = err, b
+        margins.record("full_size_vs_oracle", f"{net}_B{B}", n_oracle_samples=len(pick), worst_abs_err=worst, worst_sample=worst_b, bar=SCORE_ATOL,
+                       max_abs_score=float(absmax.max()), min_top2_gap=float(gap.min()), min_top2_gap_among_checked=float(gap[pick].min()),
+                       max_scored_nodes=int(n_scored.max()), weights="shipped")
+        print(f"{net} B={B}: {len(pick)} samples vs oracle, worst |score - oracle| {worst:.3e} (sample {worst_b}; bar {SCORE_ATOL:g}), max |score| {absmax.max():.4g}, "
+              f"min top-2 gap {gap.min():.3e}")
+        assert worst <= SCORE_ATOL, (net, B, worst, worst_b)
 
 
 @pytest.mark.parametrize("net,B", [("cifar_base_kw", 256), ("cifar_wide_kw", 64), ("cifar_deep_kw", 128), ("cifar_base_kw", 3)])
@@ -86,37 +116,6 @@ def test_fused_halfpass_kernel_at_size(monkeypatch, net, B):
             out[fuse] = (res.scores.cpu(), res.decisions.cpu().tolist())
     assert torch.equal(out["0"][0], out["1"][0])
     assert out["0"][1] == out["1"][1]
-
-
-@pytest.mark.parametrize("net,B", [("cifar_base_kw", 256), ("cifar_deep_kw", 256), ("cifar_wide_kw", 256), ("cifar_base_kw", 512)])
-def test_sweep_kernel_is_bit_identical_to_one_launch_per_halfpass(monkeypatch, net, B):
-    """GNNB_SWEEP=1, for batches that are a multiple of the CU count: consecutive fused conv half-passes go out as ONE launch (k_sweep: every
-    workgroup owns whole samples, a workgroup barrier between phases; graph_conv.py:107-192 / :222-385 are loops over layers inside one
-    call) -- against GNNB_SWEEP=0 (one k_gather_update_q launch per half-pass, tiles dealt across all samples): the same arithmetic per
-    node, so identical scores and decisions bit for bit, on the shipped checkpoint and on a seeded random weight set; fewer launches."""
-    from gnn_branching_amd import synth
-    from oracle.gnn_oracle import random_gnn_state
-    for state in (shipped_state(), random_gnn_state(20240917)):
-        batch = synth.make_batch(net, B, seed=77)
-        out, launches = {}, {}
-        for sweep in ("0", "1"):
-            monkeypatch.setenv("GNNB_SWEEP", sweep)          # (default 0: opt-in, see DESIGN.md section 5)
-            model = model_for(state)
-            eng = model.engine()
-            with torch.no_grad():
-                model.forward_device(*batch.forward_args()).check()
-                eng.profile_enable(True)
-                eng.profile_read(reset=True)
-                res = model.forward_device(*batch.forward_args()).check()
-                torch.cuda.synchronize()
-                launches[sweep] = sum(v[1] for v in eng.profile_read(reset=True).values())
-                eng.profile_enable(False)
-                again = model.forward_device(*batch.forward_args()).check()        # a second forward on the same workspace
-            out[sweep] = (res.scores.cpu(), res.decisions.cpu().tolist())
-            assert torch.equal(again.scores.cpu(), out[sweep][0])
-        assert torch.equal(out["0"][0], out["1"][0])
-        assert out["0"][1] == out["1"][1]
-        assert launches["1"] < launches["0"], launches
 
 
 @pytest.mark.parametrize("net,B", [("cifar_base_kw", 256), ("cifar_wide_kw", 256), ("cifar_deep_kw", 128)])

@@ -94,9 +94,11 @@ def test_amb_record_image_and_scatter(net, B):
     d_prim = [torch.full(tuple(t.shape), float("nan"), device=dev) for t in prims]
     dptr = (C.c_void_p * nd)(*[t.data_ptr() for t in d_dual])
     pptr = (C.c_void_p * npr)(*[t.data_ptr() for t in d_prim])
-    _lib.check(eng.lib.gnnb_scatter_amb_records(eng.h, d_img.data_ptr(), B, dptr, nd, pptr, npr, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
-               "gnnb_scatter_amb_records")
+    st = torch.zeros(1, dtype=torch.int32, device=dev)
+    cur = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(eng.lib.gnnb_scatter_amb_records(eng.h, d_img.data_ptr(), B, dptr, nd, pptr, npr, st.data_ptr(), cur), "gnnb_scatter_amb_records")
     torch.cuda.synchronize()
+    assert int(st.cpu()[0]) == 0
     for k in range(L):
         lb, ub = lbs[k + 1].reshape(-1), ubs[k + 1].reshape(-1)
         amb = (lb < 0) & (ub > 0)
@@ -107,3 +109,57 @@ def test_amb_record_image_and_scatter(net, B):
             gp = d_prim[m].cpu().reshape(-1)
             assert torch.equal(gp[amb], prims[m].reshape(-1)[amb]) and torch.isnan(gp[~amb]).all()
     assert torch.equal(d_prim[-1].cpu().reshape(-1), prims[-1].reshape(-1))
+    # ---- a foreign or corrupt image is refused, not scattered (status bit 2): wrong batch size in the header, a record beyond its array
+    for how in ("batch", "index", "layer"):
+        bad = img[:used.value // 4].clone()
+        if how == "batch":
+            bad[3] = B + 1
+        elif how == "index":
+            bad[16 + 1] = B * eng.sizes[1 + int(bad[16])] + 5          # record 0: flat node index past the end of its layer
+        else:
+            bad[16] = L + 3
+        d_bad = bad.to(dev)
+        p_dual = [torch.full(tuple(t.shape), float("nan"), device=dev) for t in duals]
+        p_prim = [torch.full(tuple(t.shape), float("nan"), device=dev) for t in prims]
+        dptr = (C.c_void_p * nd)(*[t.data_ptr() for t in p_dual])
+        pptr = (C.c_void_p * npr)(*[t.data_ptr() for t in p_prim])
+        st.zero_()
+        _lib.check(eng.lib.gnnb_scatter_amb_records(eng.h, d_bad.data_ptr(), B, dptr, nd, pptr, npr, st.data_ptr(), cur), "gnnb_scatter_amb_records")
+        torch.cuda.synchronize()
+        assert int(st.cpu()[0]) == 4, how
+        if how == "batch":                                       # header mismatch: nothing at all is written
+            assert all(torch.isnan(t).all() for t in p_dual + p_prim)
+
+
+def test_two_networks_alternate_through_one_engine_and_pipeline():
+    """ADVICE (round 5): the compact path packs with the sizes of whatever network the HANDLE is bound to.  Two networks of equal depth
+    (cifar_base_kw, cifar_wide_kw) alternating through one engine -- through the pipeline and through eng.forward between submits -- must
+    each be packed under their own binding: scores equal the device-resident forward's; tensors of the wrong size raise ValueError
+    before the C packer sees a pointer."""
+    from gnn_branching_amd import engine as E, synth
+    model = make_model("shipped")
+    eng = model.engine()
+    dev = eng.device
+    batches = [synth.make_batch(net, 6, seed=300 + i) for i, net in enumerate(["cifar_base_kw", "cifar_wide_kw", "cifar_base_kw", "cifar_wide_kw", "cifar_wide_kw"])]
+    want = []
+    with torch.no_grad():
+        for b in batches:
+            args = b.forward_args()
+            d = [[t.to(dev) for t in g] if isinstance(g, list) else g for g in args]
+            d[4], d[6] = args[4].to(dev), args[6].to(dev)
+            want.append(eng.forward(*d).check().scores.cpu().numpy())
+    pipe = E.HostFedPipeline(eng, compact=True)
+    other = synth.make_batch("cifar_deep_kw", 2, seed=9)
+    got = []
+    with torch.no_grad():
+        for i, b in enumerate(batches):
+            got.append(pipe.submit(*b.forward_args()))
+            if i == 1:                                            # someone else rebinds the shared engine between two submits
+                eng.forward(*other.forward_args()).check()
+    for r, w in zip(got, want):
+        r.check()
+        assert np.array_equal(r.scores.cpu().numpy(), w, equal_nan=True)
+    bad = list(batches[0].forward_args())
+    bad[2] = [t[:-3] for t in bad[2]]                             # dual_vars three rows short
+    with pytest.raises(ValueError):
+        pipe.submit(*bad)

@@ -7,6 +7,7 @@ import torch
 
 from gnn_branching_amd import synth
 from gnn_branching_amd.graphnet.graph_conv import GraphNet
+from tests import margins
 from tests.common import SCORE_ATOL, score_tol, state_of
 
 pytestmark = pytest.mark.gpu
@@ -51,6 +52,8 @@ def test_random_batches_masks_and_weights(net):
                         assert dec[b] == [-1, -1]
                 n += 1
     print(f"{net}: {n} cases, worst |score - oracle| shipped {worst['shipped']:.3e}, random {worst['random']:.3e}")
+    for fam in worst:
+        margins.record("random_batches_masks_weights", f"{net}_{fam}", n_cases=n // 2, worst_abs_err=worst[fam], bar=score_tol(fam))
 
 
 def lp_like(batch, rng, dual_scale, decided_frac=0.25):
@@ -87,9 +90,10 @@ def lp_like(batch, rng, dual_scale, decided_frac=0.25):
 @pytest.mark.parametrize("net", ["cifar_base_kw", "cifar_wide_kw", "cifar_deep_kw"])
 def test_lp_like_duals_and_decided_nodes(net):
     """Signed / large duals and masks with decided nodes (bounds clamped to exactly 0 on either side): what the synthetic
-    generator never produces and a BaB run always does.  Shipped weights: 1e-4 absolute while the scores stay in the range the
-    budget was stated for, 2e-6 of the largest score beyond it (large duals scale the scores; the reference's own fp32-vs-fp64
-    noise is ~5e-7 of the score range)."""
+    generator never produces and a BaB run always does.  The bar is 1e-4 absolute (north_star) while the scores stay in the range that
+    budget was stated for.  Large duals scale the scores beyond it (duals <= 30: |score| in the hundreds), where fp32 itself cannot hold
+    1e-4: there the yardstick is MEASURED, not set by hand -- the oracle is run in fp64 on the same inputs, e_ref = max |oracle_fp32 -
+    oracle_fp64| is the reference arithmetic's own rounding error, and the HIP path must stay within twice that of the fp64 truth."""
     from oracle import gnn_oracle
     torch.set_num_threads(min(16, torch.get_num_threads()))
     models = {}
@@ -111,9 +115,17 @@ def test_lp_like_duals_and_decided_nodes(net):
                 assert np.array_equal(np.isfinite(got), fin) and fin.any()
                 err = float(np.abs(got[fin] - want[fin]).max())
                 big = float(np.abs(want[fin]).max())
-                tol = max(score_tol(fam, want[fin]), 2e-6 * big)
-                print(f"{net} B={B} duals<= {dual_scale:g} {fam}: max|score - oracle| {err:.3e} (bar {tol:.1e}), scores in [{want[fin].min():.4g}, {want[fin].max():.4g}]")
-                assert err <= tol, (net, B, dual_scale, fam, err, tol)
+                tol = score_tol(fam, want[fin])
+                with torch.no_grad():
+                    w64 = gnn_oracle.padded_scores(gnn_oracle.oracle_forward(state_of(fam), *args, dtype=torch.float64), args[6]).numpy()
+                e_ref = float(np.abs(want[fin].astype(np.float64) - w64[fin]).max())       # the reference arithmetic's own fp32 rounding on these inputs
+                e_hip = float(np.abs(got[fin].astype(np.float64) - w64[fin]).max())        # the HIP path against the same fp64 truth
+                print(f"{net} B={B} duals<= {dual_scale:g} {fam}: max|score - oracle| {err:.3e} (bar {tol:.1e}); vs fp64: HIP {e_hip:.3e}, oracle fp32 {e_ref:.3e} "
+                      f"(ratio {e_hip / max(e_ref, 1e-30):.2f}), scores in [{want[fin].min():.4g}, {want[fin].max():.4g}]")
+                margins.record("lp_like_duals", f"{net}_{fam}_duals_le_{dual_scale:g}", worst_abs_err=err, worst_err_vs_fp64_hip=e_hip,
+                               worst_err_vs_fp64_oracle_fp32=e_ref, worst_ratio_hip_over_oracle_fp32=e_hip / max(e_ref, 1e-30), max_abs_score=big, bar_abs=tol)
+                # inside the stated budget, or -- where fp32 cannot hold it -- within twice the reference arithmetic's own error
+                assert err <= tol or e_hip <= 2.0 * e_ref, (net, B, dual_scale, fam, err, tol, e_hip, e_ref)
                 sizes = [int(np.prod(t.shape[1:])) for t in args[0][1:-1]]
                 for b in range(B):
                     m1 = torch.from_numpy(want[b][fin[b]])

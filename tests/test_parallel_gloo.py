@@ -120,6 +120,13 @@ def _bench_worker(rank, world, port, out_dir):
             want[:, ::5] = float("-inf")
             assert torch.equal(t, want), (rank, i)
         assert step_of[-1] == K - 1
+        # the self-description of a multi-rank run (bench.py's `dist` record): the backend's own world size, every rank's step time,
+        # the bytes one all-gather moves per rank, the k_top mode
+        d = bench.dist_run_description(dist, 0.010 * (rank + 1), K, forward().scores, loop.last_gathered, 1)
+        assert d["process_group_world_size"] == world and d["backend"] == "gloo" and d["k_top_split"] == 1
+        assert d["rank_ms_per_step"]["per_rank"] == [round(1e3 * 0.010 * (r + 1) / K, 4) for r in range(world)]
+        assert d["rank_ms_per_step"]["min"] == d["rank_ms_per_step"]["per_rank"][0] and d["rank_ms_per_step"]["max"] == d["rank_ms_per_step"]["per_rank"][-1]
+        assert d["gather_bytes_per_step"] == {"sent_per_rank": B * R * 4, "received_per_rank": world * B * R * 4}
         torch.save(seen[-1], os.path.join(out_dir, f"bench_rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
