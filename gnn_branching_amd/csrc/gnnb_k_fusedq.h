@@ -72,7 +72,10 @@ struct FArgs {
 #ifndef QG_WAVES
 #define QG_WAVES 8            // gather waves (8 + 8 chain waves measured best on base B = 256; 10 + 6 and 12 + 4 are 2-8 % slower)
 #endif
-#define QC_WAVES (16 - QG_WAVES)      // chain waves
+#ifndef Q_TOTAL_WAVES
+#define Q_TOTAL_WAVES 16      // waves per workgroup = per CU (128 VGPRs each: the whole register file).  dev A/B: 8 / 12 with QG_WAVES 4 / 6 = one / one and a
+#endif                        // half wave pairs per SIMD instead of two -- how the half-pass time scales with resident waves (profiles/r06_wave_scaling_ab.txt)
+#define QC_WAVES (Q_TOTAL_WAVES - QG_WAVES)      // chain waves
 #define QTILES 4              // ring slots of 32 rows at most; FArgs.qtiles (2..4) says how many this launch has room for
 #define QROW 72               // floats per ring row: 64 channels, {node id | ambiguous << 31, r0, r1, s}, 4 pad (16-B rows, <= 2-way bank conflicts)
 #define QHDR_INTS 16

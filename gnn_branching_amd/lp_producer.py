@@ -426,6 +426,12 @@ def branch_and_bound_threshold(lp, scorer, kw_scorer, layers, eps=1e-4, max_bran
     icp_score)`` (BaBSR; the counter is the loop's state as at :119, :157).  ``log`` receives the per-branch line of :204 (= the line
     of :201-202 in the dump), ``dump`` the dump file's lines (:201-202, :256-257).  A domain's GNN decision is computed when the domain
     is picked (the reference computes it when the domain is created, :230 / :239: the same function of the same domain).
+    With a ``decision_bound`` the dumped global lower bound follows the reference's rule (:251-255): the lowest bound among the open domains,
+    or ``global_ub - eps`` once none is left, so a dump compares line for line.  Remaining deviations, none of which changes a decision: the
+    loop stops after ``max_branches`` branches (the reference runs until its caller's timeout); a domain whose bound is already >= 0 would get
+    GNN improvement 1.0 instead of the reference's division by ``-2 * lower_bound`` (with ``decision_bound`` = 0 such a domain is never
+    added, :226 / :235); infeasible children count as lower bound +inf (Gurobi reports them infeasible too; the reference has no such branch
+    because its children inherit feasible parents' bounds); without a ``decision_bound`` leaves closed at optimality keep the minimum honest.
     Returns (global_lb, global_ub, LP solves, branches, branches that bounded a KW decision, branches that used it)."""
     from .bab_caller import gnn_improvement, resolve_branching, trace_line
     fixed = {"fixed_layers": list(layers[:-1]), "prop_layers": [layers[-1]]}
@@ -489,7 +495,10 @@ def branch_and_bound_threshold(lp, scorer, kw_scorer, layers, eps=1e-4, max_bran
                 domains.append(c)
             else:
                 closed_lb = min(closed_lb, c.lb)
-        global_lb = min([d.lb for d in domains] + [closed_lb, global_ub])
+        if decision_bound is not None:                                                                     # :251-255
+            global_lb = min(d.lb for d in domains) if domains else global_ub - eps
+        else:
+            global_lb = min([d.lb for d in domains] + [closed_lb, global_ub])
         if dump is not None:
             dump(line)
             dump(f"{global_lb}\n")                                                                         # :256-257

@@ -38,14 +38,23 @@ def dump(root):
         out["library_build_id"] = _lib.library_build_id()
     except Exception:      # noqa: BLE001
         pass
-    paths = [os.path.join(root, "profiles", "r06_parity_margins.json")]
+    dirs = [os.path.join(root, "profiles")]
     if os.path.isdir(os.path.join(root, "gpurun_out")) or os.environ.get("GRAFT_REPO_ROOT"):
         os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
-        paths.append(os.path.join(root, "gpurun_out", "r06_parity_margins.json"))
-    for p in paths:
-        try:
-            with open(p, "w") as f:
-                json.dump(out, f, indent=1, sort_keys=True)
-        except OSError:
-            pass
-    return paths[0]
+        dirs.append(os.path.join(root, "gpurun_out"))
+    # the wall-clock records of the BaB-loop stand-in (BASELINE config 5) go to a file of their own
+    wall = out["records"].pop("bab_loop_wallclock", None)
+    files = [("r06_parity_margins.json", out)] if out["records"] else []
+    if wall:
+        files.append(("r06_bab_loop_wallclock.json", {k: v for k, v in out.items() if k != "records"} | {
+            "note": "BASELINE config 5 stand-in (no Gurobi / CIFAR-10 here): the reference loop's control flow (relu_conv_gnnkwthreshold.py:126-243) on HiGHS-produced "
+                    "inputs; GNN scorer calls timed on the MI355X path (GraphChoice.decision, host tensors in, synchronous) and on the CPU twin of the reference "
+                    "path (oracle, 1 thread as scripts/bab_mip.sh:3-5 deploys it); tests/test_gpu_bab_trace.py", "records": wall}))
+    for d in dirs:
+        for name, obj in files:
+            try:
+                with open(os.path.join(d, name), "w") as f:
+                    json.dump(obj, f, indent=1, sort_keys=True)
+            except OSError:
+                pass
+    return os.path.join(dirs[0], files[0][0]) if files else None

@@ -18,6 +18,7 @@ The LP solves are cached by (parent mask, child mask), so run B costs only its o
 """
 import copy
 import os
+import time
 
 import numpy as np
 import pytest
@@ -36,7 +37,7 @@ class CachedLP:
     """lp_producer.LayerGraphLP whose `solve` remembers its results: both runs pose the same LPs while their traces agree."""
 
     def __init__(self, lp):
-        self._lp, self._cache, self.hits, self.solves = lp, {}, 0, 0
+        self._lp, self._cache, self.hits, self.solves, self.solve_s = lp, {}, 0, 0, 0.0
 
     def __getattr__(self, name):
         return getattr(self._lp, name)
@@ -51,7 +52,9 @@ class CachedLP:
             self.hits += 1
             return self._cache[key]
         self.solves += 1
+        t0 = time.perf_counter()
         sub = self._lp.solve(mask, parent=parent, split_layer=split_layer)
+        self.solve_s += time.perf_counter() - t0
         self._cache[key] = sub
         return sub
 
@@ -171,6 +174,25 @@ def test_decision_trace_on_lp_inputs(name, gt, cls, seed, eps, min_nodes):
 
 # ---- the reference loop's OWN control flow (round 5): GNN decision -> improvement below the branching threshold -> BaBSR decision -> two more
 # LPs -> keep the better pair (plnn/relu_conv_gnnkwthreshold.py:150-199), with both scorers on the device against an oracle twin ------------
+def record_wallclock(key, r, extra=None):
+    """BASELINE config 5's other half ("wall-clock vs reference CPU GNN path"), for the stand-in: what the loop's scorer calls cost on the
+    MI355X path (GraphChoice.decision: host tensors in, decision out, synchronous -- the reference's own call form) and on the CPU twin of
+    the reference path (oracle, ONE thread as scripts/bab_mip.sh deploys it), over the same LP inputs; and what the LPs cost (HiGHS here,
+    Gurobi in the reference).  Collected by tests/margins.py into profiles/r06_bab_loop_wallclock.json."""
+    from tests import margins
+    c, res = r["clock"], r["res_a"]
+    rec = {"branches": int(res[3]), "lp_solves_posed": int(res[2]), "branches_that_bounded_a_kw_decision": int(res[4]), "branches_that_kept_it": int(res[5]),
+           "gnn_decisions": int(c["hip_gnn_calls"]), "gnn_ms_total_hip": round(1e3 * c["hip_gnn_s"], 3), "gnn_ms_total_cpu_1_thread": round(1e3 * c["cpu_gnn_s"], 3),
+           "gnn_ms_per_decision_hip": round(1e3 * c["hip_gnn_s"] / max(1, c["hip_gnn_calls"]), 4),
+           "gnn_ms_per_decision_cpu_1_thread": round(1e3 * c["cpu_gnn_s"] / max(1, c["cpu_gnn_calls"]), 3),
+           "kw_decisions": int(c["hip_kw_calls"]), "kw_ms_total_hip": round(1e3 * c["hip_kw_s"], 3), "kw_ms_total_cpu_1_thread": round(1e3 * c["cpu_kw_s"], 3),
+           "lp_ms_total_highs": round(1e3 * r["lp"].solve_s, 1), "lp_solves_run": int(r["lp"].solves),
+           "trace_lines_equal_hip_vs_cpu_twin": bool(r["lines_a"] == r["lines_b"]), "final_bounds": [float(res[0]), float(res[1])]}
+    rec.update(extra or {})
+    margins.record("bab_loop_wallclock", key, **rec)
+    return rec
+
+
 def run_threshold_trace(name, gt, cls, seed, eps, max_branches, branching_threshold=0.2):
     from gnn_branching_amd.graphnet.graph_score import GraphChoice
     from gnn_branching_amd.plnn import kw_score_conv as kw
@@ -187,13 +209,23 @@ def run_threshold_trace(name, gt, cls, seed, eps, max_branches, branching_thresh
     graph = GraphChoice([torch.full((n,), -1, dtype=torch.long) for n in sizes], CKPT)
     graph.verbose = False
 
+    clock = {"hip_gnn_s": 0.0, "hip_gnn_calls": 0, "hip_kw_s": 0.0, "hip_kw_calls": 0, "cpu_gnn_s": 0.0, "cpu_gnn_calls": 0, "cpu_kw_s": 0.0, "cpu_kw_calls": 0}
+
     # ---- run A: both scorers on the MI355X, called the way the reference driver calls them
     def hip_gnn(sub, _layers):
         lbg, ubg = sub.graph_bounds(lp.pre_relu_indices, len(lp.layers))
-        return graph.decision(lbg, ubg, sub.dual_vars, sub.ub_point, sub.primals, dev_layers, sub.mask)
+        t0 = time.perf_counter()
+        dec = graph.decision(lbg, ubg, sub.dual_vars, sub.ub_point, sub.primals, dev_layers, sub.mask)      # (synchronous: host tensors in, two ints out)
+        clock["hip_gnn_s"] += time.perf_counter() - t0
+        clock["hip_gnn_calls"] += 1
+        return dec
 
     def hip_kw(sub, icp, random_order, sparsest_layer):
-        return kw.choose_node_conv(sub.lower_all, sub.upper_all, sub.mask, lp.layers, lp.pre_relu_indices, icp, random_order, sparsest_layer)
+        t0 = time.perf_counter()
+        out = kw.choose_node_conv(sub.lower_all, sub.upper_all, sub.mask, lp.layers, lp.pre_relu_indices, icp, random_order, sparsest_layer)
+        clock["hip_kw_s"] += time.perf_counter() - t0
+        clock["hip_kw_calls"] += 1
+        return out
     lines_a, dump_a = [], []
     res_a = lp_producer.branch_and_bound_threshold(lp, hip_gnn, hip_kw, layers, max_branches=max_branches, branching_threshold=branching_threshold,
                                                    decision_bound=0.0, log=lines_a.append, dump=dump_a.append)
@@ -203,8 +235,14 @@ def run_threshold_trace(name, gt, cls, seed, eps, max_branches, branching_thresh
 
     def oracle_gnn(sub, _layers):
         lbg, ubg = sub.graph_bounds(lp.pre_relu_indices, len(lp.layers))
+        nthr = torch.get_num_threads()
+        torch.set_num_threads(1)                  # the reference deploys its BaB on ONE core (scripts/bab_mip.sh:3-5: taskset -c <core>)
+        t0 = time.perf_counter()
         with torch.no_grad():
             s = gnn_oracle.oracle_forward(state, lbg, ubg, sub.dual_vars, sub.primals, sub.ub_point, host_layers, mask_1d(sub))[0]
+        clock["cpu_gnn_s"] += time.perf_counter() - t0
+        clock["cpu_gnn_calls"] += 1
+        torch.set_num_threads(nthr)
         top = torch.sort(s, descending=True)[0]
         gaps.append(float(top[0] - top[1]) if len(top) > 1 else float("inf"))
         return gnn_oracle.decision_from_scores(s, mask_1d(sub)[0], sizes)
@@ -213,13 +251,19 @@ def run_threshold_trace(name, gt, cls, seed, eps, max_branches, branching_thresh
         lbs = [sub.lower_all[i].unsqueeze(0) for i in lp.pre_relu_indices]
         ubs = [sub.upper_all[i].unsqueeze(0) for i in lp.pre_relu_indices]
         masks = [(m == -1).float().reshape(1, -1) for m in sub.mask]
+        nthr = torch.get_num_threads()
+        torch.set_num_threads(1)
+        t0 = time.perf_counter()
         with torch.no_grad():
             score, icpt = babsr_oracle.babsr_scores(lbs, ubs, masks, list(layers[:-1]), layers[-1].weight.detach().reshape(1, -1))
+        clock["cpu_kw_s"] += time.perf_counter() - t0
+        clock["cpu_kw_calls"] += 1
+        torch.set_num_threads(nthr)
         return babsr_oracle.decide([t[0] for t in score], [t[0] for t in icpt], [m[0] for m in masks], icp, random_order, sparsest_layer)
     lines_b = []
     res_b = lp_producer.branch_and_bound_threshold(lp, oracle_gnn, oracle_kw, layers, max_branches=max_branches, branching_threshold=branching_threshold,
                                                    decision_bound=0.0, log=lines_b.append)
-    return dict(lines_a=lines_a, lines_b=lines_b, dump_a=dump_a, res_a=res_a, res_b=res_b, gaps=gaps, lp=lp)
+    return dict(lines_a=lines_a, lines_b=lines_b, dump_a=dump_a, res_a=res_a, res_b=res_b, gaps=gaps, lp=lp, clock=clock)
 
 
 # eps chosen so that the ROOT is undecided (lower bound < 0 < upper bound: at eps = 0.02 these properties hold at the root and the reference loop would
@@ -239,6 +283,7 @@ def test_threshold_loop_trace_with_the_kw_fallback(name, gt, cls, seed, eps, bra
         f.writelines(r["dump_a"])
     la, lb = r["lines_a"], r["lines_b"]
     n_kw = sum("kw: improvement -1 decision None" not in l for l in la)
+    print("wall-clock of the loop's scorer calls:", record_wallclock(f"{name}_gt{gt}_cls{cls}_seed{seed}_eps{eps}_branches{branches}", r, {"input": "seeded N(0,1) image", "eps": eps}))
     print(f"\n{name}: {len(la)} branches with the KW fall-back (threshold 0.2): {r['res_a'][4]} bounded a KW decision, {r['res_a'][5]} kept it; "
           f"{r['res_a'][2]} LPs posed (LP solves {r['lp'].solves}, cache hits {r['lp'].hits}); bounds {r['res_a'][0]:.5f} / {r['res_a'][1]:.5f}; "
           f"smallest oracle top-2 GNN gap {min(r['gaps']):.3e}")
@@ -253,3 +298,50 @@ def test_threshold_loop_trace_with_the_kw_fallback(name, gt, cls, seed, eps, bra
         assert min(r["gaps"]) < 1e-3, (la[first_diff], lb[first_diff])
     else:
         assert la == lb and r["res_a"] == r["res_b"]            # same tree, same bounds, same counters, line by line
+
+
+def _predicted_class(name, x):
+    with torch.no_grad():
+        z = x.unsqueeze(0)
+        for l in nets.build_net(name):
+            z = l(z)
+    return int(z.argmax())
+
+
+@pytest.mark.parametrize("row", [0, 1])
+def test_threshold_loop_on_base_easy_rows_with_wallclock(row):
+    """(Eps, prop) of rows of the reference's experiment table cifar_exp/base_easy.pkl (fixture tests/golden/base_easy_props.npz, made by
+    oracle/make_golden_props.py) -- the properties `bab_mip.py --bab_gnn` runs (bab_mip.py:91-120) -- on a seeded stand-in image (CIFAR-10 is
+    not available offline; ground truth := the class the network predicts for the stand-in): the reference loop's control flow, HIP scorers
+    against the CPU twin, trace lines equal, and the wall-clock of the GNN calls on both paths on record beside what the reference's own run
+    of that table row took (BBran_gnnkwT branches, BTime_gnnkwT seconds, with Gurobi and the real image: context, not a comparison)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "base_easy_props.npz"))
+    table_eps, prop = float(g["Eps"][row]), int(g["prop"][row])
+    seed = 100 + row
+    x = torch.from_numpy(np.random.RandomState(seed).standard_normal((3, 32, 32)).astype(np.float32))
+    gt = _predicted_class("cifar_base_kw", x)
+    cls = prop if prop != gt else (prop + 1) % 10
+    # On the stand-in image the table's eps is already violated at the root (upper bound < 0: nothing to branch on), so eps is shrunk in
+    # fixed steps until the root is undecided (lower bound < 0 < upper bound) -- the state the reference loop starts branching from
+    layers = nets.load_verified_net("cifar_base_kw", gt, cls)
+    eps = None
+    for f in (1.0, 0.75, 0.55, 0.4, 0.3, 0.2):
+        lp0 = lp_producer.LayerGraphLP(layers, x - f * table_eps, x + f * table_eps)
+        root = lp0.solve([torch.full((int(np.prod(lp0.shapes[i + 1])),), -1, dtype=torch.long) for i in lp0.pre_relu_indices])
+        if root is not None and root.lb < 0 < root.ub:
+            eps = round(f * table_eps, 6)
+            break
+    assert eps is not None, "no eps step leaves the root undecided"
+    branches = 5
+    r = run_threshold_trace("cifar_base_kw", gt, cls, seed, eps, max_branches=branches)
+    rec = record_wallclock(f"base_easy_row{row}_prop{prop}", r, {
+        "input": "seeded N(0,1) stand-in for CIFAR-10 image %d" % int(g["Idx"][row]), "table_eps": table_eps, "eps": eps, "target_class": cls, "ground_truth_class": gt,
+        "reference_recorded_for_this_row": {"BBran_gnnkwT": float(g["BBran_gnnkwT"][row]), "BTime_gnnkwT_s": float(g["BTime_gnnkwT"][row]), "BSAT_gnnkwT": str(g["BSAT_gnnkwT"][row])}})
+    print(f"\nbase_easy row {row} (eps {eps}, prop {prop}):", rec)
+    la, lb = r["lines_a"], r["lines_b"]
+    assert len(la) >= 1
+    first_diff = next((i for i in range(min(len(la), len(lb))) if la[i] != lb[i]), None)
+    if first_diff is not None:
+        assert min(r["gaps"]) < 1e-3, (la[first_diff], lb[first_diff])
+    else:
+        assert la == lb and r["res_a"] == r["res_b"]

@@ -75,6 +75,7 @@ def test_full_size_batch_properties(net, B):
         pick |= set(int(i) for i in np.random.RandomState(6).choice(B, size=min(B, 64), replace=False))
         pick = sorted(pick)
         worst, worst_b = 0.0, -1
+        excused = []                                 # nodes where the REFERENCE arithmetic itself is further than the bar from its fp64 evaluation
         torch.set_num_threads(min(16, torch.get_num_threads()))
         for c in range(0, len(pick), 16):
             idx = pick[c:c + 16]
@@ -88,15 +89,32 @@ def test_full_size_batch_properties(net, B):
             want = gnn_oracle.oracle_forward(state, *sub.forward_args())
             for b, w in zip(idx, want):
                 got = scores[b][batch.masks[b] != 0]
-                err = (got - w).abs().max().item() if w.numel() else 0.0
+                e32 = (got - w).abs()
+                if w.numel() and e32.max().item() > SCORE_ATOL:
+                    # Past the bar against the fp32 oracle.  Before calling it a failure, ask what the reference's own fp32 arithmetic is worth
+                    # at those nodes: the same formulas in fp64 (oracle dtype=float64).  A node is excused only if the fp32 REFERENCE is itself
+                    # further from the fp64 value than the HIP score is, and the HIP score is within the bar of the fp64 value -- i.e. the
+                    # disagreement is the reference's rounding at an ill-conditioned node, not ours.  Everything else fails.
+                    w64 = gnn_oracle.oracle_forward(state, *batch.slice(b, b + 1).forward_args(), dtype=torch.float64)[0]
+                    e_hip64, e_ref64 = (got.double() - w64).abs(), (w.double() - w64).abs()
+                    bad = e32 > SCORE_ATOL
+                    ok = bad & (e_hip64 <= SCORE_ATOL) & (e_ref64 > e_hip64)
+                    for i in torch.nonzero(bad).reshape(-1).tolist():
+                        excused.append({"sample": int(b), "node": int(i), "score": float(w64[i]), "hip_minus_ref_fp32": float(e32[i]), "hip_minus_fp64": float(e_hip64[i]),
+                                        "ref_fp32_minus_fp64": float(e_ref64[i]), "excused": bool(ok[i])})
+                    assert bool((ok == bad).all()), (net, B, b, excused[-3:])
+                    e32 = torch.where(bad, torch.zeros_like(e32), e32)
+                err = e32.max().item() if w.numel() else 0.0
                 if err > worst:
                     worst, worst_b = err, b
-        margins.record("full_size_vs_oracle", f"{net}_B{B}", n_oracle_samples=len(pick), worst_abs_err=worst, worst_sample=worst_b, bar=SCORE_ATOL,
+        n_nodes = int(sum(int((batch.masks[b] != 0).sum()) for b in pick))
+        margins.record("full_size_vs_oracle", f"{net}_B{B}", n_oracle_samples=len(pick), n_scored_nodes_checked=n_nodes, worst_abs_err=worst, worst_sample=worst_b, bar=SCORE_ATOL,
                        max_abs_score=float(absmax.max()), min_top2_gap=float(gap.min()), min_top2_gap_among_checked=float(gap[pick].min()),
-                       max_scored_nodes=int(n_scored.max()), weights="shipped")
-        print(f"{net} B={B}: {len(pick)} samples vs oracle, worst |score - oracle| {worst:.3e} (sample {worst_b}; bar {SCORE_ATOL:g}), max |score| {absmax.max():.4g}, "
-              f"min top-2 gap {gap.min():.3e}")
+                       max_scored_nodes=int(n_scored.max()), weights="shipped", nodes_where_the_fp32_reference_is_off_its_fp64_value=excused)
+        print(f"{net} B={B}: {len(pick)} samples ({n_nodes} scored nodes) vs oracle, worst |score - oracle| {worst:.3e} (sample {worst_b}; bar {SCORE_ATOL:g}), max |score| {absmax.max():.4g}, "
+              f"min top-2 gap {gap.min():.3e}; nodes past the bar where the fp32 reference itself is off its fp64 value: {excused}")
         assert worst <= SCORE_ATOL, (net, B, worst, worst_b)
+        assert len(excused) <= max(1, n_nodes // 5000), excused      # an exception, not a class: at most one node in 5000
 
 
 @pytest.mark.parametrize("net,B", [("cifar_base_kw", 256), ("cifar_wide_kw", 64), ("cifar_deep_kw", 128), ("cifar_base_kw", 3)])
