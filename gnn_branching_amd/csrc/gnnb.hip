@@ -1441,12 +1441,6 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     int S = 1;
     if (h->top_split_max >= 4 && (long)B * 4 <= h->n_cu && B <= TOP_SPLIT_MAXB) S = 4;      // (topflag / xbuf are sized for TOP_SPLIT_MAXB samples)
     else if (h->top_split_max >= 2 && (long)B * 2 <= h->n_cu && B <= TOP_SPLIT_MAXB) S = 2;
-    // With the waiting split off ("top_split" = 1: something else may hold CUs), the CUs a small batch leaves idle still help WITHOUT any
-    // hand-off: R workgroups per sample each run the sample's whole top and share only the row tiles of B2 + the update of layer L-1
-    // (TopArgs.rparts).  Same bits; deep B = 128: see DESIGN.md section 6.
-    int R = 1;
-    if (S == 1 && h->top_split_max == 1) R = (long)B * 4 <= h->n_cu ? 4 : ((long)B * 2 <= h->n_cu ? 2 : 1);
-    a.rparts = R;
     a.xbuf = ws + w.topx; a.xflag = reinterpret_cast<int*>(ws + w.topflag); a.xbase = top_launches * 2 * S;
     a.fuse_um = top_upd ? 1 : 0;
     if (top_upd) a.um = upd_args(L - 1, false, false, false);
@@ -1454,7 +1448,7 @@ extern "C" int gnnb_forward(gnnb_t* h, const gnnb_batch* in, int B, float* score
     lz.run(PC_TOP, [&] {
       if (S == 4) hipLaunchKernelGGL(k_top<1>, dim3(B * 4), dim3(512), TOP_LDS_FLOATS * 4, st, a);
       else if (S == 2) hipLaunchKernelGGL(k_top<2>, dim3(B * 2), dim3(512), TOP_LDS_FLOATS * 4, st, a);
-      else hipLaunchKernelGGL(k_top<4>, dim3(B * R), dim3(512), TOP_LDS_FLOATS * 4, st, a);
+      else hipLaunchKernelGGL(k_top<4>, dim3(B), dim3(512), TOP_LDS_FLOATS * 4, st, a);
     });
     proj[L] = L_BC4_1;
   };

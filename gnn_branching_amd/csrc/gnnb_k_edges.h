@@ -843,12 +843,6 @@ struct TopArgs {
   // fuse_um != 0: the backward node update of layer L-1 runs on B2's row tiles in here (its aggregate never reaches memory, the
   // k_node_update launch behind k_top is gone); um = that update's arguments (list / nb fields unused)
   UpdArgs um; int fuse_um;
-  // rparts (1 / 2 / 4; with TS = 4 only): REDUNDANT split -- rparts workgroups per sample each run the whole top of the sample (F1 .. B1: every
-  // one of them needs all of layer L) and share only the row tiles of B2 + the update of layer L-1, which are independent per tile.  Nothing
-  // crosses workgroups, nothing waits: the form for handles that run beside other work on the GPU (option "top_split" = 1), on CUs a batch
-  // of B <= n_cu / 2 leaves idle.  Workgroup 0 of a sample writes the rows of layer L and the property node; the tiles are the bits of the
-  // unsplit kernel whoever computes them.
-  int rparts;
 };
 #define TOP_A_FLOATS (PackUpd::FLOATS > DENSE_FWD_LDS_FLOATS ? PackUpd::FLOATS : DENSE_FWD_LDS_FLOATS)
 #define TOP_FIXED_FLOATS (TOP_A_FLOATS + PackProp::FLOATS + DENSE_BWD_ROWS * 64 + 8 * 64 + 128 + 64 + 64)
@@ -887,10 +881,8 @@ static_assert(TOP_IMG_FLOATS + PackUpdL3::FLOATS <= TOP_A_FLOATS + PackProp::FLO
 // other streams or processes (so that the partner workgroups may be dispatched late) should set GNNB_TOP_SPLIT=1.
 // needs 512 threads and TOP_LDS_FLOATS of LDS
 template <int TS>
-__device__ __forceinline__ void top_sample(const TopArgs& a, const int b, const int part, float* lds, const int rpart = 0, const int rparts = 1) {
+__device__ __forceinline__ void top_sample(const TopArgs& a, const int b, const int part, float* lds) {
   constexpr int S = 4 / TS;
-  const int bpart = S > 1 ? part : rpart, bparts = S > 1 ? S : rparts;      // who takes which row tile of B2 (and of the update of layer L-1)
-  const bool writer = rpart == 0;                                            // redundant split: one workgroup of a sample writes what all of them compute
   const int t0 = part * TS;
   float* A = lds;
   float* Bp = A + TOP_A_FLOATS;
@@ -1141,7 +1133,7 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, const 
     float o = part3[lane];
 #pragma unroll
     for (int w8 = 1; w8 < 8; ++w8) o += part3[w8 * 64 + lane];
-    if (part == 0 && writer) a.mu_prop[(long)b * 64 + lane] = o;
+    if (part == 0) a.mu_prop[(long)b * 64 + lane] = o;
     outv[lane] = o;
   }
   __syncthreads();
@@ -1167,7 +1159,7 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, const 
     if (valid) {
       if (frag_has_nan(E)) atomicOr(a.status, 1);
       store_row(E, Cr + n * 64, csw(n));
-      if (S == 1) { if (writer) store_row(E, a.mu + g * 64); }
+      if (S == 1) store_row(E, a.mu + g * 64);
       else {                                           // the other workgroups of the sample read these rows: write-through stores
         float* base = a.mu + g * 64 + 4 * h;
 #pragma unroll
@@ -1229,7 +1221,7 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, const 
     const long mbase = (long)b * a.db.M;
     struct NodeIn { float lb, ub, s; };
     dense_bwd_sample_bf3<true>(
-        a.db, Cr, A, put, klist, K_eff, a.sb_out ? a.sb_out + mbase : nullptr, a.df.At, a.df.ldA, xs, bpart, bparts,
+        a.db, Cr, A, put, klist, K_eff, a.sb_out ? a.sb_out + mbase : nullptr, a.df.At, a.df.ldA, xs, part, S,
         [&]() {
 #pragma unroll
           for (int u = 0; u < PER; ++u) {
@@ -1247,8 +1239,8 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, const 
           upd_chain_frag<false>(a.um, W2, X, in ? (int)(mbase + arow) : 0, in ? rt.r0 : 0.0f, in ? rt.r1 : 0.0f, in && rt.amb != 0.0f,
                                 in ? (a.sb_out ? ssum : nd.s) : 0.0f, in, lane);
         });
-  } else if (keep) dense_bwd_sample_bf3(a.db, Cr, A, put, klist, K_eff, a.sb_out ? a.sb_out + (long)b * a.db.M : nullptr, a.df.At, a.df.ldA, xs, bpart, bparts);
-  else dense_bwd_sample_bf3(a.db, Cr, A, put, nullptr, 0, nullptr, a.df.At, a.df.ldA, xs, bpart, bparts);
+  } else if (keep) dense_bwd_sample_bf3(a.db, Cr, A, put, klist, K_eff, a.sb_out ? a.sb_out + (long)b * a.db.M : nullptr, a.df.At, a.df.ldA, xs, part, S);
+  else dense_bwd_sample_bf3(a.db, Cr, A, put, nullptr, 0, nullptr, a.df.At, a.df.ldA, xs, part, S);
 #endif
 #ifdef FUSED_TIMING
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1257,16 +1249,10 @@ __device__ __forceinline__ void top_sample(const TopArgs& a, const int b, const 
 #endif
 }
 
-// TS = 4: one workgroup per sample (or TopArgs.rparts redundant ones: grid = B x rparts); TS = 2 / 1: 2 / 4 workgroups per sample that hand
-// partial results to each other (grid = B x 4 / TS, the parts of a sample adjacent)
+// TS = 4: one workgroup per sample; TS = 2 / 1: 2 / 4 workgroups per sample (grid = B x 4 / TS, the parts of a sample adjacent)
 template <int TS>
 __global__ __launch_bounds__(512, 1) void k_top(TopArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int S = 4 / TS;
-  if constexpr (TS == 4) {
-    const int R = a.rparts > 1 ? a.rparts : 1;
-    top_sample<4>(a, blockIdx.x / R, 0, lds, blockIdx.x % R, R);
-  } else {
-    top_sample<TS>(a, blockIdx.x / S, blockIdx.x % S, lds);
-  }
+  top_sample<TS>(a, blockIdx.x / S, blockIdx.x % S, lds);
 }

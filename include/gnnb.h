@@ -85,9 +85,7 @@ int gnnb_create(gnnb_t** out, const float* w_blob, size_t n_floats, int T, int p
  *   "dense_lds" (*) 1: Linear edges one workgroup per sample out of LDS; 0: the per-tile kernel (what very wide layers fall back to)
  *   "tail_max_b"   batches up to it run the last restricted update + score head (graph_conv.py:442-470) as ONE launch; 0: three kernels
  *   "top_split"    1 / 2 / 4: most workgroups k_top spreads one sample over.  2 and 4 make workgroups WAIT for partner workgroups and
- *                  need all of them resident: set 1 when anything else may occupy CUs while a forward runs (status bit 1 otherwise).
- *                  With 1 nothing ever waits: where a small batch leaves CUs idle, 2 or 4 workgroups per sample each run the sample's
- *                  whole top redundantly and share only the independent row tiles below it (same bits)
+ *                  need all of them resident: set 1 when anything else may occupy CUs while a forward runs (status bit 1 otherwise)
  *   "top_fuse_upd" 1: the backward update of layer L-1 (graph_conv.py:253-350) inside k_top; 0: its own launch
  *   "clspre_max_b" batches up to it classify nodes and run the hoisted feature chains in one launch
  * gnnb_option_count / gnnb_option_name enumerate the table; gnnb_get_option reads a value back. */
