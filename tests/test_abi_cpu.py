@@ -136,3 +136,9 @@ def test_library_carries_the_hash_of_its_sources(lib, tmp_path, monkeypatch):
     assert _lib.needs_build()
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "missing.so"))
     assert _lib.needs_build()
+
+
+def test_graft_entry_build_runs():
+    """The driver's "does it build" step (__graft_entry__.build) must pass on the tree as it is -- its ABI assertions included."""
+    import __graft_entry__ as g
+    g.build()
