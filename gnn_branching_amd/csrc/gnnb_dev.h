@@ -183,10 +183,14 @@ __device__ __forceinline__ void frag_bias(Frag& a, const float* bl, int h) {
 
 // torch's relu propagates NaN (fmaxf would swallow it and hide a 0/0 of compute_ratio)
 __device__ __forceinline__ float relu_nan(float x) { return x < 0.0f ? 0.0f : x; }
+// the same in ONE vector instruction: IEEE-754-2019 maximum propagates NaN (v_maximum3_f32 on gfx950; compare + select costs two).  Differs from
+// relu_nan only in the sign of a zero it returns for -0.0 (+0.0 here); used where 32 values per lane go through it (round 6: -64 vector
+// instructions per relu of a fragment, on kernels whose vector issue is 87 % busy, profiles/r06_input_update_ablation.txt)
+__device__ __forceinline__ float relu_max(float x) { return __builtin_elementwise_maximum(x, 0.0f); }
 
 __device__ __forceinline__ void frag_relu(Frag& a) {
 #pragma unroll
-  for (int R = 0; R < 32; ++R) FRAG_AT(a, R) = relu_nan(FRAG_AT(a, R));
+  for (int R = 0; R < 32; ++R) FRAG_AT(a, R) = relu_max(FRAG_AT(a, R));
 }
 
 __device__ __forceinline__ void frag_scale(Frag& a, float s) {
@@ -258,11 +262,14 @@ __device__ __forceinline__ void frag_store_rows3(const Frag& x, void* base, long
   }
 }
 
+// any NaN among the 32 values of a lane: a NaN-propagating maximum over them (v_maximum3_f32: two values per instruction) and ONE compare,
+// instead of 32 compares and 32 scalar ORs
 __device__ __forceinline__ bool frag_has_nan(const Frag& x) {
-  bool bad = false;
+  float m = FRAG_AT(x, 0);
 #pragma unroll
-  for (int R = 0; R < 32; ++R) bad |= (FRAG_AT(x, R) != FRAG_AT(x, R));
-  return bad;
+  for (int R = 1; R + 1 < 32; R += 2) m = __builtin_elementwise_maximum(__builtin_elementwise_maximum(m, FRAG_AT(x, R)), FRAG_AT(x, R + 1));
+  m = __builtin_elementwise_maximum(m, FRAG_AT(x, 31));
+  return m != m;
 }
 
 // compute_ratio (graph_conv.py:499-514), op for op

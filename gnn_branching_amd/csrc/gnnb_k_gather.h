@@ -140,7 +140,7 @@ __device__ __forceinline__ void gather_tile_sparse(Frag& X, const float* cm, con
 #pragma unroll
     for (int u = 0; u < GATHER_CHS; ++u) {
       const uint2 e = tab[2 * (s0 + u) + h];
-      c.v[u] = buf_load2(rsrc, e.x == BUF_OOB ? BUF_OOB : e.x + lane_off);
+      c.v[u] = buf_load2(rsrc, e.x + lane_off);      // (a padding entry's BUF_OOB + lane_off is still past the buffer's end: the load returns 0)
       c.cr[u] = e.y;
     }
   };
@@ -318,8 +318,8 @@ __device__ __forceinline__ void gather_tile_embed(Frag& X, const float* cm, cons
 #pragma unroll
     for (int q = 0; q < GATHER_CH; ++q) {
       const float b = cm[(s0 + q) * 64 + lane];
-      float e0 = relu_nan(fmaf(c.u[q], w[0][2], fmaf(c.x[q], w[0][1], fmaf(c.l[q], w[0][0], bias[0]))));
-      float e1 = relu_nan(fmaf(c.u[q], w[1][2], fmaf(c.x[q], w[1][1], fmaf(c.l[q], w[1][0], bias[1]))));
+      float e0 = relu_max(fmaf(c.u[q], w[0][2], fmaf(c.x[q], w[0][1], fmaf(c.l[q], w[0][0], bias[0]))));
+      float e1 = relu_max(fmaf(c.u[q], w[1][2], fmaf(c.x[q], w[1][1], fmaf(c.l[q], w[1][0], bias[1]))));
       if (!INTERIOR) {
         const bool v = c.o[q] != BUF_OOB;
         e0 = v ? e0 : 0.0f;
@@ -447,7 +447,7 @@ __device__ __forceinline__ void gather_tile16_sparse(f32x4 (&acc)[4], const floa
 #pragma unroll
     for (int u = 0; u < GATHER_CHS16; ++u) {
       const uint2 e = tab[4 * (s0 + u) + g];
-      const unsigned o = e.x == BUF_OOB ? BUF_OOB : e.x + lane_off;
+      const unsigned o = e.x + lane_off;               // (a padding entry's BUF_OOB + lane_off is still past the buffer's end: the load returns 0)
       const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, 0, 0);
       c.v[u] = f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
       c.cr[u] = e.y;
@@ -523,7 +523,7 @@ __device__ __forceinline__ void gather_tile16_embed(f32x4 (&acc)[4], const float
       const bool v = INTERIOR || c.o[q] != BUF_OOB;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        float e = relu_nan(fmaf(c.u[q], w[t][2], fmaf(c.x[q], w[t][1], fmaf(c.l[q], w[t][0], bias[t]))));
+        float e = relu_max(fmaf(c.u[q], w[t][2], fmaf(c.x[q], w[t][1], fmaf(c.l[q], w[t][0], bias[t]))));
         e = v ? e : 0.0f;
         acc[t] = mfma16(e, b, acc[t]);
       }
@@ -712,7 +712,7 @@ __device__ __forceinline__ void gather_tile16_embed_mfma(f32x4 (&acc)[4], const 
     for (int t = 0; t < 4; ++t) {
       e[t] = mfma16(cur, bw[t], f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-      for (int r = 0; r < 4; ++r) e[t][r] = relu_nan(e[t][r]);
+      for (int r = 0; r < 4; ++r) e[t][r] = relu_max(e[t][r]);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void k_embed(EmbedArgs a) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         // torch addmm order: bias + sum_k in_k w_k
-        o[c] = relu_nan(fmaf(u[r], w[c][2], fmaf(x[r], w[c][1], fmaf(l[r], w[c][0], bias[c]))));
+        o[c] = relu_max(fmaf(u[r], w[c][2], fmaf(x[r], w[c][1], fmaf(l[r], w[c][0], bias[c]))));
       }
       if (gg < a.G) *reinterpret_cast<f32x4*>(a.mu + gg * 64 + 4 * q) = o;
     }
