@@ -65,16 +65,14 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b) { return __builtin
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 
 // three-piece split of the 8 B-operand values of k-step fk (registers 8 fk .. 8 fk + 7 of the input fragment)
+__device__ __forceinline__ void split_pair_bf3(float a, float b, unsigned& u1, unsigned& u2, unsigned& u3);
 template <class GetB>
 __device__ __forceinline__ void split_bf3(GetB& getB, int fk, u32x4& p1, u32x4& p2, u32x4& p3) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const float a = getB(8 * fk + 2 * q), b = getB(8 * fk + 2 * q + 1);
-    const unsigned u1 = pk_bf16(a, b);
-    const float ra = a - __uint_as_float(u1 << 16), rb = b - __uint_as_float(u1 & 0xffff0000u);
-    const unsigned u2 = pk_bf16(ra, rb);
-    const float sa = ra - __uint_as_float(u2 << 16), sb = rb - __uint_as_float(u2 & 0xffff0000u);
-    p1[q] = u1; p2[q] = u2; p3[q] = pk_bf16(sa, sb);
+    unsigned u1, u2, u3;
+    split_pair_bf3(getB(8 * fk + 2 * q), getB(8 * fk + 2 * q + 1), u1, u2, u3);
+    p1[q] = u1; p2[q] = u2; p3[q] = u3;
   }
 }
 

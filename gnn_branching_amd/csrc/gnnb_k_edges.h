@@ -382,11 +382,7 @@ __global__ __launch_bounds__(512, 2) void k_dense_bwd_lds(DenseLArgs a) {
 struct Split3 { unsigned u1, u2, u3; };
 __device__ __forceinline__ Split3 split3(float a, float b) {
   Split3 r;
-  r.u1 = pk_bf16(a, b);
-  const float ra = a - __uint_as_float(r.u1 << 16), rb = b - __uint_as_float(r.u1 & 0xffff0000u);
-  r.u2 = pk_bf16(ra, rb);
-  const float sa = ra - __uint_as_float(r.u2 << 16), sb = rb - __uint_as_float(r.u2 & 0xffff0000u);
-  r.u3 = pk_bf16(sa, sb);
+  split_pair_bf3(a, b, r.u1, r.u2, r.u3);
   return r;
 }
 __device__ __forceinline__ void split3_to(u32x4 (&d)[3], int q, float a, float b) {
