@@ -712,7 +712,8 @@ static TileMap bwd_map(const gnnb_t* h, int k) {
 static long map_tiles(const TileMap& t, int B) { return t.mode ? (long)B * t.TPS : ((long)B * t.N + 31) / 32; }
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static DTileMap to_dtm(const TileMap& t) {
-  return DTileMap{t.mode, t.N, t.C, t.H, t.W, t.CT, t.PY, t.PX, t.ay, t.ax, t.NBY, t.NBX, t.NCG, t.TPS, ilog2(t.PY), ilog2(t.PX)};
+  return DTileMap{t.mode, t.N, t.C, t.H, t.W, t.CT, t.PY, t.PX, t.ay, t.ax, t.NBY, t.NBX, t.NCG, t.TPS, ilog2(t.PY), ilog2(t.PX),
+                  t.TPS > 1 ? (unsigned)((1ull << 32) / (unsigned)t.TPS) + 1u : 0u};      // tile_sample (gnnb_dev.h); TPS <= 1 is handled there
 }
 static DGather to_dg(const DevGather& d, const float* zero) {
   const GatherGeom& g = d.g;

@@ -330,7 +330,17 @@ __device__ __forceinline__ void stage_pack(float* lds, const float* pack, int nf
 }
 
 // ---- tile -> node mapping (gnnb_pack.h TileMap) ----
-struct DTileMap { int mode, N, C, H, W, CT, PY, PX, ay, ax, NBY, NBX, NCG, TPS, lpy, lpx; };
+struct DTileMap { int mode, N, C, H, W, CT, PY, PX, ay, ax, NBY, NBX, NCG, TPS, lpy, lpx; unsigned tps_magic; };
+// sample = tile / TPS for a wave-uniform tile index: the loops carry it as a `long`, and a 64-bit signed division by a run-time divisor is ~60 vector
+// instructions per tile (an eighth of what a tile of the input update issues, profiles/r06_vector_trims_ab.txt).  tps_magic = floor(2^32 / TPS) + 1 (host,
+// to_dtm): the high word of tile * magic is the quotient or one above it for every tile < 2^32, the compare puts it right -- three scalar instructions.
+__device__ __forceinline__ int tile_sample(const DTileMap& tm, long tile) {
+  const unsigned n = (unsigned)__builtin_amdgcn_readfirstlane((int)tile), d = (unsigned)tm.TPS;
+  if (d <= 1u) return (int)n;
+  unsigned q = __umulhi(n, tm.tps_magic);      // floor(n / d) or one above it (magic > 2^32 / d)
+  if (q * d > n) --q;
+  return (int)q;
+}
 struct TileCtx { long sample; int n, cg, by, bx, y, x; bool valid; };
 
 // lane j of tile `tile`: which node of which sample.  mode 0: 32 consecutive rows of the flat (B*N) layer;

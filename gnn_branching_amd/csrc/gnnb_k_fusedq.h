@@ -144,7 +144,9 @@ __device__ __forceinline__ void q_chain(const FArgs& a, const float* lds, const 
   const int gc = valid ? (gc_amb & 0x7fffffff) : 0;
   const float r0 = valid ? sc[1] : 0.0f, r1 = valid ? sc[2] : 0.0f;
   const bool amb = valid && gc_amb < 0;
-  const float sw = !valid ? 0.0f : (a.sw_from_gather ? sc[3] : a.u.sarr[a.u.smod > 0 ? gc % a.u.smod : gc]);
+  // the bias-sum scalar: out of the sparse gather itself (rides in the row), or looked up in u.sarr -- by the index the gather wave left in its place: the
+  // node's index inside its sample for the per-sample table of edge 1 (smod > 0; no modulo of the flat index here), else the flat index
+  const float sw = !valid ? 0.0f : (a.sw_from_gather ? sc[3] : a.u.sarr[__float_as_int(sc[3])]);
   Frag X;                                    // fragment order: register 4 q + c = feature 8 q + 4 h + c
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
@@ -293,7 +295,7 @@ __device__ __forceinline__ bool fusedq_body(const FArgs& a, float* lds) {
     const long tile = r * QG_WAVES + wave;
     nx.in = r < nrounds && tile < ntl;
     const long tl = nx.in ? tile : 0;
-    const int si = __builtin_amdgcn_readfirstlane((int)(tl / a.g.tm.TPS));
+    const int si = tile_sample(a.g.tm, tl);
     nx.sample = si;
     const int t = __builtin_amdgcn_readfirstlane((int)(tl - (long)si * a.g.tm.TPS));
     nx.tc = block_decode(a.g.tm, gl.tt, nx.sample, t, jn);
@@ -317,6 +319,7 @@ __device__ __forceinline__ bool fusedq_body(const FArgs& a, float* lds) {
     f32x4 acc[4];
     if (LANES == 32) gather_compute_tile<false, SPARSE>(a.g, tc, sample, gl.cm, gl.ko, gl.kvo, tab, el, lane, X, ssum);
     else gather_compute_tile16<EMBED, SPARSE>(a.g, tc, sample, gl.cm, gl.ko, gl.kvo, tab, ew, eb, lane, acc, ssum);
+    if (!a.sw_from_gather) ssum = __int_as_float(a.u.smod > 0 ? tc.n : gc);      // (q_chain: the index of the node's entry in u.sarr)
 
     QT_MARK(2);                                     // table build + walk
     // ---- the live nodes of the tile -> consecutive rows of the ring ----

@@ -145,12 +145,23 @@ __device__ __forceinline__ void gather_tile_sparse(Frag& X, const float* cm, con
     }
   };
   auto mma = [&](const Chunk& c, int s0) {
+    float b[GATHER_CHS];
 #pragma unroll
     for (int u = 0; u < GATHER_CHS; ++u) {
-      const float b = cm[c.cr[u] + j];
-      if (ssum) sacc += 2 * (s0 + u) + h < n ? b : 0.0f;        // (padding entries point at tap row 0)
-      X.t[0] = mfma32(c.v[u].x, b, X.t[0]);
-      X.t[1] = mfma32(c.v[u].y, b, X.t[1]);
+      b[u] = cm[c.cr[u] + j];
+      X.t[0] = mfma32(c.v[u].x, b[u], X.t[0]);
+      X.t[1] = mfma32(c.v[u].y, b[u], X.t[1]);
+    }
+    if (ssum) {
+      // padding entries point at tap row 0 and must not count for the bias sum: only the chunk that holds entry n can have them -- a wave-uniform
+      // test, so every other chunk adds its taps without the per-entry compare and select (2 of its ~6 vector instructions per k-step)
+      if (2 * (s0 + GATHER_CHS) <= n) {
+#pragma unroll
+        for (int u = 0; u < GATHER_CHS; ++u) sacc += b[u];
+      } else {
+#pragma unroll
+        for (int u = 0; u < GATHER_CHS; ++u) sacc += 2 * (s0 + u) + h < n ? b[u] : 0.0f;
+      }
     }
   };
   load(cur, 0);
@@ -454,12 +465,21 @@ __device__ __forceinline__ void gather_tile16_sparse(f32x4 (&acc)[4], const floa
     }
   };
   auto mma = [&](const Chunk& c, int s0) {
+    float b[GATHER_CHS16];
 #pragma unroll
     for (int u = 0; u < GATHER_CHS16; ++u) {
-      const float b = cm[c.cr[u] + i];
-      if (ssum) sacc += 4 * (s0 + u) + g < n ? b : 0.0f;
+      b[u] = cm[c.cr[u] + i];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = mfma16(c.v[u][t], b, acc[t]);
+      for (int t = 0; t < 4; ++t) acc[t] = mfma16(c.v[u][t], b[u], acc[t]);
+    }
+    if (ssum) {
+      if (4 * (s0 + GATHER_CHS16) <= n) {              // (wave-uniform: no padding entry in this chunk, see gather_tile_sparse)
+#pragma unroll
+        for (int u = 0; u < GATHER_CHS16; ++u) sacc += b[u];
+      } else {
+#pragma unroll
+        for (int u = 0; u < GATHER_CHS16; ++u) sacc += 4 * (s0 + u) + g < n ? b[u] : 0.0f;
+      }
     }
   };
   load(cur, 0);
@@ -862,7 +882,7 @@ __global__ __launch_bounds__(WG_MLP, 2) void k_gather(GArgs a) {
     const long tile = r * WAVES_MLP + wave;
     if (tile >= a.ntiles) break;
     // tile, sample and t are wave-uniform by construction; make them provably so (scalar registers, scalar base address)
-    const int sample = __builtin_amdgcn_readfirstlane((int)(tile / a.tm.TPS));
+    const int sample = tile_sample(a.tm, tile);
     const int t = __builtin_amdgcn_readfirstlane((int)(tile - (long)sample * a.tm.TPS));
     const TileCtx tc = block_decode(a.tm, gl.tt, sample, t, j);
     gather_process_tile<EMBED, SPARSE>(a, tc, sample, gl.cm, gl.ko, gl.kvo, tab, el, lane);
@@ -906,7 +926,7 @@ __global__ __launch_bounds__(WG_MLP, 4) void k_gather16(GArgs a) {
   for (long r = wg; r < nrounds; r += nwg) {
     const long tile = r * WAVES_MLP + wave;
     if (tile >= a.ntiles) break;
-    const int sample = __builtin_amdgcn_readfirstlane((int)(tile / a.tm.TPS));
+    const int sample = tile_sample(a.tm, tile);
     const int t = __builtin_amdgcn_readfirstlane((int)(tile - (long)sample * a.tm.TPS));
     const TileCtx tc = block_decode(a.tm, gl.tt, sample, t, j);
 #ifdef FUSED_TIMING
@@ -1039,7 +1059,7 @@ __global__ __launch_bounds__(R3 ? GIU_R3_WAVES * 64 : WG_MLP, R3 ? 3 : 2) void k
   for (long r = wg; r < nrounds; r += nwg) {
     const long tile = r * NW + wave;
     if (tile >= a.ntiles) break;
-    const int sample = __builtin_amdgcn_readfirstlane((int)(tile / a.tm.TPS));
+    const int sample = tile_sample(a.tm, tile);
     const int t = __builtin_amdgcn_readfirstlane((int)(tile - (long)sample * a.tm.TPS));
     const TileCtx tc = block_decode(a.tm, gl.tt, sample, t, j);
     input_update_tile<SPARSE, BF3, R3>(a, tc, sample, lds, lds_pre, gl, tab, lane);
