@@ -142,3 +142,17 @@ def test_graft_entry_build_runs():
     """The driver's "does it build" step (__graft_entry__.build) must pass on the tree as it is -- its ABI assertions included."""
     import __graft_entry__ as g
     g.build()
+
+
+def test_tile_sample_magic_division_is_exact():
+    """gnnb_dev.h tile_sample: sample = tile / TPS as the high word of tile * (floor(2^32 / TPS) + 1) plus one compare (the magic number comes from
+    gnnb.hip to_dtm).  Emulated here over every divisor the tile tables allow and tile indices up to 2^32 - 1: the quotient is exact."""
+    import numpy as np
+    rng = np.random.RandomState(0)
+    for d in list(range(2, 4097)) + [65535, 1 << 20, (1 << 31) - 1]:
+        magic = ((1 << 32) // d + 1) & 0xFFFFFFFF
+        n = np.concatenate([np.arange(0, min(4 * d + 2, 4096), dtype=np.uint64), rng.randint(0, 1 << 32, size=64, dtype=np.uint64),
+                            np.array([(1 << 32) - 1, (1 << 31), d * ((1 << 32) // d) - 1, d * ((1 << 32) // d)], dtype=np.uint64) & np.uint64(0xFFFFFFFF)])
+        q = (n * np.uint64(magic)) >> np.uint64(32)
+        q = q - ((q * np.uint64(d)) > n).astype(np.uint64)
+        assert np.array_equal(q, n // np.uint64(d)), d
