@@ -238,7 +238,10 @@ class StepLoop:
             word = res.status[0:1]
             for c in range(1, res.status.numel()):
                 word = word | res.status[c:c + 1]
-            self.status_acc = word if not self.status_acc.numel() else (self.status_acc | word)
+            if not self.status_acc.numel():
+                self.status_acc = word.clone()
+            else:
+                self.status_acc |= word             # (in place: one small kernel per step, no allocation)
         if self.use_dist:
             from gnn_branching_amd import parallel
             nxt = parallel.gather_scores_async(res.scores, self.total_batch)
