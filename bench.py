@@ -629,6 +629,8 @@ def main():
             # what ran, untimed, before the K timed steps besides the W warm-up steps the contract asks for: 4 steps (allocator, first status
             # read) + BENCH_PREWARM steps (clocks); Python's cyclic collector is run once before them and kept off while the K steps are timed
             "prewarm_steps": 4 + prewarm, "gc_disabled": True,
+            # handle options the timed engine was created with (include/gnnb.h gnnb_set_option; {} = the library's defaults)
+            "engine_options": dict(eng.options),
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (bf16x3-split 64x64 blocks)" if plan.get("bf3") else "f32", "data": "synthetic",
